@@ -1,0 +1,84 @@
+/*
+ * oracle/poseidon.c -- TEST INFRASTRUCTURE ONLY (CPU oracle; never linked into the product).
+ *
+ * Restatement of plonky2 1.0.0 Poseidon over Goldilocks ([EXT] plonky2/src/hash/poseidon.rs:
+ * `Poseidon::poseidon` = full_rounds(4), partial_rounds(22), full_rounds(4); `constant_layer`,
+ * `sbox_layer` (x^7), `mds_layer` via `mds_row_shf`; plonky2/src/hash/hashing.rs:
+ * `hash_n_to_m_no_pad` (rate 8, OVERWRITE absorption), `compress` (two_to_one);
+ * plonky2/src/hash/poseidon.rs `PoseidonHash::hash_or_noop` via hash_types `from_partial`).
+ * The crate is not vendored; this follows the *naive* (non-"fast partial round") definition, which
+ * upstream asserts to be equivalent (`partial_rounds_naive` test).
+ *
+ * Pinned by reference-tree KATs: smt_trie/src/keys.rs:10-15 (HASH_ZEROS),
+ * evm_arithmetization/src/proof.rs:505-510 (EMPTY_CONSOLIDATED_BLOCKHASH),
+ * smt_trie/src/code.rs:56-84 (hash_contract_bytecode) -- see tests/test_oracle_kat.py.
+ */
+#include "goldilocks.h"
+#include "../include/poseidon_constants.h"
+#include "oracle.h"
+#include <string.h>
+
+static const uint64_t RC[ZK_POSEIDON_ROUNDS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RC_INIT;
+static const uint64_t MDS_CIRC[12] = ZK_POSEIDON_MDS_CIRC_INIT;
+static const uint64_t MDS_DIAG[12] = ZK_POSEIDON_MDS_DIAG_INIT;
+
+static inline uint64_t sbox7(uint64_t x) {
+    uint64_t x2 = gl_sqr(x), x4 = gl_sqr(x2), x3 = gl_mul(x, x2);
+    return gl_mul(x3, x4);
+}
+
+/* [EXT] poseidon.rs `mds_row_shf`: res = sum_i v[(i+r)%12]*CIRC[i] + v[r]*DIAG[r]. */
+static void mds_layer(uint64_t st[12]) {
+    uint64_t out[12];
+    for (int r = 0; r < 12; ++r) {
+        u128 acc = 0;
+        for (int i = 0; i < 12; ++i) acc += (u128)st[(i + r) % 12] * MDS_CIRC[i];
+        acc += (u128)st[r] * MDS_DIAG[r];
+        out[r] = gl_reduce128(acc);
+    }
+    memcpy(st, out, sizeof out);
+}
+
+void orc_poseidon_permute(uint64_t st[12]) {
+    for (int i = 0; i < 12; ++i) st[i] = gl_canon(st[i]);
+    int round = 0;
+    for (int phase = 0; phase < 3; ++phase) {
+        int n = phase == 1 ? ZK_POSEIDON_PARTIAL_ROUNDS : ZK_POSEIDON_HALF_FULL_ROUNDS;
+        for (int k = 0; k < n; ++k, ++round) {
+            for (int i = 0; i < 12; ++i) st[i] = gl_add(st[i], RC[round * 12 + i]);
+            if (phase == 1) st[0] = sbox7(st[0]);
+            else for (int i = 0; i < 12; ++i) st[i] = sbox7(st[i]);
+            mds_layer(st);
+        }
+    }
+}
+
+/* [EXT] hashing.rs `hash_n_to_m_no_pad` with m = 4. */
+void orc_poseidon_hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4]) {
+    uint64_t st[12] = {0};
+    for (size_t off = 0; off < n; off += 8) {
+        size_t len = n - off < 8 ? n - off : 8;
+        for (size_t i = 0; i < len; ++i) st[i] = gl_canon(in[off + i]);
+        orc_poseidon_permute(st);
+    }
+    /* n == 0: no permutation at all, output = zeros (matches upstream loop structure). */
+    memcpy(out, st, 4 * sizeof(uint64_t));
+}
+
+/* [EXT] `hash_or_noop`: <= 4 elements are copied (zero padded), not hashed. */
+void orc_poseidon_hash_or_noop(const uint64_t *in, size_t n, uint64_t out[4]) {
+    if (n <= 4) {
+        for (size_t i = 0; i < 4; ++i) out[i] = i < n ? gl_canon(in[i]) : 0;
+    } else {
+        orc_poseidon_hash_no_pad(in, n, out);
+    }
+}
+
+/* [EXT] hashing.rs `compress`. */
+void orc_poseidon_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]) {
+    uint64_t st[12] = {0};
+    memcpy(st, l, 32);
+    memcpy(st + 4, r, 32);
+    orc_poseidon_permute(st);
+    memcpy(out, st, 32);
+}
