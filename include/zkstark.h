@@ -1,0 +1,142 @@
+/*
+ * zkstark.h -- C ABI of libzkstark_hip.so, the MI355X (gfx950) STARK commitment / proving backend.
+ *
+ * Drop-in boundary: the reference has no runtime plugin API for this
+ * path; the seam is the crate boundary to plonky2/starky.  Each entry point below names the
+ * reference call site it replaces (paths relative to the zk_evm checkout).  All pointers are plain
+ * host or device pointers, no C++/torch types.  Every function returns 0 on success or a negative
+ * zk_status; zk_last_error(ctx) gives a human-readable message for the last failure on that ctx.
+ *
+ * Conventions (parity-critical):
+ *   - field elements are u64 Goldilocks representatives; inputs may be non-canonical (any u64),
+ *     outputs are always canonical (< p = 2^64 - 2^32 + 1);
+ *   - a "column" is a contiguous array of n = 2^log_n elements, values[i] = f(w^i) (natural order),
+ *     exactly plonky2 `PolynomialValues<F>`;
+ *   - a digest occupies a 32-byte slot: Poseidon = 4 x u64; Keccak-25 = 25 bytes + 7 zero bytes;
+ *   - leaf index i of a committed batch is the LDE row at natural index bitrev(i) (plonky2's
+ *     `reverse_index_bits_in_place` on the transposed LDE).
+ */
+#ifndef ZKSTARK_H
+#define ZKSTARK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ZK_OK = 0,
+    ZK_ERR_BAD_ARG = -1,
+    ZK_ERR_OOM = -2,
+    ZK_ERR_HIP = -3,
+    ZK_ERR_ABORTED = -4,
+    ZK_ERR_UNSUPPORTED = -5,
+} zk_status;
+
+typedef enum { ZK_HASH_POSEIDON = 0, ZK_HASH_KECCAK25 = 1 } zk_hasher;
+
+/* Mirrors the fields of plonky2 `FriConfig` / starky `StarkConfig` the path consumes
+ * (reference: StarkConfig::standard_fast_config() at zero/src/prover_state/mod.rs:283,
+ * TEST_STARK_CONFIG at evm_arithmetization/src/testing_utils.rs:41-51). */
+typedef struct {
+    uint32_t rate_bits;          /* LDE blow-up = 2^rate_bits (1 in production) */
+    uint32_t cap_height;         /* Merkle cap has 2^cap_height digests (4) */
+    uint32_t hasher;             /* zk_hasher */
+    uint32_t num_challenges;     /* 2 */
+    uint32_t proof_of_work_bits; /* 16 */
+    uint32_t num_query_rounds;   /* 84 */
+    uint32_t arity_bits;         /* FRI ConstantArityBits(4, 5): arity_bits = 4 */
+    uint32_t final_poly_bits;    /* ... final_poly_bits = 5 */
+} zk_cfg;
+
+typedef struct zk_ctx zk_ctx;     /* one per GPU / stream; re-entrant per ctx */
+typedef struct zk_batch zk_batch; /* device-resident PolynomialBatch */
+
+/* ---- context ---------------------------------------------------------------------------- */
+int zk_ctx_create(int device, zk_ctx **out);
+void zk_ctx_destroy(zk_ctx *ctx);
+/* Run all work of this ctx on an existing hipStream_t (e.g. torch's current stream). NULL = the
+ * ctx's own stream. */
+int zk_ctx_set_stream(zk_ctx *ctx, void *hip_stream);
+int zk_ctx_synchronize(zk_ctx *ctx);
+const char *zk_last_error(const zk_ctx *ctx);
+/* Cooperative cancellation, polled between kernels: mirrors `abort_signal` /
+ * `check_abort_signal` (evm_arithmetization/src/prover.rs:56,346-354). NULL disables. */
+int zk_ctx_set_abort_flag(zk_ctx *ctx, volatile const int *abort_flag);
+/* Per-stage device timings of the last commit on this ctx, in ms, keyed like the reference's
+ * TimingTree scopes (prover.rs:92,99): [0]=ifft [1]=lde/coset-fft [2]=leaf hash [3]=tree. */
+int zk_ctx_last_timings(const zk_ctx *ctx, float out_ms[4]);
+
+/* ---- PolynomialBatch::from_values / from_coeffs ------------------------------------------
+ * Replaces plonky2 `PolynomialBatch::from_values(values, rate_bits, blinding=false, cap_height,
+ * timing, None)` as called at evm_arithmetization/src/prover.rs:100-107, verifier.rs:68-77 and
+ * keccak/keccak_stark.rs:718; `from_coeffs` is the form used for the quotient chunks
+ * (starky prover, reached from prover.rs:322). */
+/* host columns: cols[c] points at n = 2^log_n u64 (exactly Vec<PolynomialValues<F>>) */
+int zk_commit_columns(zk_ctx *ctx, const zk_cfg *cfg, const uint64_t *const *cols, size_t n_cols,
+                      unsigned log_n, zk_batch **out);
+/* device-resident values: column c starts at d_values + c * col_stride (elements) */
+int zk_commit_columns_device(zk_ctx *ctx, const zk_cfg *cfg, const uint64_t *d_values,
+                             size_t col_stride, size_t n_cols, unsigned log_n, zk_batch **out);
+/* device-resident natural-order coefficients */
+int zk_commit_coeffs_device(zk_ctx *ctx, const zk_cfg *cfg, const uint64_t *d_coeffs,
+                            size_t col_stride, size_t n_cols, unsigned log_n, zk_batch **out);
+void zk_batch_free(zk_batch *b);
+
+/* shape */
+size_t zk_batch_num_cols(const zk_batch *b);
+unsigned zk_batch_log_n(const zk_batch *b);
+unsigned zk_batch_log_lde(const zk_batch *b);
+/* `merkle_tree.cap` : 2^cap_height 32-byte slots -> host */
+int zk_batch_cap(const zk_batch *b, uint64_t *out);
+/* natural-order coefficients of column `col` (plonky2 `polynomials[col].coeffs`) -> host */
+int zk_batch_coeffs(const zk_batch *b, size_t col, uint64_t *out);
+/* `merkle_tree.leaves[leaf_index]` (n_cols elements) -> host */
+int zk_batch_leaf(const zk_batch *b, size_t leaf_index, uint64_t *out);
+/* `merkle_tree.prove(leaf_index).siblings`: (log_lde - cap_height) 32-byte slots, bottom-up */
+int zk_batch_merkle_path(const zk_batch *b, size_t leaf_index, uint64_t *out);
+/* `get_lde_values(index, step)` = leaves[bitrev(index * step)] -> host */
+int zk_batch_lde_values(const zk_batch *b, size_t index, size_t step, uint64_t *out);
+/* device views (valid until zk_batch_free):
+ *   lde: [n_cols][N] natural row order, column-major;  digests: level-concatenated 32-B slots,
+ *   level 0 = N leaf digests in leaf order, last 2^cap_height slots = cap. */
+const uint64_t *zk_batch_lde_device(const zk_batch *b);
+const uint64_t *zk_batch_digests_device(const zk_batch *b);
+
+/* ---- primitive entry points (used by the parity tests and by later stages) ---------------
+ * All operate on device memory, in place, on the ctx stream.  Orders are plonky2's:
+ * zk_ifft / zk_fft   = `PolynomialValues::ifft` / `PolynomialCoeffs::fft` (natural <-> natural);
+ * zk_coset_fft       = `coset_fft(shift)`; zk_coset_ifft = `coset_ifft(shift)`;
+ * zk_lde             = `p.lde(rate_bits).coset_fft(F::coset_shift())`. */
+int zk_ifft(zk_ctx *ctx, uint64_t *d_data, size_t col_stride, size_t n_cols, unsigned log_n);
+int zk_fft(zk_ctx *ctx, uint64_t *d_data, size_t col_stride, size_t n_cols, unsigned log_n);
+int zk_coset_fft(zk_ctx *ctx, uint64_t *d_data, size_t col_stride, size_t n_cols, unsigned log_n,
+                 uint64_t shift);
+int zk_coset_ifft(zk_ctx *ctx, uint64_t *d_data, size_t col_stride, size_t n_cols, unsigned log_n,
+                  uint64_t shift);
+int zk_lde(zk_ctx *ctx, const uint64_t *d_coeffs, size_t in_stride, uint64_t *d_out,
+           size_t out_stride, size_t n_cols, unsigned log_n, unsigned rate_bits);
+/* Poseidon permutation applied independently to n_states 12-element states (row-major). */
+int zk_poseidon_permute(zk_ctx *ctx, uint64_t *d_states, size_t n_states);
+/* Keccak-f[1600] applied independently to n_states 25-lane states (row-major). */
+int zk_keccak_f1600(zk_ctx *ctx, uint64_t *d_states, size_t n_states);
+/* `H::hash_or_noop` of every row of a column-major matrix [n_cols][n_rows] (row r =
+ * (col_0[r], .., col_{C-1}[r])); digest of row r is written to slot r (no bit reversal). */
+int zk_hash_rows(zk_ctx *ctx, uint32_t hasher, const uint64_t *d_cols, size_t col_stride,
+                 size_t n_cols, size_t n_rows, uint64_t *d_digests);
+/* `MerkleTree::new` on precomputed leaf digests: d_digests holds 2^log_leaves leaf slots followed
+ * by room for all upper levels (zk_merkle_num_digests slots in total). */
+size_t zk_merkle_num_digests(unsigned log_leaves, unsigned cap_height);
+int zk_merkle_build(zk_ctx *ctx, uint32_t hasher, uint64_t *d_digests, unsigned log_leaves,
+                    unsigned cap_height);
+
+/* library / device info */
+const char *zk_version(void);
+int zk_device_info(int device, char *name_out, size_t name_len, int *cu_count, size_t *hbm_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZKSTARK_H */

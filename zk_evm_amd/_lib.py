@@ -1,0 +1,81 @@
+"""ctypes binding of libzkstark_hip.so (C ABI in include/zkstark.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``zk_evm_amd.build``; if it is
+missing this module raises -- there is deliberately no fallback implementation.
+"""
+import ctypes as C
+import os
+
+from .config import ZkCfg
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libzkstark_hip.so"
+
+
+class ZkStarkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"zkstark error {code}: {msg}")
+        self.code = code
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, _LIB_NAME)
+
+
+_lib = None
+
+# name -> (restype, argtypes); must list every symbol include/zkstark.h declares
+vp, u64p, sz, u32, ui = C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint
+SIGNATURES = {
+    "zk_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "zk_ctx_destroy": (None, [vp]),
+    "zk_ctx_set_stream": (C.c_int, [vp, vp]),
+    "zk_ctx_synchronize": (C.c_int, [vp]),
+    "zk_last_error": (C.c_char_p, [vp]),
+    "zk_ctx_set_abort_flag": (C.c_int, [vp, vp]),
+    "zk_ctx_last_timings": (C.c_int, [vp, C.POINTER(C.c_float)]),
+    "zk_commit_columns": (C.c_int, [vp, C.POINTER(ZkCfg), C.POINTER(vp), sz, ui, C.POINTER(vp)]),
+    "zk_commit_columns_device": (C.c_int, [vp, C.POINTER(ZkCfg), u64p, sz, sz, ui, C.POINTER(vp)]),
+    "zk_commit_coeffs_device": (C.c_int, [vp, C.POINTER(ZkCfg), u64p, sz, sz, ui, C.POINTER(vp)]),
+    "zk_batch_free": (None, [vp]),
+    "zk_batch_num_cols": (sz, [vp]),
+    "zk_batch_log_n": (ui, [vp]),
+    "zk_batch_log_lde": (ui, [vp]),
+    "zk_batch_cap": (C.c_int, [vp, u64p]),
+    "zk_batch_coeffs": (C.c_int, [vp, sz, u64p]),
+    "zk_batch_leaf": (C.c_int, [vp, sz, u64p]),
+    "zk_batch_merkle_path": (C.c_int, [vp, sz, u64p]),
+    "zk_batch_lde_values": (C.c_int, [vp, sz, sz, u64p]),
+    "zk_batch_lde_device": (vp, [vp]),
+    "zk_batch_digests_device": (vp, [vp]),
+    "zk_ifft": (C.c_int, [vp, u64p, sz, sz, ui]),
+    "zk_fft": (C.c_int, [vp, u64p, sz, sz, ui]),
+    "zk_coset_fft": (C.c_int, [vp, u64p, sz, sz, ui, C.c_uint64]),
+    "zk_coset_ifft": (C.c_int, [vp, u64p, sz, sz, ui, C.c_uint64]),
+    "zk_lde": (C.c_int, [vp, u64p, sz, u64p, sz, sz, ui, ui]),
+    "zk_poseidon_permute": (C.c_int, [vp, u64p, sz]),
+    "zk_keccak_f1600": (C.c_int, [vp, u64p, sz]),
+    "zk_hash_rows": (C.c_int, [vp, u32, u64p, sz, sz, sz, u64p]),
+    "zk_merkle_num_digests": (sz, [ui, ui]),
+    "zk_merkle_build": (C.c_int, [vp, u32, u64p, ui, ui]),
+    "zk_version": (C.c_char_p, []),
+    "zk_device_info": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(sz)]),
+}
+
+
+def load_library():
+    """dlopen the HIP library and type every entry point.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ZkStarkError(-3, f"{path} not found: build it with `python -m zk_evm_amd.build` "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

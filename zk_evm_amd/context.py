@@ -1,0 +1,75 @@
+"""``zk_ctx`` wrapper: one per GPU / stream (SURVEY 8(b) threading row)."""
+import ctypes as C
+import threading
+
+from ._lib import ZkStarkError, load_library
+
+
+class Context:
+    """Owns a ``zk_ctx``.  ``stream`` may be a ``torch.cuda.Stream`` (its ``cuda_stream`` handle is
+    used) so the kernels interleave correctly with torch work on the same stream."""
+
+    def __init__(self, device: int = 0, stream=None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.zk_ctx_create(int(device), C.byref(h))
+        if rc != 0 or not h:
+            raise ZkStarkError(rc, f"zk_ctx_create(device={device}) failed: no usable HIP device "
+                                   "(this backend has no CPU fallback)")
+        self.handle = h
+        self.device = int(device)
+        self._abort = None
+        if stream is not None:
+            self.set_stream(stream)
+
+    def set_stream(self, stream):
+        raw = getattr(stream, "cuda_stream", stream)
+        self.check(self.lib.zk_ctx_set_stream(self.handle, C.c_void_p(raw)))
+
+    def use_torch_current_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device))
+
+    def set_abort_flag(self, flag: "C.c_int | None"):
+        """`flag` is a ctypes c_int the caller may set non-zero from another thread
+        (reference: abort_signal, evm_arithmetization/src/prover.rs:346-354)."""
+        self._abort = flag
+        ptr = C.cast(C.byref(flag), C.c_void_p) if flag is not None else None
+        self.check(self.lib.zk_ctx_set_abort_flag(self.handle, ptr))
+
+    def synchronize(self):
+        self.check(self.lib.zk_ctx_synchronize(self.handle))
+
+    def last_timings(self):
+        arr = (C.c_float * 4)()
+        self.check(self.lib.zk_ctx_last_timings(self.handle, arr))
+        return dict(zip(("ifft", "lde", "leaf_hash", "tree"), [float(x) for x in arr]))
+
+    def last_error(self) -> str:
+        return self.lib.zk_last_error(self.handle).decode()
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise ZkStarkError(rc, self.last_error())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.zk_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = {}
+_lock = threading.Lock()
+
+
+def default_context(device: int = 0) -> Context:
+    with _lock:
+        if device not in _default:
+            _default[device] = Context(device)
+        return _default[device]

@@ -1,0 +1,174 @@
+// Batched Goldilocks NTT for gfx950: LDS-tiled multi-pass radix-2^k kernels.
+//
+// Replaces plonky2_field 1.0.0 `ifft` / `fft` / `coset_fft` / `lde` ([EXT] field/src/fft.rs,
+// polynomial/mod.rs) as driven by PolynomialBatch::from_values (reference
+// evm_arithmetization/src/prover.rs:100).
+//
+// Design (MI355X-first, not the CPU's per-column recursive FFT):
+//   * value-form data is always NATURAL order, coefficient-form data is always kept in
+//     BIT-REVERSED order on the device.  values -> coeffs is decimation-in-frequency (natural in,
+//     bit-reversed out), coeffs -> values is decimation-in-time (bit-reversed in, natural out), so
+//     no pass ever performs a bit-reversal permutation through HBM.
+//   * a transform of size 2^L is split into passes of r <= 10/11 consecutive stages.  One
+//     workgroup owns a tile of R = 2^r "rows" spaced d apart (d = smallest butterfly distance of
+//     the pass) times T contiguous elements, stages it in LDS once, runs all r stages there in
+//     radix-8 register steps, and writes it back in place: HBM traffic is one read + one write
+//     per pass per element, every access a T*8-byte contiguous segment (T=1 pass: fully linear).
+//   * the zero-padding of `lde` is never materialised: in bit-reversed order the padded
+//     coefficient vector is (c, 0, .., 0) groups, and the first rate_bits DIT stages just
+//     replicate c, so the first forward pass loads n coefficients, applies the coset factor
+//     g^i, and starts at stage rate_bits.
+//   * columns are independent: grid = (tiles per column) x (columns); twiddles come from one
+//     per-size table shared by all columns (L2 / Infinity-Cache resident).
+#pragma once
+#include "gl.cuh"
+
+struct NttPass {
+    const u64 *src;      // column c at src + c*src_stride
+    u64 *dst;            // column c at dst + c*dst_stride
+    size_t src_stride, dst_stride;
+    const u64 *tw;       // tw[k] = w^k, k < 2^(log_tw-1), w of order 2^log_tw (or its inverse)
+    const u64 *in_scale; // optional per-source-index factor applied on load (coset powers)
+    const u64 *out_scale;// optional per-index factor applied on store
+    u64 out_const;       // constant factor applied on store when apply_out_const
+    int log_tw;
+    int log_n;           // transform size of the DESTINATION array
+    int log_d;           // smallest butterfly distance handled by this pass
+    int r;               // tile rows = 2^r (stages first_stage .. r-1 are executed)
+    int log_t;           // tile cols = 2^log_t contiguous elements (<= d)
+    int first_stage;     // DIT: number of leading stages already satisfied by replication
+    int log_rep;         // load: dst index x reads src index x >> log_rep
+    int apply_out_const;
+};
+
+// One radix-2 butterfly with the twiddle of global pair (x, x + D), x & D == 0.
+template <bool DIT>
+__device__ __forceinline__ void ntt_bfly(u64 &a, u64 &b, u64 w) {
+    if (DIT) {
+        u64 t = gl_mul(b, w);
+        u64 na = gl_add(a, t);
+        b = gl_sub(a, t);
+        a = na;
+    } else {
+        u64 s = gl_add(a, b);
+        b = gl_mul(gl_sub(a, b), w);
+        a = s;
+    }
+}
+
+// One register step of K (<= 3) consecutive stages over the LDS tile.
+// rows of one sub-problem: t0 + m*q, m in [0, 2^K)
+//   DIF: stage half sizes (rows) q*2^(K-1) .. q     DIT: q .. q*2^(K-1)
+template <bool DIT, int K>
+__device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q, size_t base,
+                                         u32 elems, u32 tid, u32 nthr) {
+    const int log_t = p.log_t;
+    const u32 T = 1u << log_t, q = 1u << log_q;
+    const size_t d = (size_t)1 << p.log_d;
+    const u32 nsub = elems >> K;
+    for (u32 sp = tid; sp < nsub; sp += nthr) {
+        u32 u = sp & (T - 1);
+        u32 w = sp >> log_t;
+        u32 j = w & (q - 1);
+        u32 blk = w >> log_q;
+        u32 t0 = (blk << (log_q + K)) + j;
+        u64 v[1 << K];
+#pragma unroll
+        for (int m = 0; m < (1 << K); ++m) v[m] = tile[((t0 + m * q) << log_t) + u];
+        const size_t x0 = base + (size_t)t0 * d + u;  // global index of v[0]
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const int lm = DIT ? i : (K - 1 - i);       // log2 of the pair distance in m units
+            const int hm = 1 << lm;
+            const int log_D = p.log_d + log_q + lm;     // global butterfly distance
+            const size_t Dm1 = ((size_t)1 << log_D) - 1;
+            const int sh = p.log_tw - 1 - log_D;        // tw index = (x mod D) << sh
+#pragma unroll
+            for (int m = 0; m < (1 << K); ++m) {
+                if (!(m & hm)) {
+                    size_t x = x0 + ((size_t)(m * q) << p.log_d);
+                    u64 tw = p.tw[(x & Dm1) << sh];
+                    ntt_bfly<DIT>(v[m], v[m + hm], tw);
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < (1 << K); ++m) tile[((t0 + m * q) << log_t) + u] = v[m];
+    }
+}
+
+// DIT = false: stages from the largest distance down (decimation in frequency).
+// DIT = true : stages from the smallest distance up (decimation in time).
+template <bool DIT>
+__global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
+    extern __shared__ __attribute__((aligned(16))) u64 tile[];
+    const int r = p.r, log_t = p.log_t;
+    const u32 T = 1u << log_t;
+    const u32 tid = threadIdx.x, nthr = blockDim.x;
+    const size_t d = (size_t)1 << p.log_d;
+    // tile -> (hi, lo_tile): base = hi * (d * R) + lo_tile * T
+    const u32 lo_tiles = (u32)(d >> log_t);
+    const u32 tile_id = blockIdx.x;
+    const size_t hi_idx = tile_id / lo_tiles, lo_tile = tile_id % lo_tiles;
+    const size_t base = hi_idx * (d << r) + (lo_tile << log_t);
+    const u64 *src = p.src + (size_t)blockIdx.y * p.src_stride;
+    u64 *dst = p.dst + (size_t)blockIdx.y * p.dst_stride;
+    const u32 elems = 1u << (r + log_t);
+
+    // ---- load (global index x = base + t*d + u  ->  lds[t*T + u]) ----
+    for (u32 e = tid; e < elems; e += nthr) {
+        u32 t = e >> log_t, u = e & (T - 1);
+        size_t x = base + (size_t)t * d + u;
+        size_t sx = x >> p.log_rep;
+        u64 v = src[sx];
+        if (p.in_scale) v = gl_mul(v, p.in_scale[sx]);
+        tile[e] = v;
+    }
+    __syncthreads();
+
+    // ---- stages first_stage .. r-1 in radix-2^k register steps ----
+    int done = p.first_stage;
+    while (done < r) {
+        const int k = r - done < 3 ? r - done : 3;
+        const int log_q = DIT ? done : (r - done - k);
+        if (k == 3) ntt_step<DIT, 3>(tile, p, log_q, base, elems, tid, nthr);
+        else if (k == 2) ntt_step<DIT, 2>(tile, p, log_q, base, elems, tid, nthr);
+        else ntt_step<DIT, 1>(tile, p, log_q, base, elems, tid, nthr);
+        __syncthreads();
+        done += k;
+    }
+
+    // ---- store ----
+    for (u32 e = tid; e < elems; e += nthr) {
+        u32 t = e >> log_t, u = e & (T - 1);
+        size_t x = base + (size_t)t * d + u;
+        u64 v = tile[e];
+        if (p.out_scale) v = gl_mul(v, p.out_scale[x]);
+        if (p.apply_out_const) v = gl_mul(v, p.out_const);
+        dst[x] = gl_canon(v);
+    }
+}
+
+// In-place bit-reversal permutation of each column (only used by the natural<->natural API
+// entry points; the commit path never calls it).
+__global__ void bitrev_permute_kernel(u64 *data, size_t stride, int log_n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> log_n) return;
+    u64 *col = data + (size_t)blockIdx.y * stride;
+    size_t j = bitrev32((u32)i, log_n);
+    if (i < j) { u64 a = col[i], b = col[j]; col[i] = b; col[j] = a; }
+}
+
+// out[i] = c * s^(bitrev(i, log_n))    (coset power tables in coefficient (bit-reversed) order)
+__global__ void coset_table_kernel(u64 *out, int log_n, u64 s, u64 c) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> log_n) return;
+    u32 e = bitrev32((u32)i, log_n);
+    out[i] = gl_canon(gl_mul(c, gl_pow(s, e)));
+}
+
+// out[k] = w^k for k < count
+__global__ void twiddle_table_kernel(u64 *out, size_t count, u64 w) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = gl_canon(gl_pow(w, i));
+}

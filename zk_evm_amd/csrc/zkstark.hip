@@ -1,0 +1,668 @@
+// libzkstark_hip.so -- host side of the C ABI declared in include/zkstark.h.
+// Single translation unit: the device headers carry __constant__ tables.
+//
+// Host responsibilities: per-context twiddle / coset tables, pass planning for the multi-pass
+// NTT, stage sequencing on one HIP stream, device-memory ownership behind zk_batch handles.
+// There is NO CPU fallback: every entry point either runs the HIP kernels or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/zkstark.h"
+#include "gl.cuh"
+#include "merkle.cuh"
+#include "ntt.cuh"
+
+// ------------------------------------------------------------------------------------------
+struct zk_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    volatile const int *abort_flag = nullptr;
+    std::map<int, u64 *> tw_fwd, tw_inv;                    // log size -> table
+    std::map<std::pair<int, u64>, u64 *> coset_tabs;        // (log_n, shift) -> s^bitrev(i)
+    std::map<std::pair<int, u64>, u64 *> coset_inv_tabs;    // (log_n, shift) -> n^-1 s^-bitrev(i)
+    hipEvent_t ev[5] = {};
+    float timings[4] = {0, 0, 0, 0};
+    int cu_count = 0;
+};
+
+struct zk_batch {
+    zk_ctx *ctx = nullptr;
+    size_t n_cols = 0;
+    unsigned log_n = 0, rate_bits = 0, cap_height = 0;
+    uint32_t hasher = 0;
+    u64 *d_coeffs = nullptr;   // [n_cols][n], bit-reversed coefficient order
+    u64 *d_lde = nullptr;      // [n_cols][N], natural order
+    u64 *d_digests = nullptr;  // level-concatenated 32-byte slots
+    size_t n_digests = 0;
+    std::vector<u64> cap;      // host copy
+};
+
+static int set_err(zk_ctx *ctx, int code, const char *fmt, ...) {
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        ctx->err = buf;
+    }
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return set_err(ctx, e_ == hipErrorOutOfMemory ? ZK_ERR_OOM : ZK_ERR_HIP,         \
+                           "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,  \
+                           __LINE__);                                                        \
+    } while (0)
+
+#define ZK_TRY(expr)               \
+    do {                           \
+        int rc_ = (expr);          \
+        if (rc_ != ZK_OK) return rc_; \
+    } while (0)
+
+static int check_abort(zk_ctx *ctx) {
+    if (ctx->abort_flag && *ctx->abort_flag) return set_err(ctx, ZK_ERR_ABORTED, "aborted");
+    return ZK_OK;
+}
+
+static int check_launch(zk_ctx *ctx, const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return set_err(ctx, ZK_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" const char *zk_version(void) { return "zkstark-hip 0.1 (gfx950)"; }
+
+extern "C" int zk_device_info(int device, char *name_out, size_t name_len, int *cu_count,
+                              size_t *hbm_bytes) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ZK_ERR_HIP;
+    if (name_out && name_len) {
+        snprintf(name_out, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
+    return ZK_OK;
+}
+
+extern "C" int zk_ctx_create(int device, zk_ctx **out) {
+    if (!out) return ZK_ERR_BAD_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count)
+        return ZK_ERR_HIP;  // no GPU: fail loudly, there is no CPU path
+    zk_ctx *ctx = new zk_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return ZK_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    for (auto &e : ctx->ev) hipEventCreate(&e);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
+    // keep freed batch memory in the stream-ordered pool (a commit re-allocates ~3 GB per call)
+    hipMemPool_t pool;
+    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
+        uint64_t thr = ~0ULL;
+        hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+    }
+    // allow the NTT kernels their full LDS tile (default dynamic limit is 64 KiB)
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    *out = ctx;
+    return ZK_OK;
+}
+
+extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->tw_fwd) hipFree(kv.second);
+    for (auto &kv : ctx->tw_inv) hipFree(kv.second);
+    for (auto &kv : ctx->coset_tabs) hipFree(kv.second);
+    for (auto &kv : ctx->coset_inv_tabs) hipFree(kv.second);
+    for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int zk_ctx_set_stream(zk_ctx *ctx, void *hip_stream) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return ZK_OK;
+}
+extern "C" int zk_ctx_synchronize(zk_ctx *ctx) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+extern "C" const char *zk_last_error(const zk_ctx *ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+extern "C" int zk_ctx_set_abort_flag(zk_ctx *ctx, volatile const int *abort_flag) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    ctx->abort_flag = abort_flag;
+    return ZK_OK;
+}
+extern "C" int zk_ctx_last_timings(const zk_ctx *ctx, float out_ms[4]) {
+    if (!ctx || !out_ms) return ZK_ERR_BAD_ARG;
+    memcpy(out_ms, ctx->timings, sizeof ctx->timings);
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// tables
+static int get_twiddles(zk_ctx *ctx, int log_size, bool inverse, const u64 **out) {
+    auto &m = inverse ? ctx->tw_inv : ctx->tw_fwd;
+    auto it = m.find(log_size);
+    if (it != m.end()) { *out = it->second; return ZK_OK; }
+    size_t count = log_size > 0 ? (size_t)1 << (log_size - 1) : 1;
+    u64 *d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, count * sizeof(u64)));
+    u64 w = gl_root_of_unity(log_size);
+    if (inverse) w = gl_canon(gl_inv(w));
+    unsigned blocks = (unsigned)((count + 255) / 256);
+    twiddle_table_kernel<<<blocks, 256, 0, ctx->stream>>>(d, count, w);
+    ZK_TRY(check_launch(ctx, "twiddle_table_kernel"));
+    m[log_size] = d;
+    *out = d;
+    return ZK_OK;
+}
+
+// s^bitrev(i) (inverse=false) or n^-1 * s^-bitrev(i) (inverse=true), i < 2^log_n
+static int get_coset_table(zk_ctx *ctx, int log_n, u64 shift, bool inverse, const u64 **out) {
+    auto &m = inverse ? ctx->coset_inv_tabs : ctx->coset_tabs;
+    auto key = std::make_pair(log_n, shift);
+    auto it = m.find(key);
+    if (it != m.end()) { *out = it->second; return ZK_OK; }
+    size_t count = (size_t)1 << log_n;
+    u64 *d = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d, count * sizeof(u64)));
+    u64 s = gl_canon(shift), c = 1;
+    if (inverse) {
+        s = gl_canon(gl_inv(s));
+        c = gl_canon(gl_inv((u64)count));
+    }
+    unsigned blocks = (unsigned)((count + 255) / 256);
+    coset_table_kernel<<<blocks, 256, 0, ctx->stream>>>(d, log_n, s, c);
+    ZK_TRY(check_launch(ctx, "coset_table_kernel"));
+    m[key] = d;
+    *out = d;
+    return ZK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// NTT pass planning
+struct PassPlan { int log_d, r; };
+static const int kMaxContigBits = 11;   // 2^11 * 8 B = 16 KiB tile
+static const int kMaxStridedBits = 10;
+static const int kTileElemBits = 13;    // strided tiles: 2^13 elements = 64 KiB of LDS
+
+// Passes in decimation-in-frequency order (largest distance first); DIT runs them reversed.
+// The last entry is always the contiguous (log_d = 0) pass.
+static std::vector<PassPlan> plan_passes(int L) {
+    std::vector<PassPlan> v;
+    if (L <= kMaxContigBits) { v.push_back({0, L}); return v; }
+    int ns = 1;
+    while (L > ns * kMaxStridedBits + kMaxContigBits) ++ns;
+    const int base = L / (ns + 1);
+    int extra = L % (ns + 1);
+    int contig = base;
+    std::vector<int> strided(ns, base);
+    while (extra > 0 && contig < kMaxContigBits) { ++contig; --extra; }
+    for (int i = 0; i < ns && extra > 0; ++i)
+        while (extra > 0 && strided[i] < kMaxStridedBits) { ++strided[i]; --extra; }
+    int acc = L;
+    for (int i = 0; i < ns; ++i) { acc -= strided[i]; v.push_back({acc, strided[i]}); }
+    v.push_back({0, acc});
+    return v;
+}
+
+template <bool DIT>
+static int launch_pass(zk_ctx *ctx, NttPass p, size_t n_cols) {
+    if (p.log_d == 0) p.log_t = 0;
+    else {
+        int lt = kTileElemBits - p.r;
+        if (lt < 0) lt = 0;
+        if (lt > p.log_d) lt = p.log_d;
+        p.log_t = lt;
+    }
+    size_t elems = (size_t)1 << (p.r + p.log_t);
+    size_t n = (size_t)1 << p.log_n;
+    size_t tiles = n / elems;
+    if (tiles == 0) tiles = 1;
+    unsigned nthr = (unsigned)(elems / 16);
+    if (nthr < 64) nthr = 64;
+    if (nthr > 512) nthr = 512;
+    size_t lds = elems * sizeof(u64);
+    size_t done = 0;
+    while (done < n_cols) {  // grid.y limit
+        size_t chunk = n_cols - done < 65535 ? n_cols - done : 65535;
+        NttPass q = p;
+        q.src = p.src + done * p.src_stride;
+        q.dst = p.dst + done * p.dst_stride;
+        dim3 grid((unsigned)tiles, (unsigned)chunk);
+        ntt_pass_kernel<DIT><<<grid, nthr, lds, ctx->stream>>>(q);
+        ZK_TRY(check_launch(ctx, DIT ? "ntt_pass_kernel<DIT>" : "ntt_pass_kernel<DIF>"));
+        done += chunk;
+    }
+    return ZK_OK;
+}
+
+// values (natural) -> coefficients (bit-reversed), size 2^log_n.
+// out_scale: optional table applied on the final store (coset_ifft); otherwise multiply by n^-1.
+static int ntt_values_to_coeffs(zk_ctx *ctx, const u64 *src, size_t src_stride, u64 *dst,
+                                size_t dst_stride, size_t n_cols, int log_n, const u64 *out_scale) {
+    const u64 *tw = nullptr;
+    ZK_TRY(get_twiddles(ctx, log_n, true, &tw));
+    auto plan = plan_passes(log_n);
+    for (size_t i = 0; i < plan.size(); ++i) {
+        NttPass p = {};
+        p.src = i == 0 ? src : dst;
+        p.src_stride = i == 0 ? src_stride : dst_stride;
+        p.dst = dst; p.dst_stride = dst_stride;
+        p.tw = tw; p.log_tw = log_n;
+        p.log_n = log_n; p.log_d = plan[i].log_d; p.r = plan[i].r;
+        if (i + 1 == plan.size()) {
+            if (out_scale) p.out_scale = out_scale;
+            else { p.apply_out_const = 1; p.out_const = gl_canon(gl_inv((u64)1 << log_n)); }
+        }
+        ZK_TRY(launch_pass<false>(ctx, p, n_cols));
+    }
+    return ZK_OK;
+}
+
+// coefficients (bit-reversed, size 2^log_n) -> values (natural) on size 2^(log_n + rate_bits),
+// optional per-coefficient factor in_scale (coset powers, bit-reversed order).
+static int ntt_coeffs_to_values(zk_ctx *ctx, const u64 *src, size_t src_stride, u64 *dst,
+                                size_t dst_stride, size_t n_cols, int log_n, int rate_bits,
+                                const u64 *in_scale) {
+    int L = log_n + rate_bits;
+    const u64 *tw = nullptr;
+    ZK_TRY(get_twiddles(ctx, L, false, &tw));
+    auto plan = plan_passes(L);
+    // the contiguous pass must be able to absorb the replication stages
+    if (plan.back().r < rate_bits)
+        return set_err(ctx, ZK_ERR_UNSUPPORTED, "rate_bits %d too large for log_n %d", rate_bits, log_n);
+    for (size_t k = 0; k < plan.size(); ++k) {
+        size_t i = plan.size() - 1 - k;  // reversed order for DIT
+        NttPass p = {};
+        p.dst = dst; p.dst_stride = dst_stride;
+        p.tw = tw; p.log_tw = L;
+        p.log_n = L; p.log_d = plan[i].log_d; p.r = plan[i].r;
+        if (k == 0) {
+            p.src = src; p.src_stride = src_stride;
+            p.in_scale = in_scale;
+            p.log_rep = rate_bits; p.first_stage = rate_bits;
+        } else {
+            p.src = dst; p.src_stride = dst_stride;
+        }
+        ZK_TRY(launch_pass<true>(ctx, p, n_cols));
+    }
+    return ZK_OK;
+}
+
+static int bitrev_columns(zk_ctx *ctx, u64 *d, size_t stride, size_t n_cols, int log_n) {
+    if (log_n <= 1) return ZK_OK;
+    size_t n = (size_t)1 << log_n;
+    size_t done = 0;
+    while (done < n_cols) {
+        size_t chunk = n_cols - done < 65535 ? n_cols - done : 65535;
+        dim3 grid((unsigned)((n + 255) / 256), (unsigned)chunk);
+        bitrev_permute_kernel<<<grid, 256, 0, ctx->stream>>>(d + done * stride, stride, log_n);
+        ZK_TRY(check_launch(ctx, "bitrev_permute_kernel"));
+        done += chunk;
+    }
+    return ZK_OK;
+}
+
+static int check_ntt_args(zk_ctx *ctx, const void *d, size_t stride, size_t n_cols, unsigned log_n) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    if (!d && n_cols) return set_err(ctx, ZK_ERR_BAD_ARG, "null data pointer");
+    if (log_n > 31) return set_err(ctx, ZK_ERR_BAD_ARG, "log_n %u exceeds the field's 2-adicity budget", log_n);
+    if (n_cols > 1 && stride < ((size_t)1 << log_n)) return set_err(ctx, ZK_ERR_BAD_ARG, "col_stride < n");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return ZK_OK;
+}
+
+extern "C" int zk_ifft(zk_ctx *ctx, uint64_t *d, size_t stride, size_t n_cols, unsigned log_n) {
+    ZK_TRY(check_ntt_args(ctx, d, stride, n_cols, log_n));
+    if (!n_cols) return ZK_OK;
+    ZK_TRY(ntt_values_to_coeffs(ctx, (u64 *)d, stride, (u64 *)d, stride, n_cols, log_n, nullptr));
+    return bitrev_columns(ctx, (u64 *)d, stride, n_cols, log_n);
+}
+extern "C" int zk_coset_ifft(zk_ctx *ctx, uint64_t *d, size_t stride, size_t n_cols, unsigned log_n,
+                             uint64_t shift) {
+    ZK_TRY(check_ntt_args(ctx, d, stride, n_cols, log_n));
+    if (!n_cols) return ZK_OK;
+    if (gl_canon(shift) == 0) return set_err(ctx, ZK_ERR_BAD_ARG, "coset shift must be non-zero");
+    const u64 *tab = nullptr;
+    ZK_TRY(get_coset_table(ctx, log_n, shift, true, &tab));
+    ZK_TRY(ntt_values_to_coeffs(ctx, (u64 *)d, stride, (u64 *)d, stride, n_cols, log_n, tab));
+    return bitrev_columns(ctx, (u64 *)d, stride, n_cols, log_n);
+}
+extern "C" int zk_fft(zk_ctx *ctx, uint64_t *d, size_t stride, size_t n_cols, unsigned log_n) {
+    ZK_TRY(check_ntt_args(ctx, d, stride, n_cols, log_n));
+    if (!n_cols) return ZK_OK;
+    ZK_TRY(bitrev_columns(ctx, (u64 *)d, stride, n_cols, log_n));
+    return ntt_coeffs_to_values(ctx, (u64 *)d, stride, (u64 *)d, stride, n_cols, log_n, 0, nullptr);
+}
+extern "C" int zk_coset_fft(zk_ctx *ctx, uint64_t *d, size_t stride, size_t n_cols, unsigned log_n,
+                            uint64_t shift) {
+    ZK_TRY(check_ntt_args(ctx, d, stride, n_cols, log_n));
+    if (!n_cols) return ZK_OK;
+    const u64 *tab = nullptr;
+    ZK_TRY(get_coset_table(ctx, log_n, shift, false, &tab));
+    ZK_TRY(bitrev_columns(ctx, (u64 *)d, stride, n_cols, log_n));
+    return ntt_coeffs_to_values(ctx, (u64 *)d, stride, (u64 *)d, stride, n_cols, log_n, 0, tab);
+}
+
+// natural-order coefficients in, natural-order LDE values out (API form; the batch path below
+// keeps coefficients bit-reversed and skips the permutation)
+extern "C" int zk_lde(zk_ctx *ctx, const uint64_t *d_coeffs, size_t in_stride, uint64_t *d_out,
+                      size_t out_stride, size_t n_cols, unsigned log_n, unsigned rate_bits) {
+    ZK_TRY(check_ntt_args(ctx, d_coeffs, in_stride, n_cols, log_n));
+    if (log_n + rate_bits > 31 || !d_out) return set_err(ctx, ZK_ERR_BAD_ARG, "bad lde size/output");
+    if (!n_cols) return ZK_OK;
+    size_t n = (size_t)1 << log_n;
+    u64 *tmp = nullptr;
+    HIP_TRY(ctx, hipMallocAsync((void **)&tmp, n_cols * n * sizeof(u64), ctx->stream));
+    HIP_TRY(ctx, hipMemcpy2DAsync(tmp, n * 8, d_coeffs, in_stride * 8, n * 8, n_cols,
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+    int rc = bitrev_columns(ctx, tmp, n, n_cols, log_n);
+    const u64 *tab = nullptr;
+    if (rc == ZK_OK) rc = get_coset_table(ctx, log_n, GL_GENERATOR, false, &tab);
+    if (rc == ZK_OK)
+        rc = ntt_coeffs_to_values(ctx, tmp, n, (u64 *)d_out, out_stride, n_cols, log_n, rate_bits, tab);
+    hipFreeAsync(tmp, ctx->stream);
+    return rc;
+}
+
+// ------------------------------------------------------------------------------------------
+// hashing
+extern "C" int zk_poseidon_permute(zk_ctx *ctx, uint64_t *d_states, size_t n_states) {
+    if (!ctx || (!d_states && n_states)) return ZK_ERR_BAD_ARG;
+    if (!n_states) return ZK_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    poseidon_permute_states_kernel<<<(unsigned)((n_states + 255) / 256), 256, 0, ctx->stream>>>(
+        (u64 *)d_states, n_states);
+    return check_launch(ctx, "poseidon_permute_states_kernel");
+}
+extern "C" int zk_keccak_f1600(zk_ctx *ctx, uint64_t *d_states, size_t n_states) {
+    if (!ctx || (!d_states && n_states)) return ZK_ERR_BAD_ARG;
+    if (!n_states) return ZK_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    keccak_f1600_states_kernel<<<(unsigned)((n_states + 255) / 256), 256, 0, ctx->stream>>>(
+        (u64 *)d_states, n_states);
+    return check_launch(ctx, "keccak_f1600_states_kernel");
+}
+
+static int hash_rows(zk_ctx *ctx, uint32_t hasher, const u64 *cols, size_t stride, size_t n_cols,
+                     size_t n_rows, int log_rows, int do_bitrev, u64 *digests) {
+    unsigned blocks = (unsigned)((n_rows + 255) / 256);
+    if (hasher == ZK_HASH_POSEIDON) {
+        poseidon_hash_rows_kernel<<<blocks, 256, 0, ctx->stream>>>(cols, stride, (u32)n_cols, n_rows,
+                                                                   log_rows, do_bitrev, digests);
+        return check_launch(ctx, "poseidon_hash_rows_kernel");
+    } else if (hasher == ZK_HASH_KECCAK25) {
+        keccak_hash_rows_kernel<<<blocks, 256, 0, ctx->stream>>>(cols, stride, (u32)n_cols, n_rows,
+                                                                 log_rows, do_bitrev, digests);
+        return check_launch(ctx, "keccak_hash_rows_kernel");
+    }
+    return set_err(ctx, ZK_ERR_BAD_ARG, "unknown hasher %u", hasher);
+}
+
+extern "C" int zk_hash_rows(zk_ctx *ctx, uint32_t hasher, const uint64_t *d_cols, size_t col_stride,
+                            size_t n_cols, size_t n_rows, uint64_t *d_digests) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    if (!d_digests || (!d_cols && n_cols)) return set_err(ctx, ZK_ERR_BAD_ARG, "null pointer");
+    if (!n_rows) return ZK_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return hash_rows(ctx, hasher, (const u64 *)d_cols, col_stride, n_cols, n_rows, 0, 0, (u64 *)d_digests);
+}
+
+extern "C" size_t zk_merkle_num_digests(unsigned log_leaves, unsigned cap_height) {
+    size_t tot = 0;
+    if (cap_height > log_leaves) return 0;
+    for (unsigned l = log_leaves + 1; l-- > cap_height;) tot += (size_t)1 << l;
+    return tot;
+}
+
+static int merkle_levels(zk_ctx *ctx, uint32_t hasher, u64 *digests, unsigned log_leaves,
+                         unsigned cap_height) {
+    u64 *child = digests;
+    for (unsigned l = log_leaves; l-- > cap_height;) {
+        size_t cnt = (size_t)1 << l;
+        u64 *parent = child + 4 * (cnt * 2);
+        unsigned blocks = (unsigned)((cnt + 255) / 256);
+        if (hasher == ZK_HASH_POSEIDON)
+            poseidon_merkle_level_kernel<<<blocks, 256, 0, ctx->stream>>>(child, parent, cnt);
+        else if (hasher == ZK_HASH_KECCAK25)
+            keccak_merkle_level_kernel<<<blocks, 256, 0, ctx->stream>>>(child, parent, cnt);
+        else
+            return set_err(ctx, ZK_ERR_BAD_ARG, "unknown hasher %u", hasher);
+        ZK_TRY(check_launch(ctx, "merkle_level_kernel"));
+        child = parent;
+    }
+    return ZK_OK;
+}
+
+extern "C" int zk_merkle_build(zk_ctx *ctx, uint32_t hasher, uint64_t *d_digests, unsigned log_leaves,
+                               unsigned cap_height) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    if (!d_digests || cap_height > log_leaves || log_leaves > 31)
+        return set_err(ctx, ZK_ERR_BAD_ARG, "bad merkle arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return merkle_levels(ctx, hasher, (u64 *)d_digests, log_leaves, cap_height);
+}
+
+// ------------------------------------------------------------------------------------------
+// PolynomialBatch
+extern "C" void zk_batch_free(zk_batch *b) {
+    if (!b) return;
+    hipSetDevice(b->ctx->device);
+    hipStream_t st = b->ctx->stream;
+    if (b->d_coeffs) hipFreeAsync(b->d_coeffs, st);
+    if (b->d_lde) hipFreeAsync(b->d_lde, st);
+    if (b->d_digests) hipFreeAsync(b->d_digests, st);
+    delete b;
+}
+
+static int check_cfg(zk_ctx *ctx, const zk_cfg *cfg, size_t n_cols, unsigned log_n) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    if (!cfg) return set_err(ctx, ZK_ERR_BAD_ARG, "null cfg");
+    if (n_cols == 0) return set_err(ctx, ZK_ERR_BAD_ARG, "empty batch (n_cols == 0)");
+    if (cfg->hasher > ZK_HASH_KECCAK25) return set_err(ctx, ZK_ERR_BAD_ARG, "unknown hasher");
+    if (log_n + cfg->rate_bits > 31) return set_err(ctx, ZK_ERR_BAD_ARG, "LDE size exceeds 2^31");
+    if (cfg->cap_height > log_n + cfg->rate_bits)
+        return set_err(ctx, ZK_ERR_BAD_ARG, "cap_height %u exceeds tree height %u (plonky2 asserts the same)",
+                       cfg->cap_height, log_n + cfg->rate_bits);
+    return ZK_OK;
+}
+
+// from_values when have_values, else from_coeffs (d_in = natural-order coefficients).
+static int commit_impl(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t in_stride,
+                       size_t n_cols, unsigned log_n, bool have_values, zk_batch **out) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ZK_TRY(check_abort(ctx));
+    const size_t n = (size_t)1 << log_n;
+    const unsigned log_N = log_n + cfg->rate_bits;
+    const size_t N = (size_t)1 << log_N;
+    zk_batch *b = new zk_batch();
+    b->ctx = ctx; b->n_cols = n_cols; b->log_n = log_n; b->rate_bits = cfg->rate_bits;
+    b->cap_height = cfg->cap_height; b->hasher = cfg->hasher;
+    b->n_digests = zk_merkle_num_digests(log_N, cfg->cap_height);
+    int rc = ZK_OK;
+    auto fail = [&](int code) { zk_batch_free(b); return code; };
+#define B_HIP(expr)                                                                          \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(set_err(ctx, e_ == hipErrorOutOfMemory ? ZK_ERR_OOM : ZK_ERR_HIP,    \
+                                "%s failed: %s", #expr, hipGetErrorString(e_)));             \
+    } while (0)
+    // stream-ordered pool allocations: repeated commits reuse the same HBM without hipMalloc cost
+    B_HIP(hipMallocAsync((void **)&b->d_coeffs, n_cols * n * sizeof(u64), ctx->stream));
+    B_HIP(hipMallocAsync((void **)&b->d_lde, n_cols * N * sizeof(u64), ctx->stream));
+    B_HIP(hipMallocAsync((void **)&b->d_digests, b->n_digests * 32, ctx->stream));
+
+    const u64 *coset = nullptr;
+    if ((rc = get_coset_table(ctx, log_n, GL_GENERATOR, false, &coset)) != ZK_OK) return fail(rc);
+    // make sure table construction is not billed to a stage
+    hipEventRecord(ctx->ev[0], ctx->stream);
+    if (have_values) {
+        rc = ntt_values_to_coeffs(ctx, d_in, in_stride, b->d_coeffs, n, n_cols, log_n, nullptr);
+    } else {
+        B_HIP(hipMemcpy2DAsync(b->d_coeffs, n * 8, d_in, in_stride * 8, n * 8, n_cols,
+                               hipMemcpyDeviceToDevice, ctx->stream));
+        rc = bitrev_columns(ctx, b->d_coeffs, n, n_cols, log_n);
+    }
+    if (rc != ZK_OK) return fail(rc);
+    hipEventRecord(ctx->ev[1], ctx->stream);
+    if ((rc = check_abort(ctx)) != ZK_OK) return fail(rc);
+    rc = ntt_coeffs_to_values(ctx, b->d_coeffs, n, b->d_lde, N, n_cols, log_n, cfg->rate_bits, coset);
+    if (rc != ZK_OK) return fail(rc);
+    hipEventRecord(ctx->ev[2], ctx->stream);
+    if ((rc = check_abort(ctx)) != ZK_OK) return fail(rc);
+    rc = hash_rows(ctx, cfg->hasher, b->d_lde, N, n_cols, N, (int)log_N, 1, b->d_digests);
+    if (rc != ZK_OK) return fail(rc);
+    hipEventRecord(ctx->ev[3], ctx->stream);
+    rc = merkle_levels(ctx, cfg->hasher, b->d_digests, log_N, cfg->cap_height);
+    if (rc != ZK_OK) return fail(rc);
+    hipEventRecord(ctx->ev[4], ctx->stream);
+    b->cap.resize((size_t)4 << cfg->cap_height);
+    B_HIP(hipMemcpyAsync(b->cap.data(), b->d_digests + 4 * (b->n_digests - ((size_t)1 << cfg->cap_height)),
+                         b->cap.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    B_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 4; ++i) hipEventElapsedTime(&ctx->timings[i], ctx->ev[i], ctx->ev[i + 1]);
+#undef B_HIP
+    *out = b;
+    return ZK_OK;
+}
+
+extern "C" int zk_commit_columns_device(zk_ctx *ctx, const zk_cfg *cfg, const uint64_t *d_values,
+                                        size_t col_stride, size_t n_cols, unsigned log_n, zk_batch **out) {
+    if (!out) return ZK_ERR_BAD_ARG;
+    *out = nullptr;
+    ZK_TRY(check_cfg(ctx, cfg, n_cols, log_n));
+    if (!d_values) return set_err(ctx, ZK_ERR_BAD_ARG, "null values");
+    if (n_cols > 1 && col_stride < ((size_t)1 << log_n)) return set_err(ctx, ZK_ERR_BAD_ARG, "col_stride < n");
+    return commit_impl(ctx, cfg, (const u64 *)d_values, col_stride, n_cols, log_n, true, out);
+}
+
+extern "C" int zk_commit_coeffs_device(zk_ctx *ctx, const zk_cfg *cfg, const uint64_t *d_coeffs,
+                                       size_t col_stride, size_t n_cols, unsigned log_n, zk_batch **out) {
+    if (!out) return ZK_ERR_BAD_ARG;
+    *out = nullptr;
+    ZK_TRY(check_cfg(ctx, cfg, n_cols, log_n));
+    if (!d_coeffs) return set_err(ctx, ZK_ERR_BAD_ARG, "null coeffs");
+    if (n_cols > 1 && col_stride < ((size_t)1 << log_n)) return set_err(ctx, ZK_ERR_BAD_ARG, "col_stride < n");
+    return commit_impl(ctx, cfg, (const u64 *)d_coeffs, col_stride, n_cols, log_n, false, out);
+}
+
+extern "C" int zk_commit_columns(zk_ctx *ctx, const zk_cfg *cfg, const uint64_t *const *cols,
+                                 size_t n_cols, unsigned log_n, zk_batch **out) {
+    if (!out) return ZK_ERR_BAD_ARG;
+    *out = nullptr;
+    ZK_TRY(check_cfg(ctx, cfg, n_cols, log_n));
+    if (!cols) return set_err(ctx, ZK_ERR_BAD_ARG, "null column array");
+    for (size_t c = 0; c < n_cols; ++c)
+        if (!cols[c]) return set_err(ctx, ZK_ERR_BAD_ARG, "null column %zu", c);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << log_n;
+    u64 *d_vals = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_vals, n_cols * n * sizeof(u64)));
+    for (size_t c = 0; c < n_cols; ++c) {
+        hipError_t e = hipMemcpyAsync(d_vals + c * n, cols[c], n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { hipFree(d_vals); return set_err(ctx, ZK_ERR_HIP, "H2D copy failed: %s", hipGetErrorString(e)); }
+    }
+    int rc = commit_impl(ctx, cfg, d_vals, n, n_cols, log_n, true, out);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(d_vals);
+    return rc;
+}
+
+extern "C" size_t zk_batch_num_cols(const zk_batch *b) { return b ? b->n_cols : 0; }
+extern "C" unsigned zk_batch_log_n(const zk_batch *b) { return b ? b->log_n : 0; }
+extern "C" unsigned zk_batch_log_lde(const zk_batch *b) { return b ? b->log_n + b->rate_bits : 0; }
+extern "C" const uint64_t *zk_batch_lde_device(const zk_batch *b) { return b ? (const uint64_t *)b->d_lde : nullptr; }
+extern "C" const uint64_t *zk_batch_digests_device(const zk_batch *b) { return b ? (const uint64_t *)b->d_digests : nullptr; }
+
+extern "C" int zk_batch_cap(const zk_batch *b, uint64_t *out) {
+    if (!b || !out) return ZK_ERR_BAD_ARG;
+    memcpy(out, b->cap.data(), b->cap.size() * 8);
+    return ZK_OK;
+}
+
+extern "C" int zk_batch_coeffs(const zk_batch *b, size_t col, uint64_t *out) {
+    if (!b || !out) return ZK_ERR_BAD_ARG;
+    zk_ctx *ctx = b->ctx;
+    if (col >= b->n_cols) return set_err(ctx, ZK_ERR_BAD_ARG, "column %zu out of range", col);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t n = (size_t)1 << b->log_n;
+    std::vector<u64> tmp(n);
+    HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), b->d_coeffs + col * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < n; ++i) out[bitrev32((u32)i, b->log_n)] = tmp[i];
+    return ZK_OK;
+}
+
+static int gather_row(const zk_batch *b, size_t natural_row, uint64_t *out) {
+    zk_ctx *ctx = b->ctx;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    size_t N = (size_t)1 << (b->log_n + b->rate_bits);
+    HIP_TRY(ctx, hipMemcpy2DAsync(out, 8, b->d_lde + natural_row, N * 8, 8, b->n_cols,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
+
+extern "C" int zk_batch_leaf(const zk_batch *b, size_t leaf_index, uint64_t *out) {
+    if (!b || !out) return ZK_ERR_BAD_ARG;
+    unsigned log_N = b->log_n + b->rate_bits;
+    if (leaf_index >> log_N) return set_err(b->ctx, ZK_ERR_BAD_ARG, "leaf index out of range");
+    return gather_row(b, bitrev32((u32)leaf_index, log_N), out);
+}
+
+extern "C" int zk_batch_lde_values(const zk_batch *b, size_t index, size_t step, uint64_t *out) {
+    if (!b || !out) return ZK_ERR_BAD_ARG;
+    unsigned log_N = b->log_n + b->rate_bits;
+    size_t nat = index * step;
+    if (nat >> log_N) return set_err(b->ctx, ZK_ERR_BAD_ARG, "lde index out of range");
+    return gather_row(b, nat, out);  // leaves[bitrev(index*step)] == natural row index*step
+}
+
+extern "C" int zk_batch_merkle_path(const zk_batch *b, size_t leaf_index, uint64_t *out) {
+    if (!b || !out) return ZK_ERR_BAD_ARG;
+    zk_ctx *ctx = b->ctx;
+    unsigned log_N = b->log_n + b->rate_bits;
+    if (leaf_index >> log_N) return set_err(ctx, ZK_ERR_BAD_ARG, "leaf index out of range");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const u64 *lvl = b->d_digests;
+    size_t idx = leaf_index;
+    for (unsigned l = log_N; l > b->cap_height; --l) {
+        HIP_TRY(ctx, hipMemcpyAsync(out, lvl + 4 * (idx ^ 1), 32, hipMemcpyDeviceToHost, ctx->stream));
+        out += 4;
+        lvl += 4 * ((size_t)1 << l);
+        idx >>= 1;
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
