@@ -620,7 +620,7 @@ extern "C" int zk_batch_coeffs(const zk_batch *b, size_t col, uint64_t *out) {
     std::vector<u64> tmp(n);
     HIP_TRY(ctx, hipMemcpyAsync(tmp.data(), b->d_coeffs + col * n, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    for (size_t i = 0; i < n; ++i) out[bitrev32((u32)i, b->log_n)] = tmp[i];
+    for (size_t i = 0; i < n; ++i) out[bitrev32((u32)i, b->log_n)] = gl_canon(tmp[i]);
     return ZK_OK;
 }
 
