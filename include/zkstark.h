@@ -56,9 +56,10 @@ typedef struct zk_batch zk_batch; /* device-resident PolynomialBatch */
 
 /* ---- context ---------------------------------------------------------------------------- */
 int zk_ctx_create(int device, zk_ctx **out);
+/* also frees every zk_batch of this ctx that is still alive (their handles become invalid) */
 void zk_ctx_destroy(zk_ctx *ctx);
-/* Run all work of this ctx on an existing hipStream_t (e.g. torch's current stream). NULL = the
- * ctx's own stream. */
+/* Run all work of this ctx on an existing hipStream_t (e.g. torch's current stream); NULL selects
+ * the HIP default (null) stream.  A fresh ctx runs on its own non-blocking stream. */
 int zk_ctx_set_stream(zk_ctx *ctx, void *hip_stream);
 int zk_ctx_synchronize(zk_ctx *ctx);
 const char *zk_last_error(const zk_ctx *ctx);
@@ -118,6 +119,11 @@ int zk_coset_ifft(zk_ctx *ctx, uint64_t *d_data, size_t col_stride, size_t n_col
                   uint64_t shift);
 int zk_lde(zk_ctx *ctx, const uint64_t *d_coeffs, size_t in_stride, uint64_t *d_out,
            size_t out_stride, size_t n_cols, unsigned log_n, unsigned rate_bits);
+/* Element-wise Goldilocks vector op on device arrays: out[i] = a[i] (op) b[i], canonical output.
+ * op: 0 = add, 1 = sub, 2 = mul, 3 = square (b ignored), 4 = inverse (b ignored; 0 -> 0).
+ * (plonky2_field `Field` ops; exists so every field primitive is testable through the ABI.) */
+int zk_gl_vec_op(zk_ctx *ctx, uint32_t op, const uint64_t *d_a, const uint64_t *d_b,
+                 uint64_t *d_out, size_t n);
 /* Poseidon permutation applied independently to n_states 12-element states (row-major). */
 int zk_poseidon_permute(zk_ctx *ctx, uint64_t *d_states, size_t n_states);
 /* Keccak-f[1600] applied independently to n_states 25-lane states (row-major). */

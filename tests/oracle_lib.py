@@ -37,6 +37,7 @@ class Oracle:
         L.orc_keccak_f1600.argtypes = [u64p]
         L.orc_keccak256.argtypes = [u8p, C.c_size_t, u8p]
         L.orc_keccak25_hash_no_pad.argtypes = [u64p, C.c_size_t, u8p]
+        L.orc_keccak25_hash_or_noop.argtypes = [u64p, C.c_size_t, u8p]
         L.orc_keccak25_two_to_one.argtypes = [u8p, u8p, u8p]
         for name in ("orc_fft", "orc_ifft"):
             getattr(L, name).argtypes = [u64p, C.c_uint]

@@ -70,6 +70,24 @@ DEF_KERNEL32(k_pk_mul_lo_u16, "v_pk_mul_lo_u16 %0, %0, %1")
 DEF_KERNEL32(k_mad_u16, "v_mad_u16 %0, %1, %2, %0")
 DEF_KERNEL32(k_fma_f32, "v_fma_f32 %0, %1, %2, %0")
 DEF_KERNEL32(k_pk_fma_f32_as32, "v_fmac_f32 %0, %1, %2")
+DEF_KERNEL32(k_mov_b32, "v_mov_b32 %0, %1")
+DEF_KERNEL32(k_and_b32, "v_and_b32 %0, %0, %1")
+DEF_KERNEL32(k_or_b32, "v_or_b32 %0, %0, %1")
+DEF_KERNEL32(k_xor_b32, "v_xor_b32 %0, %0, %1")
+DEF_KERNEL32(k_lshlrev_b32, "v_lshlrev_b32 %0, 3, %0")
+DEF_KERNEL32(k_lshrrev_b32, "v_lshrrev_b32 %0, 3, %0")
+DEF_KERNEL32(k_sub_u32, "v_sub_u32 %0, %0, %1")
+DEF_KERNEL32(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+DEF_KERNEL32(k_cndmask_e64, "v_cndmask_b32_e64 %0, 0, -1, vcc")
+DEF_KERNEL32(k_add_co_only, "v_add_co_u32 %0, vcc, %0, %1")
+DEF_KERNEL32(k_addc_co_only, "v_addc_co_u32 %0, vcc, %0, %1, vcc")
+DEF_KERNEL32(k_cmp_lt_u32, "v_cmp_lt_u32 vcc, %0, %1\n v_mov_b32 %0, %2")
+DEF_KERNEL32(k_bfi, "v_bfi_b32 %0, %0, %1, %2")
+DEF_KERNEL32(k_add_lshl, "v_add_lshl_u32 %0, %0, %1, 3")
+DEF_KERNEL32(k_min_u32, "v_min_u32 %0, %0, %1")
+DEF_KERNEL64(k_cmp_lt_u64, "v_cmp_lt_u64 vcc, %0, %0")
+DEF_KERNEL64(k_mov_b64, "v_mov_b64 %0, %0")
+DEF_KERNEL64(k_lshrrev_b64, "v_lshrrev_b64 %0, 1, %0")
 DEF_KERNEL64(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
 DEF_KERNEL64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 3, %0")
 DEF_KERNEL64(k_lshlrev_b64, "v_lshlrev_b64 %0, 1, %0")
@@ -116,6 +134,13 @@ int main() {
         {"v_mad_u64_u32", k_mad_u64_u32, 1}, {"v_lshl_add_u64", k_lshl_add_u64, 1},
         {"v_lshlrev_b64", k_lshlrev_b64, 1}, {"v_fma_f64", k_fma_f64, 1}, {"v_pk_fma_f32", k_pk_fma_f32, 1},
         {"v_pk_add_f32", k_pk_add_u32x, 1}, {"add_co+addc (64b add)", k_add_co_pair, 2},
+        {"v_mov_b32", k_mov_b32, 1}, {"v_and_b32", k_and_b32, 1}, {"v_or_b32", k_or_b32, 1}, {"v_xor_b32", k_xor_b32, 1},
+        {"v_lshlrev_b32", k_lshlrev_b32, 1}, {"v_lshrrev_b32", k_lshrrev_b32, 1}, {"v_sub_u32", k_sub_u32, 1},
+        {"v_cndmask_b32 (e32)", k_cndmask, 1}, {"v_cndmask_b32_e64 const", k_cndmask_e64, 1},
+        {"v_add_co_u32", k_add_co_only, 1}, {"v_addc_co_u32", k_addc_co_only, 1},
+        {"v_cmp_lt_u32+v_mov", k_cmp_lt_u32, 2}, {"v_bfi_b32", k_bfi, 1},
+        {"v_add_lshl_u32", k_add_lshl, 1}, {"v_min_u32", k_min_u32, 1}, {"v_cmp_lt_u64", k_cmp_lt_u64, 1},
+        {"v_mov_b64", k_mov_b64, 1}, {"v_lshrrev_b64", k_lshrrev_b64, 1},
     };
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);

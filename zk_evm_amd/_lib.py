@@ -53,6 +53,7 @@ SIGNATURES = {
     "zk_coset_fft": (C.c_int, [vp, u64p, sz, sz, ui, C.c_uint64]),
     "zk_coset_ifft": (C.c_int, [vp, u64p, sz, sz, ui, C.c_uint64]),
     "zk_lde": (C.c_int, [vp, u64p, sz, u64p, sz, sz, ui, ui]),
+    "zk_gl_vec_op": (C.c_int, [vp, u32, u64p, u64p, u64p, sz]),
     "zk_poseidon_permute": (C.c_int, [vp, u64p, sz]),
     "zk_keccak_f1600": (C.c_int, [vp, u64p, sz]),
     "zk_hash_rows": (C.c_int, [vp, u32, u64p, sz, sz, sz, u64p]),

@@ -22,28 +22,21 @@ typedef unsigned int u32;
 
 GL_HD u64 gl_canon(u64 a) { return a >= GL_P ? a - GL_P : a; }
 
-// a, b arbitrary u64 representatives; result arbitrary representative of a+b.
-GL_HD u64 gl_add(u64 a, u64 b) {
+// ---- portable forms (host-side table setup; also the readable statement of each algorithm) ----
+GL_HD u64 gl_add_ref(u64 a, u64 b) {
     u64 s = a + b;
     u64 c = s < a ? GL_EPS : 0;
     u64 s2 = s + c;
     u64 c2 = s2 < s ? GL_EPS : 0;  // only reachable when both inputs were >= 2^64 - 2^32
     return s2 + c2;
 }
-// b must be canonical (< p): one correction is enough.
-GL_HD u64 gl_add_canon(u64 a, u64 b) {
-    u64 s = a + b;
-    return s + (s < a ? GL_EPS : 0);
-}
-GL_HD u64 gl_sub(u64 a, u64 b) {
+GL_HD u64 gl_sub_ref(u64 a, u64 b) {
     u64 d = a - b;
     u64 br = a < b ? GL_EPS : 0;
     u64 d2 = d - br;
     u64 br2 = d2 > d ? GL_EPS : 0;
     return d2 - br2;
 }
-GL_HD u64 gl_neg(u64 a) { return gl_sub(0, a); }
-
 // Fold a 128-bit value hi:lo to a u64 representative.
 GL_HD u64 gl_reduce128(u64 hi, u64 lo) {
     u32 hh = (u32)(hi >> 32), hl = (u32)hi;
@@ -61,8 +54,7 @@ GL_HD u64 gl_reduce96(u32 hi, u64 lo) {
     if (r < t1) r += GL_EPS;
     return r;
 }
-
-GL_HD u64 gl_mul(u64 a, u64 b) {
+GL_HD u64 gl_mul_ref(u64 a, u64 b) {
     u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     u64 p00 = (u64)a0 * b0;
     u64 mid = (u64)a0 * b1 + (p00 >> 32);          // <= (2^32-1)^2 + 2^32 - 1 : no overflow
@@ -71,16 +63,116 @@ GL_HD u64 gl_mul(u64 a, u64 b) {
     u64 lo = (mid2 << 32) | (u32)p00;
     return gl_reduce128(hi, lo);
 }
-GL_HD u64 gl_sqr(u64 a) {
-    u32 a0 = (u32)a, a1 = (u32)(a >> 32);
-    u64 p00 = (u64)a0 * a0;
-    u64 p01 = (u64)a0 * a1;
-    u64 mid = p01 + (p00 >> 32);
-    u64 mid2 = p01 + (u32)mid;
-    u64 hi = (u64)a1 * a1 + (mid >> 32) + (mid2 >> 32);
-    u64 lo = (mid2 << 32) | (u32)p00;
-    return gl_reduce128(hi, lo);
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 forms -----------------------------------------------------------------------------
+// Hand-scheduled carry chains on 32-bit halves.  On this chip every carry/64-bit/select VALU op
+// issues at ~4.3 cycles per wave (v_mov/and/or/xor/add_u32 at ~2.4), so the goal is the fewest
+// instructions and no register-pair shuffling (v_mov) around v_mad_u64_u32 results.
+
+// [T3:T2:T1:T0] (T0 = %[p0]) -> lazy u64 in (%[lo], %[hi]); uses 2^64 = 2^32-1, 2^96 = -1.
+// In: %[t1] %[t2] %[t3] (clobbered), %[p0].  Tmp: %[e].
+#define GL_ASM_REDUCE                                                                            \
+    "v_sub_co_u32 %[lo], vcc, %[p0], %[t3]\n\t"      /* [t1:lo] = [T1:T0] - T3            */      \
+    "v_subbrev_co_u32 %[t1], vcc, 0, %[t1], vcc\n\t"                                              \
+    "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"         /* borrow: -= EPS (== += p)          */      \
+    "v_sub_co_u32 %[lo], vcc, %[lo], %[e]\n\t"                                                    \
+    "v_subbrev_co_u32 %[t1], vcc, 0, %[t1], vcc\n\t"                                              \
+    "v_sub_co_u32 %[lo], vcc, %[lo], %[t2]\n\t"      /* += T2*(2^32-1) = [T2:0] - [0:T2]  */      \
+    "v_subbrev_co_u32 %[e], vcc, 0, %[t2], vcc\n\t"  /* e = T2 - borrow (>= 0)            */      \
+    "v_add_co_u32 %[hi], vcc, %[t1], %[e]\n\t"                                                    \
+    "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"         /* carry: += EPS                     */      \
+    "v_add_co_u32 %[lo], vcc, %[lo], %[e]\n\t"                                                    \
+    "v_addc_co_u32 %[hi], vcc, 0, %[hi], vcc"
+
+__device__ __forceinline__ u64 gl_mul(u64 a, u64 b) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 P = (u64)a0 * b0, Q = (u64)a0 * b1, R = (u64)a1 * b0, S = (u64)a1 * b1;  // 4 v_mad_u64_u32
+    u32 lo, hi, t1, t2, t3, e, x0, x1;
+    asm("v_add_co_u32 %[x0], vcc, %[q0], %[r0]\n\t"          // X = Q + R (65 bit)
+        "v_addc_co_u32 %[x1], vcc, %[q1], %[r1], vcc\n\t"
+        "v_addc_co_u32 %[t3], vcc, 0, %[s1], vcc\n\t"        // t3 = S1 + carry(X)   (cannot overflow)
+        "v_add_co_u32 %[t1], vcc, %[p1], %[x0]\n\t"          // T1 = P1 + X0
+        "v_addc_co_u32 %[t2], vcc, %[s0], %[x1], vcc\n\t"    // T2 = S0 + X1 + c
+        "v_addc_co_u32 %[t3], vcc, 0, %[t3], vcc\n\t"        // T3 += c
+        GL_ASM_REDUCE
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+          [e] "=&v"(e), [x0] "=&v"(x0), [x1] "=&v"(x1)
+        : [p0] "v"((u32)P), [p1] "v"((u32)(P >> 32)), [q0] "v"((u32)Q), [q1] "v"((u32)(Q >> 32)),
+          [r0] "v"((u32)R), [r1] "v"((u32)(R >> 32)), [s0] "v"((u32)S), [s1] "v"((u32)(S >> 32))
+        : "vcc");
+    return ((u64)hi << 32) | lo;
 }
+
+__device__ __forceinline__ u64 gl_sqr(u64 a) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32);
+    u64 P = (u64)a0 * a0, Q = (u64)a0 * a1, S = (u64)a1 * a1;  // 3 v_mad_u64_u32
+    u64 X = Q << 1;                                            // v_lshlrev_b64
+    u32 c = (u32)(Q >> 63);
+    u32 lo, hi, t1, t2, t3, e;
+    asm("v_add_co_u32 %[t1], vcc, %[p1], %[x0]\n\t"
+        "v_addc_co_u32 %[t2], vcc, %[s0], %[x1], vcc\n\t"
+        "v_addc_co_u32 %[t3], vcc, %[s1], %[c], vcc\n\t"
+        GL_ASM_REDUCE
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [e] "=&v"(e)
+        : [p0] "v"((u32)P), [p1] "v"((u32)(P >> 32)), [x0] "v"((u32)X), [x1] "v"((u32)(X >> 32)),
+          [c] "v"(c), [s0] "v"((u32)S), [s1] "v"((u32)(S >> 32))
+        : "vcc");
+    return ((u64)hi << 32) | lo;
+}
+
+// a, b arbitrary u64 representatives; result arbitrary representative of a+b.
+__device__ __forceinline__ u64 gl_add(u64 a, u64 b) {
+    u32 lo, hi, e;
+    asm("v_add_co_u32 %[lo], vcc, %[a0], %[b0]\n\t"
+        "v_addc_co_u32 %[hi], vcc, %[a1], %[b1], vcc\n\t"
+        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"
+        "v_add_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
+        "v_addc_co_u32 %[hi], vcc, 0, %[hi], vcc\n\t"
+        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"   // second wrap: only if both inputs >= 2^64-2^32
+        "v_add_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
+        "v_addc_co_u32 %[hi], vcc, 0, %[hi], vcc"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [e] "=&v"(e)
+        : [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32))
+        : "vcc");
+    return ((u64)hi << 32) | lo;
+}
+// b must be canonical (< p): one correction is enough.
+__device__ __forceinline__ u64 gl_add_canon(u64 a, u64 b) {
+    u32 lo, hi, e;
+    asm("v_add_co_u32 %[lo], vcc, %[a0], %[b0]\n\t"
+        "v_addc_co_u32 %[hi], vcc, %[a1], %[b1], vcc\n\t"
+        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"
+        "v_add_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
+        "v_addc_co_u32 %[hi], vcc, 0, %[hi], vcc"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [e] "=&v"(e)
+        : [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32))
+        : "vcc");
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 gl_sub(u64 a, u64 b) {
+    u32 lo, hi, e;
+    asm("v_sub_co_u32 %[lo], vcc, %[a0], %[b0]\n\t"
+        "v_subb_co_u32 %[hi], vcc, %[a1], %[b1], vcc\n\t"
+        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"
+        "v_sub_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
+        "v_subbrev_co_u32 %[hi], vcc, 0, %[hi], vcc\n\t"
+        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"   // second wrap: only if b > 2^64-2^32 and a tiny
+        "v_sub_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
+        "v_subbrev_co_u32 %[hi], vcc, 0, %[hi], vcc"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [e] "=&v"(e)
+        : [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32))
+        : "vcc");
+    return ((u64)hi << 32) | lo;
+}
+#else
+GL_HD u64 gl_add(u64 a, u64 b) { return gl_add_ref(a, b); }
+GL_HD u64 gl_add_canon(u64 a, u64 b) { return gl_add_ref(a, b); }
+GL_HD u64 gl_sub(u64 a, u64 b) { return gl_sub_ref(a, b); }
+GL_HD u64 gl_mul(u64 a, u64 b) { return gl_mul_ref(a, b); }
+GL_HD u64 gl_sqr(u64 a) { return gl_mul_ref(a, a); }
+#endif
+GL_HD u64 gl_neg(u64 a) { return gl_sub(0, a); }
 
 GL_HD u64 gl_pow(u64 b, u64 e) {
     u64 r = 1;

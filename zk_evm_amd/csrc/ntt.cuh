@@ -172,3 +172,18 @@ __global__ void twiddle_table_kernel(u64 *out, size_t count, u64 w) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) out[i] = gl_canon(gl_pow(w, i));
 }
+
+// element-wise field op (ABI-level access to the device field primitives)
+__global__ void gl_vec_op_kernel(u32 op, const u64 *a, const u64 *b, u64 *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 x = a[i], y = (op == 3 || op == 4) ? 0 : b[i], r;
+    switch (op) {
+        case 0: r = gl_add(x, y); break;
+        case 1: r = gl_sub(x, y); break;
+        case 2: r = gl_mul(x, y); break;
+        case 3: r = gl_sqr(x); break;
+        default: r = gl_canon(x) == 0 ? 0 : gl_inv(x); break;
+    }
+    out[i] = gl_canon(r);
+}

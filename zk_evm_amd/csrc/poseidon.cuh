@@ -6,15 +6,28 @@
 // PolynomialBatch::from_values (evm_arithmetization/src/prover.rs:100) and through Challenger
 // (prover.rs:118).
 //
-// MI355X mapping: the permutation is integer-ALU bound (no HBM traffic beyond the absorbed
-// words).  The MDS layer exploits the <= 6-bit matrix entries: each state word is split into two
-// 32-bit halves, each half-row is a chain of 12 v_mad_u64_u32 with an inline constant (no 128-bit
-// products, no modular reduction inside the sum), and the two 41-bit sums are folded once.
+// MI355X mapping.  The permutation is integer-ALU bound, and on gfx950 every useful integer op
+// (v_mad_u64_u32, carry adds, 64-bit shifts, cndmask) issues at ~4.3 cycles per wave64 per SIMD
+// (profiles/r01_ubench_valu_issue_rates.txt), so the design minimises *instruction count*:
+//   * MDS layer: each state word is split into 32-bit halves; row r accumulates
+//     sum_i C[i]*half[(i+r)%12] in one 64-bit register with 12 v_mad_u64_u32 (inline constants,
+//     no per-term reduction: sums stay < 2^43).  The NEXT round's constant is the accumulator's
+//     initial value (an SGPR pair from constant memory), so constant addition costs nothing.
+//   * the two 43-bit sums are folded to one lazy u64 with 5 instructions (one mad by 2^32-1, one
+//     carry add, one conditional +EPS) -- see pos_fold().
+//   * an MFMA formulation was evaluated and rejected: the i8 matrix pipe could do the 12x12
+//     byte-limb products, but re-laying 64-bit lane-private words out as MFMA operands and
+//     recombining 8 i32 partial sums per word costs more VALU work than the 288 mads it replaces
+//     ("Why not MFMA").
 #pragma once
 #include "gl.cuh"
 #include "../../include/poseidon_constants.h"
 
+// Round constants split into zero-extended 32-bit halves: ZK_RCS[round*12+i] = {lo32, hi32} as two
+// u64, directly usable as the 64-bit addend of v_mad_u64_u32.
+struct RcSplit { u64 lo, hi; };
 __constant__ u64 ZK_RC[ZK_POSEIDON_ROUNDS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RC_INIT;
+__constant__ RcSplit ZK_RCS[ZK_POSEIDON_ROUNDS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RCS_INIT;
 
 __device__ __forceinline__ u64 pos_sbox(u64 x) {
     u64 x2 = gl_sqr(x);
@@ -23,48 +36,121 @@ __device__ __forceinline__ u64 pos_sbox(u64 x) {
     return gl_mul(x3, x4);
 }
 
-__device__ __forceinline__ void pos_mds(u64 (&s)[12]) {
+// acc += x * C  (one v_mad_u64_u32)
+template <u32 C>
+__device__ __forceinline__ void pos_mac(u64 &acc, u32 x) {
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "n"(C) : "vcc");
+}
+
+// One MDS row for both 32-bit halves as ONE asm statement (24 v_mad_u64_u32 with inline
+// constants; hipcc would otherwise strength-reduce x*16, x*2 .. into shift/zero-extend/add chains
+// and pad every single-instruction asm with s_nop).  x[i] / y[i] are the low / high halves of
+// state word (i + r) % 12 -- the rotation is done by operand binding at the call site.
+// Operands: %0 al, %1 ah, %2/%3 initial accumulators (SGPR pairs: next round's constant halves),
+// %4..%15 x0..x11, %16..%27 y0..y11.
+#define POS_MAC2_FIRST(XI, YI, C)                                   \
+    "v_mad_u64_u32 %0, vcc, %" #XI ", " #C ", %2\n\t"               \
+    "v_mad_u64_u32 %1, vcc, %" #YI ", " #C ", %3\n\t"
+#define POS_MAC2_FIRST0(XI, YI, C)                                  \
+    "v_mad_u64_u32 %0, vcc, %" #XI ", " #C ", 0\n\t"                \
+    "v_mad_u64_u32 %1, vcc, %" #YI ", " #C ", 0\n\t"
+#define POS_MAC2(XI, YI, C)                                         \
+    "v_mad_u64_u32 %0, vcc, %" #XI ", " #C ", %0\n\t"               \
+    "v_mad_u64_u32 %1, vcc, %" #YI ", " #C ", %1\n\t"
+// MDS_MATRIX_CIRC = 17 15 41 16 2 28 13 13 39 18 34 20 (static_assert'ed below)
+#define POS_ROW_TAIL                                                               \
+    POS_MAC2(5, 17, 15) POS_MAC2(6, 18, 41) POS_MAC2(7, 19, 16) POS_MAC2(8, 20, 2) \
+    POS_MAC2(9, 21, 28) POS_MAC2(10, 22, 13) POS_MAC2(11, 23, 13)                  \
+    POS_MAC2(12, 24, 39) POS_MAC2(13, 25, 18) POS_MAC2(14, 26, 34) POS_MAC2(15, 27, 20)
+
+template <bool HAS_RC>
+__device__ __forceinline__ void pos_row(u64 &al, u64 &ah, u64 rcl, u64 rch, const u32 (&lo)[12],
+                                        const u32 (&hi)[12], int r) {
+#define X(i) "v"(lo[((i) + r) % 12])
+#define Y(i) "v"(hi[((i) + r) % 12])
+    if (HAS_RC) {
+        asm(POS_MAC2_FIRST(4, 16, 17) POS_ROW_TAIL
+            : "=&v"(al), "=&v"(ah)
+            : "s"(rcl), "s"(rch), X(0), X(1), X(2), X(3), X(4), X(5), X(6), X(7), X(8), X(9), X(10),
+              X(11), Y(0), Y(1), Y(2), Y(3), Y(4), Y(5), Y(6), Y(7), Y(8), Y(9), Y(10), Y(11)
+            : "vcc");
+    } else {
+        asm(POS_MAC2_FIRST0(4, 16, 17) POS_ROW_TAIL
+            : "=&v"(al), "=&v"(ah)
+            : "s"(rcl), "s"(rch), X(0), X(1), X(2), X(3), X(4), X(5), X(6), X(7), X(8), X(9), X(10),
+              X(11), Y(0), Y(1), Y(2), Y(3), Y(4), Y(5), Y(6), Y(7), Y(8), Y(9), Y(10), Y(11)
+            : "vcc");
+    }
+#undef X
+#undef Y
+}
+
+// value = al + ah * 2^32  (al, ah < 2^44)  ->  lazy u64 representative
+__device__ __forceinline__ u64 pos_fold(u64 al, u64 ah) {
+    u32 ah0 = (u32)ah, ah1 = (u32)(ah >> 32);
+    // ah1 * 2^64 == ah1 * (2^32 - 1); al + that < 2^45: no overflow
+    asm("v_mad_u64_u32 %0, vcc, %1, -1, %0" : "+v"(al) : "v"(ah1) : "vcc");
+    u32 l = (u32)al, h = (u32)(al >> 32), e;
+    // h += ah0; on carry-out add 2^64 == EPS (cannot carry twice: the wrapped h is < 2^13)
+    asm("v_add_co_u32 %1, vcc, %1, %3\n\t"
+        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
+        "v_add_co_u32 %0, vcc, %0, %2\n\t"
+        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+        : "+v"(l), "+v"(h), "=&v"(e)
+        : "v"(ah0)
+        : "vcc");
+    return ((u64)h << 32) | l;
+}
+
+// s <- MDS * s + rc   (rc = constants of the following round, or nothing when HAS_RC is false)
+template <bool HAS_RC>
+__device__ __forceinline__ void pos_mds(u64 (&s)[12], const RcSplit *rc) {
     constexpr u32 C[12] = ZK_POSEIDON_MDS_CIRC_INIT;
+    static_assert(C[0] == 17 && C[1] == 15 && C[2] == 41 && C[3] == 16 && C[4] == 2 && C[5] == 28 &&
+                  C[6] == 13 && C[7] == 13 && C[8] == 39 && C[9] == 18 && C[10] == 34 && C[11] == 20,
+                  "POS_ROW asm hard-codes MDS_MATRIX_CIRC");
     u32 lo[12], hi[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
 #pragma unroll
     for (int r = 0; r < 12; ++r) {
-        u64 al = 0, ah = 0;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            al += (u64)lo[(i + r) % 12] * C[i];
-            ah += (u64)hi[(i + r) % 12] * C[i];
+        u64 al, ah;
+        pos_row<HAS_RC>(al, ah, HAS_RC ? rc[r].lo : 0, HAS_RC ? rc[r].hi : 0, lo, hi, r);
+        if (r == 0) {  // MDS_MATRIX_DIAG = (8, 0, .., 0)
+            pos_mac<8>(al, lo[0]);
+            pos_mac<8>(ah, hi[0]);
         }
-        if (r == 0) { al += (u64)lo[0] * 8u; ah += (u64)hi[0] * 8u; }  // MDS_MATRIX_DIAG
-        // value = al + ah * 2^32, al, ah < 2^41
-        u64 t = al + (ah << 32);             // low 64 bits of al + (ah_lo32 << 32)
-        u64 carry = t < al ? 1 : 0;
-        u32 top = (u32)(ah >> 32) + (u32)carry;   // coefficient of 2^64 (< 2^10)
-        s[r] = gl_reduce96(top, t);
+        s[r] = pos_fold(al, ah);
     }
-}
-
-template <bool FULL>
-__device__ __forceinline__ void pos_round(u64 (&s)[12], int round) {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) s[i] = gl_add_canon(s[i], ZK_RC[round * 12 + i]);
-    if (FULL) {
-#pragma unroll
-        for (int i = 0; i < 12; ++i) s[i] = pos_sbox(s[i]);
-    } else {
-        s[0] = pos_sbox(s[0]);
-    }
-    pos_mds(s);
 }
 
 // In/out: arbitrary u64 representatives; callers canonicalise what they emit.
 __device__ __forceinline__ void poseidon_permute(u64 (&s)[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = gl_add_canon(s[i], ZK_RC[i]);
     int round = 0;
 #pragma unroll 1
-    for (int k = 0; k < ZK_POSEIDON_HALF_FULL_ROUNDS; ++k) pos_round<true>(s, round++);
+    for (int k = 0; k < ZK_POSEIDON_HALF_FULL_ROUNDS; ++k) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s[i] = pos_sbox(s[i]);
+        ++round;
+        pos_mds<true>(s, &ZK_RCS[round * 12]);
+    }
 #pragma unroll 1
-    for (int k = 0; k < ZK_POSEIDON_PARTIAL_ROUNDS; ++k) pos_round<false>(s, round++);
+    for (int k = 0; k < ZK_POSEIDON_PARTIAL_ROUNDS; ++k) {
+        s[0] = pos_sbox(s[0]);
+        ++round;
+        pos_mds<true>(s, &ZK_RCS[round * 12]);
+    }
 #pragma unroll 1
-    for (int k = 0; k < ZK_POSEIDON_HALF_FULL_ROUNDS; ++k) pos_round<true>(s, round++);
+    for (int k = 0; k < ZK_POSEIDON_HALF_FULL_ROUNDS - 1; ++k) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s[i] = pos_sbox(s[i]);
+        ++round;
+        pos_mds<true>(s, &ZK_RCS[round * 12]);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = pos_sbox(s[i]);
+    pos_mds<false>(s, nullptr);
 }
+

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <utility>
 #include <vector>
@@ -32,6 +33,7 @@ struct zk_ctx {
     hipEvent_t ev[5] = {};
     float timings[4] = {0, 0, 0, 0};
     int cu_count = 0;
+    std::set<zk_batch *> live_batches;  // freed by zk_ctx_destroy if the caller leaked them
 };
 
 struct zk_batch {
@@ -132,9 +134,12 @@ extern "C" int zk_ctx_create(int device, zk_ctx **out) {
     return ZK_OK;
 }
 
+extern "C" void zk_batch_free(zk_batch *b);
+
 extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    while (!ctx->live_batches.empty()) zk_batch_free(*ctx->live_batches.begin());
     hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->tw_fwd) hipFree(kv.second);
     for (auto &kv : ctx->tw_inv) hipFree(kv.second);
@@ -147,7 +152,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
 
 extern "C" int zk_ctx_set_stream(zk_ctx *ctx, void *hip_stream) {
     if (!ctx) return ZK_ERR_BAD_ARG;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;  // NULL is the HIP default (null) stream
     return ZK_OK;
 }
 extern "C" int zk_ctx_synchronize(zk_ctx *ctx) {
@@ -395,6 +400,18 @@ extern "C" int zk_lde(zk_ctx *ctx, const uint64_t *d_coeffs, size_t in_stride, u
     return rc;
 }
 
+extern "C" int zk_gl_vec_op(zk_ctx *ctx, uint32_t op, const uint64_t *d_a, const uint64_t *d_b,
+                            uint64_t *d_out, size_t n) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    if (op > 4) return set_err(ctx, ZK_ERR_BAD_ARG, "unknown field op %u", op);
+    if (!n) return ZK_OK;
+    if (!d_a || !d_out || (!d_b && op < 3)) return set_err(ctx, ZK_ERR_BAD_ARG, "null pointer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    gl_vec_op_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(
+        op, (const u64 *)d_a, (const u64 *)d_b, (u64 *)d_out, n);
+    return check_launch(ctx, "gl_vec_op_kernel");
+}
+
 // ------------------------------------------------------------------------------------------
 // hashing
 extern "C" int zk_poseidon_permute(zk_ctx *ctx, uint64_t *d_states, size_t n_states) {
@@ -478,6 +495,7 @@ extern "C" int zk_merkle_build(zk_ctx *ctx, uint32_t hasher, uint64_t *d_digests
 extern "C" void zk_batch_free(zk_batch *b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
+    b->ctx->live_batches.erase(b);
     hipStream_t st = b->ctx->stream;
     if (b->d_coeffs) hipFreeAsync(b->d_coeffs, st);
     if (b->d_lde) hipFreeAsync(b->d_lde, st);
@@ -506,6 +524,7 @@ static int commit_impl(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t i
     const unsigned log_N = log_n + cfg->rate_bits;
     const size_t N = (size_t)1 << log_N;
     zk_batch *b = new zk_batch();
+    ctx->live_batches.insert(b);
     b->ctx = ctx; b->n_cols = n_cols; b->log_n = log_n; b->rate_bits = cfg->rate_bits;
     b->cap_height = cfg->cap_height; b->hasher = cfg->hasher;
     b->n_digests = zk_merkle_num_digests(log_N, cfg->cap_height);

@@ -193,9 +193,11 @@ class PolynomialBatch:
         return int(self.ctx.lib.zk_batch_digests_device(self.handle) or 0)
 
     def free(self):
-        if self.handle:
+        # zk_ctx_destroy frees any batch still alive on that ctx, so never touch a handle whose
+        # context is already closed (finaliser order during garbage collection is arbitrary)
+        if self.handle and getattr(self.ctx, "handle", None):
             self.ctx.lib.zk_batch_free(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:
