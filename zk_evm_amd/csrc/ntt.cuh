@@ -59,13 +59,16 @@ __device__ __forceinline__ void ntt_bfly(u64 &a, u64 &b, u64 w) {
 // One register step of K (<= 3) consecutive stages over the LDS tile.
 // rows of one sub-problem: t0 + m*q, m in [0, 2^K)
 //   DIF: stage half sizes (rows) q*2^(K-1) .. q     DIT: q .. q*2^(K-1)
+// All index math is 32-bit (transforms are <= 2^31 points).  A stage whose pairs are hm apart (in
+// m units) has only hm distinct twiddles per sub-problem (the twiddle of pair (m, m+hm) depends on
+// m mod hm), so a radix-8 step issues 1+2+4 = 7 twiddle loads, not 12.
 template <bool DIT, int K>
-__device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q, size_t base,
+__device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q, u32 base,
                                          u32 elems, u32 tid, u32 nthr) {
     const int log_t = p.log_t;
     const u32 T = 1u << log_t, q = 1u << log_q;
-    const size_t d = (size_t)1 << p.log_d;
     const u32 nsub = elems >> K;
+    const int log_D0 = p.log_d + log_q;                 // global distance of adjacent m
     for (u32 sp = tid; sp < nsub; sp += nthr) {
         u32 u = sp & (T - 1);
         u32 w = sp >> log_t;
@@ -75,21 +78,18 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
         u64 v[1 << K];
 #pragma unroll
         for (int m = 0; m < (1 << K); ++m) v[m] = tile[((t0 + m * q) << log_t) + u];
-        const size_t x0 = base + (size_t)t0 * d + u;  // global index of v[0]
+        // g = x0 mod D0 (x0 = global index of v[0]); x_m mod D = g + (m mod hm) * D0
+        const u32 g = ((base + (t0 << p.log_d) + u) & ((1u << log_D0) - 1));
 #pragma unroll
         for (int i = 0; i < K; ++i) {
             const int lm = DIT ? i : (K - 1 - i);       // log2 of the pair distance in m units
             const int hm = 1 << lm;
-            const int log_D = p.log_d + log_q + lm;     // global butterfly distance
-            const size_t Dm1 = ((size_t)1 << log_D) - 1;
-            const int sh = p.log_tw - 1 - log_D;        // tw index = (x mod D) << sh
+            const int sh = p.log_tw - 1 - (log_D0 + lm); // tw index = (x mod D) << sh, D = D0 << lm
 #pragma unroll
-            for (int m = 0; m < (1 << K); ++m) {
-                if (!(m & hm)) {
-                    size_t x = x0 + ((size_t)(m * q) << p.log_d);
-                    u64 tw = p.tw[(x & Dm1) << sh];
-                    ntt_bfly<DIT>(v[m], v[m + hm], tw);
-                }
+            for (int mm = 0; mm < hm; ++mm) {
+                const u64 tw = p.tw[(g + ((u32)mm << log_D0)) << sh];
+#pragma unroll
+                for (int m = mm; m < (1 << K); m += 2 * hm) ntt_bfly<DIT>(v[m], v[m + hm], tw);
             }
         }
 #pragma unroll
@@ -105,12 +105,11 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
     const int r = p.r, log_t = p.log_t;
     const u32 T = 1u << log_t;
     const u32 tid = threadIdx.x, nthr = blockDim.x;
-    const size_t d = (size_t)1 << p.log_d;
-    // tile -> (hi, lo_tile): base = hi * (d * R) + lo_tile * T
-    const u32 lo_tiles = (u32)(d >> log_t);
+    // tile -> (hi, lo_tile): base = hi * (d * R) + lo_tile * T     (d = 2^log_d)
+    const int log_lo_tiles = p.log_d - log_t;
     const u32 tile_id = blockIdx.x;
-    const size_t hi_idx = tile_id / lo_tiles, lo_tile = tile_id % lo_tiles;
-    const size_t base = hi_idx * (d << r) + (lo_tile << log_t);
+    const u32 hi_idx = tile_id >> log_lo_tiles, lo_tile = tile_id & ((1u << log_lo_tiles) - 1);
+    const u32 base = (hi_idx << (p.log_d + r)) + (lo_tile << log_t);
     const u64 *src = p.src + (size_t)blockIdx.y * p.src_stride;
     u64 *dst = p.dst + (size_t)blockIdx.y * p.dst_stride;
     const u32 elems = 1u << (r + log_t);
@@ -118,8 +117,8 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
     // ---- load (global index x = base + t*d + u  ->  lds[t*T + u]) ----
     for (u32 e = tid; e < elems; e += nthr) {
         u32 t = e >> log_t, u = e & (T - 1);
-        size_t x = base + (size_t)t * d + u;
-        size_t sx = x >> p.log_rep;
+        u32 x = base + (t << p.log_d) + u;
+        u32 sx = x >> p.log_rep;
         u64 v = src[sx];
         if (p.in_scale) v = gl_mul(v, p.in_scale[sx]);
         tile[e] = v;
@@ -141,7 +140,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
     // ---- store ----
     for (u32 e = tid; e < elems; e += nthr) {
         u32 t = e >> log_t, u = e & (T - 1);
-        size_t x = base + (size_t)t * d + u;
+        u32 x = base + (t << p.log_d) + u;
         u64 v = tile[e];
         if (p.out_scale) v = gl_mul(v, p.out_scale[x]);
         if (p.apply_out_const) v = gl_mul(v, p.out_const);

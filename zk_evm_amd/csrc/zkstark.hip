@@ -216,9 +216,16 @@ static int get_coset_table(zk_ctx *ctx, int log_n, u64 shift, bool inverse, cons
 // ------------------------------------------------------------------------------------------
 // NTT pass planning
 struct PassPlan { int log_d, r; };
-static const int kMaxContigBits = 11;   // 2^11 * 8 B = 16 KiB tile
-static const int kMaxStridedBits = 10;
-static const int kTileElemBits = 13;    // strided tiles: 2^13 elements = 64 KiB of LDS
+#include <cstdlib>
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+// tunables (environment overrides exist for on-GPU tuning experiments only)
+static const int kMaxContigBits = env_int("ZK_NTT_CONTIG_BITS", 11);   // 2^11 * 8 B = 16 KiB tile
+static const int kMaxStridedBits = env_int("ZK_NTT_STRIDED_BITS", 10);
+static const int kTileElemBits = env_int("ZK_NTT_TILE_BITS", 13);      // strided tile elements (2^13 = 64 KiB)
+static const int kThreadsShift = env_int("ZK_NTT_THREADS_SHIFT", 3);   // threads = elems >> shift
 
 // Passes in decimation-in-frequency order (largest distance first); DIT runs them reversed.
 // The last entry is always the contiguous (log_d = 0) pass.
@@ -253,9 +260,9 @@ static int launch_pass(zk_ctx *ctx, NttPass p, size_t n_cols) {
     size_t n = (size_t)1 << p.log_n;
     size_t tiles = n / elems;
     if (tiles == 0) tiles = 1;
-    unsigned nthr = (unsigned)(elems / 16);
+    unsigned nthr = (unsigned)(elems >> kThreadsShift);
     if (nthr < 64) nthr = 64;
-    if (nthr > 512) nthr = 512;
+    if (nthr > 1024) nthr = 1024;
     size_t lds = elems * sizeof(u64);
     size_t done = 0;
     while (done < n_cols) {  // grid.y limit
