@@ -144,11 +144,26 @@ def main():
         commit_bytes = 32.0 * a.cols * n + 128.0 * n
         ntt_bytes = 40.0 * a.cols * n
         ntt_ms = stage["ifft"] + stage["lde"]
+        # HBM traffic and VALU instruction counts of the dominant kernel come from separate
+        # rocprofv3 --pmc passes (tools/collect_pmc.sh), summarised in profiles/pmc_latest.json;
+        # they only apply to the default workload they were collected on.
         traffic = None
+        valu = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path):
+        if os.path.exists(pmc_path) and a.cols == 116 and a.log_n == 20 and a.hasher == 0:
             try:
-                traffic = json.load(open(pmc_path)).get("leaf_hash_hbm_bytes_per_launch")
+                pmc = json.load(open(pmc_path))
+                traffic = pmc.get("leaf_hash_hbm_bytes_per_launch")
+                insts = pmc.get("leaf_hash_valu_wave_insts_per_launch")
+                if insts:
+                    # integer-issue roofline: every useful integer VALU op on gfx950 issues at
+                    # ~4 cycles per wave64 per SIMD (profiles/r01_ubench_valu_issue_rates.txt)
+                    peak = 1024 * 2.4e9 / 4.0
+                    ach = insts / (dom_ms * 1e-3)
+                    valu = {"wave_insts_per_launch": insts, "achieved_wave_insts_per_s": ach,
+                            "peak_wave_insts_per_s": peak, "frac": ach / peak,
+                            "assumes": "1024 SIMDs x 2.4 GHz / 4 cycles per integer VALU wave-instruction",
+                            "source": pmc.get("source")}
             except Exception:
                 traffic = None
         out = {
@@ -173,7 +188,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "ms_per_launch": dom_ms, "algorithmic_bytes": dom_bytes,
                          "note": "kernel is integer-ALU bound (Poseidon), see DESIGN.md; "
-                                 "permutations/s = %.3e" % (perms / (dom_ms * 1e-3) if dom_ms else 0)},
+                                 "permutations/s = %.3e" % (perms / (dom_ms * 1e-3) if dom_ms else 0),
+                         "valu": valu},
             "stages_ms": stage,
             "ntt": {"achieved_GBs": ntt_bytes / (ntt_ms * 1e-3) / 1e9, "algorithmic_bytes": ntt_bytes,
                     "frac_of_hbm_peak": ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
