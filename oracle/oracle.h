@@ -72,6 +72,64 @@ void orc_commit_coeffs(const uint64_t *coeffs, size_t n_cols, unsigned log_n, un
                        unsigned cap_height, int hasher, uint64_t *leaves_out,
                        uint64_t *digests_out, uint64_t *cap_out);
 
+/* ---- Challenger (plonky2 iop/challenger.rs) ------------------------------------------------ */
+typedef struct {
+    int hasher;
+    uint64_t state[12];
+    uint64_t in[8];
+    int n_in;
+    uint64_t out[8];
+    int n_out;
+} orc_challenger;
+void orc_challenger_init(orc_challenger *c, int hasher);
+void orc_challenger_observe(orc_challenger *c, const uint64_t *e, size_t n);
+void orc_challenger_observe_cap(orc_challenger *c, const uint64_t *slots, size_t n_digests);
+uint64_t orc_challenger_get(orc_challenger *c);
+void orc_challenger_get_ext(orc_challenger *c, uint64_t out[2]);
+void orc_challenger_compact(orc_challenger *c, uint64_t out_state[12]);
+void orc_hash_to_elements(int hasher, const uint64_t *slot, uint64_t out[4]);
+
+/* ---- FRI (plonky2 fri/{oracle,prover,verifier,reduction_strategies}.rs) -------------------- */
+typedef struct {
+    uint32_t rate_bits, cap_height, hasher, num_challenges, proof_of_work_bits, num_query_rounds,
+        arity_bits, final_poly_bits;
+} orc_cfg; /* same layout as zk_cfg */
+
+/* a committed PolynomialBatch as produced by orc_commit_values/orc_commit_coeffs */
+typedef struct {
+    size_t n_cols;
+    unsigned log_n;
+    const uint64_t *coeffs;  /* [n_cols][n] natural order */
+    const uint64_t *leaves;  /* [N][n_cols] row-major, bit-reversed rows */
+    const uint64_t *digests; /* level-concatenated */
+} orc_batch;
+
+/* FriInstanceInfo: batches of (point, [(oracle, poly)]) */
+typedef struct {
+    uint64_t point[2];
+    size_t n_polys;
+    const uint32_t *oracle_idx;
+    const uint32_t *poly_idx;
+} orc_fri_batch;
+
+/* [EXT] FriReductionStrategy::ConstantArityBits -> reduction_arity_bits; returns count */
+size_t orc_fri_reduction_arity_bits(unsigned degree_bits, const orc_cfg *cfg, uint32_t *out, size_t max);
+/* number of u64 words of the flat FriProof layout documented in include/zkstark.h */
+size_t orc_fri_proof_words(const orc_cfg *cfg, unsigned degree_bits, const size_t *oracle_cols, size_t n_oracles);
+/* evaluate every polynomial of every batch at the batch point: out = concatenated ext values */
+void orc_fri_openings(const orc_batch *oracles, const orc_fri_batch *batches, size_t n_batches, uint64_t *out);
+/* PolynomialBatch::prove_openings: advances the challenger, writes the flat proof. */
+void orc_fri_prove_openings(const orc_cfg *cfg, unsigned degree_bits, const orc_batch *oracles,
+                            size_t n_oracles, const orc_fri_batch *batches, size_t n_batches,
+                            orc_challenger *ch, uint64_t *proof_out);
+/* verify_fri_proof restatement.  `ch` must be in the state right after the openings were observed
+ * (the function re-derives alpha, betas, pow response and query indices).  caps[k] = cap slots of
+ * oracle k; openings = orc_fri_openings layout.  Returns 1 if the proof verifies, 0 and a reason
+ * code in *why otherwise. */
+int orc_fri_verify(const orc_cfg *cfg, unsigned degree_bits, const size_t *oracle_cols, size_t n_oracles,
+                   const uint64_t *const *caps, const orc_fri_batch *batches, size_t n_batches,
+                   const uint64_t *openings, orc_challenger *ch, const uint64_t *proof, int *why);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

@@ -130,3 +130,133 @@ def splitmix64(seed: int, n: int) -> np.ndarray:
     z = z ^ (z >> np.uint64(31))
     out[:] = z
     return out
+
+
+# ---- FRI / challenger helpers (oracle side) ---------------------------------------------------
+class OrcCfg(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("rate_bits", "cap_height", "hasher", "num_challenges",
+                                          "proof_of_work_bits", "num_query_rounds", "arity_bits",
+                                          "final_poly_bits")]
+
+
+class OrcChallenger(C.Structure):
+    _fields_ = [("hasher", C.c_int), ("state", C.c_uint64 * 12), ("inb", C.c_uint64 * 8),
+                ("n_in", C.c_int), ("out", C.c_uint64 * 8), ("n_out", C.c_int)]
+
+
+class OrcBatch(C.Structure):
+    _fields_ = [("n_cols", C.c_size_t), ("log_n", C.c_uint), ("coeffs", C.c_void_p),
+                ("leaves", C.c_void_p), ("digests", C.c_void_p)]
+
+
+class OrcFriBatch(C.Structure):
+    _fields_ = [("point", C.c_uint64 * 2), ("n_polys", C.c_size_t), ("oracle_idx", C.c_void_p),
+                ("poly_idx", C.c_void_p)]
+
+
+def make_cfg(rate_bits=1, cap_height=4, hasher=0, num_challenges=2, pow_bits=16, queries=84,
+             arity_bits=4, final_poly_bits=5):
+    return OrcCfg(rate_bits, cap_height, hasher, num_challenges, pow_bits, queries, arity_bits,
+                  final_poly_bits)
+
+
+class FriInstance:
+    """FriInstanceInfo in flat form: list of (point(2,), [(oracle, poly), ...])."""
+
+    def __init__(self, batches):
+        self.batches = batches
+        self._keep = []
+        arr = (OrcFriBatch * len(batches))()
+        for i, (pt, polys) in enumerate(batches):
+            oi = np.array([p[0] for p in polys], dtype=np.uint32)
+            pi = np.array([p[1] for p in polys], dtype=np.uint32)
+            self._keep += [oi, pi]
+            arr[i].point[0], arr[i].point[1] = int(pt[0]), int(pt[1])
+            arr[i].n_polys = len(polys)
+            arr[i].oracle_idx = oi.ctypes.data
+            arr[i].poly_idx = pi.ctypes.data
+        self.c = arr
+
+    @property
+    def n_openings(self):
+        return sum(len(p) for _, p in self.batches)
+
+
+def stark_fri_instance(zeta, g_zeta, n_trace, n_aux, n_quot, ctl_zs_range=None):
+    """[EXT] starky `Stark::fri_instance`: oracles trace(0), aux(1), quotient(2); batches at zeta
+    (all), g*zeta (trace+aux) and, if the table has CTLs, 1 (the ctl Z columns of the aux oracle)."""
+    trace = [(0, i) for i in range(n_trace)]
+    aux = [(1, i) for i in range(n_aux)]
+    qo = 2 if n_aux else 1
+    quot = [(qo, i) for i in range(n_quot)]
+    batches = [(zeta, trace + aux + quot), (g_zeta, trace + aux)]
+    if ctl_zs_range is not None:
+        batches.append(((1, 0), [(1, i) for i in range(*ctl_zs_range)]))
+    return FriInstance(batches)
+
+
+def setup_fri_api(o):
+    L = o.lib
+    vp = C.c_void_p
+    L.orc_challenger_init.argtypes = [C.POINTER(OrcChallenger), C.c_int]
+    L.orc_challenger_observe.argtypes = [C.POINTER(OrcChallenger), u64p, C.c_size_t]
+    L.orc_challenger_observe_cap.argtypes = [C.POINTER(OrcChallenger), u64p, C.c_size_t]
+    L.orc_challenger_get.restype = C.c_uint64
+    L.orc_challenger_get.argtypes = [C.POINTER(OrcChallenger)]
+    L.orc_challenger_get_ext.argtypes = [C.POINTER(OrcChallenger), u64p]
+    L.orc_challenger_compact.argtypes = [C.POINTER(OrcChallenger), u64p]
+    L.orc_fri_reduction_arity_bits.restype = C.c_size_t
+    L.orc_fri_reduction_arity_bits.argtypes = [C.c_uint, C.POINTER(OrcCfg), vp, C.c_size_t]
+    L.orc_fri_proof_words.restype = C.c_size_t
+    L.orc_fri_proof_words.argtypes = [C.POINTER(OrcCfg), C.c_uint, vp, C.c_size_t]
+    L.orc_fri_openings.argtypes = [C.POINTER(OrcBatch), C.POINTER(OrcFriBatch), C.c_size_t, u64p]
+    L.orc_fri_prove_openings.argtypes = [C.POINTER(OrcCfg), C.c_uint, C.POINTER(OrcBatch), C.c_size_t,
+                                         C.POINTER(OrcFriBatch), C.c_size_t, C.POINTER(OrcChallenger), u64p]
+    L.orc_fri_verify.restype = C.c_int
+    L.orc_fri_verify.argtypes = [C.POINTER(OrcCfg), C.c_uint, vp, C.c_size_t, vp, C.POINTER(OrcFriBatch),
+                                 C.c_size_t, u64p, C.POINTER(OrcChallenger), u64p, C.POINTER(C.c_int)]
+
+
+def oracle_batches(commits):
+    """commits: list of dicts from Oracle.commit_values -> (OrcBatch array, keepalive)."""
+    arr = (OrcBatch * len(commits))()
+    for i, r in enumerate(commits):
+        arr[i].n_cols = r["coeffs"].shape[0]
+        arr[i].log_n = r["coeffs"].shape[1].bit_length() - 1
+        arr[i].coeffs = r["coeffs"].ctypes.data
+        arr[i].leaves = r["leaves"].ctypes.data
+        arr[i].digests = r["digests"].ctypes.data
+    return arr
+
+
+def new_challenger(o, hasher=0):
+    ch = OrcChallenger()
+    o.lib.orc_challenger_init(C.byref(ch), hasher)
+    return ch
+
+
+def oracle_fri_prove(o, cfg, degree_bits, commits, inst, ch):
+    """Returns (openings (n,2) u64, proof words).  Advances `ch` exactly like the prover does:
+    observes the openings, then runs prove_openings."""
+    L = o.lib
+    ob = oracle_batches(commits)
+    opn = np.zeros(2 * inst.n_openings, dtype=np.uint64)
+    L.orc_fri_openings(ob, inst.c, len(inst.batches), opn)
+    L.orc_challenger_observe(C.byref(ch), opn, opn.size)
+    cols = np.array([r["coeffs"].shape[0] for r in commits], dtype=np.uint64)
+    nw = L.orc_fri_proof_words(C.byref(cfg), degree_bits, cols.ctypes.data, len(commits))
+    proof = np.zeros(nw, dtype=np.uint64)
+    L.orc_fri_prove_openings(C.byref(cfg), degree_bits, ob, len(commits), inst.c, len(inst.batches),
+                             C.byref(ch), proof)
+    return opn, proof
+
+
+def oracle_fri_verify(o, cfg, degree_bits, commits_caps, cols, inst, opn, proof, ch):
+    L = o.lib
+    caps = (C.c_void_p * len(commits_caps))(*[c.ctypes.data for c in commits_caps])
+    colsa = np.array(cols, dtype=np.uint64)
+    L.orc_challenger_observe(C.byref(ch), opn, opn.size)
+    why = C.c_int(0)
+    ok = L.orc_fri_verify(C.byref(cfg), degree_bits, colsa.ctypes.data, len(cols), caps, inst.c,
+                          len(inst.batches), opn, C.byref(ch), proof, C.byref(why))
+    return ok, why.value
