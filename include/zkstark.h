@@ -138,6 +138,57 @@ size_t zk_merkle_num_digests(unsigned log_leaves, unsigned cap_height);
 int zk_merkle_build(zk_ctx *ctx, uint32_t hasher, uint64_t *d_digests, unsigned log_leaves,
                     unsigned cap_height);
 
+/* ---- Challenger -------------------------------------------------------------------------------
+ * plonky2 `Challenger<F, H>` (duplex sponge, overwrite mode; reference use:
+ * evm_arithmetization/src/prover.rs:118-127 `observe_cap`, get_challenges.rs:11-227
+ * `observe_elements`, prover.rs:320 `compact`).  Host-side object: the transcript is tiny. */
+typedef struct zk_challenger zk_challenger;
+int zk_challenger_create(uint32_t hasher, zk_challenger **out);
+void zk_challenger_free(zk_challenger *ch);
+int zk_challenger_clone(const zk_challenger *ch, zk_challenger **out);
+int zk_challenger_observe_elements(zk_challenger *ch, const uint64_t *elements, size_t n);
+/* `observe_cap`: n_digests 32-byte slots (Keccak-25 digests are observed as 7,7,7,4-byte elements) */
+int zk_challenger_observe_cap(zk_challenger *ch, const uint64_t *slots, size_t n_digests);
+uint64_t zk_challenger_get_challenge(zk_challenger *ch);
+int zk_challenger_get_extension_challenge(zk_challenger *ch, uint64_t out[2]);
+/* `compact()`: flush pending inputs, drop buffered outputs, return the 12-element sponge state
+ * (stored as `init_challenger_state` in StarkProofWithMetadata, prover.rs:335-338) */
+int zk_challenger_compact(zk_challenger *ch, uint64_t state_out[12]);
+
+/* ---- openings + FRI ---------------------------------------------------------------------------
+ * `FriInstanceInfo` in flat form: a batch is an opening point in F_{p^2} and the list of
+ * (oracle index, polynomial index) opened there (starky `Stark::fri_instance`: batches at zeta,
+ * g*zeta and, for tables with CTLs, 1). */
+typedef struct {
+    uint64_t point[2];
+    size_t n_polys;
+    const uint32_t *oracle_idx;
+    const uint32_t *poly_idx;
+} zk_fri_batch;
+
+/* [EXT] FriReductionStrategy::ConstantArityBits -> reduction_arity_bits; returns the count */
+size_t zk_fri_reduction_arity_bits(const zk_cfg *cfg, unsigned degree_bits, uint32_t *out, size_t max);
+/* Evaluate every polynomial of every batch at the batch point (the evaluation work of starky
+ * `StarkOpeningSet::new`): out = 2 u64 per (batch, poly), batch-major, host memory. */
+int zk_fri_openings(zk_ctx *ctx, const zk_batch *const *oracles, size_t n_oracles,
+                    const zk_fri_batch *batches, size_t n_batches, uint64_t *out);
+/* Size in u64 words of the flat FriProof below (0 on bad arguments). */
+size_t zk_fri_proof_words(const zk_cfg *cfg, unsigned degree_bits, const size_t *oracle_cols,
+                          size_t n_oracles);
+/* `PolynomialBatch::prove_openings(instance, oracles, challenger, fri_params)` -> FriProof.
+ * `openings` = the zk_fri_openings output (already observed by the caller, as starky does);
+ * the challenger is advanced exactly as plonky2 advances it (alpha, per-round cap/beta, final
+ * polynomial, PoW witness + response, query indices).  The proof-of-work witness is the SMALLEST
+ * valid one (the reference's rayon `find_any` is not deterministic).  Flat layout (u64 words):
+ *   [0]=R rounds [1]=cap_len [2]=Q queries [3]=K oracles [4]=F final-poly length [5]=log2(LDE size)
+ *   arity_bits[R]; n_cols[K];
+ *   commit_phase_merkle_caps: R x cap_len x 4;  final_poly: F x 2;  pow_witness: 1;
+ *   per query: per oracle { leaf[n_cols], siblings[(log_lde - cap_height) x 4] },
+ *              per round  { evals[arity x 2], siblings[(log2(#leaves of that tree) - cap_height) x 4] } */
+int zk_fri_prove_openings(zk_ctx *ctx, const zk_cfg *cfg, const zk_batch *const *oracles,
+                          size_t n_oracles, const zk_fri_batch *batches, size_t n_batches,
+                          const uint64_t *openings, zk_challenger *challenger, uint64_t *proof_out);
+
 /* library / device info */
 const char *zk_version(void);
 int zk_device_info(int device, char *name_out, size_t name_len, int *cu_count, size_t *hbm_bytes);

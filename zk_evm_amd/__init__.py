@@ -12,8 +12,12 @@ from .config import FriConfig, StarkConfig  # noqa: F401
 from ._lib import ZkStarkError, lib_path, load_library  # noqa: F401
 from .context import Context, default_context  # noqa: F401
 from .polynomial_batch import MerkleCap, MerkleProof, PolynomialBatch  # noqa: F401
+from .challenger import Challenger  # noqa: F401
+from .fri import (FriBatchInfo, FriInstanceInfo, fri_openings, prove_openings,  # noqa: F401
+                  stark_fri_instance)
 
 __all__ = [
     "FriConfig", "StarkConfig", "ZkStarkError", "Context", "default_context",
-    "PolynomialBatch", "MerkleCap", "MerkleProof", "lib_path", "load_library",
+    "PolynomialBatch", "MerkleCap", "MerkleProof", "lib_path", "load_library", "Challenger",
+    "FriBatchInfo", "FriInstanceInfo", "fri_openings", "prove_openings", "stark_fri_instance",
 ]

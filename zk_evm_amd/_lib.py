@@ -59,6 +59,18 @@ SIGNATURES = {
     "zk_hash_rows": (C.c_int, [vp, u32, u64p, sz, sz, sz, u64p]),
     "zk_merkle_num_digests": (sz, [ui, ui]),
     "zk_merkle_build": (C.c_int, [vp, u32, u64p, ui, ui]),
+    "zk_challenger_create": (C.c_int, [u32, C.POINTER(vp)]),
+    "zk_challenger_free": (None, [vp]),
+    "zk_challenger_clone": (C.c_int, [vp, C.POINTER(vp)]),
+    "zk_challenger_observe_elements": (C.c_int, [vp, u64p, sz]),
+    "zk_challenger_observe_cap": (C.c_int, [vp, u64p, sz]),
+    "zk_challenger_get_challenge": (C.c_uint64, [vp]),
+    "zk_challenger_get_extension_challenge": (C.c_int, [vp, u64p]),
+    "zk_challenger_compact": (C.c_int, [vp, u64p]),
+    "zk_fri_reduction_arity_bits": (sz, [C.POINTER(ZkCfg), ui, vp, sz]),
+    "zk_fri_openings": (C.c_int, [vp, vp, sz, vp, sz, u64p]),
+    "zk_fri_proof_words": (sz, [C.POINTER(ZkCfg), ui, vp, sz]),
+    "zk_fri_prove_openings": (C.c_int, [vp, C.POINTER(ZkCfg), vp, sz, vp, sz, u64p, vp, u64p]),
     "zk_version": (C.c_char_p, []),
     "zk_device_info": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(sz)]),
 }

@@ -1,0 +1,176 @@
+// Host-side Poseidon / Keccak permutations and the Fiat-Shamir Challenger of the product library.
+//
+// The transcript is a few thousand field elements per segment: it stays on the
+// host, exactly where the reference keeps it (`Challenger::new()` at
+// evm_arithmetization/src/prover.rs:118, `challenger.compact()` at prover.rs:320).  Semantics:
+// plonky2 1.0.0 `iop/challenger.rs` ([EXT]): rate 8 / width 12 duplex sponge in overwrite mode,
+// outputs popped from the end of the buffer.  This is product code; it shares nothing with oracle/.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "gl.cuh"
+#include "../../include/poseidon_constants.h"
+
+namespace zkhost {
+
+inline void poseidon_permute(u64 (&s)[12]) {
+    static const u64 RC[ZK_POSEIDON_ROUNDS * 12] = ZK_POSEIDON_RC_INIT;
+    static const u32 CIRC[12] = ZK_POSEIDON_MDS_CIRC_INIT;
+    for (int i = 0; i < 12; ++i) s[i] = gl_canon(s[i]);
+    for (int round = 0; round < ZK_POSEIDON_ROUNDS; ++round) {
+        const bool full = round < ZK_POSEIDON_HALF_FULL_ROUNDS ||
+                          round >= ZK_POSEIDON_HALF_FULL_ROUNDS + ZK_POSEIDON_PARTIAL_ROUNDS;
+        for (int i = 0; i < 12; ++i) s[i] = gl_add_ref(s[i], RC[round * 12 + i]);
+        for (int i = 0; i < (full ? 12 : 1); ++i) {
+            u64 x = s[i], x2 = gl_mul_ref(x, x), x4 = gl_mul_ref(x2, x2);
+            s[i] = gl_mul_ref(gl_mul_ref(x, x2), x4);
+        }
+        u64 out[12];
+        for (int r = 0; r < 12; ++r) {
+            // 12 terms of (< 2^64) * (<= 41): accumulate high and low 32-bit halves separately
+            u64 lo = 0, hi = 0;
+            for (int i = 0; i < 12; ++i) {
+                u64 v = s[(i + r) % 12];
+                lo += (v & 0xFFFFFFFFULL) * CIRC[i];
+                hi += (v >> 32) * CIRC[i];
+            }
+            if (r == 0) { lo += (s[0] & 0xFFFFFFFFULL) * 8; hi += (s[0] >> 32) * 8; }
+            u64 t = lo + (hi << 32);
+            u32 top = (u32)(hi >> 32) + (t < lo ? 1u : 0u);
+            out[r] = gl_reduce96(top, t);
+        }
+        for (int r = 0; r < 12; ++r) s[r] = gl_canon(out[r]);
+    }
+}
+
+inline u64 rotl(u64 x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+
+inline void keccak_f1600(u64 (&a)[25]) {
+    static const u64 RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    // rho offsets by (x, y) and the pi destination, derived rather than tabulated
+    for (int rnd = 0; rnd < 24; ++rnd) {
+        u64 c[5];
+        for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+        for (int x = 0; x < 5; ++x) {
+            u64 d = c[(x + 4) % 5] ^ rotl(c[(x + 1) % 5], 1);
+            for (int y = 0; y < 5; ++y) a[x + 5 * y] ^= d;
+        }
+        u64 b[25];
+        b[0] = a[0];
+        int x = 1, y = 0;
+        for (int t = 0; t < 24; ++t) {  // rho offset of the t-th lane on the (x,y) walk = (t+1)(t+2)/2
+            int r = ((t + 1) * (t + 2) / 2) % 64;
+            int nx = y, ny = (2 * x + 3 * y) % 5;
+            b[nx + 5 * ny] = rotl(a[x + 5 * y], r);
+            x = nx; y = ny;
+        }
+        for (int yy = 0; yy < 5; ++yy)
+            for (int xx = 0; xx < 5; ++xx)
+                a[xx + 5 * yy] = b[xx + 5 * yy] ^ (~b[(xx + 1) % 5 + 5 * yy] & b[(xx + 2) % 5 + 5 * yy]);
+        a[0] ^= RC[rnd];
+    }
+}
+
+inline void keccak256(const uint8_t *in, size_t len, uint8_t out[32]) {
+    u64 st[25] = {0};
+    uint8_t blk[136];
+    while (true) {
+        size_t take = len < 136 ? len : 136;
+        memset(blk, 0, sizeof blk);
+        memcpy(blk, in, take);
+        bool last = len < 136;
+        if (last) { blk[take] ^= 0x01; blk[135] ^= 0x80; }
+        for (int i = 0; i < 17; ++i) { u64 w; memcpy(&w, blk + 8 * i, 8); st[i] ^= w; }
+        keccak_f1600(st);
+        if (last) break;
+        in += 136; len -= 136;
+    }
+    memcpy(out, st, 32);
+}
+
+// [EXT] plonky2 hash/keccak.rs KeccakPermutation: hash onion, words >= p rejected
+inline void keccak_permutation(u64 (&s)[12]) {
+    uint8_t cur[96], h[32];
+    for (int i = 0; i < 12; ++i) { u64 w = gl_canon(s[i]); memcpy(cur + 8 * i, &w, 8); }
+    size_t len = 96;
+    int got = 0;
+    while (got < 12) {
+        keccak256(cur, len, h);
+        memcpy(cur, h, 32);
+        len = 32;
+        for (int k = 0; k < 4 && got < 12; ++k) {
+            u64 w; memcpy(&w, h + 8 * k, 8);
+            if (w < GL_P) s[got++] = w;
+        }
+    }
+}
+
+struct Challenger {
+    uint32_t hasher = 0;
+    u64 state[12] = {0};
+    u64 in[8];
+    int n_in = 0;
+    u64 out[8];
+    int n_out = 0;
+
+    void permute() { if (hasher == 0) poseidon_permute(state); else keccak_permutation(state); }
+    void duplexing() {
+        for (int i = 0; i < n_in; ++i) state[i] = in[i];
+        n_in = 0;
+        permute();
+        memcpy(out, state, sizeof out);
+        n_out = 8;
+    }
+    void observe(u64 e) {
+        n_out = 0;
+        in[n_in++] = gl_canon(e);
+        if (n_in == 8) duplexing();
+    }
+    void observe_slice(const u64 *e, size_t n) { for (size_t i = 0; i < n; ++i) observe(e[i]); }
+    // GenericHashOut::to_vec: Poseidon = 4 elements; BytesHash<25> = 7,7,7,4-byte LE chunks
+    void observe_hash(const u64 *slot) {
+        if (hasher == 0) { observe_slice(slot, 4); return; }
+        const uint8_t *b = reinterpret_cast<const uint8_t *>(slot);
+        for (int k = 0; k < 4; ++k) {
+            u64 w = 0;
+            memcpy(&w, b + 7 * k, k < 3 ? 7 : 4);
+            observe(w);
+        }
+    }
+    void observe_cap(const u64 *slots, size_t n) { for (size_t i = 0; i < n; ++i) observe_hash(slots + 4 * i); }
+    u64 get() {
+        if (n_in != 0 || n_out == 0) duplexing();
+        return out[--n_out];
+    }
+    void get_ext(u64 (&e)[2]) { e[0] = get(); e[1] = get(); }
+    void compact(u64 *state_out) {
+        if (n_in != 0) duplexing();
+        n_out = 0;
+        if (state_out) memcpy(state_out, state, sizeof state);
+    }
+};
+
+// host extension-field helpers (tiny, transcript-side only)
+struct Ext { u64 a, b; };
+inline Ext ext_mul(Ext x, Ext y) {
+    u64 aa = gl_mul_ref(x.a, y.a), bb = gl_mul_ref(x.b, y.b);
+    u64 ab = gl_mul_ref(x.a, y.b), ba = gl_mul_ref(x.b, y.a);
+    u64 bb7 = gl_mul_ref(bb, 7);
+    return Ext{gl_canon(gl_add_ref(aa, bb7)), gl_canon(gl_add_ref(ab, ba))};
+}
+inline Ext ext_add(Ext x, Ext y) { return Ext{gl_canon(gl_add_ref(x.a, y.a)), gl_canon(gl_add_ref(x.b, y.b))}; }
+inline Ext ext_pow(Ext b, u64 e) {
+    Ext r{1, 0};
+    while (e) { if (e & 1) r = ext_mul(r, b); b = ext_mul(b, b); e >>= 1; }
+    return r;
+}
+
+}  // namespace zkhost

@@ -15,10 +15,19 @@
 #include "poseidon.cuh"
 #include "keccak.cuh"
 
+// Column c of the matrix starts at cols + (GATHER ? col_off[c] : c * col_stride): the GATHER form
+// hashes rows of a matrix whose columns are arbitrary strided views (FRI commit-phase leaves).
+template <bool GATHER>
+__device__ __forceinline__ size_t col_offset(u32 c, size_t col_stride, const u64 *col_off) {
+    return GATHER ? (size_t)col_off[c] : (size_t)c * col_stride;
+}
+
 // Poseidon `hash_or_noop` of each row; digest of row j -> slot (bitrev ? bitrev(j) : j).
+template <bool GATHER>
 __global__ void __launch_bounds__(256)
-poseidon_hash_rows_kernel(const u64 *__restrict__ cols, size_t col_stride, u32 n_cols,
-                          size_t n_rows, int log_rows, int do_bitrev, u64 *__restrict__ digests) {
+poseidon_hash_rows_kernel(const u64 *__restrict__ cols, size_t col_stride, const u64 *__restrict__ col_off,
+                          u32 n_cols, size_t n_rows, int log_rows, int do_bitrev,
+                          u64 *__restrict__ digests) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_rows) return;
     u64 s[12];
@@ -26,18 +35,18 @@ poseidon_hash_rows_kernel(const u64 *__restrict__ cols, size_t col_stride, u32 n
     for (int i = 0; i < 12; ++i) s[i] = 0;
     const u64 *p = cols + j;
     if (n_cols <= 4) {
-        for (u32 c = 0; c < n_cols; ++c) s[c] = gl_canon(p[(size_t)c * col_stride]);
+        for (u32 c = 0; c < n_cols; ++c) s[c] = gl_canon(p[col_offset<GATHER>(c, col_stride, col_off)]);
     } else {
         u32 c = 0;
         for (; c + 8 <= n_cols; c += 8) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s[i] = p[(size_t)(c + i) * col_stride];
+            for (int i = 0; i < 8; ++i) s[i] = p[col_offset<GATHER>(c + i, col_stride, col_off)];
             poseidon_permute(s);
         }
         if (c < n_cols) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                if (c + i < n_cols) s[i] = p[(size_t)(c + i) * col_stride];
+                if (c + i < n_cols) s[i] = p[col_offset<GATHER>(c + i, col_stride, col_off)];
             poseidon_permute(s);
         }
     }
@@ -91,9 +100,11 @@ __device__ __forceinline__ void keccak25_store(const u64 (&a)[25], u64 *slot) {
 }
 
 // KeccakHash<25>::hash_or_noop of each row (elements encoded as canonical LE u64).
+template <bool GATHER>
 __global__ void __launch_bounds__(256)
-keccak_hash_rows_kernel(const u64 *__restrict__ cols, size_t col_stride, u32 n_cols,
-                        size_t n_rows, int log_rows, int do_bitrev, u64 *__restrict__ digests) {
+keccak_hash_rows_kernel(const u64 *__restrict__ cols, size_t col_stride, const u64 *__restrict__ col_off,
+                        u32 n_cols, size_t n_rows, int log_rows, int do_bitrev,
+                        u64 *__restrict__ digests) {
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_rows) return;
     const u64 *p = cols + j;
@@ -102,7 +113,7 @@ keccak_hash_rows_kernel(const u64 *__restrict__ cols, size_t col_stride, u32 n_c
     for (int i = 0; i < 25; ++i) a[i] = 0;
     size_t slot = do_bitrev ? (size_t)bitrev32((u32)j, log_rows) : j;
     if (n_cols * 8 <= 25) {  // noop: raw bytes
-        for (u32 c = 0; c < n_cols; ++c) a[c] = gl_canon(p[(size_t)c * col_stride]);
+        for (u32 c = 0; c < n_cols; ++c) a[c] = gl_canon(p[col_offset<GATHER>(c, col_stride, col_off)]);
         ulonglong2 *o = reinterpret_cast<ulonglong2 *>(digests + 4 * slot);
         o[0] = make_ulonglong2(a[0], a[1]);
         o[1] = make_ulonglong2(a[2], 0);
@@ -111,14 +122,14 @@ keccak_hash_rows_kernel(const u64 *__restrict__ cols, size_t col_stride, u32 n_c
     u32 c = 0;
     for (; c + 17 <= n_cols; c += 17) {  // full 136-byte blocks
 #pragma unroll
-        for (int i = 0; i < 17; ++i) a[i] ^= gl_canon(p[(size_t)(c + i) * col_stride]);
+        for (int i = 0; i < 17; ++i) a[i] ^= gl_canon(p[col_offset<GATHER>(c + i, col_stride, col_off)]);
         keccak_f1600(a);
     }
     // final (possibly empty) partial block + padding; message is word aligned
     u32 rem = n_cols - c;
 #pragma unroll
     for (int i = 0; i < 17; ++i) {
-        if ((u32)i < rem) a[i] ^= gl_canon(p[(size_t)(c + i) * col_stride]);
+        if ((u32)i < rem) a[i] ^= gl_canon(p[col_offset<GATHER>(c + i, col_stride, col_off)]);
         if ((u32)i == rem) a[i] ^= 0x01ULL;
     }
     a[16] ^= 0x8000000000000000ULL;

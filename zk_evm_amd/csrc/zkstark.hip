@@ -19,6 +19,8 @@
 #include "gl.cuh"
 #include "merkle.cuh"
 #include "ntt.cuh"
+#include "fri.cuh"
+#include "host_hash.hpp"
 
 // ------------------------------------------------------------------------------------------
 struct zk_ctx {
@@ -438,16 +440,26 @@ extern "C" int zk_keccak_f1600(zk_ctx *ctx, uint64_t *d_states, size_t n_states)
     return check_launch(ctx, "keccak_f1600_states_kernel");
 }
 
+// col_off == nullptr: column c at cols + c*stride; else column c at cols + col_off[c] (device array)
 static int hash_rows(zk_ctx *ctx, uint32_t hasher, const u64 *cols, size_t stride, size_t n_cols,
-                     size_t n_rows, int log_rows, int do_bitrev, u64 *digests) {
+                     size_t n_rows, int log_rows, int do_bitrev, u64 *digests,
+                     const u64 *col_off = nullptr) {
     unsigned blocks = (unsigned)((n_rows + 255) / 256);
     if (hasher == ZK_HASH_POSEIDON) {
-        poseidon_hash_rows_kernel<<<blocks, 256, 0, ctx->stream>>>(cols, stride, (u32)n_cols, n_rows,
-                                                                   log_rows, do_bitrev, digests);
+        if (col_off)
+            poseidon_hash_rows_kernel<true><<<blocks, 256, 0, ctx->stream>>>(
+                cols, stride, col_off, (u32)n_cols, n_rows, log_rows, do_bitrev, digests);
+        else
+            poseidon_hash_rows_kernel<false><<<blocks, 256, 0, ctx->stream>>>(
+                cols, stride, nullptr, (u32)n_cols, n_rows, log_rows, do_bitrev, digests);
         return check_launch(ctx, "poseidon_hash_rows_kernel");
     } else if (hasher == ZK_HASH_KECCAK25) {
-        keccak_hash_rows_kernel<<<blocks, 256, 0, ctx->stream>>>(cols, stride, (u32)n_cols, n_rows,
-                                                                 log_rows, do_bitrev, digests);
+        if (col_off)
+            keccak_hash_rows_kernel<true><<<blocks, 256, 0, ctx->stream>>>(
+                cols, stride, col_off, (u32)n_cols, n_rows, log_rows, do_bitrev, digests);
+        else
+            keccak_hash_rows_kernel<false><<<blocks, 256, 0, ctx->stream>>>(
+                cols, stride, nullptr, (u32)n_cols, n_rows, log_rows, do_bitrev, digests);
         return check_launch(ctx, "keccak_hash_rows_kernel");
     }
     return set_err(ctx, ZK_ERR_BAD_ARG, "unknown hasher %u", hasher);
@@ -692,3 +704,5 @@ extern "C" int zk_batch_merkle_path(const zk_batch *b, size_t leaf_index, uint64
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return ZK_OK;
 }
+
+#include "fri_host.inc"
