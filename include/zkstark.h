@@ -189,6 +189,33 @@ int zk_fri_prove_openings(zk_ctx *ctx, const zk_cfg *cfg, const zk_batch *const 
                           size_t n_oracles, const zk_fri_batch *batches, size_t n_batches,
                           const uint64_t *openings, zk_challenger *challenger, uint64_t *proof_out);
 
+/* ---- logUp / cross-table-lookup auxiliary columns --------------------------------
+ * The AIR side conditions are data.  Flat "program" encoding (u64 words, host memory):
+ *   Column  := n_local, n_next, constant, (col_idx, coef) x n_local, (col_idx, coef) x n_next
+ *              = sum coef*local[idx] + sum coef*next[idx] + constant   (starky `Column<F>`)
+ *   Filter  := n_products, n_constants, (Column, Column) x n_products, Column x n_constants
+ *              = sum a*b + sum c   (starky `Filter<F>`; the default filter is the constant 1)
+ *   Entry   := n_columns, Column x n_columns, Filter      (one `(columns, filter)` looking entry)
+ *   program := n_entries, entry_offset[n_entries], table_col_offset, freq_col_offset, payload
+ *              (offsets are word indices into the program; the last two are 0 for CTL programs)
+ * Outputs are column-major on the device: ceil(n_entries/(constraint_degree-1)) helper columns,
+ * then Z. */
+/* starky `lookup_helper_columns(lookup, trace, challenge, constraint_degree)`: single-column
+ * entries, denominator = column + challenge; Z(first) = 0, Z(next) = Z + sum h - freq/(table+challenge).
+ * (reference lookups: arithmetic_stark.rs:320-327, byte_packing_stark.rs:426-437,
+ * keccak_sponge_stark.rs:946-953, memory_stark.rs:858-885) */
+int zk_lookup_helper_columns(zk_ctx *ctx, const uint64_t *d_trace, size_t col_stride,
+                             size_t n_trace_cols, unsigned log_n, const uint64_t *program,
+                             size_t program_words, uint64_t challenge, unsigned constraint_degree,
+                             uint64_t *d_out, size_t out_stride, size_t *n_out_cols);
+/* starky `cross_table_lookup::partial_sums(trace, columns_filters, (beta, gamma), degree)`:
+ * denominator = sum_j beta^j col_j + gamma; Z[i] = sum_{j >= i} sum_h h[j].  With a single entry
+ * only Z is produced (n_out_cols = 1).  (reference CTL registry: all_stark.rs:153-417) */
+int zk_ctl_partial_sums(zk_ctx *ctx, const uint64_t *d_trace, size_t col_stride, size_t n_trace_cols,
+                        unsigned log_n, const uint64_t *program, size_t program_words, uint64_t beta,
+                        uint64_t gamma, unsigned constraint_degree, uint64_t *d_out,
+                        size_t out_stride, size_t *n_out_cols);
+
 /* library / device info */
 const char *zk_version(void);
 int zk_device_info(int device, char *name_out, size_t name_len, int *cu_count, size_t *hbm_bytes);

@@ -1,0 +1,140 @@
+"""-m gpu: logUp helper columns and CTL partial sums on the GPU vs the pure-Python restatement of
+starky (oracle/stark.py), on random traces with random column / filter programs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+
+
+def _rand_trace(rng, n_cols, n, binary_cols):
+    t = rng.integers(0, 1 << 64, size=(n_cols, n), dtype=np.uint64)
+    for c in binary_cols:
+        t[c] = rng.integers(0, 2, size=n, dtype=np.uint64)
+    return t
+
+
+def _pairs(mod):
+    """Build equivalent (product, oracle) Column / Filter factories from one description."""
+    return mod.Column, mod.Filter
+
+
+def _mk(desc, Col, Fil):
+    kind = desc[0]
+    if kind == "single":
+        return Col.single(desc[1])
+    if kind == "next":
+        return Col.single_next_row(desc[1])
+    if kind == "lc":
+        return Col.linear_combination_and_next_row_with_constant(desc[1], desc[2], desc[3])
+    raise ValueError(kind)
+
+
+def _mkf(desc, Col, Fil):
+    if desc is None:
+        return Fil()
+    if desc[0] == "simple":
+        return Fil.new_simple(_mk(desc[1], Col, Fil))
+    return Fil.new([(_mk(a, Col, Fil), _mk(b, Col, Fil)) for a, b in desc[1]], [_mk(c, Col, Fil) for c in desc[2]])
+
+
+@pytest.mark.parametrize("log_n,n_lookup_cols,degree", [(4, 1, 3), (6, 5, 3), (8, 17, 3), (7, 6, 2), (12, 33, 3)])
+def test_lookup_helper_columns(log_n, n_lookup_cols, degree):
+    import torch
+    import zk_evm_amd.stark as prod
+    from oracle import stark as orc
+    rng = np.random.default_rng(log_n * 31 + n_lookup_cols)
+    n = 1 << log_n
+    n_cols = n_lookup_cols + 6
+    bin_cols = [n_cols - 1, n_cols - 2]
+    trace = _rand_trace(rng, n_cols, n, bin_cols)
+    col_descs = []
+    filt_descs = []
+    for k in range(n_lookup_cols):
+        if k % 5 == 3:
+            col_descs.append(("next", k))
+        elif k % 7 == 4:
+            col_descs.append(("lc", [(k, 3), ((k + 1) % n_lookup_cols, P - 1)], [(k, 5)], 9))
+        else:
+            col_descs.append(("single", k))
+        r = k % 4
+        if r == 0:
+            filt_descs.append(None)
+        elif r == 1:
+            filt_descs.append(("simple", ("single", bin_cols[0])))
+        elif r == 2:   # product of two binary columns
+            filt_descs.append(("full", [(("single", bin_cols[0]), ("single", bin_cols[1]))], []))
+        else:
+            filt_descs.append(None)
+    table_desc, freq_desc = ("single", n_lookup_cols), ("single", n_lookup_cols + 1)
+    challenge = int(rng.integers(1, 1 << 63))
+
+    def build(mod):
+        Col, Fil = mod.Column, mod.Filter
+        return mod.Lookup([_mk(d, Col, Fil) for d in col_descs], _mk(table_desc, Col, Fil),
+                          _mk(freq_desc, Col, Fil), [_mkf(d, Col, Fil) for d in filt_descs])
+
+    exp = orc.lookup_helper_columns(build(orc), [[int(x) for x in col] for col in trace], challenge, degree)
+    dev = torch.from_numpy(trace.view(np.int64)).cuda()
+    got = prod.lookup_helper_columns(build(prod), dev, challenge, degree).cpu().numpy().view(np.uint64)
+    assert got.shape == (len(exp), n)
+    for h in range(len(exp)):
+        assert got[h].tolist() == exp[h], h
+
+
+@pytest.mark.parametrize("log_n,n_entries,degree", [(4, 1, 3), (5, 2, 3), (6, 3, 3), (8, 7, 3), (9, 40, 3), (6, 3, 2)])
+def test_ctl_partial_sums(log_n, n_entries, degree):
+    import torch
+    import zk_evm_amd.stark as prod
+    from oracle import stark as orc
+    rng = np.random.default_rng(log_n * 17 + n_entries)
+    n = 1 << log_n
+    n_cols = 12
+    bin_cols = [10, 11]
+    trace = _rand_trace(rng, n_cols, n, bin_cols)
+    entries = []
+    for e in range(n_entries):
+        width = 1 + (e % 4)
+        cols = []
+        for j in range(width):
+            if (e + j) % 3 == 0:
+                cols.append(("lc", [((e + j) % 10, 1 << (j + 1)), ((e + 2 * j + 1) % 10, 7)], [], j))
+            elif (e + j) % 3 == 1:
+                cols.append(("single", (e * 3 + j) % 10))
+            else:
+                cols.append(("next", (e + 5 * j) % 10))
+        f = [None, ("simple", ("single", 10)), ("full", [(("single", 10), ("single", 11))], []),
+             ("full", [], [("lc", [(10, 1)], [], 0)])][e % 4]
+        entries.append((cols, f))
+    beta, gamma = int(rng.integers(1, 1 << 63)), int(rng.integers(1, 1 << 63))
+
+    def build(mod):
+        Col, Fil = mod.Column, mod.Filter
+        return [([_mk(c, Col, Fil) for c in cols], _mkf(f, Col, Fil)) for cols, f in entries]
+
+    exp = orc.partial_sums([[int(x) for x in col] for col in trace], build(orc),
+                           orc.GrandProductChallenge(beta, gamma), degree)
+    dev = torch.from_numpy(trace.view(np.int64)).cuda()
+    got = prod.ctl_partial_sums(dev, build(prod), beta, gamma, degree).cpu().numpy().view(np.uint64)
+    assert got.shape == (len(exp), n)
+    for h in range(len(exp)):
+        assert got[h].tolist() == exp[h], h
+
+
+def test_non_binary_filter_is_rejected():
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.stark as prod
+    trace = torch.full((3, 16), 2, dtype=torch.int64, device="cuda")
+    with pytest.raises(zk.ZkStarkError):
+        prod.ctl_partial_sums(trace, [([prod.Column.single(0)], prod.Filter.new_simple(prod.Column.single(1)))],
+                              3, 5, 3)
+
+
+def test_malformed_program_is_rejected():
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.stark as prod
+    trace = torch.zeros((3, 16), dtype=torch.int64, device="cuda")
+    with pytest.raises(zk.ZkStarkError):   # column index out of range
+        prod.ctl_partial_sums(trace, [([prod.Column.single(7)], prod.Filter())], 3, 5, 3)

@@ -71,6 +71,10 @@ SIGNATURES = {
     "zk_fri_openings": (C.c_int, [vp, vp, sz, vp, sz, u64p]),
     "zk_fri_proof_words": (sz, [C.POINTER(ZkCfg), ui, vp, sz]),
     "zk_fri_prove_openings": (C.c_int, [vp, C.POINTER(ZkCfg), vp, sz, vp, sz, u64p, vp, u64p]),
+    "zk_lookup_helper_columns": (C.c_int, [vp, u64p, sz, sz, ui, u64p, sz, C.c_uint64, ui, u64p, sz,
+                                           C.POINTER(sz)]),
+    "zk_ctl_partial_sums": (C.c_int, [vp, u64p, sz, sz, ui, u64p, sz, C.c_uint64, C.c_uint64, ui, u64p, sz,
+                                      C.POINTER(sz)]),
     "zk_version": (C.c_char_p, []),
     "zk_device_info": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(sz)]),
 }

@@ -20,6 +20,7 @@
 #include "merkle.cuh"
 #include "ntt.cuh"
 #include "fri.cuh"
+#include "stark.cuh"
 #include "host_hash.hpp"
 
 // ------------------------------------------------------------------------------------------
@@ -706,3 +707,4 @@ extern "C" int zk_batch_merkle_path(const zk_batch *b, size_t leaf_index, uint64
 }
 
 #include "fri_host.inc"
+#include "stark_host.inc"
