@@ -216,6 +216,31 @@ int zk_ctl_partial_sums(zk_ctx *ctx, const uint64_t *d_trace, size_t col_stride,
                         uint64_t gamma, unsigned constraint_degree, uint64_t *d_out,
                         size_t out_stride, size_t *n_out_cols);
 
+/* ---- quotient polynomials -----------------------------------------------------
+ * Table AIRs restated from the reference (`Stark::eval_packed_generic` of each table). */
+typedef enum {
+    ZK_AIR_NONE = 0,             /* no table constraints: lookup / CTL checks only (tests) */
+    ZK_AIR_MEM_CONTINUATION = 1, /* MemBefore / MemAfter: memory_continuation_stark.rs:110-122 */
+    ZK_AIR_LOGIC = 2,            /* logic.rs:249-303 */
+} zk_air;
+/* starky `compute_quotient_polys` + chunk split + `PolynomialBatch::from_coeffs`:
+ * evaluates, on the coset of size n * quotient_degree_factor, the alpha-combination of
+ *   (1) the table constraints, (2) the logUp checks (`eval_packed_lookups_generic`),
+ *   (3) the CTL checks (`eval_cross_table_lookup_checks`), divides by Z_H, interpolates, splits
+ * into degree-n chunks and commits them.  Returns the quotient batch
+ * (num_challenges * quotient_degree_factor polynomials).
+ *   lookup_program := n_lookups, offset[n_lookups], payload  (each lookup = a
+ *                     zk_lookup_helper_columns program); lookup_challenges as starky: the CTL betas.
+ *   ctl_program    := n_zdata, offset[n_zdata], payload; each z-data := beta, gamma, n_helpers,
+ *                     then a zk_ctl_partial_sums program.  The auxiliary batch must hold, in
+ *                     order: all lookup columns, all CTL helper columns, all CTL Z columns. */
+int zk_quotient_polys(zk_ctx *ctx, const zk_cfg *cfg, uint32_t air_id, const uint64_t *air_consts,
+                      size_t n_air_consts, const zk_batch *trace, const zk_batch *aux,
+                      const uint64_t *alphas, const uint64_t *lookup_program, size_t lookup_words,
+                      const uint64_t *lookup_challenges, size_t n_lookup_challenges,
+                      const uint64_t *ctl_program, size_t ctl_words, unsigned constraint_degree,
+                      zk_batch **quotient_out);
+
 /* library / device info */
 const char *zk_version(void);
 int zk_device_info(int device, char *name_out, size_t name_len, int *cu_count, size_t *hbm_bytes);

@@ -169,3 +169,145 @@ def partial_sums(trace, columns_filters, challenge: GrandProductChallenge, const
         run = (run + sum(h[i] for h in helpers)) % P
         z[i] = run
     return helpers + [z] if len(columns_filters) > 1 else [z]
+
+
+# ---- constraint consumer + checks ([EXT] constraint_consumer.rs, lookup.rs, cross_table_lookup.rs)
+class ConstraintConsumer:
+    def __init__(self, alphas, z_last, lagrange_first, lagrange_last):
+        self.alphas = list(alphas)
+        self.z_last, self.lf, self.ll = z_last, lagrange_first, lagrange_last
+        self.accs = [0] * len(self.alphas)
+
+    def constraint(self, c):
+        c %= P
+        self.accs = [(a * al + c) % P for a, al in zip(self.accs, self.alphas)]
+
+    def constraint_transition(self, c): self.constraint(c * self.z_last)
+    def constraint_first_row(self, c): self.constraint(c * self.lf)
+    def constraint_last_row(self, c): self.constraint(c * self.ll)
+
+
+def eval_helper_columns(filters, columns_evals, lv, nv, helper_values, constraint_degree, challenge, consumer):
+    if not helper_values:
+        return
+    chunk = constraint_degree - 1
+    h = 0
+    for s in range(0, len(columns_evals), chunk):
+        cols = columns_evals[s:s + chunk]
+        fs = filters[s:s + chunk]
+        hv = helper_values[h]
+        h += 1
+        if len(cols) == 2:
+            c0, c1 = challenge.combine(cols[0]), challenge.combine(cols[1])
+            f0, f1 = fs[0].eval_filter(lv, nv), fs[1].eval_filter(lv, nv)
+            consumer.constraint(c1 * c0 * hv - f0 * c1 - f1 * c0)
+        elif len(cols) == 1:
+            consumer.constraint(challenge.combine(cols[0]) * hv - fs[0].eval_filter(lv, nv))
+        else:
+            raise NotImplementedError
+
+
+def eval_packed_lookups(lookups, challenges, lv, nv, aux_lv, aux_nv, consumer, degree):
+    start = 0
+    for lookup in lookups:
+        nh = lookup.num_helper_columns(degree)
+        for ch in challenges:
+            gc = GrandProductChallenge(1, ch)
+            col_evals = [[c.eval_with_next(lv, nv)] for c in lookup.columns]
+            eval_helper_columns(lookup.filter_columns, col_evals, lv, nv, aux_lv[start:start + nh - 1], degree, gc, consumer)
+            z, next_z = aux_lv[start + nh - 1], aux_nv[start + nh - 1]
+            table = (lookup.table_column.eval(lv) + ch) % P
+            y = (sum(aux_lv[start:start + nh - 1]) * table - lookup.frequencies_column.eval(lv)) % P
+            consumer.constraint_first_row(z)
+            consumer.constraint((next_z - z) * table - y)
+            start += nh
+
+
+@dataclass
+class CtlZData:
+    """One `CtlZData`: challenge, the looking (columns, filter) entries of THIS table, helper count."""
+    challenge: GrandProductChallenge
+    columns_filters: list
+    n_helpers: int
+
+
+def eval_cross_table_lookup_checks(zdatas, lv, nv, aux_lv, aux_nv, num_lookup_columns, consumer, degree):
+    total_helpers = sum(z.n_helpers for z in zdatas)
+    start = 0
+    for i, zd in enumerate(zdatas):
+        helpers = aux_lv[num_lookup_columns + start: num_lookup_columns + start + zd.n_helpers]
+        local_z = aux_lv[num_lookup_columns + total_helpers + i]
+        next_z = aux_nv[num_lookup_columns + total_helpers + i]
+        evals = [[c.eval_with_next(lv, nv) for c in cols] for cols, _ in zd.columns_filters]
+        filters = [f for _, f in zd.columns_filters]
+        eval_helper_columns(filters, evals, lv, nv, helpers, degree, zd.challenge, consumer)
+        if helpers:
+            hs = sum(helpers) % P
+            consumer.constraint_last_row(local_z - hs)
+            consumer.constraint_transition(local_z - next_z - hs)
+        elif len(evals) > 1:
+            c0, c1 = zd.challenge.combine(evals[0]), zd.challenge.combine(evals[1])
+            f0, f1 = filters[0].eval_filter(lv, nv), filters[1].eval_filter(lv, nv)
+            consumer.constraint_last_row(c0 * c1 * local_z - f0 * c1 - f1 * c0)
+            consumer.constraint_transition(c0 * c1 * (local_z - next_z) - f0 * c1 - f1 * c0)
+        else:
+            c0 = zd.challenge.combine(evals[0])
+            f0 = filters[0].eval_filter(lv, nv)
+            consumer.constraint_last_row(c0 * local_z - f0)
+            consumer.constraint_transition(c0 * (local_z - next_z) - f0)
+        start += zd.n_helpers
+
+
+G = 14293326489335486720
+POW2_GEN = 7277203076849721926
+
+
+def root_of_unity(log_n):
+    return pow(POW2_GEN, 1 << (32 - log_n), P)
+
+
+def bitrev(x, bits):
+    return int(format(x, "0%db" % bits)[::-1], 2) if bits else 0
+
+
+def compute_quotient_values(air_eval, lookups, lookup_challenges, zdatas, alphas, degree_bits, rate_bits,
+                            constraint_degree, trace_leaves, aux_leaves):
+    """[EXT] starky prover.rs `compute_quotient_polys`, up to (excluding) the coset_ifft.
+    trace_leaves / aux_leaves: committed leaves (bit-reversed rows, as MerkleTree stores them).
+    Returns [num_challenges][size] quotient VALUES on the coset of size n * 2^quotient_degree_bits."""
+    n = 1 << degree_bits
+    qdf = max(1, constraint_degree - 1)
+    qdb = (qdf - 1).bit_length()
+    assert qdb <= rate_bits
+    step = 1 << (rate_bits - qdb)
+    next_step = 1 << qdb
+    size = n << qdb
+    log_lde = degree_bits + rate_bits
+    w_size = root_of_unity(degree_bits + qdb)
+    last = inv(root_of_unity(degree_bits))
+    num_lookup_columns = sum(l.num_helper_columns(constraint_degree) for l in lookups) * len(lookup_challenges)
+    out = [[0] * size for _ in alphas]
+
+    def row(leaves, i):
+        return [int(v) for v in leaves[bitrev(i * step, log_lde)]]   # get_lde_values(i, step)
+
+    n_inv = inv(n)
+    for i in range(size):
+        x = G * pow(w_size, i, P) % P
+        zh = (pow(x, n, P) - 1) % P
+        lf = zh * n_inv % P * inv(x - 1) % P
+        ll = zh * n_inv % P * last % P * inv(x - last) % P
+        cons = ConstraintConsumer(alphas, (x - last) % P, lf, ll)
+        i_next = (i + next_step) % size
+        lv, nv = row(trace_leaves, i), row(trace_leaves, i_next)
+        air_eval(lv, nv, cons)
+        if aux_leaves is not None:
+            alv, anv = row(aux_leaves, i), row(aux_leaves, i_next)
+            if lookups:
+                eval_packed_lookups(lookups, lookup_challenges, lv, nv, alv, anv, cons, constraint_degree)
+            if zdatas:
+                eval_cross_table_lookup_checks(zdatas, lv, nv, alv, anv, num_lookup_columns, cons, constraint_degree)
+        zinv = inv(zh)
+        for k, a in enumerate(cons.accs):
+            out[k][i] = a * zinv % P
+    return out

@@ -1,0 +1,133 @@
+"""-m gpu: per-table STARK proof (starky prove_with_commitment) on the GPU vs the oracle
+restatement, word for word: auxiliary cap, quotient cap, openings, FRI proof.  Random traces
+(the prover does not require the trace to satisfy the AIR; acceptance by a verifier does -- see
+test_gpu_stark_verify.py for valid traces)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import tests.oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+
+
+def _descs_to(mod, col_descs):
+    from tests.test_gpu_stark_aux import _mk
+    return [_mk(d, mod.Column, mod.Filter) for d in col_descs]
+
+
+def _run_case(oracle, air_id, n_cols, log_n, hasher, lookup_spec, ctl_spec, seed, binary_cols=(), kw=None,
+              trace_fix=None):
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.prover as zp
+    import zk_evm_amd.stark as prod
+    from oracle import airs as oairs
+    from oracle import stark as orc
+    from oracle import stark_prover as oprover
+    from tests.test_gpu_stark_aux import _mk, _mkf
+    kw = kw or dict(pow_bits=3, queries=3)
+    ol.setup_fri_api(oracle)
+    L = oracle.lib
+    rng = np.random.default_rng(seed)
+    n = 1 << log_n
+    trace = rng.integers(0, 1 << 64, size=(n_cols, n), dtype=np.uint64)
+    for c in binary_cols:
+        trace[c] = rng.integers(0, 2, size=n, dtype=np.uint64)
+    if trace_fix:
+        trace_fix(trace, rng)
+    cfg = ol.make_cfg(hasher=hasher, **kw)
+    nchal = cfg.num_challenges
+    # --- commit + transcript prefix (both sides) ---
+    tcommit = oracle.commit_values(trace, rate_bits=1, cap_height=4, hasher=hasher)
+    dev = torch.from_numpy(trace.view(np.int64)).cuda()
+    tbatch = zk.PolynomialBatch.from_values(dev, 1, False, 4, hasher=hasher)
+    och = ol.new_challenger(oracle, hasher)
+    ch = zk.Challenger(hasher)
+    L.orc_challenger_observe_cap(C.byref(och), tcommit["cap"], 16)
+    ch.observe_cap(tcommit["cap"])
+    ctl_challenges = [(ch.get_challenge(), ch.get_challenge()) for _ in range(nchal)]
+    for b, g in ctl_challenges:
+        assert (b, g) == (L.orc_challenger_get(C.byref(och)), L.orc_challenger_get(C.byref(och)))
+
+    def lookups_for(mod):
+        out = []
+        for cols, table, freq, filts in lookup_spec:
+            out.append(mod.Lookup([_mk(c, mod.Column, mod.Filter) for c in cols], _mk(table, mod.Column, mod.Filter),
+                                  _mk(freq, mod.Column, mod.Filter), [_mkf(f, mod.Column, mod.Filter) for f in filts]))
+        return out
+
+    def entries_for(mod, entries):
+        return [([_mk(c, mod.Column, mod.Filter) for c in cols], _mkf(f, mod.Column, mod.Filter)) for cols, f in entries]
+
+    # CTL z-data: for each CTL group in ctl_spec, one z-data per challenge (cross_table_lookup_data order)
+    o_z, p_z = [], []
+    for entries in ctl_spec:
+        for b, g in ctl_challenges:
+            o_z.append(orc.CtlZData(orc.GrandProductChallenge(b, g), entries_for(orc, entries), 0))
+            aux = prod.ctl_partial_sums(dev, entries_for(prod, entries), b, g, 3)
+            p_z.append(zp.CtlZData(b, g, entries_for(prod, entries), aux))
+    exp = oprover.prove_with_commitment(oracle, ol, cfg, oairs.AIRS[air_id][0], trace, tcommit, lookups_for(orc),
+                                        o_z, ctl_challenges, och)
+    scfg = zk.StarkConfig(hasher=hasher, num_challenges=nchal,
+                          fri_config=zk.FriConfig(proof_of_work_bits=kw["pow_bits"], num_query_rounds=kw["queries"]))
+    got = zp.prove_with_commitment(air_id, scfg, dev, tbatch, lookups_for(prod), p_z, ctl_challenges, ch)
+    if exp["aux_cap"] is None:
+        assert got.auxiliary_polys_cap is None
+    else:
+        assert np.array_equal(got.auxiliary_polys_cap, exp["aux_cap"])
+    assert np.array_equal(got.quotient_polys_cap, exp["quotient_cap"])
+    assert np.array_equal(got.openings.reshape(-1), exp["openings"])
+    assert np.array_equal(got.opening_proof, exp["fri"])
+    assert ch.get_challenge() == L.orc_challenger_get(C.byref(och))
+    return exp, got
+
+
+LOOKUP_A = ([("single", 0), ("single", 1), ("next", 2)], ("single", 3), ("single", 4),
+            [None, ("simple", ("single", 10)), ("full", [(("single", 10), ("single", 11))], [])])
+CTL_MULTI = [([("single", 0), ("lc", [(1, 3), (2, 5)], [(3, 7)], 11)], ("simple", ("single", 10))),
+             ([("single", 4), ("single", 5)], None),
+             ([("next", 6), ("single", 7)], ("full", [(("single", 10), ("single", 11))], []))]
+CTL_SINGLE = [([("single", 1), ("single", 2), ("single", 3)], ("simple", ("single", 11)))]
+
+
+@pytest.mark.parametrize("hasher", [0, 1])
+def test_generic_machinery_no_air(oracle, hasher):
+    # AIR_NONE: only lookup + CTL constraints; 12 columns, cols 10/11 binary filters
+    _run_case(oracle, 0, 12, 6, hasher, [LOOKUP_A], [CTL_MULTI, CTL_SINGLE], seed=5, binary_cols=(10, 11))
+
+
+def test_no_aux_at_all(oracle):
+    _run_case(oracle, 0, 5, 5, 0, [], [], seed=6)
+
+
+def test_lookups_only_and_ctl_only(oracle):
+    _run_case(oracle, 0, 12, 5, 0, [LOOKUP_A, LOOKUP_A], [], seed=7, binary_cols=(10, 11))
+    _run_case(oracle, 0, 12, 7, 0, [], [CTL_SINGLE], seed=8, binary_cols=(10, 11))
+
+
+@pytest.mark.parametrize("hasher", [0, 1])
+def test_mem_continuation_table(oracle, hasher):
+    # MemBefore / MemAfter: ctl_data + ctl_filter of memory_continuation_stark.rs:28-39 (looked side of CTL 7/8)
+    ctl = [([("single", 1), ("single", 2), ("single", 3)] + [("single", 4 + i) for i in range(8)],
+            ("simple", ("single", 0)))]
+    _run_case(oracle, 1, 12, 7, hasher, [], [ctl], seed=9, binary_cols=(0,))
+
+
+def test_logic_table(oracle):
+    # Logic: ctl_data (logic.rs:84-113): opcode combination, 2 x 8 le_bits limbs, 8 result limbs
+    cols = [("lc", [(0, 0x16), (1, 0x17), (2, 0x18)], [], 0)]
+    for base in (3, 259):
+        for limb in range(8):
+            cols.append(("lc", [(base + 32 * limb + i, 1 << i) for i in range(32)], [], 0))
+    cols += [("single", 515 + i) for i in range(8)]
+    ctl = [(cols, ("simple", ("lc", [(0, 1), (1, 1), (2, 1)], [], 0)))]
+    # make the op flags one-hot-or-zero so the CTL filter (their sum) is binary
+    def fix(trace, rng):
+        n = trace.shape[1]
+        which = rng.integers(0, 4, size=n)
+        for k in range(3):
+            trace[k] = (which == k).astype(np.uint64)
+    _run_case(oracle, 2, 523, 5, 0, [], [ctl], seed=10, trace_fix=fix)

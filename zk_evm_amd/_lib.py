@@ -75,6 +75,8 @@ SIGNATURES = {
                                            C.POINTER(sz)]),
     "zk_ctl_partial_sums": (C.c_int, [vp, u64p, sz, sz, ui, u64p, sz, C.c_uint64, C.c_uint64, ui, u64p, sz,
                                       C.POINTER(sz)]),
+    "zk_quotient_polys": (C.c_int, [vp, C.POINTER(ZkCfg), u32, u64p, sz, vp, vp, u64p, u64p, sz, u64p, sz,
+                                    u64p, sz, ui, C.POINTER(vp)]),
     "zk_version": (C.c_char_p, []),
     "zk_device_info": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(sz)]),
 }

@@ -1,0 +1,273 @@
+// Quotient-polynomial evaluation: starky `compute_quotient_polys` / `eval_vanishing_poly`
+// ([EXT] starky/src/prover.rs, vanishing_poly.rs, constraint_consumer.rs, lookup.rs
+// `eval_packed_lookups_generic`, cross_table_lookup.rs `eval_cross_table_lookup_checks`), reached
+// from the reference at evm_arithmetization/src/prover.rs:322.  The table AIRs themselves
+// (`eval_packed_generic`) are restated in airs.cuh from the reference tree.
+//
+// MI355X mapping: one lane per point of the quotient coset (size n * 2^quotient_degree_bits);
+// the LDE matrices are column-major in natural row order, so "row i" and "row i + next_step" are
+// both coalesced reads.  The CPU code evaluates 4 points per AVX2 vector; here a wave evaluates
+// 64.  Z_H, the Lagrange selectors and z_last are computed in closed form per point (one shared
+// inversion) instead of via extra NTTs.
+#pragma once
+#include "gl.cuh"
+#include "stark.cuh"
+
+#define ZK_MAX_CHALLENGES 4
+
+// ---- lazy field element with operators (AIR code reads like the Rust `P: PackedField` code) ----
+struct Fe {
+    u64 v;
+    __device__ __forceinline__ Fe() : v(0) {}
+    __device__ __forceinline__ explicit Fe(u64 x) : v(x) {}
+};
+__device__ __forceinline__ Fe operator+(Fe a, Fe b) { return Fe(gl_add(a.v, b.v)); }
+__device__ __forceinline__ Fe operator-(Fe a, Fe b) { return Fe(gl_sub(a.v, b.v)); }
+__device__ __forceinline__ Fe operator*(Fe a, Fe b) { return Fe(gl_mul(a.v, b.v)); }
+__device__ __forceinline__ Fe operator-(Fe a) { return Fe(gl_neg(a.v)); }
+__device__ __forceinline__ Fe &operator+=(Fe &a, Fe b) { a = a + b; return a; }
+__device__ __forceinline__ Fe &operator-=(Fe &a, Fe b) { a = a - b; return a; }
+__device__ __forceinline__ Fe &operator*=(Fe &a, Fe b) { a = a * b; return a; }
+__device__ __forceinline__ Fe fe(u64 k) { return Fe(k); }  // canonical constant
+#define FE_ONE fe(1)
+#define FE_ZERO fe(0)
+
+// One row of a column-major matrix (values are loaded on demand; L1/L2 serve re-reads).
+struct RowView {
+    const u64 *base;
+    size_t stride;
+    u32 row;
+    __device__ __forceinline__ Fe operator[](u32 col) const { return Fe(base[(size_t)col * stride + row]); }
+};
+
+// starky `ConstraintConsumer`: acc_k <- acc_k * alpha_k + c, in yield order.
+struct Consumer {
+    u64 alpha[ZK_MAX_CHALLENGES];
+    u64 acc[ZK_MAX_CHALLENGES];
+    int nc;
+    Fe z_last, lagrange_first, lagrange_last;
+    __device__ __forceinline__ void constraint(Fe c) {
+#pragma unroll
+        for (int k = 0; k < ZK_MAX_CHALLENGES; ++k)
+            if (k < nc) acc[k] = gl_add(gl_mul(acc[k], alpha[k]), c.v);
+    }
+    __device__ __forceinline__ void constraint_transition(Fe c) { constraint(c * z_last); }
+    __device__ __forceinline__ void constraint_first_row(Fe c) { constraint(c * lagrange_first); }
+    __device__ __forceinline__ void constraint_last_row(Fe c) { constraint(c * lagrange_last); }
+};
+
+// ---- program evaluation on an evaluation frame (`Column::eval_with_next`, `Filter::eval_filter`) --
+__device__ __forceinline__ Fe frame_eval_column(const u64 *__restrict__ prog, u32 &pc, const RowView &lv,
+                                                const RowView &nv, bool use_next) {
+    const u32 nl = (u32)prog[pc], nn = (u32)prog[pc + 1];
+    Fe acc(prog[pc + 2]);
+    pc += 3;
+    for (u32 i = 0; i < nl; ++i, pc += 2) {
+        Fe v = lv[(u32)prog[pc]];
+        u64 c = prog[pc + 1];
+        acc += c == 1 ? v : v * Fe(c);
+    }
+    for (u32 i = 0; i < nn; ++i, pc += 2) {
+        if (use_next) {
+            Fe v = nv[(u32)prog[pc]];
+            u64 c = prog[pc + 1];
+            acc += c == 1 ? v : v * Fe(c);
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ Fe frame_eval_filter(const u64 *__restrict__ prog, u32 &pc, const RowView &lv,
+                                                const RowView &nv) {
+    const u32 np = (u32)prog[pc], nc = (u32)prog[pc + 1];
+    pc += 2;
+    Fe acc;
+    for (u32 i = 0; i < np; ++i) {
+        Fe a = frame_eval_column(prog, pc, lv, nv, true);
+        Fe b = frame_eval_column(prog, pc, lv, nv, true);
+        acc += a * b;
+    }
+    for (u32 i = 0; i < nc; ++i) acc += frame_eval_column(prog, pc, lv, nv, true);
+    return acc;
+}
+// combine(evals) = sum_j beta^j e_j + gamma and the entry's filter; pc0 = entry offset
+__device__ __forceinline__ void frame_eval_entry(const u64 *__restrict__ prog, u32 pc, const RowView &lv,
+                                                 const RowView &nv, u64 beta, u64 gamma, Fe &combin, Fe &filt) {
+    const u32 ncols = (u32)prog[pc++];
+    Fe acc, bp(1);
+    for (u32 j = 0; j < ncols; ++j) {
+        Fe c = frame_eval_column(prog, pc, lv, nv, true);
+        acc += j == 0 ? c : c * bp;
+        bp = j == 0 ? Fe(beta) : bp * Fe(beta);
+    }
+    combin = acc + Fe(gamma);
+    filt = frame_eval_filter(prog, pc, lv, nv);
+}
+
+// starky `eval_helper_columns`: entries [0, n_entries) of the sub-program at prog+sub, helper h at
+// aux column h0 + h.
+__device__ __forceinline__ void check_helper_columns(const u64 *__restrict__ prog, u32 sub, u32 n_entries, u32 chunk,
+                                                     const RowView &lv, const RowView &nv, const RowView &aux_lv,
+                                                     u32 h0, u64 beta, u64 gamma, Consumer &cons) {
+    u32 h = 0;
+    for (u32 e = 0; e < n_entries; e += chunk, ++h) {
+        Fe hv = aux_lv[h0 + h];
+        Fe c0, f0;
+        frame_eval_entry(prog, sub + (u32)prog[sub + 1 + e], lv, nv, beta, gamma, c0, f0);
+        if (chunk == 2 && e + 1 < n_entries) {
+            Fe c1, f1;
+            frame_eval_entry(prog, sub + (u32)prog[sub + 2 + e], lv, nv, beta, gamma, c1, f1);
+            cons.constraint(c1 * c0 * hv - f0 * c1 - f1 * c0);
+        } else {
+            cons.constraint(c0 * hv - f0);
+        }
+    }
+}
+
+// Argument block of the quotient kernel.
+struct QuotientArgs {
+    const u64 *trace; size_t trace_stride;   // LDE, [C][N] natural
+    const u64 *aux; size_t aux_stride;       // LDE of the auxiliary polys (may be null)
+    u32 log_n;            // trace degree
+    u32 qd_bits;          // quotient_degree_bits
+    u32 step_log;         // rate_bits - qd_bits : LDE row = point index << step_log
+    u32 log_lde;          // log2 of the LDE size N
+    const u64 *tw;        // w_size^k, k < size/2, size = n << qd_bits
+    u64 coset_shift;      // g
+    u64 w_n_inv;          // (primitive n-th root)^-1  ("last" of the subgroup)
+    u64 n_inv;            // 1/n
+    u64 g_pow_n;          // g^n
+    int n_challenges;
+    u64 alphas[ZK_MAX_CHALLENGES];
+    // lookups: program := n_lookups, off[n_lookups], then per lookup a helper program
+    const u64 *lookup_prog; u32 n_lookup_challenges; u64 lookup_challenges[ZK_MAX_CHALLENGES];
+    // ctl: program := n_zdata, off[n_zdata]; each := beta, gamma, n_helpers, helper program
+    const u64 *ctl_prog; u32 num_lookup_columns; u32 total_ctl_helper_cols;
+    u32 constraint_degree;
+    const u64 *air_consts;
+    u64 *out; size_t out_stride;  // [n_challenges][size] quotient VALUES on the coset
+};
+
+template <class Air>
+__global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs A) {
+    const u32 size_log = A.log_n + A.qd_bits;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> size_log) return;
+    const u32 size = 1u << size_log, half = size >> 1;
+    // x = g * w_size^i
+    u64 w = A.tw[i & (half - 1)];
+    if (i & half) w = gl_neg(w);
+    const Fe x(gl_mul(w, A.coset_shift));
+    // Z_H(x) = x^n - 1 = g^n * (w_size^n)^i - 1, and w_size^n has order 2^qd_bits
+    u64 wn = 1;
+    {
+        const u32 k = i & ((1u << A.qd_bits) - 1);      // exponent of the 2^qd_bits-th root
+        if (k) {                                        // w_size^(n*k) = tw[k * n mod size]
+            u32 idx = k << A.log_n;
+            u64 t = A.tw[idx & (half - 1)];
+            wn = (idx & half) ? gl_neg(t) : t;
+        }
+    }
+    const Fe zh = Fe(gl_mul(A.g_pow_n, wn)) - FE_ONE;
+    const Fe xm1 = x - FE_ONE, xml = x - Fe(A.w_n_inv);
+    // one shared inversion for 1/zh, 1/(x-1), 1/(x-last)   (x is never in H: all non-zero)
+    Fe p01 = zh * xm1, p012 = p01 * xml;
+    Fe inv(gl_inv(p012.v));
+    Fe inv_xml = inv * p01;
+    Fe inv01 = inv * xml;
+    Fe inv_xm1 = inv01 * zh, inv_zh = inv01 * xm1;
+    Consumer cons;
+    cons.nc = A.n_challenges;
+#pragma unroll
+    for (int k = 0; k < ZK_MAX_CHALLENGES; ++k) { cons.alpha[k] = A.alphas[k]; cons.acc[k] = 0; }
+    cons.z_last = xml;
+    const Fe zh_over_n = zh * Fe(A.n_inv);
+    cons.lagrange_first = zh_over_n * inv_xm1;                    // L_0(x)     = Z_H(x) / (n (x - 1))
+    cons.lagrange_last = zh_over_n * Fe(A.w_n_inv) * inv_xml;     // L_{n-1}(x) = w^-1 Z_H(x) / (n (x - w^-1))
+
+    const u32 row = i << A.step_log;
+    const u32 row_next = ((i + (1u << A.qd_bits)) & (size - 1)) << A.step_log;
+    RowView lv{A.trace, A.trace_stride, row}, nv{A.trace, A.trace_stride, row_next};
+    Air::eval(lv, nv, cons, A.air_consts);
+
+    RowView alv{A.aux, A.aux_stride, row}, anv{A.aux, A.aux_stride, row_next};
+    const u32 chunk = A.constraint_degree - 1;
+    // ---- starky eval_packed_lookups_generic ----
+    if (A.lookup_prog) {
+        const u64 *lp = A.lookup_prog;
+        const u32 n_lookups = (u32)lp[0];
+        u32 start = 0;
+        for (u32 l = 0; l < n_lookups; ++l) {
+            const u32 sub = (u32)lp[1 + l];
+            const u32 ne = (u32)lp[sub];
+            const u32 n_help = (ne + chunk - 1) / chunk + 1;
+            for (u32 c = 0; c < A.n_lookup_challenges; ++c) {
+                const u64 ch = A.lookup_challenges[c];
+                check_helper_columns(lp, sub, ne, chunk, lv, nv, alv, start, 1, ch, cons);
+                Fe z = alv[start + n_help - 1], next_z = anv[start + n_help - 1];
+                u32 pc = sub + (u32)lp[sub + 1 + ne];
+                Fe table = frame_eval_column(lp, pc, lv, nv, false) + Fe(ch);   // Column::eval: local row only
+                pc = sub + (u32)lp[sub + 2 + ne];
+                Fe freq = frame_eval_column(lp, pc, lv, nv, false);
+                Fe hs;
+                for (u32 h = 0; h + 1 < n_help; ++h) hs += alv[start + h];
+                Fe y = hs * table - freq;
+                cons.constraint_first_row(z);
+                cons.constraint((next_z - z) * table - y);
+                start += n_help;
+            }
+        }
+    }
+    // ---- starky eval_cross_table_lookup_checks ----
+    if (A.ctl_prog) {
+        const u64 *cp = A.ctl_prog;
+        const u32 n_z = (u32)cp[0];
+        u32 start_index = 0;
+        for (u32 zi = 0; zi < n_z; ++zi) {
+            const u32 off = (u32)cp[1 + zi];
+            const u64 beta = cp[off], gamma = cp[off + 1];
+            const u32 n_help = (u32)cp[off + 2];
+            const u32 sub = off + 3;
+            const u32 ne = (u32)cp[sub];
+            const u32 h0 = A.num_lookup_columns + start_index;
+            if (n_help) check_helper_columns(cp, sub, ne, chunk, lv, nv, alv, h0, beta, gamma, cons);
+            const u32 zcol = A.num_lookup_columns + A.total_ctl_helper_cols + zi;
+            Fe local_z = alv[zcol], next_z = anv[zcol];
+            if (n_help) {
+                Fe hs;
+                for (u32 h = 0; h < n_help; ++h) hs += alv[h0 + h];
+                cons.constraint_last_row(local_z - hs);
+                cons.constraint_transition(local_z - next_z - hs);
+            } else if (ne > 1) {
+                Fe c0, f0, c1, f1;
+                frame_eval_entry(cp, sub + (u32)cp[sub + 1], lv, nv, beta, gamma, c0, f0);
+                frame_eval_entry(cp, sub + (u32)cp[sub + 2], lv, nv, beta, gamma, c1, f1);
+                cons.constraint_last_row(c0 * c1 * local_z - f0 * c1 - f1 * c0);
+                cons.constraint_transition(c0 * c1 * (local_z - next_z) - f0 * c1 - f1 * c0);
+            } else {
+                Fe c0, f0;
+                frame_eval_entry(cp, sub + (u32)cp[sub + 1], lv, nv, beta, gamma, c0, f0);
+                cons.constraint_last_row(c0 * local_z - f0);
+                cons.constraint_transition(c0 * (local_z - next_z) - f0);
+            }
+            start_index += n_help;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < ZK_MAX_CHALLENGES; ++k)
+        if (k < A.n_challenges) A.out[(size_t)k * A.out_stride + i] = gl_canon(gl_mul(cons.acc[k], inv_zh.v));
+}
+
+// de-interleave the bit-reversed coefficients of a size-(n*Q) polynomial into its Q degree-n
+// chunks (chunk j = coefficients [j*n, (j+1)*n)): in bit-reversed order chunk j is the positions
+// p with (p mod Q) == bitrev(j, log Q), already in bit-reversed order of size n.
+__global__ void split_quotient_chunks_kernel(const u64 *__restrict__ coef, size_t coef_stride, u32 n_polys,
+                                             u32 log_n, u32 qd_bits, u64 *__restrict__ out, size_t out_stride) {
+    const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >> log_n) return;
+    const u32 Q = 1u << qd_bits;
+    for (u32 k = 0; k < n_polys; ++k)
+        for (u32 j = 0; j < Q; ++j) {
+            u32 jr = bitrev32(j, qd_bits);
+            out[(size_t)(k * Q + j) * out_stride + p] = coef[(size_t)k * coef_stride + ((size_t)p << qd_bits) + jr];
+        }
+}

@@ -21,6 +21,8 @@
 #include "ntt.cuh"
 #include "fri.cuh"
 #include "stark.cuh"
+#include "quotient.cuh"
+#include "airs.cuh"
 #include "host_hash.hpp"
 
 // ------------------------------------------------------------------------------------------
@@ -535,9 +537,11 @@ static int check_cfg(zk_ctx *ctx, const zk_cfg *cfg, size_t n_cols, unsigned log
     return ZK_OK;
 }
 
-// from_values when have_values, else from_coeffs (d_in = natural-order coefficients).
+// mode: values (from_values), natural-order coefficients (from_coeffs), or coefficients already in
+// the device's bit-reversed order (internal: quotient chunks).
+enum CommitMode { COMMIT_VALUES = 0, COMMIT_COEFFS = 1, COMMIT_COEFFS_BITREV = 2 };
 static int commit_impl(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t in_stride,
-                       size_t n_cols, unsigned log_n, bool have_values, zk_batch **out) {
+                       size_t n_cols, unsigned log_n, CommitMode mode, zk_batch **out) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ZK_TRY(check_abort(ctx));
     const size_t n = (size_t)1 << log_n;
@@ -566,12 +570,12 @@ static int commit_impl(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t i
     if ((rc = get_coset_table(ctx, log_n, GL_GENERATOR, false, &coset)) != ZK_OK) return fail(rc);
     // make sure table construction is not billed to a stage
     hipEventRecord(ctx->ev[0], ctx->stream);
-    if (have_values) {
+    if (mode == COMMIT_VALUES) {
         rc = ntt_values_to_coeffs(ctx, d_in, in_stride, b->d_coeffs, n, n_cols, log_n, nullptr);
     } else {
         B_HIP(hipMemcpy2DAsync(b->d_coeffs, n * 8, d_in, in_stride * 8, n * 8, n_cols,
                                hipMemcpyDeviceToDevice, ctx->stream));
-        rc = bitrev_columns(ctx, b->d_coeffs, n, n_cols, log_n);
+        if (mode == COMMIT_COEFFS) rc = bitrev_columns(ctx, b->d_coeffs, n, n_cols, log_n);
     }
     if (rc != ZK_OK) return fail(rc);
     hipEventRecord(ctx->ev[1], ctx->stream);
@@ -603,7 +607,7 @@ extern "C" int zk_commit_columns_device(zk_ctx *ctx, const zk_cfg *cfg, const ui
     ZK_TRY(check_cfg(ctx, cfg, n_cols, log_n));
     if (!d_values) return set_err(ctx, ZK_ERR_BAD_ARG, "null values");
     if (n_cols > 1 && col_stride < ((size_t)1 << log_n)) return set_err(ctx, ZK_ERR_BAD_ARG, "col_stride < n");
-    return commit_impl(ctx, cfg, (const u64 *)d_values, col_stride, n_cols, log_n, true, out);
+    return commit_impl(ctx, cfg, (const u64 *)d_values, col_stride, n_cols, log_n, COMMIT_VALUES, out);
 }
 
 extern "C" int zk_commit_coeffs_device(zk_ctx *ctx, const zk_cfg *cfg, const uint64_t *d_coeffs,
@@ -613,7 +617,7 @@ extern "C" int zk_commit_coeffs_device(zk_ctx *ctx, const zk_cfg *cfg, const uin
     ZK_TRY(check_cfg(ctx, cfg, n_cols, log_n));
     if (!d_coeffs) return set_err(ctx, ZK_ERR_BAD_ARG, "null coeffs");
     if (n_cols > 1 && col_stride < ((size_t)1 << log_n)) return set_err(ctx, ZK_ERR_BAD_ARG, "col_stride < n");
-    return commit_impl(ctx, cfg, (const u64 *)d_coeffs, col_stride, n_cols, log_n, false, out);
+    return commit_impl(ctx, cfg, (const u64 *)d_coeffs, col_stride, n_cols, log_n, COMMIT_COEFFS, out);
 }
 
 extern "C" int zk_commit_columns(zk_ctx *ctx, const zk_cfg *cfg, const uint64_t *const *cols,
@@ -632,7 +636,7 @@ extern "C" int zk_commit_columns(zk_ctx *ctx, const zk_cfg *cfg, const uint64_t 
         hipError_t e = hipMemcpyAsync(d_vals + c * n, cols[c], n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) { hipFree(d_vals); return set_err(ctx, ZK_ERR_HIP, "H2D copy failed: %s", hipGetErrorString(e)); }
     }
-    int rc = commit_impl(ctx, cfg, d_vals, n, n_cols, log_n, true, out);
+    int rc = commit_impl(ctx, cfg, d_vals, n, n_cols, log_n, COMMIT_VALUES, out);
     hipStreamSynchronize(ctx->stream);
     hipFree(d_vals);
     return rc;
@@ -708,3 +712,4 @@ extern "C" int zk_batch_merkle_path(const zk_batch *b, size_t leaf_index, uint64
 
 #include "fri_host.inc"
 #include "stark_host.inc"
+#include "quotient_host.inc"
