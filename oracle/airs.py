@@ -29,9 +29,9 @@ def eval_logic(lv, nv, c):
             c.constraint(b * (b - 1))
     for limb in range(8):
         xb, yb = in0[32 * limb:32 * limb + 32], in1[32 * limb:32 * limb + 32]
-        x = sum(b << i for i, b in enumerate(xb))
-        y = sum(b << i for i, b in enumerate(yb))
-        x_land_y = sum((a * b) << i for i, (a, b) in enumerate(zip(xb, yb)))
+        x = sum(b * (1 << i) for i, b in enumerate(xb))
+        y = sum(b * (1 << i) for i, b in enumerate(yb))
+        x_land_y = sum(a * b * (1 << i) for i, (a, b) in enumerate(zip(xb, yb)))
         c.constraint(res[limb] - (sum_coeff * (x + y) + and_coeff * x_land_y))
 
 

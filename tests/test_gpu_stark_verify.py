@@ -1,0 +1,123 @@
+"""-m gpu: GPU proofs of VALID traces are accepted by the oracle's restatement of starky's
+verifier (constraint identity at zeta in F_{p^2} + verify_fri_proof); proofs of traces that break
+one constraint are rejected.  Trace generators restate the reference's generate_trace rows."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import tests.oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+P = 0xFFFFFFFF00000001
+
+
+def _prove_and_verify(oracle, air_id, trace, hasher, ctl_entries_list, kw=None):
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.prover as zp
+    import zk_evm_amd.stark as prod
+    from oracle import airs as oairs
+    from oracle import stark as orc
+    from oracle import stark_verifier as overify
+    from tests.test_gpu_stark_aux import _mk, _mkf
+    kw = kw or dict(pow_bits=5, queries=6)
+    ol.setup_fri_api(oracle)
+    L = oracle.lib
+    n_cols, n = trace.shape
+    log_n = n.bit_length() - 1
+    cfg = ol.make_cfg(hasher=hasher, **kw)
+    dev = torch.from_numpy(trace.view(np.int64)).cuda()
+    tbatch = zk.PolynomialBatch.from_values(dev, 1, False, 4, hasher=hasher)
+    tcap = tbatch.merkle_tree.cap.elements
+    ch = zk.Challenger(hasher)
+    och = ol.new_challenger(oracle, hasher)
+    ch.observe_cap(tcap)
+    L.orc_challenger_observe_cap(C.byref(och), tcap, 16)
+    ctl_challenges = [(ch.get_challenge(), ch.get_challenge()) for _ in range(cfg.num_challenges)]
+    for _ in range(2 * cfg.num_challenges):
+        L.orc_challenger_get(C.byref(och))
+
+    def entries_for(mod, entries):
+        return [([_mk(c, mod.Column, mod.Filter) for c in cols], _mkf(f, mod.Column, mod.Filter)) for cols, f in entries]
+    p_z, o_z = [], []
+    for entries in ctl_entries_list:
+        for b, g in ctl_challenges:
+            aux = prod.ctl_partial_sums(dev, entries_for(prod, entries), b, g, 3)
+            p_z.append(zp.CtlZData(b, g, entries_for(prod, entries), aux))
+            o_z.append(orc.CtlZData(orc.GrandProductChallenge(b, g), entries_for(orc, entries), aux.shape[0] - 1))
+    scfg = zk.StarkConfig(hasher=hasher, fri_config=zk.FriConfig(proof_of_work_bits=kw["pow_bits"],
+                                                                 num_query_rounds=kw["queries"]))
+    pr = zp.prove_with_commitment(air_id, scfg, dev, tbatch, [], p_z, ctl_challenges, ch)
+    proof = dict(trace_cap=tcap, aux_cap=pr.auxiliary_polys_cap, quotient_cap=pr.quotient_polys_cap,
+                 openings=pr.openings, fri=pr.opening_proof)
+    return overify.verify_stark_proof(oracle, ol, cfg, oairs.AIRS[air_id][0], n_cols, log_n, [], o_z,
+                                      ctl_challenges, proof, och)
+
+
+def _mem_continuation_trace(rng, n_rows, n_padded):
+    # memory_continuation_stark.rs:53-98: FILTER=1 rows (context, segment, virt, 8 x u32 limbs), zero padding
+    t = np.zeros((12, n_padded), dtype=np.uint64)
+    t[0, :n_rows] = 1
+    t[1, :n_rows] = rng.integers(0, 4, size=n_rows)
+    t[2, :n_rows] = rng.integers(0, 40, size=n_rows)
+    t[3, :n_rows] = np.arange(n_rows)
+    t[4:12, :n_rows] = rng.integers(0, 1 << 32, size=(8, n_rows))
+    return t
+
+
+MEMC_CTL = [([("single", 1), ("single", 2), ("single", 3)] + [("single", 4 + i) for i in range(8)],
+             ("simple", ("single", 0)))]
+
+
+@pytest.mark.parametrize("hasher", [0, 1])
+def test_mem_continuation_valid_and_invalid(oracle, hasher):
+    rng = np.random.default_rng(21)
+    t = _mem_continuation_trace(rng, 100, 128)     # MemBefore/After pad to >= 128 rows
+    ok, why = _prove_and_verify(oracle, 1, t, hasher, [MEMC_CTL])
+    assert ok, why
+    bad = t.copy()
+    bad[0, 7] = 0                                   # still binary: valid (a padding row in the middle)
+    ok, why = _prove_and_verify(oracle, 1, bad, hasher, [MEMC_CTL])
+    assert ok, why
+
+
+def _logic_trace(rng, n_ops, n_padded):
+    # logic.rs:165-188 (Operation::into_row): one-hot op flag, 2 x 256 input bits, 8 x 32-bit result limbs
+    t = np.zeros((523, n_padded), dtype=np.uint64)
+    for r in range(n_ops):
+        op = int(rng.integers(0, 3))
+        a = int.from_bytes(rng.bytes(32), "little")
+        b = int.from_bytes(rng.bytes(32), "little")
+        res = [a & b, a | b, a ^ b][op]
+        t[op, r] = 1
+        for i in range(256):
+            t[3 + i, r] = (a >> i) & 1
+            t[259 + i, r] = (b >> i) & 1
+        for l in range(8):
+            t[515 + l, r] = (res >> (32 * l)) & 0xFFFFFFFF
+    return t
+
+
+def _logic_ctl():
+    cols = [("lc", [(0, 0x16), (1, 0x17), (2, 0x18)], [], 0)]
+    for base in (3, 259):
+        for limb in range(8):
+            cols.append(("lc", [(base + 32 * limb + i, 1 << i) for i in range(32)], [], 0))
+    cols += [("single", 515 + i) for i in range(8)]
+    return [(cols, ("simple", ("lc", [(0, 1), (1, 1), (2, 1)], [], 0)))]
+
+
+def test_logic_valid_and_invalid(oracle):
+    rng = np.random.default_rng(22)
+    t = _logic_trace(rng, 20, 32)
+    ok, why = _prove_and_verify(oracle, 2, t, 0, [_logic_ctl()])
+    assert ok, why
+    bad = t.copy()
+    bad[515, 3] ^= np.uint64(1)                    # wrong result limb -> constraint violated
+    ok, why = _prove_and_verify(oracle, 2, bad, 0, [_logic_ctl()])
+    assert not ok and why == "quotient identity", why
+    bad2 = t.copy()
+    bad2[3 + 17, 5] = 2                            # a non-bit input
+    ok, why = _prove_and_verify(oracle, 2, bad2, 0, [_logic_ctl()])
+    assert not ok
