@@ -222,6 +222,8 @@ typedef enum {
     ZK_AIR_NONE = 0,             /* no table constraints: lookup / CTL checks only (tests) */
     ZK_AIR_MEM_CONTINUATION = 1, /* MemBefore / MemAfter: memory_continuation_stark.rs:110-122 */
     ZK_AIR_LOGIC = 2,            /* logic.rs:249-303 */
+    ZK_AIR_MEMORY = 3,           /* memory/memory_stark.rs:474-626 */
+    ZK_AIR_BYTE_PACKING = 4,     /* byte_packing/byte_packing_stark.rs:296-352 */
 } zk_air;
 /* starky `compute_quotient_polys` + chunk split + `PolynomialBatch::from_coeffs`:
  * evaluates, on the coset of size n * quotient_degree_factor, the alpha-combination of

@@ -131,3 +131,38 @@ def test_logic_table(oracle):
         for k in range(3):
             trace[k] = (which == k).astype(np.uint64)
     _run_case(oracle, 2, 523, 5, 0, [], [ctl], seed=10, trace_fix=fix)
+
+
+def test_memory_table(oracle):
+    # lookups(): memory_stark.rs:858-885; CTL looked data: memory_stark.rs:35-60 (is_read, ctx, seg, virt, 8 limbs, ts)
+    lk1 = ([("single", 27), ("next", 6)], ("single", 28), ("single", 29),
+           [None, ("simple", ("lc", [(15, 1), (16, 1)], [], 0))])
+    lk2 = ([("lc", [(4, 1)], [], 1)], ("single", 21), ("single", 23), [("simple", ("single", 24))])
+    ctl = [([("single", 3), ("single", 4), ("single", 5), ("single", 6)] + [("single", 7 + i) for i in range(8)] +
+            [("single", 1)], ("simple", ("single", 0)))]
+
+    def fix(trace, rng):
+        n = trace.shape[1]
+        which = rng.integers(0, 3, size=n)
+        trace[15] = (which == 0).astype(np.uint64)
+        trace[16] = (which == 1).astype(np.uint64)
+        trace[24] = rng.integers(0, 2, size=n, dtype=np.uint64)
+        trace[0] = rng.integers(0, 2, size=n, dtype=np.uint64)
+    _run_case(oracle, 3, 30, 6, 0, [lk1, lk2], [ctl], seed=12, trace_fix=fix)
+
+
+def test_byte_packing_table(oracle):
+    # lookups(): byte_packing_stark.rs:426-437 (32 value bytes range-checked against range_counter)
+    lk = ([("single", 37 + i) for i in range(32)], ("single", 69), ("single", 70), [None] * 32)
+    # CTL looked side (ctl_looked_data, byte_packing_stark.rs:55-90): filter = sum of index_len
+    ctl = [([("single", 0), ("single", 33), ("single", 34), ("single", 35),
+             ("lc", [(1 + i, i + 1) for i in range(32)], [], 0), ("single", 36)] +
+            [("lc", [(37 + 4 * l + k, 1 << (8 * k)) for k in range(4)], [], 0) for l in range(8)],
+            ("simple", ("lc", [(1 + i, 1) for i in range(32)], [], 0)))]
+
+    def fix(trace, rng):
+        n = trace.shape[1]
+        which = rng.integers(0, 33, size=n)
+        for i in range(32):
+            trace[1 + i] = (which == i).astype(np.uint64)
+    _run_case(oracle, 4, 71, 5, 0, [lk], [ctl], seed=13, trace_fix=fix)
