@@ -102,3 +102,213 @@ def eval_byte_packing(lv, nv, c):
 
 
 AIRS.update({3: (eval_memory, 30), 4: (eval_byte_packing, 71)})
+
+
+# ---- ArithmeticStark -----------------------------------------------------------------------------
+# evm_arithmetization/src/arithmetic/{arithmetic_stark.rs:203-252, mul.rs:123-185, addcy.rs:98-172,
+# divmod.rs:86-145, modular.rs:382-612, byte.rs:201-296, shift.rs:85-128, utils.rs, columns.rs}
+N_LIMBS = 16
+A_IS = dict(ADD=0, MUL=1, SUB=2, DIV=3, MOD=4, ADDMOD=5, MULMOD=6, ADDFP254=7, MULFP254=8, SUBFP254=9,
+            SUBMOD=10, LT=11, GT=12, BYTE=13, SHL=14, SHR=15, RANGE_CHECK=16)
+A_OPCODE = 17
+A_IN0, A_IN1, A_IN2, A_OUT, A_AUX0, A_AUX1 = 18, 34, 50, 66, 82, 98
+A_RANGE_COUNTER, A_RC_FREQ = 114, 115
+A_BASE = 1 << 16
+A_OFFSET = 1 << 20          # AUX_COEFF_ABS_MAX
+A_OVERFLOW_INV = 18446462594437939201   # GOLDILOCKS_INVERSE_65536 (addcy.rs:67)
+BN_BASE = [0x3c208c16d87cfd47, 0x97816a916871ca8d, 0xb85045b68181585d, 0x30644e72e131a029]
+BN254_LIMBS = [(BN_BASE[i // 4] >> (16 * (i % 4))) & 0xFFFF for i in range(16)]
+
+
+def _rd(v, start, n=N_LIMBS):
+    return list(v[start:start + n])
+
+
+def _pol_adjoin_root(a, root):
+    res = [(-root) * a[0]]
+    for d in range(1, len(a)):
+        res.append(a[d - 1] - root * a[d])
+    return res
+
+
+def _arith_addcy(c, filt, x, y, z, given_cy, two_row):
+    cy = 0
+    for xi, yi, zi in zip(x, y, z):
+        t = cy + xi + yi - zi
+        (c.constraint_transition if two_row else c.constraint)(filt * t * (A_BASE - t))
+        cy = t * A_OVERFLOW_INV
+    if two_row:
+        c.constraint_transition(filt * (cy - given_cy[0]))
+        for i in range(1, N_LIMBS):
+            c.constraint_transition(filt * given_cy[i])
+    else:
+        c.constraint(filt * given_cy[0] * (given_cy[0] - 1))
+        c.constraint(filt * (cy - given_cy[0]))
+        for i in range(1, N_LIMBS):
+            c.constraint(filt * given_cy[i])
+
+
+def _arith_mul(lv, c, filt, left, right):
+    out = _rd(lv, A_OUT)
+    aux = [lv[A_AUX0 + i] + lv[A_AUX1 + i] * A_BASE - A_OFFSET for i in range(N_LIMBS)]
+    cp = [sum(left[i] * right[d - i] for i in range(d + 1)) for d in range(N_LIMBS)]   # pol_mul_lo
+    cp = [a - b for a, b in zip(cp, out)]
+    adj = _pol_adjoin_root(aux, A_BASE)
+    cp = [a - b for a, b in zip(cp, adj)]
+    for x in cp:
+        c.constraint(filt * x)
+
+
+def _modular_constr_poly(lv, nv, c, filt, output, modulus, quot):
+    output, modulus = list(output), list(modulus)
+    mod_is_zero = nv[34]
+    c.constraint_transition(filt * (mod_is_zero * mod_is_zero - mod_is_zero))
+    limb_sum = sum(modulus)
+    c.constraint_transition(filt * limb_sum * mod_is_zero)
+    modulus[0] = modulus[0] + mod_is_zero
+    div_denom_is_zero = nv[97]
+    c.constraint_transition(filt * (mod_is_zero * (lv[A_IS["DIV"]] + lv[A_IS["SHR"]]) - div_denom_is_zero))
+    output[0] = output[0] + div_denom_is_zero
+    # check_reduced
+    is_less_than = [0] * N_LIMBS
+    is_less_than[0] = 1 - mod_is_zero * (lv[A_IS["DIV"]] + lv[A_IS["SHR"]])
+    _arith_addcy(c, filt, modulus, _rd(nv, 18), output, is_less_than, True)
+    output[0] = output[0] - div_denom_is_zero
+    prod = [0] * (3 * N_LIMBS - 1)                           # pol_mul_wide2(quot, modulus)
+    for i, ai in enumerate(quot):
+        for j, bj in enumerate(modulus):
+            prod[i + j] = prod[i + j] + ai * bj
+    for x in prod[2 * N_LIMBS:]:
+        c.constraint_transition(filt * x)
+    cp = prod[:2 * N_LIMBS]
+    for i in range(N_LIMBS):
+        cp[i] = cp[i] + output[i]
+    aux = [0] * (2 * N_LIMBS)
+    for i in range(2 * N_LIMBS - 1):
+        aux[i] = nv[35 + i] - A_OFFSET                       # MODULAR_AUX_INPUT_LO = 35..66
+    for i in range(2 * N_LIMBS - 1):
+        aux[i] = aux[i] + A_BASE * nv[66 + i]                # MODULAR_AUX_INPUT_HI = 66..97
+    adj = _pol_adjoin_root(aux, A_BASE)
+    return [a + b for a, b in zip(cp, adj)]
+
+
+def _submod_constr_poly(lv, nv, c, filt, output, modulus, quot):
+    quot = list(quot)
+    sign = quot[N_LIMBS]
+    c.constraint(filt * sign * (sign - 1))
+    for i in range(N_LIMBS):
+        quot[i] = quot[i] - 0xFFFF * sign
+    quot[N_LIMBS] = 0
+    for d in quot[N_LIMBS:]:
+        c.constraint(filt * d)
+    return _modular_constr_poly(lv, nv, c, filt, output, modulus, quot)
+
+
+def _arith_divmod_helper(lv, nv, c, filt, num_s, den_s, quo_s, rem_s):
+    c.constraint_last_row(filt)
+    num = _rd(lv, num_s)
+    den = _rd(lv, den_s)
+    quo = _rd(lv, quo_s) + [0] * N_LIMBS
+    rem = _rd(lv, rem_s)
+    cp = _modular_constr_poly(lv, nv, c, filt, rem, den, quo)
+    for i in range(N_LIMBS):
+        cp[i] = cp[i] - num[i]
+    for x in cp:
+        c.constraint_transition(filt * x)
+
+
+def eval_arithmetic(lv, nv, c):
+    # arithmetic_stark.rs:203-252
+    for f in range(17):
+        c.constraint(lv[f] * (lv[f] - 1))
+    all_flags = sum(lv[0:17])
+    c.constraint(all_flags * (all_flags - 1))
+    c.constraint((1 - lv[A_IS["RANGE_CHECK"]]) * lv[A_OPCODE])
+    rc1, rc2 = lv[A_RANGE_COUNTER], nv[A_RANGE_COUNTER]
+    c.constraint_first_row(rc1)
+    incr = rc2 - rc1
+    c.constraint_transition(incr * incr - incr)
+    c.constraint_last_row(rc1 - 65535)
+    # mul.rs:177-185
+    _arith_mul(lv, c, lv[A_IS["MUL"]], _rd(lv, A_IN0), _rd(lv, A_IN1))
+    # addcy.rs:153-172
+    in0, in1, out, aux = _rd(lv, A_IN0), _rd(lv, A_IN1), _rd(lv, A_OUT), _rd(lv, A_AUX0)
+    _arith_addcy(c, lv[A_IS["ADD"]], in0, in1, out, aux, False)
+    _arith_addcy(c, lv[A_IS["SUB"]], in1, out, in0, aux, False)
+    _arith_addcy(c, lv[A_IS["LT"]], in1, aux, in0, out, False)
+    _arith_addcy(c, lv[A_IS["GT"]], in0, aux, in1, out, False)
+    # divmod.rs:118-145
+    _arith_divmod_helper(lv, nv, c, lv[A_IS["DIV"]], A_IN0, A_IN1, A_OUT, A_AUX0)
+    _arith_divmod_helper(lv, nv, c, lv[A_IS["MOD"]], A_IN0, A_IN1, A_AUX0, A_OUT)
+    # modular.rs:542-612
+    bn = lv[A_IS["ADDFP254"]] + lv[A_IS["MULFP254"]] + lv[A_IS["SUBFP254"]]
+    filt = lv[A_IS["ADDMOD"]] + lv[A_IS["SUBMOD"]] + lv[A_IS["MULMOD"]] + bn
+    c.constraint_last_row(filt)
+    modulus = _rd(lv, A_IN2)
+    for mi, bi in zip(modulus, BN254_LIMBS):
+        c.constraint_transition(bn * (mi - bi))
+    output = _rd(lv, A_OUT)
+    quo_input = _rd(lv, A_AUX0, 2 * N_LIMBS)
+    add_f = lv[A_IS["ADDMOD"]] + lv[A_IS["ADDFP254"]]
+    sub_f = lv[A_IS["SUBMOD"]] + lv[A_IS["SUBFP254"]]
+    mul_f = lv[A_IS["MULMOD"]] + lv[A_IS["MULFP254"]]
+    sub_cp = _submod_constr_poly(lv, nv, c, sub_f, output, modulus, quo_input)
+    mod_cp = _modular_constr_poly(lv, nv, c, add_f + mul_f, output, modulus, quo_input)
+    i0, i1 = _rd(lv, A_IN0), _rd(lv, A_IN1)
+    add_in = [a + b for a, b in zip(i0, i1)] + [0] * (N_LIMBS - 1)
+    sub_in = [a - b for a, b in zip(i0, i1)] + [0] * (N_LIMBS - 1)
+    mul_in = [0] * (2 * N_LIMBS - 1)
+    for i, ai in enumerate(i0):
+        for j, bj in enumerate(i1):
+            mul_in[i + j] = mul_in[i + j] + ai * bj
+    for inp, f, cp in ((add_in, add_f, mod_cp), (sub_in, sub_f, sub_cp), (mul_in, mul_f, mod_cp)):
+        cpc = list(cp)
+        for i in range(2 * N_LIMBS - 1):
+            cpc[i] = cpc[i] - inp[i]
+        for x in cpc:
+            c.constraint_transition(f * x)
+    # byte.rs:201-296
+    is_byte = lv[A_IS["BYTE"]]
+    idx, val, outb = _rd(lv, A_IN0), _rd(lv, A_IN1), _rd(lv, A_OUT)
+    dec, tree = _rd(lv, A_AUX0), _rd(lv, A_AUX1)
+    idx0_lo5 = 0
+    for i in range(5):
+        bit = dec[i]
+        c.constraint(is_byte * (bit * bit - bit))
+        idx0_lo5 = idx0_lo5 + bit * (1 << i)
+    idx0_hi = dec[5] * 32
+    c.constraint(is_byte * (idx[0] - (idx0_lo5 + idx0_hi)))
+    bit = dec[4]
+    for i in range(8):
+        c.constraint(is_byte * (tree[i] - (bit * val[i] + (1 - bit) * val[i + 8])))
+    bit = dec[3]
+    for i in range(4):
+        c.constraint(is_byte * (tree[i + 8] - (bit * tree[i] + (1 - bit) * tree[i + 4])))
+    bit = dec[2]
+    for i in range(2):
+        c.constraint(is_byte * (tree[i + 12] - (bit * tree[i + 8] + (1 - bit) * tree[i + 10])))
+    bit = dec[1]
+    limb = bit * tree[12] + (1 - bit) * tree[13]
+    c.constraint(is_byte * (tree[14] - limb))
+    base8 = 256
+    lo_byte, hi_byte = lv[88], lv[89]
+    c.constraint(is_byte * (lo_byte + base8 * (base8 * hi_byte - limb)))
+    bit = dec[0]
+    t = bit * lo_byte + (1 - bit) * base8 * hi_byte
+    c.constraint(is_byte * (base8 * tree[15] - t))
+    expected = tree[15]
+    hi_limb_sum = lv[87] + sum(idx[1:])
+    idx_is_large = lv[90]
+    c.constraint(is_byte * (idx_is_large * idx_is_large - idx_is_large))
+    c.constraint(is_byte * hi_limb_sum * (idx_is_large - 1))
+    hi_inv = lv[91] + lv[92] * (1 << 16) + lv[93] * (1 << 32) + lv[94] * (1 << 48)
+    c.constraint(is_byte * (hi_limb_sum * hi_inv - idx_is_large))
+    c.constraint(is_byte * (outb[0] - (1 - idx_is_large) * expected))
+    for i in range(1, N_LIMBS):
+        c.constraint(is_byte * outb[i])
+    # shift.rs:85-128
+    _arith_mul(lv, c, lv[A_IS["SHL"]], _rd(lv, A_IN1), _rd(lv, A_IN2))
+    _arith_divmod_helper(lv, nv, c, lv[A_IS["SHR"]], A_IN1, A_IN2, A_OUT, A_AUX0)
+
+
+AIRS.update({5: (eval_arithmetic, 116)})

@@ -166,3 +166,20 @@ def test_byte_packing_table(oracle):
         for i in range(32):
             trace[1 + i] = (which == i).astype(np.uint64)
     _run_case(oracle, 4, 71, 5, 0, [lk], [ctl], seed=13, trace_fix=fix)
+
+
+def test_arithmetic_table(oracle):
+    # lookups(): arithmetic_stark.rs:320-327 (96 shared columns range-checked against RANGE_COUNTER);
+    # CTL looked side: arithmetic_stark.rs:33-117 (opcode + 4 registers packed as x + 2^16 y limb pairs)
+    lk = ([("single", 18 + i) for i in range(96)], ("single", 114), ("single", 115), [None] * 96)
+    cols = [("single", 17)]
+    for reg in (18, 34, 50, 66):
+        cols += [("lc", [(reg + 2 * k, 1), (reg + 2 * k + 1, 1 << 16)], [], 0) for k in range(8)]
+    ctl = [(cols, ("simple", ("lc", [(i, 1) for i in range(17)], [], 0)))]
+
+    def fix(trace, rng):
+        n = trace.shape[1]
+        which = rng.integers(0, 18, size=n)
+        for i in range(17):
+            trace[i] = (which == i).astype(np.uint64)
+    _run_case(oracle, 5, 116, 5, 0, [lk], [ctl], seed=14, trace_fix=fix)

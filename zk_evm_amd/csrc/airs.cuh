@@ -138,3 +138,220 @@ struct AirBytePacking {
         }
     }
 };
+
+// ArithmeticStark: arithmetic/arithmetic_stark.rs:203-252 and its operation modules
+// (mul.rs:123-185, addcy.rs:98-172, divmod.rs:86-145, modular.rs:382-612, byte.rs:201-296,
+// shift.rs:85-128, polynomial helpers utils.rs), columns arithmetic/columns.rs:24-120.
+// 116 columns: op flags 0..16, OPCODE 17, six 16-limb registers 18..113, RANGE_COUNTER 114,
+// RC_FREQUENCIES 115.  Constraints are yielded in exactly the reference's order.
+struct AirArithmetic {
+    static constexpr u32 COLUMNS = 116;
+    static constexpr u32 NL = 16;
+    enum { IS_ADD = 0, IS_MUL, IS_SUB, IS_DIV, IS_MOD, IS_ADDMOD, IS_MULMOD, IS_ADDFP254, IS_MULFP254,
+           IS_SUBFP254, IS_SUBMOD, IS_LT, IS_GT, IS_BYTE, IS_SHL, IS_SHR, IS_RANGE_CHECK, OPCODE_COL };
+    enum { IN0 = 18, IN1 = 34, IN2 = 50, OUT = 66, AUX0 = 82, AUX1 = 98, RANGE_COUNTER = 114 };
+    static constexpr u64 BASE = 1ULL << 16, OFFSET = 1ULL << 20;
+    static constexpr u64 OVERFLOW_INV = 18446462594437939201ULL;  // 2^-16 (addcy.rs:67)
+
+    __device__ static __forceinline__ void rd(const RowView &v, u32 start, Fe *out, u32 n = NL) {
+        for (u32 i = 0; i < n; ++i) out[i] = v[start + i];
+    }
+
+    // addcy.rs:98-151
+    __device__ static void addcy(Consumer &c, Fe filt, const Fe *x, const Fe *y, const Fe *z, const Fe *given_cy,
+                                 bool two_row) {
+        Fe cy;
+        for (u32 i = 0; i < NL; ++i) {
+            Fe t = cy + x[i] + y[i] - z[i];
+            Fe v = filt * t * (fe(BASE) - t);
+            if (two_row) c.constraint_transition(v); else c.constraint(v);
+            cy = t * fe(OVERFLOW_INV);
+        }
+        if (two_row) {
+            c.constraint_transition(filt * (cy - given_cy[0]));
+            for (u32 i = 1; i < NL; ++i) c.constraint_transition(filt * given_cy[i]);
+        } else {
+            c.constraint(filt * given_cy[0] * (given_cy[0] - FE_ONE));
+            c.constraint(filt * (cy - given_cy[0]));
+            for (u32 i = 1; i < NL; ++i) c.constraint(filt * given_cy[i]);
+        }
+    }
+
+    // mul.rs:123-173 (eval_packed_generic_mul)
+    __device__ static void mul(const RowView &lv, Consumer &c, Fe filt, const Fe *left, const Fe *right) {
+        for (u32 d = 0; d < NL; ++d) {
+            Fe cp;                                                     // pol_mul_lo
+            for (u32 i = 0; i <= d; ++i) cp += left[i] * right[d - i];
+            cp -= lv[OUT + d];
+            // (x - beta) * s(x), s = aux limbs with the 2^20 offset undone
+            Fe aux_d = lv[AUX0 + d] + lv[AUX1 + d] * fe(BASE) - fe(OFFSET);
+            Fe adj;
+            if (d == 0) adj = -(fe(BASE) * aux_d);
+            else {
+                Fe aux_p = lv[AUX0 + d - 1] + lv[AUX1 + d - 1] * fe(BASE) - fe(OFFSET);
+                adj = aux_p - fe(BASE) * aux_d;
+            }
+            cp -= adj;
+            c.constraint(filt * cp);
+        }
+    }
+
+    // modular.rs:419-501 (modular_constr_poly incl. check_reduced); cp_out has 2*NL entries
+    __device__ static void modular_constr_poly(const RowView &lv, const RowView &nv, Consumer &c, Fe filt,
+                                               const Fe *output_in, const Fe *modulus_in, const Fe *quot, Fe *cp) {
+        Fe output[NL], modulus[NL];
+        for (u32 i = 0; i < NL; ++i) { output[i] = output_in[i]; modulus[i] = modulus_in[i]; }
+        Fe mod_is_zero = nv[34];                                        // MODULAR_MOD_IS_ZERO
+        c.constraint_transition(filt * (mod_is_zero * mod_is_zero - mod_is_zero));
+        Fe limb_sum;
+        for (u32 i = 0; i < NL; ++i) limb_sum += modulus[i];
+        c.constraint_transition(filt * limb_sum * mod_is_zero);
+        modulus[0] += mod_is_zero;
+        Fe div_denom_is_zero = nv[97];                                  // MODULAR_DIV_DENOM_IS_ZERO
+        Fe div_or_shr = lv[IS_DIV] + lv[IS_SHR];
+        c.constraint_transition(filt * (mod_is_zero * div_or_shr - div_denom_is_zero));
+        output[0] += div_denom_is_zero;
+        {   // check_reduced (modular.rs:382-414)
+            Fe out_aux_red[NL], is_less_than[NL];
+            rd(nv, 18, out_aux_red);                                    // MODULAR_OUT_AUX_RED in nv
+            is_less_than[0] = FE_ONE - mod_is_zero * div_or_shr;
+            addcy(c, filt, modulus, out_aux_red, output, is_less_than, true);
+        }
+        output[0] -= div_denom_is_zero;
+        // prod = q(x) * m(x)  (pol_mul_wide2): degrees 0 .. 3*NL-2; the top NL-1 must vanish
+        for (u32 d = 2 * NL; d < 3 * NL - 1; ++d) {
+            Fe p;
+            for (u32 j = 0; j < NL; ++j) { u32 i = d - j; if (i < 2 * NL) p += quot[i] * modulus[j]; }
+            c.constraint_transition(filt * p);
+        }
+        for (u32 d = 0; d < 2 * NL; ++d) {
+            Fe p;
+            for (u32 j = 0; j < NL && j <= d; ++j) p += quot[d - j] * modulus[j];
+            if (d < NL) p += output[d];
+            // + (x - beta) * s(x): aux[i] = nv[35+i] - 2^20 + 2^16 * nv[66+i] (i < 31), aux[31] = 0
+            Fe aux_d = d < 2 * NL - 1 ? nv[35 + d] - fe(OFFSET) + fe(BASE) * nv[66 + d] : Fe();
+            Fe adj;
+            if (d == 0) adj = -(fe(BASE) * aux_d);
+            else {
+                Fe aux_p = nv[35 + d - 1] - fe(OFFSET) + fe(BASE) * nv[66 + d - 1];
+                adj = aux_p - fe(BASE) * aux_d;
+            }
+            cp[d] = p + adj;
+        }
+    }
+
+    // divmod.rs:86-116 (eval_packed_divmod_helper)
+    __device__ static void divmod_helper(const RowView &lv, const RowView &nv, Consumer &c, Fe filt, u32 num_s,
+                                         u32 den_s, u32 quo_s, u32 rem_s) {
+        c.constraint_last_row(filt);
+        Fe den[NL], quo[2 * NL], rem[NL], cp[2 * NL];
+        rd(lv, den_s, den);
+        rd(lv, quo_s, quo);
+        for (u32 i = NL; i < 2 * NL; ++i) quo[i] = Fe();
+        rd(lv, rem_s, rem);
+        modular_constr_poly(lv, nv, c, filt, rem, den, quo, cp);
+        for (u32 i = 0; i < 2 * NL; ++i) {
+            Fe v = i < NL ? cp[i] - lv[num_s + i] : cp[i];
+            c.constraint_transition(filt * v);
+        }
+    }
+
+    __device__ static void eval(const RowView &lv, const RowView &nv, Consumer &c, const u64 *) {
+        const Fe one = FE_ONE;
+        Fe all_flags;
+        for (u32 f = 0; f <= IS_RANGE_CHECK; ++f) { Fe fl = lv[f]; c.constraint(fl * (fl - one)); all_flags += fl; }
+        c.constraint(all_flags * (all_flags - one));
+        c.constraint((one - lv[IS_RANGE_CHECK]) * lv[OPCODE_COL]);
+        Fe rc1 = lv[RANGE_COUNTER], rc2 = nv[RANGE_COUNTER];
+        c.constraint_first_row(rc1);
+        Fe incr = rc2 - rc1;
+        c.constraint_transition(incr * incr - incr);
+        c.constraint_last_row(rc1 - fe(65535));
+        Fe in0[NL], in1[NL], in2[NL], out[NL], aux[NL];
+        rd(lv, IN0, in0); rd(lv, IN1, in1); rd(lv, IN2, in2); rd(lv, OUT, out); rd(lv, AUX0, aux);
+        mul(lv, c, lv[IS_MUL], in0, in1);
+        addcy(c, lv[IS_ADD], in0, in1, out, aux, false);
+        addcy(c, lv[IS_SUB], in1, out, in0, aux, false);
+        addcy(c, lv[IS_LT], in1, aux, in0, out, false);
+        addcy(c, lv[IS_GT], in0, aux, in1, out, false);
+        divmod_helper(lv, nv, c, lv[IS_DIV], IN0, IN1, OUT, AUX0);
+        divmod_helper(lv, nv, c, lv[IS_MOD], IN0, IN1, AUX0, OUT);
+        {   // modular.rs:542-612
+            // BN254 base-field modulus, 16-bit limbs (extension_tower.rs:25-30)
+            constexpr u64 BN[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+            Fe bn = lv[IS_ADDFP254] + lv[IS_MULFP254] + lv[IS_SUBFP254];
+            Fe filt = lv[IS_ADDMOD] + lv[IS_SUBMOD] + lv[IS_MULMOD] + bn;
+            c.constraint_last_row(filt);
+            for (u32 i = 0; i < NL; ++i) c.constraint_transition(bn * (in2[i] - fe((BN[i / 4] >> (16 * (i % 4))) & 0xFFFF)));
+            Fe quo_input[2 * NL];
+            rd(lv, AUX0, quo_input, 2 * NL);
+            Fe add_f = lv[IS_ADDMOD] + lv[IS_ADDFP254], sub_f = lv[IS_SUBMOD] + lv[IS_SUBFP254];
+            Fe mul_f = lv[IS_MULMOD] + lv[IS_MULFP254];
+            Fe sub_cp[2 * NL], mod_cp[2 * NL];
+            {   // submod_constr_poly (modular.rs:515-539)
+                Fe q[2 * NL];
+                Fe sign = quo_input[NL];
+                c.constraint(sub_f * sign * (sign - one));
+                for (u32 i = 0; i < NL; ++i) q[i] = quo_input[i] - fe(0xFFFF) * sign;
+                q[NL] = Fe();
+                for (u32 i = NL + 1; i < 2 * NL; ++i) q[i] = quo_input[i];
+                for (u32 i = NL; i < 2 * NL; ++i) c.constraint(sub_f * q[i]);
+                modular_constr_poly(lv, nv, c, sub_f, out, in2, q, sub_cp);
+            }
+            modular_constr_poly(lv, nv, c, add_f + mul_f, out, in2, quo_input, mod_cp);
+            for (u32 d = 0; d < 2 * NL; ++d)                      // add: input0 + input1
+                c.constraint_transition(add_f * (d < NL ? mod_cp[d] - (in0[d] + in1[d]) : mod_cp[d]));
+            for (u32 d = 0; d < 2 * NL; ++d)                      // sub: input0 - input1
+                c.constraint_transition(sub_f * (d < NL ? sub_cp[d] - (in0[d] - in1[d]) : sub_cp[d]));
+            for (u32 d = 0; d < 2 * NL; ++d) {                    // mul: pol_mul_wide(input0, input1)
+                Fe v = mod_cp[d];
+                if (d < 2 * NL - 1) {
+                    Fe p;
+                    for (u32 i = 0; i < NL; ++i) { u32 j = d - i; if (j < NL) p += in0[i] * in1[j]; }
+                    v -= p;
+                }
+                c.constraint_transition(mul_f * v);
+            }
+        }
+        {   // byte.rs:201-296
+            Fe is_byte = lv[IS_BYTE];
+            Fe tree[NL];
+            rd(lv, AUX1, tree);
+            Fe idx0_lo5;
+            for (u32 i = 0; i < 5; ++i) {
+                Fe bit = aux[i];
+                c.constraint(is_byte * (bit * bit - bit));
+                idx0_lo5 += bit * fe(1ULL << i);
+            }
+            Fe idx0_hi = aux[5] * fe(32);
+            c.constraint(is_byte * (in0[0] - (idx0_lo5 + idx0_hi)));
+            Fe bit = aux[4];
+            for (u32 i = 0; i < 8; ++i) c.constraint(is_byte * (tree[i] - (bit * in1[i] + (one - bit) * in1[i + 8])));
+            bit = aux[3];
+            for (u32 i = 0; i < 4; ++i) c.constraint(is_byte * (tree[i + 8] - (bit * tree[i] + (one - bit) * tree[i + 4])));
+            bit = aux[2];
+            for (u32 i = 0; i < 2; ++i) c.constraint(is_byte * (tree[i + 12] - (bit * tree[i + 8] + (one - bit) * tree[i + 10])));
+            bit = aux[1];
+            Fe limb = bit * tree[12] + (one - bit) * tree[13];
+            c.constraint(is_byte * (tree[14] - limb));
+            const Fe base8 = fe(256);
+            Fe lo_byte = lv[88], hi_byte = lv[89];
+            c.constraint(is_byte * (lo_byte + base8 * (base8 * hi_byte - limb)));
+            bit = aux[0];
+            Fe t = bit * lo_byte + (one - bit) * base8 * hi_byte;
+            c.constraint(is_byte * (base8 * tree[15] - t));
+            Fe hi_limb_sum = lv[87];
+            for (u32 i = 1; i < NL; ++i) hi_limb_sum += in0[i];
+            Fe idx_is_large = lv[90];
+            c.constraint(is_byte * (idx_is_large * idx_is_large - idx_is_large));
+            c.constraint(is_byte * hi_limb_sum * (idx_is_large - one));
+            Fe hi_inv = lv[91] + lv[92] * fe(1ULL << 16) + lv[93] * fe(1ULL << 32) + lv[94] * fe(1ULL << 48);
+            c.constraint(is_byte * (hi_limb_sum * hi_inv - idx_is_large));
+            c.constraint(is_byte * (out[0] - (one - idx_is_large) * tree[15]));
+            for (u32 i = 1; i < NL; ++i) c.constraint(is_byte * out[i]);
+        }
+        // shift.rs:85-128: SHL = MUL on (IN1, IN2); SHR = DIV helper on (IN1, IN2, OUT, AUX0)
+        mul(lv, c, lv[IS_SHL], in1, in2);
+        divmod_helper(lv, nv, c, lv[IS_SHR], IN1, IN2, OUT, AUX0);
+    }
+};

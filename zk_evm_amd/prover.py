@@ -16,7 +16,7 @@ from .fri import fri_openings, prove_openings, stark_fri_instance
 from .polynomial_batch import PolynomialBatch
 from .stark import Column, Filter, Lookup, ctl_partial_sums, encode_program, lookup_helper_columns
 
-AIR_NONE, AIR_MEM_CONTINUATION, AIR_LOGIC, AIR_MEMORY, AIR_BYTE_PACKING = 0, 1, 2, 3, 4
+AIR_NONE, AIR_MEM_CONTINUATION, AIR_LOGIC, AIR_MEMORY, AIR_BYTE_PACKING, AIR_ARITHMETIC = 0, 1, 2, 3, 4, 5
 P = 0xFFFFFFFF00000001
 
 
