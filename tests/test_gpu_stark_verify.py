@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 P = 0xFFFFFFFF00000001
 
 
-def _prove_and_verify(oracle, air_id, trace, hasher, ctl_entries_list, kw=None):
+def _prove_and_verify(oracle, air_id, trace, hasher, ctl_entries_list, kw=None, lookup_spec=()):
     import torch
     import zk_evm_amd as zk
     import zk_evm_amd.prover as zp
@@ -46,12 +46,16 @@ def _prove_and_verify(oracle, air_id, trace, hasher, ctl_entries_list, kw=None):
             aux = prod.ctl_partial_sums(dev, entries_for(prod, entries), b, g, 3)
             p_z.append(zp.CtlZData(b, g, entries_for(prod, entries), aux))
             o_z.append(orc.CtlZData(orc.GrandProductChallenge(b, g), entries_for(orc, entries), aux.shape[0] - 1))
+    def lookups_for(mod):
+        return [mod.Lookup([_mk(c, mod.Column, mod.Filter) for c in cols], _mk(table, mod.Column, mod.Filter),
+                           _mk(freq, mod.Column, mod.Filter), [_mkf(f, mod.Column, mod.Filter) for f in filts])
+                for cols, table, freq, filts in lookup_spec]
     scfg = zk.StarkConfig(hasher=hasher, fri_config=zk.FriConfig(proof_of_work_bits=kw["pow_bits"],
                                                                  num_query_rounds=kw["queries"]))
-    pr = zp.prove_with_commitment(air_id, scfg, dev, tbatch, [], p_z, ctl_challenges, ch)
+    pr = zp.prove_with_commitment(air_id, scfg, dev, tbatch, lookups_for(prod), p_z, ctl_challenges, ch)
     proof = dict(trace_cap=tcap, aux_cap=pr.auxiliary_polys_cap, quotient_cap=pr.quotient_polys_cap,
                  openings=pr.openings, fri=pr.opening_proof)
-    return overify.verify_stark_proof(oracle, ol, cfg, oairs.AIRS[air_id][0], n_cols, log_n, [], o_z,
+    return overify.verify_stark_proof(oracle, ol, cfg, oairs.AIRS[air_id][0], n_cols, log_n, lookups_for(orc), o_z,
                                       ctl_challenges, proof, och)
 
 
@@ -121,3 +125,62 @@ def test_logic_valid_and_invalid(oracle):
     bad2[3 + 17, 5] = 2                            # a non-bit input
     ok, why = _prove_and_verify(oracle, 2, bad2, 0, [_logic_ctl()])
     assert not ok
+
+
+def _arith_trace(rng, n_ops):
+    """ADD / SUB / LT / GT rows (arithmetic/addcy.rs:31-65), range-check rows (arithmetic/mod.rs:343-359),
+    zero padding to 2^16 rows and the RANGE_COUNTER / RC_FREQUENCIES columns
+    (arithmetic_stark.rs:130-156)."""
+    n = 1 << 16
+    t = np.zeros((116, n), dtype=np.uint64)
+    M = (1 << 256) - 1
+
+    def put(r, start, x):
+        for i in range(16):
+            t[start + i, r] = (x >> (16 * i)) & 0xFFFF
+    for r in range(n_ops):
+        a = int.from_bytes(rng.bytes(32), "little")
+        b = int.from_bytes(rng.bytes(32), "little")
+        kind = int(rng.integers(0, 5))
+        if kind == 4:                                  # range check row
+            t[16, r] = 1
+            t[17, r] = int(rng.integers(0, 256))
+            put(r, 18, a); put(r, 34, b); put(r, 50, a ^ b); put(r, 66, (a + b) & M)
+            continue
+        flag = [0, 2, 11, 12][kind]
+        t[flag, r] = 1
+        put(r, 18, a); put(r, 34, b)
+        if kind == 0:
+            s = a + b
+            put(r, 82, s >> 256); put(r, 66, s & M)
+        elif kind == 1:
+            put(r, 82, 1 if a < b else 0); put(r, 66, (a - b) & M)
+        elif kind == 2:
+            put(r, 82, (a - b) & M); put(r, 66, 1 if a < b else 0)
+        else:
+            put(r, 82, (b - a) & M); put(r, 66, 1 if b < a else 0)
+    t[114] = np.arange(n, dtype=np.uint64)             # n == RANGE_MAX
+    freq = np.zeros(n, dtype=np.uint64)
+    for col in range(18, 114):
+        freq += np.bincount(t[col].astype(np.int64), minlength=n).astype(np.uint64)
+    t[115] = freq
+    return t
+
+
+def test_arithmetic_valid_and_invalid(oracle):
+    rng = np.random.default_rng(23)
+    t = _arith_trace(rng, 300)
+    lk = ([("single", 18 + i) for i in range(96)], ("single", 114), ("single", 115), [None] * 96)
+    cols = [("single", 17)]
+    for reg in (18, 34, 50, 66):
+        cols += [("lc", [(reg + 2 * k, 1), (reg + 2 * k + 1, 1 << 16)], [], 0) for k in range(8)]
+    ctl = [(cols, ("simple", ("lc", [(i, 1) for i in range(17)], [], 0)))]
+    ok, why = _prove_and_verify(oracle, 5, t, 0, [ctl], lookup_spec=[lk])
+    assert ok, why
+    bad = t.copy()
+    bad[66, 1] ^= np.uint64(1)                         # corrupt an output limb (stays < 2^16)
+    bad[115] = 0
+    for col in range(18, 114):
+        bad[115] += np.bincount(bad[col].astype(np.int64), minlength=1 << 16).astype(np.uint64)
+    ok, why = _prove_and_verify(oracle, 5, bad, 0, [ctl], lookup_spec=[lk])
+    assert not ok and why == "quotient identity", why
