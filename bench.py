@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--hasher", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=16)
+    ap.add_argument("--proof-steps", type=int, default=2,
+                    help="also time N full ArithmeticStark table proofs (0 disables)")
     return ap.parse_args()
 
 
@@ -69,6 +71,61 @@ def cpu_baseline(cols, log_n, sample_log_n, hasher):
                   f"{per_sample:.3f} s each), scaled x{int(scale)} rows to 2^{log_n}",
         "seconds_per_full_commit_est": per_sample * scale,
     }
+
+
+def table_proof_bench(ctx, dev, log_n, steps):
+    """Secondary measurement (not `value`): one full ArithmeticStark TABLE proof = starky
+    prove_with_commitment (logUp helper columns, CTL partial sums, auxiliary commit, quotient with
+    the complete Arithmetic AIR, quotient commit, openings, FRI with the production parameters)
+    on top of the trace commit.  Synthetic trace: one-hot op flags, 16-bit limbs, real range-counter
+    and frequency columns, so the lookup argument is the real one."""
+    import numpy as np
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.prover as zp
+    from zk_evm_amd.stark import Column, Filter, Lookup, ctl_partial_sums
+    n = 1 << log_n
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    trace = torch.zeros((116, n), dtype=torch.int64, device=dev)
+    which = torch.randint(0, 18, (n,), device=dev, generator=g)
+    for i in range(17):
+        trace[i] = (which == i).to(torch.int64)
+    trace[18:114] = torch.randint(0, 1 << 16, (96, n), dtype=torch.int64, device=dev, generator=g)
+    trace[114] = torch.clamp(torch.arange(n, device=dev), max=65535)
+    trace[115, : 1 << 16] = torch.bincount(trace[18:114].reshape(-1), minlength=1 << 16)
+    lookup = Lookup(Column.singles(range(18, 114)), Column.single(114), Column.single(115), [Filter() for _ in range(96)])
+    cols = [Column.single(17)]
+    for reg in (18, 34, 50, 66):
+        cols += [Column.linear_combination([(reg + 2 * k, 1), (reg + 2 * k + 1, 1 << 16)]) for k in range(8)]
+    ctl_entry = [(cols, Filter.new_simple(Column.sum(range(17))))]
+    cfg = zk.StarkConfig.standard_fast_config()
+    times = []
+    stages = {}
+    for it in range(steps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tb = zk.PolynomialBatch.from_values(trace, 1, False, 4, ctx=ctx)
+        ch = zk.Challenger(0)
+        ch.observe_cap(tb.merkle_tree.cap)
+        chal = [(ch.get_challenge(), ch.get_challenge()) for _ in range(cfg.num_challenges)]
+        t1 = time.perf_counter()
+        zd = []
+        for b, gm in chal:
+            zd.append(zp.CtlZData(b, gm, ctl_entry, ctl_partial_sums(trace, ctl_entry, b, gm, 3, ctx=ctx)))
+        t2 = time.perf_counter()
+        pr = zp.prove_with_commitment(zp.AIR_ARITHMETIC, cfg, trace, tb, [lookup], zd, chal, ch)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        tb.free()
+        if it:  # first iteration is warm-up
+            times.append(t3 - t0)
+            for k, v in (("trace_commit", t1 - t0), ("ctl_data", t2 - t1), ("prove_with_commitment", t3 - t2)):
+                stages[k] = stages.get(k, 0.0) + v * 1e3 / steps
+    sec = sum(times) / len(times)
+    return {"what": f"ArithmeticStark table proof, 2^{log_n} rows, standard_fast_config (2 challenges, 84 queries, 16 PoW bits)",
+            "proofs_per_s": 1.0 / sec, "ms_per_proof": sec * 1e3, "steps": steps, "stages_ms": stages,
+            "proof_words": int(pr.opening_proof.size)}
 
 
 def main():
@@ -196,6 +253,11 @@ def main():
             "commit": {"achieved_GBs": commit_bytes / (ms_per_step * 1e-3) / 1e9,
                        "algorithmic_bytes": commit_bytes},
         }
+        if a.proof_steps > 0 and a.cols == 116 and a.hasher == 0:
+            try:
+                out["table_proof"] = table_proof_bench(ctx, dev, a.log_n, a.proof_steps)
+            except Exception as e:
+                out["table_proof"] = {"error": repr(e)}
         if not a.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.cols, a.log_n, min(a.cpu_sample_log_n, a.log_n), a.hasher)

@@ -158,7 +158,7 @@ struct AirArithmetic {
     }
 
     // addcy.rs:98-151
-    __device__ static void addcy(Consumer &c, Fe filt, const Fe *x, const Fe *y, const Fe *z, const Fe *given_cy,
+    __device__ static __forceinline__ void addcy(Consumer &c, Fe filt, const Fe *x, const Fe *y, const Fe *z, const Fe *given_cy,
                                  bool two_row) {
         Fe cy;
         for (u32 i = 0; i < NL; ++i) {
@@ -178,7 +178,7 @@ struct AirArithmetic {
     }
 
     // mul.rs:123-173 (eval_packed_generic_mul)
-    __device__ static void mul(const RowView &lv, Consumer &c, Fe filt, const Fe *left, const Fe *right) {
+    __device__ static __forceinline__ void mul(const RowView &lv, Consumer &c, Fe filt, const Fe *left, const Fe *right) {
         for (u32 d = 0; d < NL; ++d) {
             Fe cp;                                                     // pol_mul_lo
             for (u32 i = 0; i <= d; ++i) cp += left[i] * right[d - i];
@@ -197,7 +197,7 @@ struct AirArithmetic {
     }
 
     // modular.rs:419-501 (modular_constr_poly incl. check_reduced); cp_out has 2*NL entries
-    __device__ static void modular_constr_poly(const RowView &lv, const RowView &nv, Consumer &c, Fe filt,
+    __device__ static __forceinline__ void modular_constr_poly(const RowView &lv, const RowView &nv, Consumer &c, Fe filt,
                                                const Fe *output_in, const Fe *modulus_in, const Fe *quot, Fe *cp) {
         Fe output[NL], modulus[NL];
         for (u32 i = 0; i < NL; ++i) { output[i] = output_in[i]; modulus[i] = modulus_in[i]; }
@@ -241,7 +241,7 @@ struct AirArithmetic {
     }
 
     // divmod.rs:86-116 (eval_packed_divmod_helper)
-    __device__ static void divmod_helper(const RowView &lv, const RowView &nv, Consumer &c, Fe filt, u32 num_s,
+    __device__ static __forceinline__ void divmod_helper(const RowView &lv, const RowView &nv, Consumer &c, Fe filt, u32 num_s,
                                          u32 den_s, u32 quo_s, u32 rem_s) {
         c.constraint_last_row(filt);
         Fe den[NL], quo[2 * NL], rem[NL], cp[2 * NL];
@@ -256,7 +256,7 @@ struct AirArithmetic {
         }
     }
 
-    __device__ static void eval(const RowView &lv, const RowView &nv, Consumer &c, const u64 *) {
+    __device__ static __forceinline__ void eval(const RowView &lv, const RowView &nv, Consumer &c, const u64 *) {
         const Fe one = FE_ONE;
         Fe all_flags;
         for (u32 f = 0; f <= IS_RANGE_CHECK; ++f) { Fe fl = lv[f]; c.constraint(fl * (fl - one)); all_flags += fl; }

@@ -148,7 +148,7 @@ struct QuotientArgs {
 };
 
 template <class Air>
-__global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs A) {
+__device__ __forceinline__ void quotient_body(const QuotientArgs &A) {
     const u32 size_log = A.log_n + A.qd_bits;
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >> size_log) return;
@@ -256,6 +256,14 @@ __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs A) {
     for (int k = 0; k < ZK_MAX_CHALLENGES; ++k)
         if (k < A.n_challenges) A.out[(size_t)k * A.out_stride + i] = gl_canon(gl_mul(cons.acc[k], inv_zh.v));
 }
+
+// Two launch-bound flavours of the same body: light AIRs keep their whole working set in VGPRs;
+// heavy AIRs (Arithmetic: ~4k field multiplies and several 32-limb polynomials per point) are
+// capped at 128 VGPRs so that 4 waves per SIMD hide the scratch / L1 latency of their spills.
+template <class Air>
+__global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs A) { quotient_body<Air>(A); }
+template <class Air>
+__global__ void __launch_bounds__(256, 4) quotient_kernel_heavy(QuotientArgs A) { quotient_body<Air>(A); }
 
 // de-interleave the bit-reversed coefficients of a size-(n*Q) polynomial into its Q degree-n
 // chunks (chunk j = coefficients [j*n, (j+1)*n)): in bit-reversed order chunk j is the positions
