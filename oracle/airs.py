@@ -312,3 +312,100 @@ def eval_arithmetic(lv, nv, c):
 
 
 AIRS.update({5: (eval_arithmetic, 116)})
+
+
+# ---- KeccakStark -----------------------------------------------------------------------------------
+# evm_arithmetization/src/keccak/{keccak_stark.rs:266-426, round_flags.rs:14-60, logic.rs:15-53,
+# columns.rs:7-134, constants.rs}
+K_ROUNDS = 24
+K_TIMESTAMP = 24
+K_R = [[0, 36, 3, 41, 18], [1, 44, 10, 45, 2], [62, 6, 43, 15, 61], [28, 55, 25, 21, 56], [27, 20, 39, 8, 14]]
+K_RC = [0x0000000000000001, 0x0000000000008082, 0x800000000000808A, 0x8000000080008000, 0x000000000000808B,
+        0x0000000080000001, 0x8000000080008081, 0x8000000000008009, 0x000000000000008A, 0x0000000000000088,
+        0x0000000080008009, 0x000000008000000A, 0x000000008000808B, 0x800000000000008B, 0x8000000000008089,
+        0x8000000000008003, 0x8000000000008002, 0x8000000000000080, 0x000000000000800A, 0x800000008000000A,
+        0x8000000080008081, 0x8000000000008080, 0x0000000080000001, 0x8000000080008008]
+
+
+def k_reg_a(x, y): return 25 + (x * 5 + y) * 2
+def k_reg_c(x, z): return 75 + x * 64 + z
+def k_reg_c_prime(x, z): return 395 + x * 64 + z
+def k_reg_a_prime(x, y, z): return 715 + x * 320 + y * 64 + z
+def k_reg_b(x, y, z):
+    a, b = (x + 3 * y) % 5, x
+    return k_reg_a_prime(a, b, (z + 64 - K_R[a][b]) % 64)
+def k_reg_a_pp(x, y): return 2315 + x * 10 + y * 2
+def k_reg_a_pp_00_bit(i): return 2365 + i
+def k_reg_a_ppp(x, y): return 2429 if (x == 0 and y == 0) else k_reg_a_pp(x, y)
+
+
+def _xor_gen(x, y): return x + y - x * (y + y)
+def _xor3_gen(x, y, z): return _xor_gen(x, _xor_gen(y, z))
+def _andn_gen(x, y): return (1 - x) * y
+
+
+def _fold_bits(get_bit, lo, hi):
+    acc = 0
+    for z in range(hi - 1, lo - 1, -1):
+        acc = acc + acc + get_bit(z)
+    return acc
+
+
+def eval_keccak(lv, nv, c):
+    # round_flags.rs:14-60
+    for i in range(K_ROUNDS):
+        c.constraint(lv[i] * (lv[i] - 1))
+    local_any = sum(lv[0:K_ROUNDS])
+    c.constraint_first_row(local_any * (lv[0] - 1))
+    for i in range(1, K_ROUNDS):
+        c.constraint_first_row(local_any * lv[i])
+    cur_any = local_any
+    next_any = sum(nv[0:K_ROUNDS])
+    last_round_flag = lv[K_ROUNDS - 1]
+    padding = (next_any - 1) * cur_any * (last_round_flag - 1)
+    for i in range(K_ROUNDS):
+        c.constraint_transition(next_any * (nv[(i + 1) % K_ROUNDS] - lv[i]) + padding)
+    c.constraint_transition(next_any * (cur_any - 1))
+    # keccak_stark.rs:281-425
+    not_final_step = 1 - lv[K_ROUNDS - 1]
+    c.constraint(local_any * not_final_step * (nv[K_TIMESTAMP] - lv[K_TIMESTAMP]))
+    for x in range(5):
+        for z in range(64):
+            xor = _xor3_gen(lv[k_reg_c(x, z)], lv[k_reg_c((x + 4) % 5, z)], lv[k_reg_c((x + 1) % 5, (z + 63) % 64)])
+            c.constraint(lv[k_reg_c_prime(x, z)] - xor)
+    for x in range(5):
+        for y in range(5):
+            gb = lambda z, x=x, y=y: _xor3_gen(lv[k_reg_a_prime(x, y, z)], lv[k_reg_c(x, z)], lv[k_reg_c_prime(x, z)])
+            c.constraint(_fold_bits(gb, 0, 32) - lv[k_reg_a(x, y)])
+            c.constraint(_fold_bits(gb, 32, 64) - lv[k_reg_a(x, y) + 1])
+    for x in range(5):
+        for z in range(64):
+            s = sum(lv[k_reg_a_prime(x, i, z)] for i in range(5))
+            diff = s - lv[k_reg_c_prime(x, z)]
+            c.constraint(diff * (diff - 2) * (diff - 4))
+    for x in range(5):
+        for y in range(5):
+            gb = lambda z, x=x, y=y: _xor_gen(lv[k_reg_b(x, y, z)],
+                                              _andn_gen(lv[k_reg_b((x + 1) % 5, y, z)], lv[k_reg_b((x + 2) % 5, y, z)]))
+            c.constraint(_fold_bits(gb, 0, 32) - lv[k_reg_a_pp(x, y)])
+            c.constraint(_fold_bits(gb, 32, 64) - lv[k_reg_a_pp(x, y) + 1])
+    bits = [lv[k_reg_a_pp_00_bit(i)] for i in range(64)]
+    c.constraint(_fold_bits(lambda z: bits[z], 0, 32) - lv[k_reg_a_pp(0, 0)])
+    c.constraint(_fold_bits(lambda z: bits[z], 32, 64) - lv[k_reg_a_pp(0, 0) + 1])
+
+    def xored_bit(i):
+        rc_bit = 0
+        for r in range(K_ROUNDS):
+            rc_bit = rc_bit + lv[r] * ((K_RC[r] >> i) & 1)
+        return _xor_gen(bits[i], rc_bit)
+    c.constraint(_fold_bits(xored_bit, 0, 32) - lv[k_reg_a_ppp(0, 0)])
+    c.constraint(_fold_bits(xored_bit, 32, 64) - lv[k_reg_a_ppp(0, 0) + 1])
+    is_last_round = lv[K_ROUNDS - 1]
+    not_last_round = 1 - is_last_round
+    for x in range(5):
+        for y in range(5):
+            c.constraint_transition(not_last_round * (lv[k_reg_a_ppp(x, y)] - nv[k_reg_a(x, y)]))
+            c.constraint_transition(not_last_round * (lv[k_reg_a_ppp(x, y) + 1] - nv[k_reg_a(x, y) + 1]))
+
+
+AIRS.update({6: (eval_keccak, 2431)})

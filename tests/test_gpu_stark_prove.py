@@ -183,3 +183,20 @@ def test_arithmetic_table(oracle):
         for i in range(17):
             trace[i] = (which == i).astype(np.uint64)
     _run_case(oracle, 5, 116, 5, 0, [lk], [ctl], seed=14, trace_fix=fix)
+
+
+def test_keccak_table(oracle):
+    # CTL looked entries: keccak_stark.rs:38-49 (inputs: reg_input_limb x 50 + TIMESTAMP, filter = round flag 0;
+    # outputs: reg_output_limb x 50 + TIMESTAMP, filter = round flag 23)
+    from oracle.airs import k_reg_a, k_reg_a_ppp
+    inputs = [("single", k_reg_a((i // 2) % 5, (i // 2) // 5) + (i % 2)) for i in range(50)] + [("single", 24)]
+    outputs = [("single", k_reg_a_ppp((i // 2) % 5, (i // 2) // 5) + (i % 2)) for i in range(50)] + [("single", 24)]
+    ctl_in = [(inputs, ("simple", ("single", 0)))]
+    ctl_out = [(outputs, ("simple", ("single", 23)))]
+
+    def fix(trace, rng):
+        n = trace.shape[1]
+        which = rng.integers(0, 25, size=n)
+        for i in range(24):
+            trace[i] = (which == i).astype(np.uint64)
+    _run_case(oracle, 6, 2431, 4, 0, [], [ctl_in, ctl_out], seed=15, trace_fix=fix)

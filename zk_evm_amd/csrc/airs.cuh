@@ -355,3 +355,109 @@ struct AirArithmetic {
         divmod_helper(lv, nv, c, lv[IS_SHR], IN1, IN2, OUT, AUX0);
     }
 };
+
+// KeccakStark: keccak/keccak_stark.rs:266-426 + keccak/round_flags.rs:14-60 (xor/andn as polynomials:
+// keccak/logic.rs:15-53); columns keccak/columns.rs:7-134 (2431 columns: 24 round flags, TIMESTAMP,
+// A 25x2 limbs, C and C' 5x64 bits, A' 5x5x64 bits, A'' 25x2 limbs, A''[0,0] bits, A'''[0,0] limbs).
+struct AirKeccak {
+    static constexpr u32 COLUMNS = 2431;
+    static constexpr u32 ROUNDS = 24, TIMESTAMP = 24;
+    __device__ static __forceinline__ u32 reg_a(u32 x, u32 y) { return 25 + (x * 5 + y) * 2; }
+    __device__ static __forceinline__ u32 reg_c(u32 x, u32 z) { return 75 + x * 64 + z; }
+    __device__ static __forceinline__ u32 reg_c_prime(u32 x, u32 z) { return 395 + x * 64 + z; }
+    __device__ static __forceinline__ u32 reg_a_prime(u32 x, u32 y, u32 z) { return 715 + x * 320 + y * 64 + z; }
+    __device__ static __forceinline__ u32 reg_b(u32 x, u32 y, u32 z) {
+        // rotation offsets R[a][b] (keccak/columns.rs:32-38)
+        constexpr unsigned char R[5][5] = {{0, 36, 3, 41, 18}, {1, 44, 10, 45, 2}, {62, 6, 43, 15, 61}, {28, 55, 25, 21, 56}, {27, 20, 39, 8, 14}};
+        u32 a = (x + 3 * y) % 5, b = x;
+        return reg_a_prime(a, b, (z + 64 - R[a][b]) % 64);
+    }
+    __device__ static __forceinline__ u32 reg_a_pp(u32 x, u32 y) { return 2315 + x * 10 + y * 2; }
+    __device__ static __forceinline__ u32 reg_a_ppp(u32 x, u32 y) { return (x == 0 && y == 0) ? 2429 : reg_a_pp(x, y); }
+    __device__ static __forceinline__ Fe xor_gen(Fe x, Fe y) { return x + y - x * (y + y); }
+    __device__ static __forceinline__ Fe xor3_gen(Fe x, Fe y, Fe z) { return xor_gen(x, xor_gen(y, z)); }
+    __device__ static __forceinline__ Fe andn_gen(Fe x, Fe y) { return (FE_ONE - x) * y; }
+
+    __device__ static void eval(const RowView &lv, const RowView &nv, Consumer &c, const u64 *) {
+        const Fe one = FE_ONE;
+        // round_flags.rs
+        Fe local_any, next_any;
+        for (u32 i = 0; i < ROUNDS; ++i) {
+            Fe f = lv[i];
+            c.constraint(f * (f - one));
+            local_any += f;
+            next_any += nv[i];
+        }
+        c.constraint_first_row(local_any * (lv[0] - one));
+        for (u32 i = 1; i < ROUNDS; ++i) c.constraint_first_row(local_any * lv[i]);
+        Fe last_round_flag = lv[ROUNDS - 1];
+        Fe padding = (next_any - one) * local_any * (last_round_flag - one);
+        for (u32 i = 0; i < ROUNDS; ++i)
+            c.constraint_transition(next_any * (nv[(i + 1) % ROUNDS] - lv[i]) + padding);
+        c.constraint_transition(next_any * (local_any - one));
+        // keccak_stark.rs
+        Fe not_final_step = one - last_round_flag;
+        c.constraint(local_any * not_final_step * (nv[TIMESTAMP] - lv[TIMESTAMP]));
+        for (u32 x = 0; x < 5; ++x)
+            for (u32 z = 0; z < 64; ++z) {
+                Fe xr = xor3_gen(lv[reg_c(x, z)], lv[reg_c((x + 4) % 5, z)], lv[reg_c((x + 1) % 5, (z + 63) % 64)]);
+                c.constraint(lv[reg_c_prime(x, z)] - xr);
+            }
+        for (u32 x = 0; x < 5; ++x)
+            for (u32 y = 0; y < 5; ++y)
+                for (u32 half = 0; half < 2; ++half) {
+                    Fe acc;
+                    for (int z = 32 * half + 31; z >= (int)(32 * half); --z) {
+                        Fe bit = xor3_gen(lv[reg_a_prime(x, y, z)], lv[reg_c(x, z)], lv[reg_c_prime(x, z)]);
+                        acc = acc + acc + bit;
+                    }
+                    c.constraint(acc - lv[reg_a(x, y) + half]);
+                }
+        for (u32 x = 0; x < 5; ++x)
+            for (u32 z = 0; z < 64; ++z) {
+                Fe s;
+                for (u32 i = 0; i < 5; ++i) s += lv[reg_a_prime(x, i, z)];
+                Fe diff = s - lv[reg_c_prime(x, z)];
+                c.constraint(diff * (diff - fe(2)) * (diff - fe(4)));
+            }
+        for (u32 x = 0; x < 5; ++x)
+            for (u32 y = 0; y < 5; ++y)
+                for (u32 half = 0; half < 2; ++half) {
+                    Fe acc;
+                    for (int z = 32 * half + 31; z >= (int)(32 * half); --z) {
+                        Fe bit = xor_gen(lv[reg_b(x, y, z)], andn_gen(lv[reg_b((x + 1) % 5, y, z)], lv[reg_b((x + 2) % 5, y, z)]));
+                        acc = acc + acc + bit;
+                    }
+                    c.constraint(acc - lv[reg_a_pp(x, y) + half]);
+                }
+        for (u32 half = 0; half < 2; ++half) {
+            Fe acc;
+            for (int z = 32 * half + 31; z >= (int)(32 * half); --z) acc = acc + acc + lv[2365 + z];
+            c.constraint(acc - lv[reg_a_pp(0, 0) + half]);
+        }
+        // A'''[0,0] = A''[0,0] xor RC (keccak/constants.rs)
+        constexpr u64 RC[24] = {
+            0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL,
+            0x000000000000808BULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+            0x000000000000008AULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000AULL,
+            0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+            0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800AULL, 0x800000008000000AULL,
+            0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+        for (u32 half = 0; half < 2; ++half) {
+            Fe acc;
+            for (int z = 32 * half + 31; z >= (int)(32 * half); --z) {
+                Fe rc_bit;
+                for (u32 r = 0; r < ROUNDS; ++r)
+                    if ((RC[r] >> z) & 1) rc_bit += lv[r];
+                acc = acc + acc + xor_gen(lv[2365 + z], rc_bit);
+            }
+            c.constraint(acc - lv[2429 + half]);
+        }
+        Fe not_last_round = one - last_round_flag;
+        for (u32 x = 0; x < 5; ++x)
+            for (u32 y = 0; y < 5; ++y) {
+                c.constraint_transition(not_last_round * (lv[reg_a_ppp(x, y)] - nv[reg_a(x, y)]));
+                c.constraint_transition(not_last_round * (lv[reg_a_ppp(x, y) + 1] - nv[reg_a(x, y) + 1]));
+            }
+    }
+};

@@ -17,6 +17,7 @@ from .polynomial_batch import PolynomialBatch
 from .stark import Column, Filter, Lookup, ctl_partial_sums, encode_program, lookup_helper_columns
 
 AIR_NONE, AIR_MEM_CONTINUATION, AIR_LOGIC, AIR_MEMORY, AIR_BYTE_PACKING, AIR_ARITHMETIC = 0, 1, 2, 3, 4, 5
+AIR_KECCAK = 6
 P = 0xFFFFFFFF00000001
 
 
