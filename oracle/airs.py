@@ -409,3 +409,59 @@ def eval_keccak(lv, nv, c):
 
 
 AIRS.update({6: (eval_keccak, 2431)})
+
+
+def eval_keccak_sponge(lv, nv, c):
+    # evm_arithmetization/src/keccak_sponge/keccak_sponge_stark.rs:546-715; columns keccak_sponge/columns.rs:31-95
+    RATE, RATE_U32, CAP_U32, DIG_U32 = 136, 34, 16, 8
+    PAD, ORATE, OCAP, BLOCK, PARTIAL, DIGEST, RC = 6, 142, 176, 192, 362, 404, 436
+    rc1, rc2 = lv[RC], nv[RC]
+    c.constraint_first_row(rc1)
+    incr = rc2 - rc1
+    c.constraint_transition(incr * incr - incr)
+    c.constraint_last_row(rc1 - 255)
+    full = lv[0]
+    c.constraint(full * (full - 1))
+    for i in range(RATE):
+        c.constraint(lv[PAD + i] * (lv[PAD + i] - 1))
+    is_final = lv[PAD + RATE - 1]
+    for i in range(1, RATE):
+        c.constraint(lv[PAD + i - 1] * (lv[PAD + i] - 1))
+    c.constraint(is_final * full)
+    absorbed = lv[5]
+    c.constraint_first_row(absorbed)
+    for i in range(RATE_U32):
+        c.constraint_first_row(lv[ORATE + i])
+    for i in range(CAP_U32):
+        c.constraint_first_row(lv[OCAP + i])
+    c.constraint_transition(is_final * nv[5])
+    for i in range(RATE_U32):
+        c.constraint_transition(is_final * nv[ORATE + i])
+    for i in range(CAP_U32):
+        c.constraint_transition(is_final * nv[OCAP + i])
+    c.constraint_transition(full * (lv[1] - nv[1]))
+    c.constraint_transition(full * (lv[2] - nv[2]))
+    c.constraint_transition(full * (lv[3] - nv[3]))
+    c.constraint_transition(full * (lv[4] - nv[4]))
+    for k in range(DIG_U32):
+        cur = lv[DIGEST + 4 * k]
+        for i in range(1, 4):
+            cur = cur + lv[DIGEST + 4 * k + i] * (1 << (8 * i))
+        c.constraint_transition(full * (nv[ORATE + k] - cur))
+    for k in range(RATE_U32 - DIG_U32):            # zip(partial[0..42], next.original_rate[8..34]) -> 26 pairs
+        c.constraint_transition(full * (nv[ORATE + DIG_U32 + k] - lv[PARTIAL + k]))
+    for k in range(CAP_U32):                        # partial.skip(26) zip next.original_capacity (16)
+        c.constraint_transition(full * (nv[OCAP + k] - lv[PARTIAL + (RATE_U32 - DIG_U32) + k]))
+    c.constraint_transition(full * (absorbed + RATE - nv[5]))
+    single = lv[PAD + RATE - 1] - lv[PAD + RATE - 2]
+    c.constraint_transition(single * (lv[BLOCK + RATE - 1] - 0b10000001))
+    for i in range(RATE - 1):
+        first = lv[PAD + i] - lv[PAD + i - 1] if i > 0 else lv[PAD + i]
+        c.constraint_transition(first * (lv[BLOCK + i] - 1))
+        c.constraint_transition(lv[PAD + i] * (first - 1) * lv[BLOCK + i])
+    c.constraint_transition(is_final * (single - 1) * (lv[BLOCK + RATE - 1] - 0b10000000))
+    is_dummy = 1 - full - is_final
+    c.constraint_transition(is_dummy * (nv[0] + nv[PAD + RATE - 1]))
+
+
+AIRS.update({7: (eval_keccak_sponge, 438)})

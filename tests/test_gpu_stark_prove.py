@@ -200,3 +200,19 @@ def test_keccak_table(oracle):
         for i in range(24):
             trace[i] = (which == i).astype(np.uint64)
     _run_case(oracle, 6, 2431, 4, 0, [], [ctl_in, ctl_out], seed=15, trace_fix=fix)
+
+
+def test_keccak_sponge_table(oracle):
+    # lookups(): keccak_sponge_stark.rs:946-953 -- block_bytes (136) + updated_digest_state_bytes ... range-checked
+    # against range_counter; here: the 136 block bytes (the real definition is exercised in the
+    # segment-level tests); one CTL looked entry (ctl_looked_data shape: 13 columns, filter = is_final block)
+    lk = ([("single", 192 + i) for i in range(136)], ("single", 436), ("single", 437), [None] * 136)
+    cols = [("single", 1), ("single", 2), ("single", 3),
+            ("lc", [(5, 1)] + [(6 + i, 1) for i in range(136)], [], 0), ("single", 4)] + \
+           [("lc", [(404 + 4 * k + i, 1 << (8 * i)) for i in range(4)], [], 0) for k in range(8)]
+    ctl = [(cols, ("simple", ("single", 6 + 135)))]
+
+    def fix(trace, rng):
+        n = trace.shape[1]
+        trace[6 + 135] = rng.integers(0, 2, size=n, dtype=np.uint64)
+    _run_case(oracle, 7, 438, 4, 0, [lk], [ctl], seed=16, trace_fix=fix)

@@ -461,3 +461,57 @@ struct AirKeccak {
             }
     }
 };
+
+// KeccakSpongeStark: keccak_sponge/keccak_sponge_stark.rs:546-715; columns keccak_sponge/columns.rs:31-95
+// (438 columns: is_full_input_block 0, context 1, segment 2, virt 3, timestamp 4,
+// already_absorbed_bytes 5, is_padding_byte 6..141, original_rate_u32s 142..175,
+// original_capacity_u32s 176..191, block_bytes 192..327, xored_rate_u32s 328..361,
+// partial_updated_state_u32s 362..403, updated_digest_state_bytes 404..435, range_counter 436,
+// rc_frequencies 437).
+struct AirKeccakSponge {
+    static constexpr u32 COLUMNS = 438;
+    __device__ static void eval(const RowView &lv, const RowView &nv, Consumer &c, const u64 *) {
+        constexpr u32 RATE = 136, RATE_U32 = 34, CAP_U32 = 16, DIG_U32 = 8;
+        constexpr u32 PAD = 6, ORATE = 142, OCAP = 176, BLOCK = 192, PARTIAL = 362, DIGEST = 404, RC = 436;
+        const Fe one = FE_ONE;
+        Fe rc1 = lv[RC], rc2 = nv[RC];
+        c.constraint_first_row(rc1);
+        Fe incr = rc2 - rc1;
+        c.constraint_transition(incr * incr - incr);
+        c.constraint_last_row(rc1 - fe(255));
+        Fe full = lv[0];
+        c.constraint(full * (full - one));
+        for (u32 i = 0; i < RATE; ++i) { Fe p = lv[PAD + i]; c.constraint(p * (p - one)); }
+        Fe is_final = lv[PAD + RATE - 1];
+        for (u32 i = 1; i < RATE; ++i) c.constraint(lv[PAD + i - 1] * (lv[PAD + i] - one));
+        c.constraint(is_final * full);
+        Fe absorbed = lv[5];
+        c.constraint_first_row(absorbed);
+        for (u32 i = 0; i < RATE_U32; ++i) c.constraint_first_row(lv[ORATE + i]);
+        for (u32 i = 0; i < CAP_U32; ++i) c.constraint_first_row(lv[OCAP + i]);
+        c.constraint_transition(is_final * nv[5]);
+        for (u32 i = 0; i < RATE_U32; ++i) c.constraint_transition(is_final * nv[ORATE + i]);
+        for (u32 i = 0; i < CAP_U32; ++i) c.constraint_transition(is_final * nv[OCAP + i]);
+        for (u32 k = 1; k <= 4; ++k) c.constraint_transition(full * (lv[k] - nv[k]));
+        for (u32 k = 0; k < DIG_U32; ++k) {
+            Fe cur = lv[DIGEST + 4 * k];
+            for (u32 i = 1; i < 4; ++i) cur += lv[DIGEST + 4 * k + i] * fe(1ULL << (8 * i));
+            c.constraint_transition(full * (nv[ORATE + k] - cur));
+        }
+        for (u32 k = 0; k < RATE_U32 - DIG_U32; ++k) c.constraint_transition(full * (nv[ORATE + DIG_U32 + k] - lv[PARTIAL + k]));
+        for (u32 k = 0; k < CAP_U32; ++k) c.constraint_transition(full * (nv[OCAP + k] - lv[PARTIAL + (RATE_U32 - DIG_U32) + k]));
+        c.constraint_transition(full * (absorbed + fe(RATE) - nv[5]));
+        Fe single = lv[PAD + RATE - 1] - lv[PAD + RATE - 2];
+        c.constraint_transition(single * (lv[BLOCK + RATE - 1] - fe(0x81)));
+        for (u32 i = 0; i + 1 < RATE; ++i) {
+            Fe pi = lv[PAD + i];
+            Fe first = i > 0 ? pi - lv[PAD + i - 1] : pi;
+            Fe bb = lv[BLOCK + i];
+            c.constraint_transition(first * (bb - one));
+            c.constraint_transition(pi * (first - one) * bb);
+        }
+        c.constraint_transition(is_final * (single - one) * (lv[BLOCK + RATE - 1] - fe(0x80)));
+        Fe is_dummy = one - full - is_final;
+        c.constraint_transition(is_dummy * (nv[0] + nv[PAD + RATE - 1]));
+    }
+};
