@@ -224,6 +224,9 @@ typedef enum {
     ZK_AIR_LOGIC = 2,            /* logic.rs:249-303 */
     ZK_AIR_MEMORY = 3,           /* memory/memory_stark.rs:474-626 */
     ZK_AIR_BYTE_PACKING = 4,     /* byte_packing/byte_packing_stark.rs:296-352 */
+    ZK_AIR_CPU = 8,              /* cpu/cpu_stark.rs:594-626 (18 modules); air_consts = {halt_final pc, init pc,
+                                    syscall_jumptable, exception_jumptable} (cpu/control_flow.rs:37-47,
+                                    cpu/syscalls_exceptions.rs:68,73) */
     ZK_AIR_KECCAK_SPONGE = 7,    /* keccak_sponge/keccak_sponge_stark.rs:546-715 */
     ZK_AIR_KECCAK = 6,           /* keccak/keccak_stark.rs:266-426 + keccak/round_flags.rs:14-60 */
     ZK_AIR_ARITHMETIC = 5,       /* arithmetic/arithmetic_stark.rs:203-252 + mul/addcy/divmod/modular/byte/shift */

@@ -465,3 +465,491 @@ def eval_keccak_sponge(lv, nv, c):
 
 
 AIRS.update({7: (eval_keccak_sponge, 438)})
+
+
+# ---- CpuStark ------------------------------------------------------------------------------------------
+# evm_arithmetization/src/cpu/cpu_stark.rs:594-626 and its 18 modules, in call order.  Columns
+# cpu/columns/{mod.rs:56-97, ops.rs:6-47, general.rs}: context 0, code_context 1, program_counter 2,
+# stack_len 3, is_kernel_mode 4, gas 5, op flags 6..23, opcode_bits 24..31, general (union) 32..39,
+# clock 40, mem_channels[3] 41..79 (13 each), partial_channel 80..84.
+C_CTX, C_CODE_CTX, C_PC, C_STACK_LEN, C_KERNEL, C_GAS = 0, 1, 2, 3, 4, 5
+C_OPS = ["binary_op", "ternary_op", "fp254_op", "eq_iszero", "logic_op", "not_pop", "shift",
+         "jumpdest_keccak_general", "jumps", "push_prover_input", "dup_swap", "context_op", "m_op_32bytes",
+         "exit_kernel", "m_op_general", "pc_push0", "syscall", "exception"]
+C_OP = {name: 6 + i for i, name in enumerate(C_OPS)}
+C_BITS, C_GEN, C_CLOCK = 24, 32, 40
+SEG_STACK, SEG_SHIFT_TABLE, SEG_JUMPDEST_BITS, SEG_CODE_ = 1, 13, 14, 0
+
+
+class _Chan:
+    def __init__(self, v, base, partial=False):
+        self.used, self.is_read, self.addr_context, self.addr_segment, self.addr_virtual = v[base:base + 5]
+        self.value = None if partial else list(v[base + 5:base + 13])
+
+
+class _CpuRow:
+    def __init__(self, v):
+        self.v = v
+        self.context, self.code_context, self.program_counter = v[0], v[1], v[2]
+        self.stack_len, self.is_kernel_mode, self.gas = v[3], v[4], v[5]
+        self.op = {name: v[C_OP[name]] for name in C_OPS}
+        self.ops = [v[6 + i] for i in range(18)]          # struct field order
+        self.opcode_bits = list(v[24:32])
+        self.g = list(v[32:40])
+        self.clock = v[40]
+        self.mem_channels = [_Chan(v, 41 + 13 * k) for k in range(3)]
+        self.partial_channel = _Chan(v, 80, True)
+    # general (union) views
+    @property
+    def exc_code_bits(self): return self.g[0:3]
+    @property
+    def diff_pinv(self): return self.g
+    @property
+    def should_jump(self): return self.g[0]
+    @property
+    def cond_sum_pinv(self): return self.g[1]
+    @property
+    def high_limb_sum_inv(self): return self.g[0]
+    @property
+    def stack_inv(self): return self.g[4]
+    @property
+    def stack_inv_aux(self): return self.g[5]
+    @property
+    def stack_inv_aux_2(self): return self.g[6]
+    @property
+    def stack_len_bounds_aux(self): return self.g[7]
+    @property
+    def is_not_kernel(self): return self.g[0]
+    @property
+    def pruning_flag(self): return self.g[0]
+
+
+# stack.rs:42-171: (num_pops, pushes, disable_other_channels), struct field order
+_SB = {"binary_op": (2, True, True), "ternary_op": (3, True, True), "fp254_op": (2, True, True),
+       "eq_iszero": None, "logic_op": (2, True, True), "not_pop": None, "shift": (2, True, False),
+       "jumpdest_keccak_general": None, "jumps": None, "push_prover_input": (0, True, True),
+       "dup_swap": None, "context_op": None, "m_op_32bytes": (2, True, False), "exit_kernel": (1, False, True),
+       "m_op_general": None, "pc_push0": (0, True, True), "syscall": (0, True, False), "exception": (0, True, False)}
+_MIGHT_OVERFLOW = {"push_prover_input", "pc_push0", "dup_swap", "exit_kernel"}
+# gas.rs:24-47 (None = handled manually)
+_GAS = {"fp254_op": 0, "eq_iszero": 3, "logic_op": 3, "shift": 3, "pc_push0": 2, "dup_swap": 3, "context_op": 0,
+        "m_op_32bytes": 0, "m_op_general": 0}
+
+
+def _stack_eval_one(lv, nv, filt, sb, c):
+    # stack.rs:173-282
+    num_pops, pushes, disable = sb
+    if num_pops > 0:
+        for i in range(1, num_pops):
+            ch = lv.mem_channels[i]
+            c.constraint(filt * (ch.used - 1))
+            c.constraint(filt * (ch.is_read - 1))
+            c.constraint(filt * (ch.addr_context - lv.context))
+            c.constraint(filt * (ch.addr_segment - SEG_STACK))
+            c.constraint(filt * (ch.addr_virtual - (lv.stack_len - (i + 1))))
+        c.constraint(filt * lv.partial_channel.used)
+        if not pushes:
+            len_diff = lv.stack_len - num_pops
+            nf = len_diff * filt
+            ch = nv.mem_channels[0]
+            c.constraint_transition(nf * (ch.used - 1))
+            c.constraint_transition(nf * (ch.is_read - 1))
+            c.constraint_transition(nf * (ch.addr_context - nv.context))
+            c.constraint_transition(nf * (ch.addr_segment - SEG_STACK))
+            c.constraint_transition(nf * (ch.addr_virtual - (nv.stack_len - 1)))
+            c.constraint(filt * (len_diff * lv.stack_inv - lv.stack_inv_aux))
+            c.constraint_transition(filt * (lv.stack_inv_aux - 1) * ch.used)
+    elif pushes:
+        nf = lv.stack_len * filt
+        ch = lv.partial_channel
+        c.constraint(nf * (ch.used - 1))
+        c.constraint(nf * ch.is_read)
+        c.constraint(nf * (ch.addr_context - lv.context))
+        c.constraint(nf * (ch.addr_segment - SEG_STACK))
+        c.constraint(nf * (ch.addr_virtual - (lv.stack_len - 1)))
+        c.constraint(filt * (lv.stack_len * lv.stack_inv - lv.stack_inv_aux))
+        c.constraint(filt * (lv.stack_inv_aux - 1) * ch.used)
+    else:
+        c.constraint(filt * nv.mem_channels[0].used)
+        for a, b in zip(lv.mem_channels[0].value, nv.mem_channels[0].value):
+            c.constraint(filt * (a - b))
+        c.constraint(filt * lv.partial_channel.used)
+    if disable:
+        for i in range(max(1, num_pops), 3 - (1 if pushes else 0)):
+            c.constraint(filt * lv.mem_channels[i].used)
+    c.constraint_transition(filt * (nv.stack_len - (lv.stack_len - num_pops + (1 if pushes else 0))))
+
+
+def make_eval_cpu(halt_pc, start_pc, syscall_jumptable, exception_jumptable):
+    def eval_cpu(lv_raw, nv_raw, c):
+        lv, nv = _CpuRow(lv_raw), _CpuRow(nv_raw)
+        b = lv.opcode_bits
+        # byte_unpacking.rs
+        filt = lv.op["m_op_32bytes"] * (b[5] - 1)
+        new_addr, written = nv.mem_channels[0].value, lv.mem_channels[0].value
+        length = sum(b[i] * (1 << i) for i in range(5)) + 1
+        c.constraint(filt * (new_addr[0] - written[0] - length))
+        c.constraint(filt * (new_addr[1] - written[1]))
+        c.constraint(filt * (new_addr[2] - written[2]))
+        for limb in new_addr[3:]:
+            c.constraint(filt * limb)
+        # clock.rs
+        c.constraint_first_row(lv.clock - 1)
+        c.constraint_transition(nv.clock - lv.clock - 1)
+        # contextops.rs: keep
+        for name in C_OPS:
+            if name != "context_op":
+                c.constraint_transition(lv.op[name] * (nv.context - lv.context))
+        is_get = lv.op["context_op"] * (b[0] - 1)
+        c.constraint_transition(is_get * (nv.context - lv.context))
+        # get
+        filt = lv.op["context_op"] * (1 - b[0])
+        nst = nv.mem_channels[0].value
+        c.constraint(filt * (nst[2] - lv.context))
+        for i, limb in enumerate(nst):
+            if i != 2:
+                c.constraint(filt * limb)
+        c.constraint(filt * lv.pruning_flag)
+        c.constraint(filt * (nv.stack_len - (lv.stack_len + 1)))
+        c.constraint(filt * lv.mem_channels[1].used)
+        c.constraint(filt * nv.mem_channels[0].used)
+        # set
+        filt = lv.op["context_op"] * b[0]
+        st = lv.mem_channels[0].value
+        c.constraint(filt * (st[2] - nv.context))
+        for i, limb in enumerate(st[1:]):
+            if i != 1:
+                c.constraint(filt * limb)
+        c.constraint(lv.op["context_op"] * lv.pruning_flag * (lv.pruning_flag - 1))
+        c.constraint(filt * (lv.pruning_flag - st[0]))
+        ntc = nv.mem_channels[0]
+        c.constraint(lv.op["context_op"] * (lv.stack_inv_aux * b[0] - lv.stack_inv_aux_2))
+        for ln, lr in zip(ntc.value, lv.mem_channels[2].value):
+            c.constraint(lv.op["context_op"] * lv.stack_inv_aux_2 * (ln - lr))
+        c.constraint(filt * lv.mem_channels[1].used)
+        c.constraint(filt * ntc.used)
+        # contextops eval_packed tail
+        filt = lv.op["context_op"]
+        ch = lv.mem_channels[2]
+        stack_len = nv.stack_len - (1 - b[0])
+        c.constraint(filt * (stack_len * lv.stack_inv - lv.stack_inv_aux))
+        c.constraint(filt * (lv.stack_inv_aux - ch.used))
+        nf = filt * lv.stack_inv_aux
+        c.constraint(nf * (ch.is_read - b[0]))
+        c.constraint(nf * (ch.addr_context - nv.context))
+        c.constraint(nf * (ch.addr_segment - SEG_STACK))
+        c.constraint(nf * (ch.addr_virtual - (stack_len - 1)))
+        # control_flow.rs
+        is_cpu = sum(lv.ops)
+        is_cpu_next = sum(nv.ops)
+        next_halt = 1 - is_cpu_next
+        c.constraint_transition(is_cpu * (is_cpu_next + next_halt - 1))
+        native = sum(lv.op[k] for k in ("binary_op", "ternary_op", "fp254_op", "eq_iszero", "logic_op", "not_pop",
+                                        "shift", "jumpdest_keccak_general", "pc_push0", "dup_swap", "context_op",
+                                        "m_op_general"))
+        c.constraint_transition(native * (lv.program_counter - nv.program_counter + 1))
+        c.constraint_transition(native * (lv.is_kernel_mode - nv.is_kernel_mode))
+        is_pi = lv.op["push_prover_input"] * b[7]
+        c.constraint_transition(is_pi * (lv.program_counter - nv.program_counter + 1))
+        c.constraint_transition(is_pi * (lv.is_kernel_mode - nv.is_kernel_mode))
+        c.constraint(lv.op["push_prover_input"] * ((lv.is_kernel_mode + lv.is_not_kernel) - 1))
+        last_noncpu = (is_cpu - 1) * is_cpu_next
+        c.constraint_transition(last_noncpu * (nv.program_counter - start_pc))
+        c.constraint_transition(last_noncpu * (nv.is_kernel_mode - 1))
+        c.constraint_transition(last_noncpu * nv.stack_len)
+        # decode.rs
+        km = lv.is_kernel_mode
+        c.constraint(km * (km - 1))
+        for bit in b:
+            c.constraint(bit * (bit - 1))
+        OPCODES = [(0x14, 1, False, "eq_iszero"), (0x56, 1, False, "jumps"), (0x80, 5, False, "dup_swap"),
+                   (0xf6, 1, True, "context_op"), (0xf9, 0, True, "exit_kernel")]
+        COMBINED = ["logic_op", "fp254_op", "binary_op", "ternary_op", "shift", "m_op_general",
+                    "jumpdest_keccak_general", "not_pop", "pc_push0", "m_op_32bytes", "push_prover_input"]
+        for _, _, _, name in OPCODES:
+            c.constraint(lv.op[name] * (lv.op[name] - 1))
+        for name in COMBINED:
+            c.constraint(lv.op[name] * (lv.op[name] - 1))
+        flag_sum = sum(lv.op[n] for _, _, _, n in OPCODES) + sum(lv.op[n] for n in COMBINED)
+        c.constraint(flag_sum * (flag_sum - 1))
+        for oc, block_len, kernel_only, name in OPCODES:
+            unavailable = (1 - km) if kernel_only else 0
+            mismatch = 0
+            for i in range(7, block_len - 1, -1):          # .rev().take(8 - block_length)
+                mismatch = mismatch + ((1 - b[i]) if (oc >> i) & 1 else b[i])
+            c.constraint(lv.op[name] * (unavailable + mismatch))
+
+        def high_bits(k):
+            return sum(b[i] * (1 << i) for i in range(7, 7 - k, -1))
+        c.constraint((km - 1) * lv.op["fp254_op"])
+        c.constraint(lv.op["ternary_op"] * b[1] * (km - 1))
+        opcode = high_bits(8)
+        c.constraint((km - 1) * lv.op["m_op_general"])
+        c.constraint((opcode - 0xfb) * (opcode - 0xfc) * lv.op["m_op_general"])
+        c.constraint((km - 1) * lv.op["jumpdest_keccak_general"] * (1 - b[1]))
+        c.constraint((opcode - 0x21) * (opcode - 0x5b) * lv.op["jumpdest_keccak_general"])
+        c.constraint((opcode - 0x58) * (opcode - 0x5f) * lv.op["pc_push0"])
+        c.constraint((opcode - 0x19) * (opcode - 0x50) * lv.op["not_pop"])
+        c.constraint((km - 1) * lv.op["m_op_32bytes"])
+        high3 = high_bits(3)
+        c.constraint((high3 - 0xc0) * (opcode - 0xf8) * lv.op["m_op_32bytes"])
+        c.constraint((opcode - 0xee) * (high3 - 0x60) * lv.op["push_prover_input"])
+        c.constraint(lv.op["push_prover_input"] * b[7] * (km - 1))
+        # dup_swap.rs
+        n = b[0] + b[1] * 2 + b[2] * 4 + b[3] * 8
+
+        def chan_eq(f, a, bb):
+            for x, y in zip(a.value, bb.value):
+                c.constraint(f * (x - y))
+
+        def constrain_chan(is_read, f, offset, ch):
+            c.constraint(f * (ch.used - 1))
+            c.constraint(f * (ch.is_read - (1 if is_read else 0)))
+            c.constraint(f * (ch.addr_context - lv.context))
+            c.constraint(f * (ch.addr_segment - SEG_STACK))
+            c.constraint(f * (ch.addr_virtual - (lv.stack_len - 1 - offset)))
+        f = lv.op["dup_swap"] * (1 - b[4])
+        chan_eq(f, lv.mem_channels[1], lv.mem_channels[0])
+        constrain_chan(False, f, 0, lv.mem_channels[1])
+        chan_eq(f, lv.mem_channels[2], nv.mem_channels[0])
+        constrain_chan(True, f, n, lv.mem_channels[2])
+        c.constraint_transition(f * (nv.stack_len - lv.stack_len - 1))
+        c.constraint(f * nv.mem_channels[0].used)
+        f = lv.op["dup_swap"] * b[4]
+        chan_eq(f, lv.mem_channels[0], lv.mem_channels[2])
+        constrain_chan(False, f, n + 1, lv.mem_channels[2])
+        chan_eq(f, lv.mem_channels[1], nv.mem_channels[0])
+        constrain_chan(True, f, n + 1, lv.mem_channels[1])
+        c.constraint(f * (nv.stack_len - lv.stack_len))
+        c.constraint(f * nv.mem_channels[0].used)
+        c.constraint(lv.op["dup_swap"] * lv.partial_channel.used)
+        # gas.rs
+        gfilt = sum(lv.op[k] for k in C_OPS if k in _GAS)
+        gas_used = sum(_GAS[k] * lv.op[k] for k in C_OPS if k in _GAS)
+        c.constraint_transition(gfilt * (nv.gas - (lv.gas + gas_used)))
+        gas_diff = nv.gas - lv.gas
+        for k in C_OPS:
+            if k in _GAS:
+                c.constraint_transition(lv.op[k] * (gas_diff - _GAS[k]))
+        c.constraint_transition(lv.op["jumps"] * (gas_diff - (8 + b[0] * 2)))
+        cost_filter = b[0] + b[4] - b[0] * b[4]
+        c.constraint_transition(lv.op["binary_op"] * (gas_diff - (5 + cost_filter * (3 - 5))))
+        c.constraint_transition(lv.op["ternary_op"] * (gas_diff - (8 - b[1] * 8)))
+        c.constraint_transition(lv.op["not_pop"] * (gas_diff - ((1 - b[0]) * 2 + b[0] * 3)))
+        c.constraint_transition(lv.op["jumpdest_keccak_general"] * (gas_diff - (b[1] * 1 + (1 - b[1]) * 0)))
+        c.constraint_transition(lv.op["push_prover_input"] * (gas_diff - ((1 - b[7]) * 3 + b[7] * 0)))
+        c.constraint_transition((is_cpu - 1) * is_cpu_next * nv.gas)
+        # halt.rs
+        halt_state = 1 - is_cpu
+        c.constraint(halt_state * (halt_state - 1))
+        c.constraint_transition(halt_state * (next_halt - 1))
+        c.constraint(halt_state * (lv.is_kernel_mode - 1))
+        for i in range(3):
+            c.constraint(halt_state * lv.mem_channels[i].used)
+        c.constraint_last_row(halt_state - 1)
+        c.constraint(halt_state * (lv.program_counter - halt_pc))
+        # jumps.rs: exit_kernel
+        inp = lv.mem_channels[0].value
+        f = lv.op["exit_kernel"]
+        c.constraint_transition(f * (inp[0] - nv.program_counter))
+        c.constraint_transition(f * (inp[1] - nv.is_kernel_mode))
+        c.constraint_transition(f * (inp[6] - nv.gas))
+        c.constraint(f * inp[7])
+        # jump / jumpi
+        dst, cond = lv.mem_channels[0].value, lv.mem_channels[1].value
+        f = lv.op["jumps"]
+        is_jump, is_jumpi = f * (1 - b[0]), f * b[0]
+        len_diff = lv.stack_len - 1 - b[0]
+        nf = len_diff * f
+        ch = nv.mem_channels[0]
+        c.constraint_transition(nf * (ch.used - 1))
+        c.constraint_transition(nf * (ch.is_read - 1))
+        c.constraint_transition(nf * (ch.addr_context - nv.context))
+        c.constraint_transition(nf * (ch.addr_segment - SEG_STACK))
+        c.constraint_transition(nf * (ch.addr_virtual - (nv.stack_len - 1)))
+        c.constraint(f * (len_diff * lv.stack_inv - lv.stack_inv_aux))
+        c.constraint_transition(f * (lv.stack_inv_aux - 1) * ch.used)
+        c.constraint(is_jump * (cond[0] - 1))
+        for limb in cond[1:]:
+            c.constraint(is_jump * limb)
+        sj = lv.should_jump
+        c.constraint(f * sj * (sj - 1))
+        cond_sum = sum(cond)
+        c.constraint(f * (sj - 1) * cond_sum)
+        c.constraint(f * (lv.cond_sum_pinv * cond_sum - sj))
+        c.constraint(f * sj * sum(dst[1:]))
+        jd = lv.mem_channels[2]
+        c.constraint(f * (jd.value[0] - 1))
+        c.constraint(f * (jd.used - sj * (1 - lv.is_kernel_mode)))
+        c.constraint(f * (jd.is_read - 1))
+        c.constraint(f * (jd.addr_context - lv.context))
+        c.constraint(f * (jd.addr_segment - SEG_JUMPDEST_BITS))
+        c.constraint(f * (jd.addr_virtual - dst[0]))
+        c.constraint(f * lv.partial_channel.used)
+        c.constraint(is_jump * lv.mem_channels[1].used)
+        c.constraint_transition(is_jump * (nv.stack_len - lv.stack_len + 1))
+        c.constraint_transition(is_jumpi * (nv.stack_len - lv.stack_len + 2))
+        c.constraint_transition(f * (sj - 1) * (nv.program_counter - (lv.program_counter + 1)))
+        c.constraint_transition(f * sj * (nv.program_counter - dst[0]))
+        # membus.rs
+        c.constraint(lv.code_context - (1 - lv.is_kernel_mode) * lv.context)
+        for ch in lv.mem_channels:
+            c.constraint(ch.used * (ch.used - 1))
+        c.constraint(lv.partial_channel.used * (lv.partial_channel.used - 1))
+        # memio.rs: load
+        f = lv.op["m_op_general"] * b[0]
+        a = lv.mem_channels[0].value
+        lc = lv.mem_channels[1]
+        c.constraint(f * (lc.used - 1))
+        c.constraint(f * (lc.is_read - 1))
+        c.constraint(f * (lc.addr_context - a[2]))
+        c.constraint(f * (lc.addr_segment - a[1]))
+        c.constraint(f * (lc.addr_virtual - a[0]))
+        for x, y in zip(lc.value, nv.mem_channels[0].value):
+            c.constraint(f * (x - y))
+        c.constraint(f * lv.mem_channels[2].used)
+        c.constraint(f * lv.partial_channel.used)
+        _stack_eval_one(lv, nv, f, (1, True, False), c)
+        # store
+        f = lv.op["m_op_general"] * (b[0] - 1)
+        a = lv.mem_channels[1].value
+        sc = lv.partial_channel
+        c.constraint(f * (sc.used - 1))
+        c.constraint(f * sc.is_read)
+        c.constraint(f * (sc.addr_context - a[2]))
+        c.constraint(f * (sc.addr_segment - a[1]))
+        c.constraint(f * (sc.addr_virtual - a[0]))
+        c.constraint(f * lv.mem_channels[2].used)
+        ch = lv.mem_channels[1]
+        c.constraint(f * (ch.used - 1))
+        c.constraint(f * (ch.is_read - 1))
+        c.constraint(f * (ch.addr_context - lv.context))
+        c.constraint(f * (ch.addr_segment - SEG_STACK))
+        c.constraint(f * (ch.addr_virtual - (lv.stack_len - 2)))
+        len_diff = lv.stack_len - 2
+        mg = lv.op["m_op_general"]
+        c.constraint(mg * (len_diff * lv.stack_inv - lv.stack_inv_aux))
+        trc = nv.mem_channels[0]
+        is_top_read = lv.stack_inv_aux * (1 - b[0])
+        c.constraint(mg * (lv.stack_inv_aux_2 - is_top_read))
+        nf = mg * lv.stack_inv_aux_2
+        c.constraint_transition(nf * (trc.used - 1))
+        c.constraint_transition(nf * (trc.is_read - 1))
+        c.constraint_transition(nf * (trc.addr_context - nv.context))
+        c.constraint_transition(nf * (trc.addr_segment - SEG_STACK))
+        c.constraint_transition(nf * (trc.addr_virtual - (nv.stack_len - 1)))
+        c.constraint(mg * (lv.stack_inv_aux - 1) * trc.used)
+        c.constraint(mg * b[0] * trc.used)
+        # modfp254.rs
+        P_LIMBS = [0xd87cfd47, 0x3c208c16, 0x6871ca8d, 0x97816a91, 0x8181585d, 0xb85045b6, 0xe131a029, 0x30644e72]
+        for limb, pl in zip(lv.mem_channels[2].value, P_LIMBS):
+            c.constraint(lv.op["fp254_op"] * (limb - pl))
+        # pc.rs
+        f = lv.op["pc_push0"] * (1 - b[0])
+        nst = nv.mem_channels[0].value
+        c.constraint(f * (nst[0] - lv.program_counter))
+        for limb in nst[1:]:
+            c.constraint(f * limb)
+        # push0.rs
+        f = lv.op["pc_push0"] * b[0]
+        for limb in nv.mem_channels[0].value:
+            c.constraint(f * limb)
+        # shift.rs
+        sh = lv.op["shift"]
+        disp, two_exp = lv.mem_channels[0], lv.mem_channels[2]
+        hz = two_exp.used
+        c.constraint(sh * hz * (two_exp.is_read - 1))
+        hsum = sum(disp.value[1:])
+        c.constraint(sh * (hsum * lv.high_limb_sum_inv - (1 - hz)))
+        c.constraint(sh * hsum * hz)
+        c.constraint(sh * two_exp.addr_context)
+        c.constraint(sh * (two_exp.addr_segment - SEG_SHIFT_TABLE))
+        c.constraint(sh * (two_exp.addr_virtual - disp.value[0]))
+        # simple_logic: not.rs
+        f = lv.op["not_pop"] * b[0]
+        for x, y in zip(lv.mem_channels[0].value, nv.mem_channels[0].value):
+            c.constraint(f * (y + x - 0xFFFFFFFF))
+        _stack_eval_one(lv, nv, f, (1, True, True), c)
+        # eq_iszero.rs
+        in0, in1, out = lv.mem_channels[0].value, lv.mem_channels[1].value, nv.mem_channels[0].value
+        eqf = lv.op["eq_iszero"] * (1 - b[0])
+        izf = lv.op["eq_iszero"] * b[0]
+        ef = lv.op["eq_iszero"]
+        equal = out[0]
+        unequal = 1 - equal
+        c.constraint(ef * equal * unequal)
+        for limb in out[1:]:
+            c.constraint(ef * limb)
+        for limb in in1:
+            c.constraint(izf * limb)
+        for x, y in zip(in0, in1):
+            c.constraint(ef * equal * (x - y))
+        dot = sum((x - y) * d for x, y, d in zip(in0, in1, lv.diff_pinv))
+        c.constraint(ef * (dot - unequal))
+        _stack_eval_one(lv, nv, eqf, (2, True, True), c)
+        _stack_eval_one(lv, nv, izf, (1, True, True), c)
+        # stack.rs eval_packed
+        for name in C_OPS:
+            if _SB[name] is not None:
+                _stack_eval_one(lv, nv, lv.op[name], _SB[name], c)
+            if name in _MIGHT_OVERFLOW:
+                diff = nv.stack_len - 1025
+                c.constraint_transition(lv.op[name] * (diff * lv.stack_len_bounds_aux - (1 - nv.is_kernel_mode)))
+        _stack_eval_one(lv, nv, lv.op["jumpdest_keccak_general"] * b[1], (0, False, True), c)
+        _stack_eval_one(lv, nv, lv.op["jumpdest_keccak_general"] * (1 - b[1]), (2, True, True), c)
+        npop = lv.op["not_pop"]
+        c.constraint(npop * ((lv.stack_len - 1) * lv.stack_inv - lv.stack_inv_aux))
+        trc = nv.mem_channels[0]
+        is_top_read = lv.stack_inv_aux * (1 - b[0])
+        c.constraint(npop * (lv.stack_inv_aux_2 - is_top_read))
+        nf = npop * lv.stack_inv_aux_2
+        c.constraint_transition(nf * (trc.used - 1))
+        c.constraint_transition(nf * (trc.is_read - 1))
+        c.constraint_transition(nf * (trc.addr_context - nv.context))
+        c.constraint_transition(nf * (trc.addr_segment - SEG_STACK))
+        c.constraint_transition(nf * (trc.addr_virtual - (nv.stack_len - 1)))
+        c.constraint(npop * (lv.stack_inv_aux_2 - 1) * trc.used)
+        for ch in lv.mem_channels[1:]:
+            c.constraint(npop * (b[0] - 1) * ch.used)
+        c.constraint(npop * (b[0] - 1) * lv.partial_channel.used)
+        c.constraint_transition(npop * (b[0] - 1) * (nv.stack_len - lv.stack_len + 1))
+        # syscalls_exceptions.rs
+        fs, fe = lv.op["syscall"], lv.op["exception"]
+        tf = fs + fe
+        c.constraint(fs * (fs - 1))
+        c.constraint(fe * (fe - 1))
+        ecb = lv.exc_code_bits
+        exc_code = sum(bit * (1 << i) for i, bit in enumerate(ecb))
+        c.constraint(fe * (exc_code - 6) * lv.is_kernel_mode)
+        for bit in ecb:
+            c.constraint(fe * bit * (bit - 1))
+        opc = sum(bit * (1 << i) for i, bit in enumerate(b))
+        op_handler = syscall_jumptable + opc * 3
+        exc_handler = exception_jumptable + exc_code * 3
+        jc = lv.mem_channels[1]
+        c.constraint(tf * jc.used)
+        c.constraint(tf * (jc.is_read - 1))
+        c.constraint(tf * jc.addr_context)
+        c.constraint(tf * (jc.addr_segment - SEG_CODE_))
+        c.constraint(fs * (jc.addr_virtual - op_handler))
+        c.constraint(fe * (jc.addr_virtual - exc_handler))
+        for limb in jc.value[1:]:
+            c.constraint(tf * limb)
+        c.constraint(tf * lv.mem_channels[2].used)
+        c.constraint_transition(tf * (nv.program_counter - jc.value[0]))
+        c.constraint_transition(tf * (nv.is_kernel_mode - 1))
+        c.constraint_transition(tf * nv.gas)
+        out = nv.mem_channels[0].value
+        c.constraint(fs * (out[0] - (lv.program_counter + 1)))
+        c.constraint(fe * (out[0] - lv.program_counter))
+        c.constraint(fs * (out[1] - lv.is_kernel_mode))
+        c.constraint(tf * (out[6] - lv.gas))
+        c.constraint(tf * out[7])
+        c.constraint(fe * (exc_code - 6) * out[1])
+        for limb in out[2:6]:
+            c.constraint(tf * limb)
+    return eval_cpu
+
+
+CPU_TEST_CONSTS = (31337, 4242, 777777, 888888)
+AIRS.update({8: (make_eval_cpu(*CPU_TEST_CONSTS), 85)})

@@ -19,7 +19,7 @@ def _descs_to(mod, col_descs):
 
 
 def _run_case(oracle, air_id, n_cols, log_n, hasher, lookup_spec, ctl_spec, seed, binary_cols=(), kw=None,
-              trace_fix=None):
+              trace_fix=None, air_consts=()):
     import torch
     import zk_evm_amd as zk
     import zk_evm_amd.prover as zp
@@ -73,7 +73,8 @@ def _run_case(oracle, air_id, n_cols, log_n, hasher, lookup_spec, ctl_spec, seed
                                         o_z, ctl_challenges, och)
     scfg = zk.StarkConfig(hasher=hasher, num_challenges=nchal,
                           fri_config=zk.FriConfig(proof_of_work_bits=kw["pow_bits"], num_query_rounds=kw["queries"]))
-    got = zp.prove_with_commitment(air_id, scfg, dev, tbatch, lookups_for(prod), p_z, ctl_challenges, ch)
+    got = zp.prove_with_commitment(air_id, scfg, dev, tbatch, lookups_for(prod), p_z, ctl_challenges, ch,
+                                   air_consts=air_consts)
     if exp["aux_cap"] is None:
         assert got.auxiliary_polys_cap is None
     else:
@@ -216,3 +217,26 @@ def test_keccak_sponge_table(oracle):
         n = trace.shape[1]
         trace[6 + 135] = rng.integers(0, 2, size=n, dtype=np.uint64)
     _run_case(oracle, 7, 438, 4, 0, [lk], [ctl], seed=16, trace_fix=fix)
+
+
+def test_cpu_table(oracle):
+    # CpuStark (cpu/cpu_stark.rs:594-626): all 18 constraint modules, 85 columns; the four kernel-label
+    # constants are passed as air_consts.  CTLs: two of the CPU's looking shapes -- a GP memory channel
+    # (ctl_data_gp_memory: is_read, ctx, seg, virt, value[8], timestamp = clock*NUM_CHANNELS + channel;
+    # filter = channel.used) and the logic CTL (opcode-derived column + 24 value limbs, filter = logic_op).
+    from oracle import airs as oairs
+    ch0 = 41
+    mem_cols = [("single", ch0 + 1), ("single", ch0 + 2), ("single", ch0 + 3), ("single", ch0 + 4)] + \
+               [("single", ch0 + 5 + i) for i in range(8)] + [("lc", [(40, 4)], [], 0)]
+    ctl_mem = [(mem_cols, ("simple", ("single", ch0 + 0)))]
+    logic_cols = [("lc", [(24 + i, 1 << i) for i in range(8)], [], 0)] + \
+                 [("single", 41 + 13 * k + 5 + i) for k in range(2) for i in range(8)] + \
+                 [("next", 41 + 5 + i) for i in range(8)]
+    ctl_logic = [(logic_cols, ("simple", ("single", 10)))]
+
+    def fix(trace, rng):
+        n = trace.shape[1]
+        for c in list(range(6, 24)) + [ch0, 4] + list(range(24, 32)):
+            trace[c] = rng.integers(0, 2, size=n, dtype=np.uint64)
+    _run_case(oracle, 8, 85, 5, 0, [], [ctl_mem, ctl_logic], seed=17, trace_fix=fix,
+              air_consts=oairs.CPU_TEST_CONSTS)

@@ -515,3 +515,436 @@ struct AirKeccakSponge {
         c.constraint_transition(is_dummy * (nv[0] + nv[PAD + RATE - 1]));
     }
 };
+
+// CpuStark: cpu/cpu_stark.rs:594-626 calling, in this order, byte_unpacking, clock, contextops,
+// control_flow, decode, dup_swap, gas, halt, jumps, membus, memio, modfp254, pc, push0, shift,
+// simple_logic (not, eq_iszero), stack, syscalls_exceptions (each cpu/<module>.rs `eval_packed`).
+// Columns cpu/columns/{mod.rs:56-97, ops.rs:6-47, general.rs}: context 0, code_context 1,
+// program_counter 2, stack_len 3, is_kernel_mode 4, gas 5, op flags 6..23 (eth_mainnet: no poseidon),
+// opcode_bits 24..31, general union 32..39, clock 40, mem_channels[3] 41..79, partial_channel 80..84.
+// air_consts = { halt_final pc, init pc, syscall_jumptable, exception_jumptable } -- kernel labels that
+// only the reference's assembler can produce (cpu/control_flow.rs:37-47, syscalls_exceptions.rs:68,73).
+struct AirCpu {
+    static constexpr u32 COLUMNS = 85;
+    enum { CTX = 0, CODE_CTX, PC, STACK_LEN, KERNEL, GAS };
+    enum { BINARY_OP = 6, TERNARY_OP, FP254_OP, EQ_ISZERO, LOGIC_OP, NOT_POP, SHIFT, JUMPDEST_KECCAK_GENERAL, JUMPS,
+           PUSH_PROVER_INPUT, DUP_SWAP, CONTEXT_OP, M_OP_32BYTES, EXIT_KERNEL, M_OP_GENERAL, PC_PUSH0, SYSCALL,
+           EXCEPTION };
+    enum { BITS = 24, GEN = 32, CLOCK = 40, CH0 = 41, CH1 = 54, CH2 = 67, PARTIAL = 80 };
+    enum { USED = 0, IS_READ = 1, ACTX = 2, ASEG = 3, AVIRT = 4, VAL = 5 };
+    enum { STACK_INV = 36, STACK_INV_AUX = 37, STACK_INV_AUX_2 = 38, STACK_LEN_BOUNDS_AUX = 39 };
+    static constexpr u64 SEG_STACK = 1, SEG_SHIFT_TABLE = 13, SEG_JUMPDEST_BITS = 14, SEG_CODE = 0;
+    __device__ static __forceinline__ u32 ch(u32 k) { return CH0 + 13 * k; }
+
+    // stack.rs:173-282 (eval_packed_one)
+    __device__ static void stack_one(const RowView &lv, const RowView &nv, Consumer &c, Fe filt, u32 num_pops,
+                                     bool pushes, bool disable) {
+        const Fe one = FE_ONE;
+        if (num_pops > 0) {
+            for (u32 i = 1; i < num_pops; ++i) {
+                u32 b = ch(i);
+                c.constraint(filt * (lv[b + USED] - one));
+                c.constraint(filt * (lv[b + IS_READ] - one));
+                c.constraint(filt * (lv[b + ACTX] - lv[CTX]));
+                c.constraint(filt * (lv[b + ASEG] - fe(SEG_STACK)));
+                c.constraint(filt * (lv[b + AVIRT] - (lv[STACK_LEN] - fe(i + 1))));
+            }
+            c.constraint(filt * lv[PARTIAL + USED]);
+            if (!pushes) {
+                Fe len_diff = lv[STACK_LEN] - fe(num_pops);
+                Fe nf = len_diff * filt;
+                c.constraint_transition(nf * (nv[CH0 + USED] - one));
+                c.constraint_transition(nf * (nv[CH0 + IS_READ] - one));
+                c.constraint_transition(nf * (nv[CH0 + ACTX] - nv[CTX]));
+                c.constraint_transition(nf * (nv[CH0 + ASEG] - fe(SEG_STACK)));
+                c.constraint_transition(nf * (nv[CH0 + AVIRT] - (nv[STACK_LEN] - one)));
+                c.constraint(filt * (len_diff * lv[STACK_INV] - lv[STACK_INV_AUX]));
+                c.constraint_transition(filt * (lv[STACK_INV_AUX] - one) * nv[CH0 + USED]);
+            }
+        } else if (pushes) {
+            Fe nf = lv[STACK_LEN] * filt;
+            c.constraint(nf * (lv[PARTIAL + USED] - one));
+            c.constraint(nf * lv[PARTIAL + IS_READ]);
+            c.constraint(nf * (lv[PARTIAL + ACTX] - lv[CTX]));
+            c.constraint(nf * (lv[PARTIAL + ASEG] - fe(SEG_STACK)));
+            c.constraint(nf * (lv[PARTIAL + AVIRT] - (lv[STACK_LEN] - one)));
+            c.constraint(filt * (lv[STACK_LEN] * lv[STACK_INV] - lv[STACK_INV_AUX]));
+            c.constraint(filt * (lv[STACK_INV_AUX] - one) * lv[PARTIAL + USED]);
+        } else {
+            c.constraint(filt * nv[CH0 + USED]);
+            for (u32 i = 0; i < 8; ++i) c.constraint(filt * (lv[CH0 + VAL + i] - nv[CH0 + VAL + i]));
+            c.constraint(filt * lv[PARTIAL + USED]);
+        }
+        if (disable) {
+            u32 lo = num_pops > 1 ? num_pops : 1, hi = 3 - (pushes ? 1 : 0);
+            for (u32 i = lo; i < hi; ++i) c.constraint(filt * lv[ch(i) + USED]);
+        }
+        c.constraint_transition(filt * (nv[STACK_LEN] - (lv[STACK_LEN] - fe(num_pops) + fe(pushes ? 1 : 0))));
+    }
+
+    __device__ static void eval(const RowView &lv, const RowView &nv, Consumer &c, const u64 *K) {
+        const Fe one = FE_ONE;
+        const Fe halt_pc(K[0]), start_pc(K[1]), syscall_jumptable(K[2]), exception_jumptable(K[3]);
+        Fe b[8];
+        for (u32 i = 0; i < 8; ++i) b[i] = lv[BITS + i];
+        // ---- byte_unpacking.rs ----
+        {
+            Fe filt = lv[M_OP_32BYTES] * (b[5] - one);
+            Fe len = one;
+            for (u32 i = 0; i < 5; ++i) len += b[i] * fe(1ULL << i);
+            c.constraint(filt * (nv[CH0 + VAL] - lv[CH0 + VAL] - len));
+            c.constraint(filt * (nv[CH0 + VAL + 1] - lv[CH0 + VAL + 1]));
+            c.constraint(filt * (nv[CH0 + VAL + 2] - lv[CH0 + VAL + 2]));
+            for (u32 i = 3; i < 8; ++i) c.constraint(filt * nv[CH0 + VAL + i]);
+        }
+        // ---- clock.rs ----
+        c.constraint_first_row(lv[CLOCK] - one);
+        c.constraint_transition(nv[CLOCK] - lv[CLOCK] - one);
+        // ---- contextops.rs ----
+        {
+            Fe dctx = nv[CTX] - lv[CTX];
+            for (u32 op = BINARY_OP; op <= EXCEPTION; ++op)
+                if (op != CONTEXT_OP) c.constraint_transition(lv[op] * dctx);
+            Fe cop = lv[CONTEXT_OP];
+            c.constraint_transition(cop * (b[0] - one) * dctx);
+            // get
+            Fe filt = cop * (one - b[0]);
+            c.constraint(filt * (nv[CH0 + VAL + 2] - lv[CTX]));
+            for (u32 i = 0; i < 8; ++i) if (i != 2) c.constraint(filt * nv[CH0 + VAL + i]);
+            Fe pruning = lv[GEN];
+            c.constraint(filt * pruning);
+            c.constraint(filt * (nv[STACK_LEN] - (lv[STACK_LEN] + one)));
+            c.constraint(filt * lv[CH1 + USED]);
+            c.constraint(filt * nv[CH0 + USED]);
+            // set
+            filt = cop * b[0];
+            c.constraint(filt * (lv[CH0 + VAL + 2] - nv[CTX]));
+            for (u32 i = 1; i < 8; ++i) if (i != 2) c.constraint(filt * lv[CH0 + VAL + i]);
+            c.constraint(cop * pruning * (pruning - one));
+            c.constraint(filt * (pruning - lv[CH0 + VAL]));
+            c.constraint(cop * (lv[STACK_INV_AUX] * b[0] - lv[STACK_INV_AUX_2]));
+            for (u32 i = 0; i < 8; ++i) c.constraint(cop * lv[STACK_INV_AUX_2] * (nv[CH0 + VAL + i] - lv[CH2 + VAL + i]));
+            c.constraint(filt * lv[CH1 + USED]);
+            c.constraint(filt * nv[CH0 + USED]);
+            // tail
+            Fe stack_len = nv[STACK_LEN] - (one - b[0]);
+            c.constraint(cop * (stack_len * lv[STACK_INV] - lv[STACK_INV_AUX]));
+            c.constraint(cop * (lv[STACK_INV_AUX] - lv[CH2 + USED]));
+            Fe nf = cop * lv[STACK_INV_AUX];
+            c.constraint(nf * (lv[CH2 + IS_READ] - b[0]));
+            c.constraint(nf * (lv[CH2 + ACTX] - nv[CTX]));
+            c.constraint(nf * (lv[CH2 + ASEG] - fe(SEG_STACK)));
+            c.constraint(nf * (lv[CH2 + AVIRT] - (stack_len - one)));
+        }
+        // ---- control_flow.rs ----
+        Fe is_cpu, is_cpu_next;
+        for (u32 op = BINARY_OP; op <= EXCEPTION; ++op) { is_cpu += lv[op]; is_cpu_next += nv[op]; }
+        const Fe next_halt = one - is_cpu_next;
+        {
+            c.constraint_transition(is_cpu * (is_cpu_next + next_halt - one));
+            Fe native = lv[BINARY_OP] + lv[TERNARY_OP] + lv[FP254_OP] + lv[EQ_ISZERO] + lv[LOGIC_OP] + lv[NOT_POP] +
+                        lv[SHIFT] + lv[JUMPDEST_KECCAK_GENERAL] + lv[PC_PUSH0] + lv[DUP_SWAP] + lv[CONTEXT_OP] +
+                        lv[M_OP_GENERAL];
+            Fe dpc = lv[PC] - nv[PC] + one, dk = lv[KERNEL] - nv[KERNEL];
+            c.constraint_transition(native * dpc);
+            c.constraint_transition(native * dk);
+            Fe is_pi = lv[PUSH_PROVER_INPUT] * b[7];
+            c.constraint_transition(is_pi * dpc);
+            c.constraint_transition(is_pi * dk);
+            c.constraint(lv[PUSH_PROVER_INPUT] * ((lv[KERNEL] + lv[GEN]) - one));
+            Fe last_noncpu = (is_cpu - one) * is_cpu_next;
+            c.constraint_transition(last_noncpu * (nv[PC] - start_pc));
+            c.constraint_transition(last_noncpu * (nv[KERNEL] - one));
+            c.constraint_transition(last_noncpu * nv[STACK_LEN]);
+        }
+        // ---- decode.rs ----
+        {
+            Fe km = lv[KERNEL];
+            c.constraint(km * (km - one));
+            for (u32 i = 0; i < 8; ++i) c.constraint(b[i] * (b[i] - one));
+            // OPCODES: (opcode, block_length, kernel_only, flag column)
+            constexpr u32 OC[5] = {0x14, 0x56, 0x80, 0xf6, 0xf9};
+            constexpr u32 BL[5] = {1, 1, 5, 1, 0};
+            constexpr bool KO[5] = {false, false, false, true, true};
+            constexpr u32 COL[5] = {EQ_ISZERO, JUMPS, DUP_SWAP, CONTEXT_OP, EXIT_KERNEL};
+            constexpr u32 COMBINED[11] = {LOGIC_OP, FP254_OP, BINARY_OP, TERNARY_OP, SHIFT, M_OP_GENERAL,
+                                          JUMPDEST_KECCAK_GENERAL, NOT_POP, PC_PUSH0, M_OP_32BYTES, PUSH_PROVER_INPUT};
+            Fe flag_sum;
+            for (u32 k = 0; k < 5; ++k) { Fe f = lv[COL[k]]; c.constraint(f * (f - one)); flag_sum += f; }
+            for (u32 k = 0; k < 11; ++k) { Fe f = lv[COMBINED[k]]; c.constraint(f * (f - one)); flag_sum += f; }
+            c.constraint(flag_sum * (flag_sum - one));
+            for (u32 k = 0; k < 5; ++k) {
+                Fe unavailable = KO[k] ? one - km : Fe();
+                Fe mismatch;
+                for (int i = 7; i >= (int)BL[k]; --i) mismatch += ((OC[k] >> i) & 1) ? one - b[i] : b[i];
+                c.constraint(lv[COL[k]] * (unavailable + mismatch));
+            }
+            Fe opcode, high3;
+            for (int i = 7; i >= 0; --i) { opcode += b[i] * fe(1ULL << i); if (i >= 5) high3 += b[i] * fe(1ULL << i); }
+            c.constraint((km - one) * lv[FP254_OP]);
+            c.constraint(lv[TERNARY_OP] * b[1] * (km - one));
+            c.constraint((km - one) * lv[M_OP_GENERAL]);
+            c.constraint((opcode - fe(0xfb)) * (opcode - fe(0xfc)) * lv[M_OP_GENERAL]);
+            c.constraint((km - one) * lv[JUMPDEST_KECCAK_GENERAL] * (one - b[1]));
+            c.constraint((opcode - fe(0x21)) * (opcode - fe(0x5b)) * lv[JUMPDEST_KECCAK_GENERAL]);
+            c.constraint((opcode - fe(0x58)) * (opcode - fe(0x5f)) * lv[PC_PUSH0]);
+            c.constraint((opcode - fe(0x19)) * (opcode - fe(0x50)) * lv[NOT_POP]);
+            c.constraint((km - one) * lv[M_OP_32BYTES]);
+            c.constraint((high3 - fe(0xc0)) * (opcode - fe(0xf8)) * lv[M_OP_32BYTES]);
+            c.constraint((opcode - fe(0xee)) * (high3 - fe(0x60)) * lv[PUSH_PROVER_INPUT]);
+            c.constraint(lv[PUSH_PROVER_INPUT] * b[7] * (km - one));
+        }
+        // ---- dup_swap.rs ----
+        {
+            Fe n = b[0] + b[1] * fe(2) + b[2] * fe(4) + b[3] * fe(8);
+            auto constrain_chan = [&](bool is_read, Fe f, Fe offset, u32 base) {
+                c.constraint(f * (lv[base + USED] - one));
+                c.constraint(f * (lv[base + IS_READ] - fe(is_read ? 1 : 0)));
+                c.constraint(f * (lv[base + ACTX] - lv[CTX]));
+                c.constraint(f * (lv[base + ASEG] - fe(SEG_STACK)));
+                c.constraint(f * (lv[base + AVIRT] - (lv[STACK_LEN] - one - offset)));
+            };
+            Fe f = lv[DUP_SWAP] * (one - b[4]);
+            for (u32 i = 0; i < 8; ++i) c.constraint(f * (lv[CH1 + VAL + i] - lv[CH0 + VAL + i]));
+            constrain_chan(false, f, Fe(), CH1);
+            for (u32 i = 0; i < 8; ++i) c.constraint(f * (lv[CH2 + VAL + i] - nv[CH0 + VAL + i]));
+            constrain_chan(true, f, n, CH2);
+            c.constraint_transition(f * (nv[STACK_LEN] - lv[STACK_LEN] - one));
+            c.constraint(f * nv[CH0 + USED]);
+            f = lv[DUP_SWAP] * b[4];
+            Fe n1 = n + one;
+            for (u32 i = 0; i < 8; ++i) c.constraint(f * (lv[CH0 + VAL + i] - lv[CH2 + VAL + i]));
+            constrain_chan(false, f, n1, CH2);
+            for (u32 i = 0; i < 8; ++i) c.constraint(f * (lv[CH1 + VAL + i] - nv[CH0 + VAL + i]));
+            constrain_chan(true, f, n1, CH1);
+            c.constraint(f * (nv[STACK_LEN] - lv[STACK_LEN]));
+            c.constraint(f * nv[CH0 + USED]);
+            c.constraint(lv[DUP_SWAP] * lv[PARTIAL + USED]);
+        }
+        // ---- gas.rs ----
+        {
+            // SIMPLE_OPCODES in struct field order: (column, cost)
+            constexpr u32 GC[9] = {FP254_OP, EQ_ISZERO, LOGIC_OP, SHIFT, DUP_SWAP, CONTEXT_OP, M_OP_32BYTES, M_OP_GENERAL, PC_PUSH0};
+            constexpr u64 GV[9] = {0, 3, 3, 3, 3, 0, 0, 0, 2};
+            Fe gfilt, gas_used;
+            for (u32 k = 0; k < 9; ++k) { Fe f = lv[GC[k]]; gfilt += f; gas_used += fe(GV[k]) * f; }
+            c.constraint_transition(gfilt * (nv[GAS] - (lv[GAS] + gas_used)));
+            Fe gas_diff = nv[GAS] - lv[GAS];
+            for (u32 k = 0; k < 9; ++k) c.constraint_transition(lv[GC[k]] * (gas_diff - fe(GV[k])));
+            c.constraint_transition(lv[JUMPS] * (gas_diff - (fe(8) + b[0] * fe(2))));
+            Fe cost_filter = b[0] + b[4] - b[0] * b[4];
+            c.constraint_transition(lv[BINARY_OP] * (gas_diff - (fe(5) + cost_filter * (fe(3) - fe(5)))));
+            c.constraint_transition(lv[TERNARY_OP] * (gas_diff - (fe(8) - b[1] * fe(8))));
+            c.constraint_transition(lv[NOT_POP] * (gas_diff - ((one - b[0]) * fe(2) + b[0] * fe(3))));
+            c.constraint_transition(lv[JUMPDEST_KECCAK_GENERAL] * (gas_diff - (b[1] * fe(1) + (one - b[1]) * fe(0))));
+            c.constraint_transition(lv[PUSH_PROVER_INPUT] * (gas_diff - ((one - b[7]) * fe(3) + b[7] * fe(0))));
+            c.constraint_transition((is_cpu - one) * is_cpu_next * nv[GAS]);
+        }
+        // ---- halt.rs ----
+        {
+            Fe halt_state = one - is_cpu;
+            c.constraint(halt_state * (halt_state - one));
+            c.constraint_transition(halt_state * (next_halt - one));
+            c.constraint(halt_state * (lv[KERNEL] - one));
+            for (u32 i = 0; i < 3; ++i) c.constraint(halt_state * lv[ch(i) + USED]);
+            c.constraint_last_row(halt_state - one);
+            c.constraint(halt_state * (lv[PC] - halt_pc));
+        }
+        // ---- jumps.rs ----
+        {
+            Fe f = lv[EXIT_KERNEL];
+            c.constraint_transition(f * (lv[CH0 + VAL] - nv[PC]));
+            c.constraint_transition(f * (lv[CH0 + VAL + 1] - nv[KERNEL]));
+            c.constraint_transition(f * (lv[CH0 + VAL + 6] - nv[GAS]));
+            c.constraint(f * lv[CH0 + VAL + 7]);
+            f = lv[JUMPS];
+            Fe is_jump = f * (one - b[0]), is_jumpi = f * b[0];
+            Fe len_diff = lv[STACK_LEN] - one - b[0];
+            Fe nf = len_diff * f;
+            c.constraint_transition(nf * (nv[CH0 + USED] - one));
+            c.constraint_transition(nf * (nv[CH0 + IS_READ] - one));
+            c.constraint_transition(nf * (nv[CH0 + ACTX] - nv[CTX]));
+            c.constraint_transition(nf * (nv[CH0 + ASEG] - fe(SEG_STACK)));
+            c.constraint_transition(nf * (nv[CH0 + AVIRT] - (nv[STACK_LEN] - one)));
+            c.constraint(f * (len_diff * lv[STACK_INV] - lv[STACK_INV_AUX]));
+            c.constraint_transition(f * (lv[STACK_INV_AUX] - one) * nv[CH0 + USED]);
+            c.constraint(is_jump * (lv[CH1 + VAL] - one));
+            for (u32 i = 1; i < 8; ++i) c.constraint(is_jump * lv[CH1 + VAL + i]);
+            Fe sj = lv[GEN], cond_sum_pinv = lv[GEN + 1];
+            c.constraint(f * sj * (sj - one));
+            Fe cond_sum, dst_hi_sum;
+            for (u32 i = 0; i < 8; ++i) cond_sum += lv[CH1 + VAL + i];
+            for (u32 i = 1; i < 8; ++i) dst_hi_sum += lv[CH0 + VAL + i];
+            c.constraint(f * (sj - one) * cond_sum);
+            c.constraint(f * (cond_sum_pinv * cond_sum - sj));
+            c.constraint(f * sj * dst_hi_sum);
+            c.constraint(f * (lv[CH2 + VAL] - one));
+            c.constraint(f * (lv[CH2 + USED] - sj * (one - lv[KERNEL])));
+            c.constraint(f * (lv[CH2 + IS_READ] - one));
+            c.constraint(f * (lv[CH2 + ACTX] - lv[CTX]));
+            c.constraint(f * (lv[CH2 + ASEG] - fe(SEG_JUMPDEST_BITS)));
+            c.constraint(f * (lv[CH2 + AVIRT] - lv[CH0 + VAL]));
+            c.constraint(f * lv[PARTIAL + USED]);
+            c.constraint(is_jump * lv[CH1 + USED]);
+            c.constraint_transition(is_jump * (nv[STACK_LEN] - lv[STACK_LEN] + one));
+            c.constraint_transition(is_jumpi * (nv[STACK_LEN] - lv[STACK_LEN] + fe(2)));
+            c.constraint_transition(f * (sj - one) * (nv[PC] - (lv[PC] + one)));
+            c.constraint_transition(f * sj * (nv[PC] - lv[CH0 + VAL]));
+        }
+        // ---- membus.rs ----
+        c.constraint(lv[CODE_CTX] - (one - lv[KERNEL]) * lv[CTX]);
+        for (u32 i = 0; i < 3; ++i) { Fe u = lv[ch(i) + USED]; c.constraint(u * (u - one)); }
+        { Fe u = lv[PARTIAL + USED]; c.constraint(u * (u - one)); }
+        // ---- memio.rs ----
+        {
+            Fe f = lv[M_OP_GENERAL] * b[0];   // load: address in channel 0 (virt, segment, ctx)
+            c.constraint(f * (lv[CH1 + USED] - one));
+            c.constraint(f * (lv[CH1 + IS_READ] - one));
+            c.constraint(f * (lv[CH1 + ACTX] - lv[CH0 + VAL + 2]));
+            c.constraint(f * (lv[CH1 + ASEG] - lv[CH0 + VAL + 1]));
+            c.constraint(f * (lv[CH1 + AVIRT] - lv[CH0 + VAL]));
+            for (u32 i = 0; i < 8; ++i) c.constraint(f * (lv[CH1 + VAL + i] - nv[CH0 + VAL + i]));
+            c.constraint(f * lv[CH2 + USED]);
+            c.constraint(f * lv[PARTIAL + USED]);
+            stack_one(lv, nv, c, f, 1, true, false);                    // MLOAD_GENERAL_OP
+            f = lv[M_OP_GENERAL] * (b[0] - one);                        // store: address in channel 1
+            c.constraint(f * (lv[PARTIAL + USED] - one));
+            c.constraint(f * lv[PARTIAL + IS_READ]);
+            c.constraint(f * (lv[PARTIAL + ACTX] - lv[CH1 + VAL + 2]));
+            c.constraint(f * (lv[PARTIAL + ASEG] - lv[CH1 + VAL + 1]));
+            c.constraint(f * (lv[PARTIAL + AVIRT] - lv[CH1 + VAL]));
+            c.constraint(f * lv[CH2 + USED]);
+            c.constraint(f * (lv[CH1 + USED] - one));
+            c.constraint(f * (lv[CH1 + IS_READ] - one));
+            c.constraint(f * (lv[CH1 + ACTX] - lv[CTX]));
+            c.constraint(f * (lv[CH1 + ASEG] - fe(SEG_STACK)));
+            c.constraint(f * (lv[CH1 + AVIRT] - (lv[STACK_LEN] - fe(2))));
+            Fe mg = lv[M_OP_GENERAL];
+            c.constraint(mg * ((lv[STACK_LEN] - fe(2)) * lv[STACK_INV] - lv[STACK_INV_AUX]));
+            Fe is_top_read = lv[STACK_INV_AUX] * (one - b[0]);
+            c.constraint(mg * (lv[STACK_INV_AUX_2] - is_top_read));
+            Fe nf = mg * lv[STACK_INV_AUX_2];
+            c.constraint_transition(nf * (nv[CH0 + USED] - one));
+            c.constraint_transition(nf * (nv[CH0 + IS_READ] - one));
+            c.constraint_transition(nf * (nv[CH0 + ACTX] - nv[CTX]));
+            c.constraint_transition(nf * (nv[CH0 + ASEG] - fe(SEG_STACK)));
+            c.constraint_transition(nf * (nv[CH0 + AVIRT] - (nv[STACK_LEN] - one)));
+            c.constraint(mg * (lv[STACK_INV_AUX] - one) * nv[CH0 + USED]);
+            c.constraint(mg * b[0] * nv[CH0 + USED]);
+        }
+        // ---- modfp254.rs ---- (BN254 base-field modulus, 32-bit limbs)
+        {
+            constexpr u64 PL[8] = {0xd87cfd47, 0x3c208c16, 0x6871ca8d, 0x97816a91, 0x8181585d, 0xb85045b6, 0xe131a029, 0x30644e72};
+            for (u32 i = 0; i < 8; ++i) c.constraint(lv[FP254_OP] * (lv[CH2 + VAL + i] - fe(PL[i])));
+        }
+        // ---- pc.rs / push0.rs ----
+        {
+            Fe f = lv[PC_PUSH0] * (one - b[0]);
+            c.constraint(f * (nv[CH0 + VAL] - lv[PC]));
+            for (u32 i = 1; i < 8; ++i) c.constraint(f * nv[CH0 + VAL + i]);
+            f = lv[PC_PUSH0] * b[0];
+            for (u32 i = 0; i < 8; ++i) c.constraint(f * nv[CH0 + VAL + i]);
+        }
+        // ---- shift.rs ----
+        {
+            Fe sh = lv[SHIFT];
+            Fe hz = lv[CH2 + USED];
+            c.constraint(sh * hz * (lv[CH2 + IS_READ] - one));
+            Fe hsum;
+            for (u32 i = 1; i < 8; ++i) hsum += lv[CH0 + VAL + i];
+            c.constraint(sh * (hsum * lv[GEN] - (one - hz)));
+            c.constraint(sh * hsum * hz);
+            c.constraint(sh * lv[CH2 + ACTX]);
+            c.constraint(sh * (lv[CH2 + ASEG] - fe(SEG_SHIFT_TABLE)));
+            c.constraint(sh * (lv[CH2 + AVIRT] - lv[CH0 + VAL]));
+        }
+        // ---- simple_logic: not.rs, eq_iszero.rs ----
+        {
+            Fe f = lv[NOT_POP] * b[0];
+            for (u32 i = 0; i < 8; ++i) c.constraint(f * (nv[CH0 + VAL + i] + lv[CH0 + VAL + i] - fe(0xFFFFFFFFULL)));
+            stack_one(lv, nv, c, f, 1, true, true);                     // BASIC_UNARY_OP
+            Fe ef = lv[EQ_ISZERO];
+            Fe eqf = ef * (one - b[0]), izf = ef * b[0];
+            Fe equal = nv[CH0 + VAL], unequal = one - equal;
+            c.constraint(ef * equal * unequal);
+            for (u32 i = 1; i < 8; ++i) c.constraint(ef * nv[CH0 + VAL + i]);
+            for (u32 i = 0; i < 8; ++i) c.constraint(izf * lv[CH1 + VAL + i]);
+            Fe dot;
+            for (u32 i = 0; i < 8; ++i) {
+                Fe diff = lv[CH0 + VAL + i] - lv[CH1 + VAL + i];
+                c.constraint(ef * equal * diff);
+            }
+            for (u32 i = 0; i < 8; ++i) dot += (lv[CH0 + VAL + i] - lv[CH1 + VAL + i]) * lv[GEN + i];
+            c.constraint(ef * (dot - unequal));
+            stack_one(lv, nv, c, eqf, 2, true, true);
+            stack_one(lv, nv, c, izf, 1, true, true);
+        }
+        // ---- stack.rs eval_packed ----
+        {
+            // STACK_BEHAVIORS / MIGHT_OVERFLOW in struct field order; num_pops < 0 = None
+            constexpr int NP[18] = {2, 3, 2, -1, 2, -1, 2, -1, -1, 0, -1, -1, 2, 1, -1, 0, 0, 0};
+            constexpr bool PU[18] = {1, 1, 1, 0, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1, 1, 1};
+            constexpr bool DI[18] = {1, 1, 1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 1, 0, 0};
+            constexpr bool OV[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
+            for (u32 k = 0; k < 18; ++k) {
+                Fe op = lv[BINARY_OP + k];
+                if (NP[k] >= 0) stack_one(lv, nv, c, op, (u32)NP[k], PU[k], DI[k]);
+                if (OV[k]) {
+                    Fe diff = nv[STACK_LEN] - fe(1025);
+                    c.constraint_transition(op * (diff * lv[STACK_LEN_BOUNDS_AUX] - (one - nv[KERNEL])));
+                }
+            }
+            stack_one(lv, nv, c, lv[JUMPDEST_KECCAK_GENERAL] * b[1], 0, false, true);          // JUMPDEST_OP
+            stack_one(lv, nv, c, lv[JUMPDEST_KECCAK_GENERAL] * (one - b[1]), 2, true, true);   // KECCAK_GENERAL_OP
+            Fe npop = lv[NOT_POP];
+            c.constraint(npop * ((lv[STACK_LEN] - one) * lv[STACK_INV] - lv[STACK_INV_AUX]));
+            Fe is_top_read = lv[STACK_INV_AUX] * (one - b[0]);
+            c.constraint(npop * (lv[STACK_INV_AUX_2] - is_top_read));
+            Fe nf = npop * lv[STACK_INV_AUX_2];
+            c.constraint_transition(nf * (nv[CH0 + USED] - one));
+            c.constraint_transition(nf * (nv[CH0 + IS_READ] - one));
+            c.constraint_transition(nf * (nv[CH0 + ACTX] - nv[CTX]));
+            c.constraint_transition(nf * (nv[CH0 + ASEG] - fe(SEG_STACK)));
+            c.constraint_transition(nf * (nv[CH0 + AVIRT] - (nv[STACK_LEN] - one)));
+            c.constraint(npop * (lv[STACK_INV_AUX_2] - one) * nv[CH0 + USED]);
+            Fe pf = npop * (b[0] - one);
+            c.constraint(pf * lv[CH1 + USED]);
+            c.constraint(pf * lv[CH2 + USED]);
+            c.constraint(pf * lv[PARTIAL + USED]);
+            c.constraint_transition(pf * (nv[STACK_LEN] - lv[STACK_LEN] + one));
+        }
+        // ---- syscalls_exceptions.rs ----
+        {
+            Fe fs = lv[SYSCALL], fex = lv[EXCEPTION];
+            Fe tf = fs + fex;
+            c.constraint(fs * (fs - one));
+            c.constraint(fex * (fex - one));
+            Fe exc_code = lv[GEN] + lv[GEN + 1] * fe(2) + lv[GEN + 2] * fe(4);
+            const Fe stop = fe(6);                                       // EXC_STOP_CODE
+            c.constraint(fex * (exc_code - stop) * lv[KERNEL]);
+            for (u32 i = 0; i < 3; ++i) { Fe bit = lv[GEN + i]; c.constraint(fex * bit * (bit - one)); }
+            Fe opcode;
+            for (u32 i = 0; i < 8; ++i) opcode += b[i] * fe(1ULL << i);
+            Fe op_handler = syscall_jumptable + opcode * fe(3);          // BYTES_PER_OFFSET = 3
+            Fe exc_handler = exception_jumptable + exc_code * fe(3);
+            c.constraint(tf * lv[CH1 + USED]);
+            c.constraint(tf * (lv[CH1 + IS_READ] - one));
+            c.constraint(tf * lv[CH1 + ACTX]);
+            c.constraint(tf * (lv[CH1 + ASEG] - fe(SEG_CODE)));
+            c.constraint(fs * (lv[CH1 + AVIRT] - op_handler));
+            c.constraint(fex * (lv[CH1 + AVIRT] - exc_handler));
+            for (u32 i = 1; i < 8; ++i) c.constraint(tf * lv[CH1 + VAL + i]);
+            c.constraint(tf * lv[CH2 + USED]);
+            c.constraint_transition(tf * (nv[PC] - lv[CH1 + VAL]));
+            c.constraint_transition(tf * (nv[KERNEL] - one));
+            c.constraint_transition(tf * nv[GAS]);
+            c.constraint(fs * (nv[CH0 + VAL] - (lv[PC] + one)));
+            c.constraint(fex * (nv[CH0 + VAL] - lv[PC]));
+            c.constraint(fs * (nv[CH0 + VAL + 1] - lv[KERNEL]));
+            c.constraint(tf * (nv[CH0 + VAL + 6] - lv[GAS]));
+            c.constraint(tf * nv[CH0 + VAL + 7]);
+            c.constraint(fex * (exc_code - stop) * nv[CH0 + VAL + 1]);
+            for (u32 i = 2; i < 6; ++i) c.constraint(tf * nv[CH0 + VAL + i]);
+        }
+    }
+};

@@ -19,6 +19,7 @@ from .stark import Column, Filter, Lookup, ctl_partial_sums, encode_program, loo
 AIR_NONE, AIR_MEM_CONTINUATION, AIR_LOGIC, AIR_MEMORY, AIR_BYTE_PACKING, AIR_ARITHMETIC = 0, 1, 2, 3, 4, 5
 AIR_KECCAK = 6
 AIR_KECCAK_SPONGE = 7
+AIR_CPU = 8
 P = 0xFFFFFFFF00000001
 
 
