@@ -1,0 +1,133 @@
+"""oracle/segment.py -- TEST INFRASTRUCTURE ONLY (never imported by the product).
+
+CPU restatement of the reference's per-segment driver, evm_arithmetization/src/prover.rs:72-298
+(`prove_with_traces`, `prove_with_commitments`, `prove_single_table` :301-341), of the transcript encoding of
+the public values (get_challenges.rs:11-227, util.rs:40-126) and of starky 1.0.0 `get_ctl_data` /
+`cross_table_lookup_data` / `verify_cross_table_lookups` ([EXT] cross_table_lookup.rs), on top of the C oracle
+and oracle/stark_prover.py.  Small sizes only."""
+import ctypes as C
+
+import numpy as np
+
+from . import all_stark as A
+from . import stark as S
+from . import stark_prover as SP
+
+P = S.P
+
+
+def pv_elements(pv: dict):
+    """pv: plain dict {roots_before: [3 x 32B], roots_after: [3 x 32B], beneficiary: 20B, timestamp, number,
+    difficulty, random: 32B, gaslimit, chain_id, base_fee, gas_used, blob_gas_used, excess_blob_gas,
+    parent_beacon_root: 32B, bloom: [8 ints], prev_hashes: [256 x 32B], cur_hash: 32B, checkpoint_root: 32B,
+    checkpoint_hash: [4], txn_before, txn_after, gas_before, gas_after}."""
+    def limbs(v): return [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+    def h(b): return limbs(int.from_bytes(b, "big"))          # util.rs:116-126 == observe_root (:11-19)
+    def u32(v):
+        assert 0 <= v < 1 << 32, "IntegerTooLarge"
+        return [v]
+    def u64(v):
+        assert 0 <= v < 1 << 64, "IntegerTooLarge"
+        return [v & 0xFFFFFFFF, v >> 32]
+    e = []
+    for r in pv["roots_before"] + pv["roots_after"]:
+        e += h(r)
+    e += limbs(int.from_bytes(pv["beneficiary"], "big"))[:5]
+    e += u32(pv["timestamp"]) + u32(pv["number"]) + u32(pv["difficulty"]) + h(pv["random"])
+    e += u32(pv["gaslimit"]) + u32(pv["chain_id"]) + u64(pv["base_fee"]) + u32(pv["gas_used"])
+    e += u64(pv["blob_gas_used"]) + u64(pv["excess_blob_gas"]) + h(pv["parent_beacon_root"])
+    for b in pv["bloom"]:
+        e += limbs(b)
+    assert len(pv["prev_hashes"]) == 256
+    for b in pv["prev_hashes"]:
+        e += h(b)
+    e += h(pv["cur_hash"]) + h(pv["checkpoint_root"]) + [x % P for x in pv["checkpoint_hash"]]
+    e += u32(pv["txn_before"]) + u32(pv["txn_after"]) + u32(pv["gas_before"]) + u32(pv["gas_after"])
+    return e
+
+
+def cross_table_lookup_data(traces, ctls, challenges, constraint_degree):
+    """[EXT] starky cross_table_lookup_data: per table, the CtlZData list in append order.  `ctl_helper_zs_cols`
+    groups *consecutive* looking entries by table; the z-data's own (columns, filter) list is every looking entry
+    of that table."""
+    per_table = [[] for _ in traces]
+    for ctl in ctls:
+        for ch in challenges:
+            runs = []
+            for t in ctl.looking_tables:
+                if runs and runs[-1][0] == t.table:
+                    runs[-1][1].append(t)
+                else:
+                    runs.append((t.table, [t]))
+            for table, _ in runs:
+                entries = [(t.columns, t.filter) for t in ctl.looking_tables if t.table == table]
+                per_table[table].append(S.CtlZData(ch, entries, 0))
+            lk = ctl.looked_table
+            per_table[lk.table].append(S.CtlZData(ch, [(lk.columns, lk.filter)], 0))
+    return per_table
+
+
+def prove_with_traces(o, fri_api, cfg, traces, table_in_use, pv, cpu_air_consts, ctls=None, lookups=None):
+    """traces: list of 9 (C_t, n_t) uint64 arrays.  Returns dict(ctl_challenges, proofs[9] (None if unused),
+    init_states[9], mem_before, mem_after, trace_caps)."""
+    from . import airs
+    L = o.lib
+    ctls = ctls if ctls is not None else A.build_ctls()
+    lookups = lookups if lookups is not None else A.build_lookups()
+    commits = [o.commit_values(t, rate_bits=cfg.rate_bits, cap_height=cfg.cap_height, hasher=cfg.hasher) for t in traces]
+    och = fri_api.new_challenger(o, cfg.hasher)
+    for i, c in enumerate(commits):
+        if i in A.OPTIONAL_TABLES and not table_in_use[i]:
+            z = np.zeros(c["cap"].size, dtype=np.uint64)
+            L.orc_challenger_observe(C.byref(och), z, z.size)
+        else:
+            L.orc_challenger_observe_cap(C.byref(och), c["cap"], c["cap"].shape[0])
+    e = np.array(pv_elements(pv), dtype=np.uint64)
+    L.orc_challenger_observe(C.byref(och), e, e.size)
+    challenges = []
+    for _ in range(cfg.num_challenges):
+        b = L.orc_challenger_get(C.byref(och))
+        g = L.orc_challenger_get(C.byref(och))
+        challenges.append(S.GrandProductChallenge(b, g))
+    ctl_pairs = [(c.beta, c.gamma) for c in challenges]
+    per_table = cross_table_lookup_data(traces, ctls, challenges, 3)
+    proofs, inits = [], []
+    for t in range(A.NUM_TABLES):
+        if not table_in_use[t]:
+            proofs.append(None)
+            inits.append(None)
+            continue
+        st = np.zeros(12, dtype=np.uint64)
+        L.orc_challenger_compact(C.byref(och), st)
+        inits.append(st)
+        air = airs.AIRS[A.TABLE_AIR[t]][0] if t != A.CPU else airs.make_eval_cpu(*cpu_air_consts)
+        proofs.append(SP.prove_with_commitment(o, fri_api, cfg, air, traces[t], commits[t], lookups[t], per_table[t],
+                                               ctl_pairs, och))
+    mem_after = commits[A.MEM_AFTER]["cap"].copy()
+    if not table_in_use[A.MEM_AFTER]:
+        mem_after[:] = 0
+    return dict(ctl_challenges=ctl_pairs, proofs=proofs, init_states=inits, mem_before=commits[A.MEM_BEFORE]["cap"],
+                mem_after=mem_after, trace_caps=[c["cap"] for c in commits], final_challenge=L.orc_challenger_get(C.byref(och)))
+
+
+def verify_cross_table_lookups(ctls, ctl_zs_first, extra_looking_sums, num_challenges):
+    """[EXT] starky verify_cross_table_lookups (called from verifier.rs:307): for each CTL and challenge, the sum of
+    the looking tables' Z(first row) plus the extra looking sum must equal the looked table's Z(first row).
+    ctl_zs_first[t]: list of that table's opened Z(1) values in z-data order; extra_looking_sums[ctl][challenge].
+    -> (ok, reason)."""
+    it = [iter(z) for z in ctl_zs_first]
+    for idx, ctl in enumerate(ctls):
+        extra = extra_looking_sums[idx] if extra_looking_sums else [0] * num_challenges
+        tables = []
+        for t in ctl.looking_tables:
+            if t.table not in tables:
+                tables.append(t.table)
+        for c in range(num_challenges):
+            looking = sum(next(it[t]) for t in tables) % P
+            looked = next(it[ctl.looked_table.table])
+            if (looking + extra[c]) % P != looked % P:
+                return False, "CTL %d challenge %d" % (idx, c)
+    for i in it:
+        if next(i, None) is not None:
+            return False, "unconsumed Z openings"
+    return True, ""

@@ -22,12 +22,16 @@ def inv(a: int) -> int:
 
 
 # ---- Column / Filter ([EXT] starky lookup.rs) -------------------------------------------------
-@dataclass
 class Column:
     """sum_i c_i * local[i] + sum_j d_j * next[j] + constant"""
-    linear_combination: List[Tuple[int, int]] = field(default_factory=list)
-    next_row_linear_combination: List[Tuple[int, int]] = field(default_factory=list)
-    constant: int = 0
+    # (a plain class: the field `linear_combination` shares its name with the reference's constructor below)
+    def __init__(self, linear_combination=None, next_row_linear_combination=None, constant=0):
+        self.linear_combination = list(linear_combination) if linear_combination is not None else []
+        self.next_row_linear_combination = list(next_row_linear_combination) if next_row_linear_combination is not None else []
+        self.constant = constant
+
+    def __repr__(self):
+        return "Column(%r, %r, %r)" % (self.linear_combination, self.next_row_linear_combination, self.constant)
 
     # constructors used by the reference (SURVEY 8(a'))
     @staticmethod

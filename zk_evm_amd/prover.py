@@ -47,6 +47,7 @@ class StarkProof:
     opening_proof: np.ndarray     # flat FriProof (include/zkstark.h)
     init_challenger_state: Optional[np.ndarray] = None
     num_ctl_zs: int = 0
+    degree_bits: Optional[int] = None
 
 
 def encode_lookup_set(lookups: Sequence[Lookup]) -> Optional[np.ndarray]:

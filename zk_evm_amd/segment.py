@@ -1,0 +1,283 @@
+"""Host mirror of the reference's per-segment driver:
+
+  * ``prove_with_traces`` / ``prove_with_commitments`` / ``prove_single_table``
+    (evm_arithmetization/src/prover.rs:72-194, 213-298, 301-341),
+  * ``observe_public_values`` (get_challenges.rs:11-227) with the limb helpers of util.rs:40-126,
+  * starky ``get_ctl_data`` -> ``cross_table_lookup_data`` / ``ctl_helper_zs_cols`` and
+    ``CrossTableLookup::num_ctl_helpers_zs_all`` ([EXT] starky 1.0.0 cross_table_lookup.rs),
+  * the output containers ``AllProof`` / ``MultiProof`` / ``StarkProofWithMetadata`` / ``MemCap`` (proof.rs:29-54,
+    587-622).
+
+Sequencing and transcript bookkeeping only -- every column, commitment, quotient and FRI step is a C-ABI call
+into the HIP library (there is no CPU fallback: without the library / a GPU these functions raise)."""
+from dataclasses import dataclass, field
+from itertools import groupby
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from ._lib import ZkStarkError
+from .all_stark import NUM_TABLES, OPTIONAL_TABLE_INDICES, AllStark, Table
+from .challenger import Challenger
+from .config import StarkConfig
+from .polynomial_batch import PolynomialBatch
+from .prover import CtlZData, StarkProof, prove_with_commitment
+from .stark import CrossTableLookup, ctl_partial_sums
+
+P = 0xFFFFFFFF00000001
+
+
+# ---- public values (proof.rs:70-91, 314-320, 357-363, 398-424, 471-487) ----------------------------------
+@dataclass
+class TrieRoots:
+    state_root: bytes = bytes(32)
+    transactions_root: bytes = bytes(32)
+    receipts_root: bytes = bytes(32)
+
+
+@dataclass
+class BlockMetadata:
+    block_beneficiary: bytes = bytes(20)
+    block_timestamp: int = 0
+    block_number: int = 0
+    block_difficulty: int = 0
+    block_random: bytes = bytes(32)
+    block_gaslimit: int = 0
+    block_chain_id: int = 0
+    block_base_fee: int = 0
+    block_gas_used: int = 0
+    block_blob_gas_used: int = 0
+    block_excess_blob_gas: int = 0
+    parent_beacon_block_root: bytes = bytes(32)
+    block_bloom: List[int] = field(default_factory=lambda: [0] * 8)
+
+
+@dataclass
+class BlockHashes:
+    prev_hashes: List[bytes] = field(default_factory=lambda: [bytes(32)] * 256)
+    cur_hash: bytes = bytes(32)
+
+
+@dataclass
+class ExtraBlockData:
+    checkpoint_state_trie_root: bytes = bytes(32)
+    checkpoint_consolidated_hash: List[int] = field(default_factory=lambda: [0] * 4)
+    txn_number_before: int = 0
+    txn_number_after: int = 0
+    gas_used_before: int = 0
+    gas_used_after: int = 0
+
+
+@dataclass
+class MemCap:
+    """proof.rs:587-622: the MemBefore / MemAfter trace caps, one [U256; 4] per cap hash."""
+    mem_cap: List[List[int]] = field(default_factory=list)
+
+    @staticmethod
+    def from_merkle_cap(cap: np.ndarray) -> "MemCap":
+        return MemCap([[int(x) % P for x in h] for h in np.asarray(cap).reshape(-1, 4)])
+
+
+@dataclass
+class PublicValues:
+    trie_roots_before: TrieRoots = field(default_factory=TrieRoots)
+    trie_roots_after: TrieRoots = field(default_factory=TrieRoots)
+    block_metadata: BlockMetadata = field(default_factory=BlockMetadata)
+    block_hashes: BlockHashes = field(default_factory=BlockHashes)
+    extra_block_data: ExtraBlockData = field(default_factory=ExtraBlockData)
+    mem_before: MemCap = field(default_factory=MemCap)
+    mem_after: MemCap = field(default_factory=MemCap)
+
+
+class PublicValuesError(ZkStarkError):
+    """`ProgramError::IntegerTooLarge` surfaced as "Invalid conversion of public values." (prover.rs:130)."""
+
+    def __init__(self):
+        super().__init__(-1, "Invalid conversion of public values.")
+
+
+def u256_limbs(v: int) -> List[int]:
+    """util.rs:101-113: eight little-endian 32-bit limbs."""
+    return [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+
+
+def h256_limbs(h: bytes) -> List[int]:
+    """util.rs:116-126: the hash read as a big-endian integer, in little-endian 32-bit limbs."""
+    if len(h) != 32:
+        raise PublicValuesError()
+    return u256_limbs(int.from_bytes(h, "big"))
+
+
+def u256_to_u32(v: int) -> int:
+    if not 0 <= v < (1 << 32):
+        raise PublicValuesError()
+    return v
+
+
+def u256_to_u64(v: int) -> Tuple[int, int]:
+    if not 0 <= v < (1 << 64):
+        raise PublicValuesError()
+    return v & 0xFFFFFFFF, v >> 32
+
+
+def public_values_elements(pv: PublicValues) -> List[int]:
+    """The exact element sequence `observe_public_values` feeds the transcript (get_challenges.rs:195-218,
+    eth_mainnet feature set)."""
+    out: List[int] = []
+    for roots in (pv.trie_roots_before, pv.trie_roots_after):          # :21-29
+        for r in (roots.state_root, roots.transactions_root, roots.receipts_root):
+            out += h256_limbs(r)
+    m = pv.block_metadata                                               # :46-83
+    out += u256_limbs(int.from_bytes(m.block_beneficiary, "big"))[:5]
+    out += [u256_to_u32(m.block_timestamp), u256_to_u32(m.block_number), u256_to_u32(m.block_difficulty)]
+    out += h256_limbs(m.block_random)
+    out += [u256_to_u32(m.block_gaslimit), u256_to_u32(m.block_chain_id)]
+    out += list(u256_to_u64(m.block_base_fee))
+    out.append(u256_to_u32(m.block_gas_used))
+    out += list(u256_to_u64(m.block_blob_gas_used))
+    out += list(u256_to_u64(m.block_excess_blob_gas))
+    out += h256_limbs(m.parent_beacon_block_root)
+    for i in range(8):
+        out += u256_limbs(m.block_bloom[i])
+    if len(pv.block_hashes.prev_hashes) != 256:                         # :170-180
+        raise PublicValuesError()
+    for h in pv.block_hashes.prev_hashes:
+        out += h256_limbs(h)
+    out += h256_limbs(pv.block_hashes.cur_hash)
+    e = pv.extra_block_data                                             # :114-128
+    out += h256_limbs(e.checkpoint_state_trie_root)
+    out += [int(x) % P for x in e.checkpoint_consolidated_hash]
+    out += [u256_to_u32(e.txn_number_before), u256_to_u32(e.txn_number_after), u256_to_u32(e.gas_used_before),
+            u256_to_u32(e.gas_used_after)]
+    return out
+
+
+def observe_public_values(challenger: Challenger, pv: PublicValues) -> None:
+    challenger.observe_elements(public_values_elements(pv))
+
+
+# ---- CTL data ([EXT] starky cross_table_lookup.rs) -------------------------------------------------------
+def num_ctl_helpers_zs_all(ctls: Sequence[CrossTableLookup], table: int, num_challenges: int,
+                           constraint_degree: int) -> Tuple[int, int, List[int]]:
+    """`CrossTableLookup::num_ctl_helpers_zs_all` -> (total helper columns, total Z columns, helpers per CTL)."""
+    num_helpers, num_ctls, by_ctl = 0, 0, [0] * len(ctls)
+    for i, ctl in enumerate(ctls):
+        n = sum(1 for t in [ctl.looked_table] + list(ctl.looking_tables) if t.table == table)
+        if n > 1:
+            by_ctl[i] = -(-n // (constraint_degree - 1))
+            num_helpers += by_ctl[i]
+        if n > 0:
+            num_ctls += 1
+    return num_helpers * num_challenges, num_ctls * num_challenges, by_ctl
+
+
+def get_ctl_data(config: StarkConfig, trace_values: Sequence, ctls: Sequence[CrossTableLookup],
+                 challenger: Challenger, constraint_degree: int, ctx=None):
+    """starky `get_ctl_data` (prover.rs:134-144): draw `num_challenges` (beta, gamma) pairs, then for every CTL,
+    every challenge: running-sum columns of each *run* of looking entries of one table (`ctl_helper_zs_cols`
+    groups consecutive entries) and of the looked table.  Returns (challenges, z-data per table) in the order
+    `cross_table_lookup_data` appends them -- that order is the order of the auxiliary polynomials."""
+    ctl_challenges = [(challenger.get_challenge(), challenger.get_challenge()) for _ in range(config.num_challenges)]
+    per_table: List[List[CtlZData]] = [[] for _ in trace_values]
+    for ctl in ctls:
+        looked = ctl.looked_table
+        for beta, gamma in ctl_challenges:
+            z_looked = ctl_partial_sums(trace_values[looked.table], [(looked.columns, looked.filter)], beta, gamma,
+                                        constraint_degree, ctx=ctx)
+            for table, group in groupby(ctl.looking_tables, key=lambda t: t.table):
+                entries = [(t.columns, t.filter) for t in group]
+                aux = ctl_partial_sums(trace_values[table], entries, beta, gamma, constraint_degree, ctx=ctx)
+                # CtlZData.columns/filter: every looking entry of this table in the CTL
+                all_entries = [(t.columns, t.filter) for t in ctl.looking_tables if t.table == table]
+                per_table[table].append(CtlZData(beta, gamma, all_entries, aux))
+            per_table[looked.table].append(CtlZData(beta, gamma, [(looked.columns, looked.filter)], z_looked))
+    return ctl_challenges, per_table
+
+
+# ---- proof containers --------------------------------------------------------------------------------------
+@dataclass
+class StarkProofWithMetadata:
+    """prover.rs:335-338: the table proof plus the challenger state it started from."""
+    proof: StarkProof
+    init_challenger_state: np.ndarray
+
+
+@dataclass
+class MultiProof:
+    stark_proofs: List[Optional[StarkProofWithMetadata]]
+    ctl_challenges: List[Tuple[int, int]]
+
+
+@dataclass
+class AllProof:
+    multi_proof: MultiProof
+    public_values: PublicValues
+    table_in_use: List[bool]
+
+    def degree_bits(self) -> List[Optional[int]]:
+        """proof.rs:58-64 (`recover_degree_bits`): from the FRI proof shape; here recorded by the prover."""
+        return [p.proof.degree_bits if p is not None else None for p in self.multi_proof.stark_proofs]
+
+
+class Aborted(ZkStarkError):
+    def __init__(self):
+        super().__init__(-4, "Stopping job from abort signal.")
+
+
+def check_abort_signal(abort_signal) -> None:
+    """prover.rs:346-354; `abort_signal` is any object with a truthy `.is_set()` or a 0/1 ctypes int."""
+    if abort_signal is None:
+        return
+    flag = abort_signal.is_set() if hasattr(abort_signal, "is_set") else bool(getattr(abort_signal, "value", abort_signal))
+    if flag:
+        raise Aborted()
+
+
+def prove_single_table(all_stark: AllStark, table: int, config: StarkConfig, trace_values, trace_commitment,
+                       ctl_data: Sequence[CtlZData], ctl_challenges, challenger: Challenger,
+                       abort_signal=None) -> StarkProofWithMetadata:
+    check_abort_signal(abort_signal)
+    init_challenger_state = challenger.compact()          # "Clear buffered outputs."
+    proof = prove_with_commitment(all_stark.table_air[table], config, trace_values, trace_commitment,
+                                  all_stark.lookups[table], ctl_data, ctl_challenges, challenger,
+                                  constraint_degree=all_stark.constraint_degree,
+                                  air_consts=all_stark.air_consts[table])
+    proof.degree_bits = trace_commitment.degree_log
+    return StarkProofWithMetadata(proof, init_challenger_state)
+
+
+def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_values: Sequence,
+                      table_in_use: Sequence[bool], public_values: PublicValues, abort_signal=None,
+                      hasher: Optional[int] = None, ctx=None) -> AllProof:
+    """prover.rs:72-194.  `trace_poly_values[t]`: CUDA int64/uint64 tensor (columns, 2^k) -- the column-major
+    `Vec<PolynomialValues<F>>` of table t (values may be non-canonical)."""
+    if len(trace_poly_values) != NUM_TABLES or len(table_in_use) != NUM_TABLES:
+        raise ZkStarkError(-1, "expected one trace and one in-use flag per table")
+    hasher = config.hasher if hasher is None else hasher
+    rate_bits, cap_height = config.fri_config.rate_bits, config.fri_config.cap_height
+    # trace commitments for every table, in use or not (prover.rs:90-111)
+    trace_commitments = [PolynomialBatch.from_values(t, rate_bits, False, cap_height, hasher=hasher, ctx=ctx)
+                         for t in trace_poly_values]
+    challenger = Challenger(hasher)
+    for i, c in enumerate(trace_commitments):
+        cap = c.merkle_tree.cap.elements
+        if i in OPTIONAL_TABLE_INDICES and not table_in_use[i]:
+            challenger.observe_elements([0] * len(c.merkle_tree.cap.flatten()))   # zero cap, prover.rs:120-123
+        else:
+            challenger.observe_cap(cap)
+    observe_public_values(challenger, public_values)
+    ctl_challenges, ctl_data_per_table = get_ctl_data(config, trace_poly_values, all_stark.cross_table_lookups,
+                                                      challenger, all_stark.constraint_degree, ctx=ctx)
+    stark_proofs: List[Optional[StarkProofWithMetadata]] = []
+    for t in Table.all():                                  # prove_with_commitments, prover.rs:251-259
+        if table_in_use[t]:
+            stark_proofs.append(prove_single_table(all_stark, t, config, trace_poly_values[t], trace_commitments[t],
+                                                   ctl_data_per_table[t], ctl_challenges, challenger, abort_signal))
+        else:
+            stark_proofs.append(None)
+    public_values.mem_before = MemCap.from_merkle_cap(trace_commitments[Table.MemBefore].merkle_tree.cap.elements)
+    mem_after = MemCap.from_merkle_cap(trace_commitments[Table.MemAfter].merkle_tree.cap.elements)
+    if not table_in_use[Table.MemAfter]:
+        mem_after = MemCap([[0] * 4 for _ in mem_after.mem_cap])
+    public_values.mem_after = mem_after
+    return AllProof(MultiProof(stark_proofs, ctl_challenges), public_values, list(table_in_use))
