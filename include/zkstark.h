@@ -62,6 +62,14 @@ void zk_ctx_destroy(zk_ctx *ctx);
  * the HIP default (null) stream.  A fresh ctx runs on its own non-blocking stream. */
 int zk_ctx_set_stream(zk_ctx *ctx, void *hip_stream);
 int zk_ctx_synchronize(zk_ctx *ctx);
+/* Device memory.  All batch and scratch HBM of a ctx comes from a grow-only arena (csrc/arena.hpp): blocks
+ * freed by zk_batch_free are handed out again in stream order instead of going back to the driver, because
+ * multi-GB hipMalloc / hipMallocAsync calls cost 0.2-2.7 s each on this platform.  zk_ctx_set_stream drains the
+ * old stream first.  reserve: make sure one free block of `bytes` exists (pre-size before a latency-critical
+ * proof); trim: synchronise and hipFree every idle slab; stats: bytes held / handed out / high-water mark. */
+int zk_ctx_mem_reserve(zk_ctx *ctx, size_t bytes);
+int zk_ctx_mem_trim(zk_ctx *ctx, size_t *released);
+int zk_ctx_mem_stats(const zk_ctx *ctx, size_t *reserved, size_t *in_use, size_t *peak_in_use);
 const char *zk_last_error(const zk_ctx *ctx);
 /* Cooperative cancellation, polled between kernels: mirrors `abort_signal` /
  * `check_abort_signal` (evm_arithmetization/src/prover.rs:56,346-354). NULL disables. */

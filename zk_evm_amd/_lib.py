@@ -31,6 +31,9 @@ SIGNATURES = {
     "zk_ctx_destroy": (None, [vp]),
     "zk_ctx_set_stream": (C.c_int, [vp, vp]),
     "zk_ctx_synchronize": (C.c_int, [vp]),
+    "zk_ctx_mem_reserve": (C.c_int, [vp, sz]),
+    "zk_ctx_mem_trim": (C.c_int, [vp, C.POINTER(sz)]),
+    "zk_ctx_mem_stats": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
     "zk_last_error": (C.c_char_p, [vp]),
     "zk_ctx_set_abort_flag": (C.c_int, [vp, vp]),
     "zk_ctx_last_timings": (C.c_int, [vp, C.POINTER(C.c_float)]),

@@ -40,6 +40,21 @@ class Context:
     def synchronize(self):
         self.check(self.lib.zk_ctx_synchronize(self.handle))
 
+    def mem_reserve(self, n_bytes: int):
+        """Pre-size the ctx's HBM arena (include/zkstark.h zk_ctx_mem_reserve)."""
+        self.check(self.lib.zk_ctx_mem_reserve(self.handle, n_bytes))
+
+    def mem_trim(self) -> int:
+        """Synchronise and give every idle slab of the arena back to the driver; returns the bytes released."""
+        r = C.c_size_t(0)
+        self.check(self.lib.zk_ctx_mem_trim(self.handle, C.byref(r)))
+        return int(r.value)
+
+    def mem_stats(self) -> dict:
+        a, b, c = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self.check(self.lib.zk_ctx_mem_stats(self.handle, C.byref(a), C.byref(b), C.byref(c)))
+        return {"reserved": int(a.value), "in_use": int(b.value), "peak_in_use": int(c.value)}
+
     def last_timings(self):
         arr = (C.c_float * 4)()
         self.check(self.lib.zk_ctx_last_timings(self.handle, arr))

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/zkstark.h"
+#include "arena.hpp"
 #include "gl.cuh"
 #include "merkle.cuh"
 #include "ntt.cuh"
@@ -39,6 +40,7 @@ struct zk_ctx {
     float timings[4] = {0, 0, 0, 0};
     int cu_count = 0;
     std::set<zk_batch *> live_batches;  // freed by zk_ctx_destroy if the caller leaked them
+    DevArena arena;                     // all batch + scratch HBM (arena.hpp)
 };
 
 struct zk_batch {
@@ -124,12 +126,6 @@ extern "C" int zk_ctx_create(int device, zk_ctx **out) {
     for (auto &e : ctx->ev) hipEventCreate(&e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
-    // keep freed batch memory in the stream-ordered pool (a commit re-allocates ~3 GB per call)
-    hipMemPool_t pool;
-    if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess) {
-        uint64_t thr = ~0ULL;
-        hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
-    }
     // allow the NTT kernels their full LDS tile (default dynamic limit is 64 KiB)
     hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -146,6 +142,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     hipSetDevice(ctx->device);
     while (!ctx->live_batches.empty()) zk_batch_free(*ctx->live_batches.begin());
     hipStreamSynchronize(ctx->stream);
+    ctx->arena.destroy();
     for (auto &kv : ctx->tw_fwd) hipFree(kv.second);
     for (auto &kv : ctx->tw_inv) hipFree(kv.second);
     for (auto &kv : ctx->coset_tabs) hipFree(kv.second);
@@ -157,7 +154,31 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
 
 extern "C" int zk_ctx_set_stream(zk_ctx *ctx, void *hip_stream) {
     if (!ctx) return ZK_ERR_BAD_ARG;
+    if ((hipStream_t)hip_stream != ctx->stream) {
+        // the arena recycles blocks in stream order: drain the old stream before work moves to another one
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     ctx->stream = (hipStream_t)hip_stream;  // NULL is the HIP default (null) stream
+    return ZK_OK;
+}
+extern "C" int zk_ctx_mem_reserve(zk_ctx *ctx, size_t bytes) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    hipError_t e = ctx->arena.reserve(bytes);
+    if (e != hipSuccess) return set_err(ctx, ZK_ERR_OOM, "cannot reserve %zu bytes of HBM: %s", bytes, hipGetErrorString(e));
+    return ZK_OK;
+}
+extern "C" int zk_ctx_mem_trim(zk_ctx *ctx, size_t *released) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    size_t r = ctx->arena.trim();
+    if (released) *released = r;
+    return ZK_OK;
+}
+extern "C" int zk_ctx_mem_stats(const zk_ctx *ctx, size_t *reserved, size_t *in_use, size_t *peak_in_use) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    if (reserved) *reserved = ctx->arena.reserved;
+    if (in_use) *in_use = ctx->arena.in_use;
+    if (peak_in_use) *peak_in_use = ctx->arena.peak_in_use;
     return ZK_OK;
 }
 extern "C" int zk_ctx_synchronize(zk_ctx *ctx) {
@@ -400,7 +421,7 @@ extern "C" int zk_lde(zk_ctx *ctx, const uint64_t *d_coeffs, size_t in_stride, u
     if (!n_cols) return ZK_OK;
     size_t n = (size_t)1 << log_n;
     u64 *tmp = nullptr;
-    HIP_TRY(ctx, hipMallocAsync((void **)&tmp, n_cols * n * sizeof(u64), ctx->stream));
+    HIP_TRY(ctx, ctx->arena.alloc((void **)&tmp, n_cols * n * sizeof(u64)));
     HIP_TRY(ctx, hipMemcpy2DAsync(tmp, n * 8, d_coeffs, in_stride * 8, n * 8, n_cols,
                                   hipMemcpyDeviceToDevice, ctx->stream));
     int rc = bitrev_columns(ctx, tmp, n, n_cols, log_n);
@@ -408,7 +429,7 @@ extern "C" int zk_lde(zk_ctx *ctx, const uint64_t *d_coeffs, size_t in_stride, u
     if (rc == ZK_OK) rc = get_coset_table(ctx, log_n, GL_GENERATOR, false, &tab);
     if (rc == ZK_OK)
         rc = ntt_coeffs_to_values(ctx, tmp, n, (u64 *)d_out, out_stride, n_cols, log_n, rate_bits, tab);
-    hipFreeAsync(tmp, ctx->stream);
+    ctx->arena.free(tmp);
     return rc;
 }
 
@@ -518,10 +539,10 @@ extern "C" void zk_batch_free(zk_batch *b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
     b->ctx->live_batches.erase(b);
-    hipStream_t st = b->ctx->stream;
-    if (b->d_coeffs) hipFreeAsync(b->d_coeffs, st);
-    if (b->d_lde) hipFreeAsync(b->d_lde, st);
-    if (b->d_digests) hipFreeAsync(b->d_digests, st);
+    zk_ctx *ctx = b->ctx;   // blocks return to the ctx arena (reused in stream order)
+    ctx->arena.free(b->d_coeffs);
+    ctx->arena.free(b->d_lde);
+    ctx->arena.free(b->d_digests);
     delete b;
 }
 
@@ -562,9 +583,9 @@ static int commit_impl(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t i
                                 "%s failed: %s", #expr, hipGetErrorString(e_)));             \
     } while (0)
     // stream-ordered pool allocations: repeated commits reuse the same HBM without hipMalloc cost
-    B_HIP(hipMallocAsync((void **)&b->d_coeffs, n_cols * n * sizeof(u64), ctx->stream));
-    B_HIP(hipMallocAsync((void **)&b->d_lde, n_cols * N * sizeof(u64), ctx->stream));
-    B_HIP(hipMallocAsync((void **)&b->d_digests, b->n_digests * 32, ctx->stream));
+    B_HIP(ctx->arena.alloc((void **)&b->d_coeffs, n_cols * n * sizeof(u64)));
+    B_HIP(ctx->arena.alloc((void **)&b->d_lde, n_cols * N * sizeof(u64)));
+    B_HIP(ctx->arena.alloc((void **)&b->d_digests, b->n_digests * 32));
 
     const u64 *coset = nullptr;
     if ((rc = get_coset_table(ctx, log_n, GL_GENERATOR, false, &coset)) != ZK_OK) return fail(rc);

@@ -8,6 +8,7 @@ timing, None)`` at evm_arithmetization/src/prover.rs:100-107 and verifier.rs:68-
 All arithmetic happens in the HIP library; this file only marshals pointers.
 """
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import List, Sequence
 
@@ -48,7 +49,16 @@ class _MerkleTreeView:
     """Read-only view with the ``MerkleTree`` accessors the prover uses."""
 
     def __init__(self, batch: "PolynomialBatch"):
-        self._b = batch
+        # weak: batch.merkle_tree -> view -> batch would be a cycle, and a cycle defers the release of
+        # tens of GB of HBM to the cyclic collector
+        self._ref = weakref.ref(batch)
+
+    @property
+    def _b(self) -> "PolynomialBatch":
+        b = self._ref()
+        if b is None or not b.handle:
+            raise ZkStarkError(-1, "the PolynomialBatch behind this MerkleTree was freed")
+        return b
 
     @property
     def cap(self) -> MerkleCap:

@@ -155,5 +155,8 @@ def prove_with_commitment(air_id: int, config: StarkConfig, trace_values, trace_
     openings = fri_openings(inst, oracles)
     challenger.observe_extension_elements(openings)
     proof = prove_openings(inst, oracles, challenger, config, openings)
+    quotient.free()                    # release HBM now (the trace commitment belongs to the caller)
+    if aux is not None:
+        aux.free()
     return StarkProof(trace_cap=trace_commitment.merkle_tree.cap.elements, auxiliary_polys_cap=aux_cap,
                       quotient_polys_cap=q_cap, openings=openings, opening_proof=proof, num_ctl_zs=n_ctl_zs)

@@ -17,7 +17,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from ._lib import ZkStarkError
-from .all_stark import NUM_TABLES, OPTIONAL_TABLE_INDICES, AllStark, Table
+from .all_stark import NUM_TABLES, OPTIONAL_TABLE_INDICES, TABLE_NAMES, AllStark, Table
 from .challenger import Challenger
 from .config import StarkConfig
 from .polynomial_batch import PolynomialBatch
@@ -246,9 +246,31 @@ def prove_single_table(all_stark: AllStark, table: int, config: StarkConfig, tra
     return StarkProofWithMetadata(proof, init_challenger_state)
 
 
+class _Timed:
+    """`timed!(timing, "label", ...)`: when the caller passes a dict, synchronise and accumulate wall seconds."""
+
+    def __init__(self, timing, label):
+        self.timing, self.label = timing, label
+
+    def __enter__(self):
+        if self.timing is not None:
+            import time
+            import torch
+            torch.cuda.synchronize()
+            self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if self.timing is not None:
+            import time
+            import torch
+            torch.cuda.synchronize()
+            self.timing[self.label] = self.timing.get(self.label, 0.0) + time.perf_counter() - self.t0
+        return False
+
+
 def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_values: Sequence,
                       table_in_use: Sequence[bool], public_values: PublicValues, abort_signal=None,
-                      hasher: Optional[int] = None, ctx=None) -> AllProof:
+                      hasher: Optional[int] = None, ctx=None, timing: Optional[dict] = None) -> AllProof:
     """prover.rs:72-194.  `trace_poly_values[t]`: CUDA int64/uint64 tensor (columns, 2^k) -- the column-major
     `Vec<PolynomialValues<F>>` of table t (values may be non-canonical)."""
     if len(trace_poly_values) != NUM_TABLES or len(table_in_use) != NUM_TABLES:
@@ -256,8 +278,9 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
     hasher = config.hasher if hasher is None else hasher
     rate_bits, cap_height = config.fri_config.rate_bits, config.fri_config.cap_height
     # trace commitments for every table, in use or not (prover.rs:90-111)
-    trace_commitments = [PolynomialBatch.from_values(t, rate_bits, False, cap_height, hasher=hasher, ctx=ctx)
-                         for t in trace_poly_values]
+    with _Timed(timing, "compute all trace commitments"):
+        trace_commitments = [PolynomialBatch.from_values(t, rate_bits, False, cap_height, hasher=hasher, ctx=ctx)
+                             for t in trace_poly_values]
     challenger = Challenger(hasher)
     for i, c in enumerate(trace_commitments):
         cap = c.merkle_tree.cap.elements
@@ -266,18 +289,26 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
         else:
             challenger.observe_cap(cap)
     observe_public_values(challenger, public_values)
-    ctl_challenges, ctl_data_per_table = get_ctl_data(config, trace_poly_values, all_stark.cross_table_lookups,
-                                                      challenger, all_stark.constraint_degree, ctx=ctx)
+    with _Timed(timing, "compute CTL data"):
+        ctl_challenges, ctl_data_per_table = get_ctl_data(config, trace_poly_values, all_stark.cross_table_lookups,
+                                                          challenger, all_stark.constraint_degree, ctx=ctx)
     stark_proofs: List[Optional[StarkProofWithMetadata]] = []
     for t in Table.all():                                  # prove_with_commitments, prover.rs:251-259
         if table_in_use[t]:
-            stark_proofs.append(prove_single_table(all_stark, t, config, trace_poly_values[t], trace_commitments[t],
-                                                   ctl_data_per_table[t], ctl_challenges, challenger, abort_signal))
+            with _Timed(timing, "prove %s STARK" % TABLE_NAMES[t]):
+                stark_proofs.append(prove_single_table(all_stark, t, config, trace_poly_values[t],
+                                                       trace_commitments[t], ctl_data_per_table[t], ctl_challenges,
+                                                       challenger, abort_signal))
         else:
             stark_proofs.append(None)
+        ctl_data_per_table[t] = None       # drop this table's CTL columns
+        if t not in (Table.MemBefore, Table.MemAfter):
+            trace_commitments[t].free()    # (the two memory caps are read below)
     public_values.mem_before = MemCap.from_merkle_cap(trace_commitments[Table.MemBefore].merkle_tree.cap.elements)
     mem_after = MemCap.from_merkle_cap(trace_commitments[Table.MemAfter].merkle_tree.cap.elements)
     if not table_in_use[Table.MemAfter]:
         mem_after = MemCap([[0] * 4 for _ in mem_after.mem_cap])
     public_values.mem_after = mem_after
+    for c in trace_commitments:
+        c.free()
     return AllProof(MultiProof(stark_proofs, ctl_challenges), public_values, list(table_in_use))
