@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MI355X STARK commitment path.
+"""bench.py -- headline benchmark: segment STARK proofs/sec on MI355X.
 
-Workload (BASELINE.json configs[1]): one ArithmeticStark-shaped trace, 116 columns x 2^20 rows,
-`PolynomialBatch::from_values(trace, rate_bits=1, blinding=false, cap_height=4)` with the Poseidon
-hasher -- iNTT, coset LDE to 2^21, Poseidon leaf hashing, Merkle cap -- i.e. the "compute trace
-commitment" scope of the reference (evm_arithmetization/src/prover.rs:92-111).  A "step" is one
-such commit over a synthetic trace already resident in HBM.
+Default workload (BASELINE.json `metric`, configs[2]): ONE full segment proof = the reference's
+`prove_with_traces` (evm_arithmetization/src/prover.rs:72-194) over all nine AllStark tables
+(Arithmetic 116, BytePacking 71, Cpu 85, Keccak 2431, KeccakSponge 438, Logic 523, Memory 30, MemBefore 12,
+MemAfter 12 columns), every table at 2^20 rows, with the real all_stark.rs CTL wiring (10 CTLs, 176 Memory
+lookers) and range-check lookups, `StarkConfig::standard_fast_config` (2 challenges, rate_bits 1, cap_height 4,
+16 PoW bits, 84 FRI queries), Poseidon hasher.  A "step" is one such proof over synthetic traces already
+resident in HBM (31.2 GB): 9 trace commitments, CTL columns, and per table lookup columns, auxiliary
+commitment, quotient with the table's full AIR, quotient commitment, openings and FRI.
 
-Multi-GPU: trace segments / tables are independent units, so each rank commits its
-own trace with no data-path collective ("scaling": "weak"); value = commits of all ranks / max time.
+Also measured in the same run (secondary objects of the same JSON line):
+  * `commit_config1`: BASELINE configs[1], the single ArithmeticStark 116 x 2^20 trace commitment
+    (`PolynomialBatch::from_values`), with stage timings, NTT GB/s and the Poseidon VALU-issue fraction;
+  * `segment_timing`: wall time per stage / table of one extra, synchronised, untimed proof.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (Poseidon leaf hashing),
-timed with HIP events on the kernel's own stream inside the timed region; `cpu_baseline` is the
-CPU oracle (OpenMP over columns / leaves, the axes rayon uses in the reference) on a bounded
-sample of the same workload.
+`--workload commit` makes the configs[1] commit the timed step instead.
+
+Multi-GPU: segments are independent units (fresh Challenger per segment), so each rank proves
+its own segment with no data-path collective ("scaling": "weak"); value = segments of all ranks / max time.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (Poseidon leaf hashing,
+poseidon_hash_rows_kernel: ~60 % of the segment), timed with HIP events on the kernel's own stream inside the
+timed region and summed over its launches (one per commitment); `cpu_baseline` is the CPU oracle (OpenMP over
+columns / leaves, the axes rayon uses in the reference) on a bounded sample.
 """
 import argparse
 import json
@@ -31,14 +41,16 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", choices=["segment", "commit"], default="segment")
+    ap.add_argument("--commit-steps", type=int, default=5, help="configs[1] commits timed as a secondary object")
     ap.add_argument("--cols", type=int, default=116)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--hasher", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=16)
-    ap.add_argument("--proof-steps", type=int, default=2,
+    ap.add_argument("--proof-steps", type=int, default=0,
                     help="also time N full ArithmeticStark table proofs (0 disables)")
     return ap.parse_args()
 
@@ -128,6 +140,136 @@ def table_proof_bench(ctx, dev, log_n, steps):
             "proof_words": int(pr.opening_proof.size)}
 
 
+def synthetic_segment_traces(log_ns, dev, seed=1):
+    """Random traces in HBM for the nine tables with every CTL / lookup *filter* column binary (one-hot op
+    flags etc.): the helper-column kernels reject non-binary filters exactly like starky's debug assert.  Values are
+    otherwise uniform 64-bit patterns (non-canonical representatives included)."""
+    import torch
+    from zk_evm_amd.all_stark import TABLE_COLUMNS
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    out = []
+    for t, (c, l) in enumerate(zip(TABLE_COLUMNS, log_ns)):
+        n = 1 << l
+        tr = torch.randint(-(1 << 63), (1 << 63) - 1, (c, n), dtype=torch.int64, device=dev, generator=g)
+
+        def binary(cols):
+            for k in cols:
+                tr[k] = torch.randint(0, 2, (n,), dtype=torch.int64, device=dev, generator=g)
+
+        def one_hot(cols, extra=1):
+            pick = torch.randint(0, len(cols) + extra, (n,), device=dev, generator=g)
+            for i, k in enumerate(cols):
+                tr[k] = (pick == i).to(torch.int64)
+        if t == 0:
+            one_hot(list(range(17)))                      # Arithmetic op flags + IS_RANGE_CHECK
+        elif t == 1:
+            one_hot(list(range(1, 33)))                   # BytePacking index_len
+        elif t == 2:
+            one_hot(list(range(6, 24)))                   # Cpu op flags
+            binary(list(range(24, 33)) + [41, 54, 67, 80])
+        elif t == 3:
+            binary([0, 23])                               # Keccak first / last round flags
+        elif t == 4:                                      # KeccakSponge: none / full block / final block of length ln
+            kind = torch.randint(0, 3, (n,), device=dev, generator=g)
+            ln = torch.randint(0, 136, (n,), device=dev, generator=g)
+            tr[0] = (kind == 1).to(torch.int64)
+            for i in range(136):
+                tr[6 + i] = ((kind == 2) & (ln <= i)).to(torch.int64)
+        elif t == 5:
+            one_hot([0, 1, 2])                            # Logic ops
+        elif t == 6:                                      # Memory
+            binary([0, 22, 24, 26])
+            one_hot([15, 16], 2)
+            f = torch.randint(0, 2, (n,), dtype=torch.int64, device=dev, generator=g)
+            tr[1] = f                                     # timestamp = timestamp_inv in {0,1}: mem_before filter binary
+            tr[2] = f
+        else:
+            binary([0])                                   # MemBefore / MemAfter filter
+        out.append(tr)
+    return out
+
+
+def segment_committed_cells(log_ns):
+    """(columns x rows) the segment commits: trace + auxiliary (lookup + CTL) + 4 quotient chunks per table."""
+    from zk_evm_amd import all_stark as A
+    from zk_evm_amd.segment import num_ctl_helpers_zs_all
+    ctls = A.all_cross_table_lookups()
+    cells = 0
+    for t in A.Table.all():
+        aux = sum(num_ctl_helpers_zs_all(ctls, t, 2, 3)[:2]) + 2 * sum(l.num_helper_columns(3) for l in A.table_lookups(t))
+        cells += (A.TABLE_COLUMNS[t] + aux + 4) << log_ns[t]
+    return cells
+
+
+def measure_commit(ctx, dev, a, rank, steps, warmup):
+    """BASELINE configs[1]: `steps` commits of one cols x 2^log_n trace; returns (elapsed_s, stage ms, trace)."""
+    import torch
+    from zk_evm_amd import PolynomialBatch
+    n = 1 << a.log_n
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED + rank)
+    # synthetic trace, uniform u64 bit patterns (non-canonical representatives included), in HBM
+    hi = torch.randint(0, 1 << 32, (a.cols, n), dtype=torch.int64, device=dev, generator=g)
+    lo = torch.randint(0, 1 << 32, (a.cols, n), dtype=torch.int64, device=dev, generator=g)
+    trace = (hi << 32) | lo
+    del hi, lo
+
+    def step():
+        b = PolynomialBatch.from_values(trace, 1, False, 4, hasher=a.hasher, ctx=ctx)
+        t = ctx.last_timings()
+        b.free()
+        return t
+    return trace, step
+
+
+def commit_report(a, stage, ms_per_step):
+    """Roofline pieces of one cols x 2^log_n commit from its HIP-event stage times (ms)."""
+    n = 1 << a.log_n
+    N = n << 1
+    # dominant kernel: poseidon_hash_rows_kernel (one launch per commit). Algorithmic bytes:
+    # read the LDE once (8*C*N) + write N 32-byte digests.
+    dom_bytes = 8.0 * a.cols * N + 32.0 * N
+    dom_ms = stage["leaf_hash"]
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
+    perms = N * ((a.cols + 7) // 8) if a.cols > 4 else 0
+    commit_bytes = 32.0 * a.cols * n + 128.0 * n          # whole-commit algorithmic bytes (SURVEY 8(d))
+    ntt_bytes = 40.0 * a.cols * n
+    ntt_ms = stage["ifft"] + stage["lde"]
+    # HBM traffic and VALU instruction counts of the dominant kernel come from separate rocprofv3 --pmc passes
+    # (tools/collect_pmc.sh), summarised in profiles/pmc_latest.json; they apply to the 116 x 2^20 Poseidon launch.
+    traffic = None
+    valu = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path) and a.cols == 116 and a.log_n == 20 and a.hasher == 0:
+        try:
+            pmc = json.load(open(pmc_path))
+            traffic = pmc.get("leaf_hash_hbm_bytes_per_launch")
+            insts = pmc.get("leaf_hash_valu_wave_insts_per_launch")
+            if insts:
+                # integer-issue roofline: every useful integer VALU op on gfx950 issues at ~4 cycles per wave64
+                # per SIMD (profiles/r01_ubench_valu_issue_rates.txt)
+                peak = 1024 * 2.4e9 / 4.0
+                ach = insts / (dom_ms * 1e-3)
+                valu = {"wave_insts_per_launch": insts, "achieved_wave_insts_per_s": ach,
+                        "peak_wave_insts_per_s": peak, "frac": ach / peak,
+                        "assumes": "1024 SIMDs x 2.4 GHz / 4 cycles per integer VALU wave-instruction",
+                        "source": pmc.get("source")}
+        except Exception:
+            traffic = None
+    roof = {"bound": "hbm", "kernel": "poseidon_hash_rows_kernel" if a.hasher == 0 else "keccak_hash_rows_kernel",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "ms_per_launch": dom_ms, "algorithmic_bytes": dom_bytes,
+            "note": "kernel is integer-ALU bound (Poseidon), see DESIGN.md; permutations/s = %.3e"
+                    % (perms / (dom_ms * 1e-3) if dom_ms else 0),
+            "valu": valu}
+    extra = {"stages_ms": stage,
+             "ntt": {"achieved_GBs": ntt_bytes / (ntt_ms * 1e-3) / 1e9, "algorithmic_bytes": ntt_bytes,
+                     "frac_of_hbm_peak": ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+             "commit": {"achieved_GBs": commit_bytes / (ms_per_step * 1e-3) / 1e9, "algorithmic_bytes": commit_bytes}}
+    return roof, extra
+
+
 def main():
     a = parse()
     import numpy as np
@@ -145,124 +287,155 @@ def main():
     dev = torch.device(f"cuda:{local}")
 
     import zk_evm_amd
-    from zk_evm_amd import PolynomialBatch
     ctx = zk_evm_amd.Context(local)
     ctx.use_torch_current_stream()
-
-    n = 1 << a.log_n
-    N = n << 1
-    g = torch.Generator(device=dev)
-    g.manual_seed(0x5EED + rank)
-    # synthetic trace, uniform u64 bit patterns (non-canonical representatives included), in HBM
-    hi = torch.randint(0, 1 << 32, (a.cols, n), dtype=torch.int64, device=dev, generator=g)
-    lo = torch.randint(0, 1 << 32, (a.cols, n), dtype=torch.int64, device=dev, generator=g)
-    trace = (hi << 32) | lo
-    del hi, lo
-
-    def step():
-        b = PolynomialBatch.from_values(trace, 1, False, 4, hasher=a.hasher, ctx=ctx)
-        t = ctx.last_timings()
-        b.free()
-        return t
+    hname = "poseidon" if a.hasher == 0 else "keccak25"
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    stage = {"ifft": 0.0, "lde": 0.0, "leaf_hash": 0.0, "tree": 0.0}
-    for _ in range(a.steps):
-        t = step()
-        for k in stage:
-            stage[k] += t[k]
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def max_over_ranks(x):
+        if world > 1:
+            tt = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return x
 
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed / a.steps
-        value = world * a.steps / elapsed
+    def timed_commits(steps, warmup):
+        trace, step = measure_commit(ctx, dev, a, rank, steps, warmup)
+        for _ in range(warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        stage = {"ifft": 0.0, "lde": 0.0, "leaf_hash": 0.0, "tree": 0.0}
+        for _ in range(steps):
+            t = step()
+            for k in stage:
+                stage[k] += t[k]
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
         for k in stage:
-            stage[k] /= a.steps
-        # dominant kernel: poseidon_hash_rows_kernel (one launch per commit). Algorithmic bytes:
-        # read the LDE once (8*C*N) + write N 32-byte digests.
-        dom_bytes = 8.0 * a.cols * N + 32.0 * N
-        dom_ms = stage["leaf_hash"]
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9
-        perms = N * ((a.cols + 7) // 8) if a.cols > 4 else 0
-        # whole-commit algorithmic bytes: 32*C*n + 128*n
-        commit_bytes = 32.0 * a.cols * n + 128.0 * n
-        ntt_bytes = 40.0 * a.cols * n
-        ntt_ms = stage["ifft"] + stage["lde"]
-        # HBM traffic and VALU instruction counts of the dominant kernel come from separate
-        # rocprofv3 --pmc passes (tools/collect_pmc.sh), summarised in profiles/pmc_latest.json;
-        # they only apply to the default workload they were collected on.
-        traffic = None
-        valu = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc_path) and a.cols == 116 and a.log_n == 20 and a.hasher == 0:
+            stage[k] /= steps
+        del trace
+        return elapsed, stage
+
+    out = None
+    if a.workload == "commit":
+        elapsed, stage = timed_commits(a.steps, a.warmup)
+        if rank == 0:
+            ms_per_step = 1e3 * elapsed / a.steps
+            roof, extra = commit_report(a, stage, ms_per_step)
+            out = {
+                "metric": "ArithmeticStark-shaped 2^20-row trace commits/sec (Goldilocks iNTT + coset LDE + "
+                          "Poseidon Merkle cap; BASELINE configs[1], the commit stage of segment STARK proofs/sec)",
+                "value": world * a.steps / elapsed, "unit": "commits/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                "config": {"workload": f"PolynomialBatch::from_values {a.cols} cols x 2^{a.log_n} rows, "
+                                       f"rate_bits 1, cap_height 4, hasher {hname}",
+                           "parallelism": f"{world} independent traces (one per GPU), no collective"},
+                "roofline": roof}
+            out.update(extra)
+            if a.proof_steps > 0 and a.cols == 116 and a.hasher == 0:
+                try:
+                    out["table_proof"] = table_proof_bench(ctx, dev, a.log_n, a.proof_steps)
+                except Exception as e:
+                    out["table_proof"] = {"error": repr(e)}
+            if not a.no_cpu_baseline and world == 1:
+                try:
+                    out["cpu_baseline"] = cpu_baseline(a.cols, a.log_n, min(a.cpu_sample_log_n, a.log_n), a.hasher)
+                except Exception as e:  # the oracle is only a reported baseline; never fatal
+                    out["cpu_baseline"] = {"error": repr(e)}
+    else:
+        import zk_evm_amd.segment as sg
+        from zk_evm_amd.all_stark import TABLE_COLUMNS, TABLE_NAMES, AllStark
+        log_ns = [a.log_n] * 9
+        traces = synthetic_segment_traces(log_ns, dev, seed=1 + rank)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        cfg = zk_evm_amd.StarkConfig(hasher=a.hasher)   # == standard_fast_config() with the chosen hasher
+        all_stark = AllStark((1, 2, 3, 4))   # kernel-label constants of the Cpu AIR: arbitrary for timing
+        in_use = [True] * 9
+
+        def step(timing=None):
+            return sg.prove_with_traces(all_stark, cfg, traces, in_use, sg.PublicValues(), ctx=ctx, timing=timing)
+        for _ in range(a.warmup):
+            step()
+        barrier()
+        ctx.commit_totals(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            proof = step()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        tot = ctx.commit_totals(reset=True)
+        mem = ctx.mem_stats()
+        if rank == 0:
+            ms_per_step = 1e3 * elapsed / a.steps
+            leaf_ms = tot["leaf_hash"]
+            achieved = tot["leaf_hash_bytes"] / (leaf_ms * 1e-3) / 1e9
+            ntt_ms = tot["ifft"] + tot["lde"]
+            proof_words = sum(int(p.proof.opening_proof.size) for p in proof.multi_proof.stark_proofs if p is not None)
+            timing = {}
+            step(timing)                     # one extra, synchronised, untimed proof for the stage breakdown
+            trace_bytes = 8.0 * sum(c << l for c, l in zip(TABLE_COLUMNS, log_ns))
+            cells = segment_committed_cells(log_ns)
+            out = {
+                "metric": "segment STARK proofs/sec (2^20-row traces, all nine AllStark tables)",
+                "value": world * a.steps / elapsed, "unit": "segment proofs/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                "config": {"workload": f"prove_with_traces: full AllStark segment proof (BASELINE configs[2]), 9 tables x "
+                                       f"2^{a.log_n} rows ({sum(TABLE_COLUMNS)} trace columns, {trace_bytes / 1e9:.1f} GB), "
+                                       f"10 CTLs + lookups, standard_fast_config, hasher {hname}",
+                           "parallelism": f"{world} independent segments (one per GPU), no collective",
+                           "committed_cells": cells, "proof_words": proof_words},
+                "roofline": {"bound": "hbm", "kernel": "poseidon_hash_rows_kernel" if a.hasher == 0 else "keccak_hash_rows_kernel",
+                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                             "traffic": None,
+                             "launches": tot["commits"], "ms_per_launch": leaf_ms / max(tot["commits"], 1),
+                             "ms_per_step": leaf_ms / a.steps, "share_of_step": leaf_ms / a.steps / ms_per_step,
+                             "algorithmic_bytes": tot["leaf_hash_bytes"] / max(tot["commits"], 1),
+                             "note": "summed over the %d leaf-hash launches of the timed region (one per commitment: "
+                                     "9 trace + 8 auxiliary + 9 quotient per segment); integer-VALU bound, not HBM bound "
+                                     "(DESIGN.md): permutations/s = %.3e; per-launch PMC traffic for the 116-column "
+                                     "launch is in commit_config1.roofline.traffic"
+                                     % (tot["commits"], tot["leaf_hash_perms"] / (leaf_ms * 1e-3))},
+                "commit_stages_ms_per_step": {k: tot[k] / a.steps for k in ("ifft", "lde", "leaf_hash", "tree")},
+                "ntt": {"achieved_GBs": tot["ntt_bytes"] / (ntt_ms * 1e-3) / 1e9,
+                        "algorithmic_bytes_per_step": tot["ntt_bytes"] / a.steps,
+                        "frac_of_hbm_peak": tot["ntt_bytes"] / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "segment_timing_s": timing,
+                "arena": {k: v / 1e9 for k, v in mem.items()},
+            }
+        del traces
+        torch.cuda.empty_cache()
+        if a.commit_steps > 0 and a.hasher == 0:
+            # BASELINE configs[1] in the same run (every rank runs it so the ranks stay in step)
+            a_cols, a_logn = a.cols, a.log_n
+            elapsed_c, stage_c = timed_commits(a.commit_steps, 2)
+            if rank == 0:
+                roof_c, extra_c = commit_report(a, stage_c, 1e3 * elapsed_c / a.commit_steps)
+                out["commit_config1"] = {"workload": f"PolynomialBatch::from_values {a_cols} cols x 2^{a_logn} rows",
+                                         "commits_per_s": world * a.commit_steps / elapsed_c,
+                                         "ms_per_commit": 1e3 * elapsed_c / a.commit_steps, "roofline": roof_c}
+                out["commit_config1"].update(extra_c)
+        if rank == 0 and not a.no_cpu_baseline and world == 1:
             try:
-                pmc = json.load(open(pmc_path))
-                traffic = pmc.get("leaf_hash_hbm_bytes_per_launch")
-                insts = pmc.get("leaf_hash_valu_wave_insts_per_launch")
-                if insts:
-                    # integer-issue roofline: every useful integer VALU op on gfx950 issues at
-                    # ~4 cycles per wave64 per SIMD (profiles/r01_ubench_valu_issue_rates.txt)
-                    peak = 1024 * 2.4e9 / 4.0
-                    ach = insts / (dom_ms * 1e-3)
-                    valu = {"wave_insts_per_launch": insts, "achieved_wave_insts_per_s": ach,
-                            "peak_wave_insts_per_s": peak, "frac": ach / peak,
-                            "assumes": "1024 SIMDs x 2.4 GHz / 4 cycles per integer VALU wave-instruction",
-                            "source": pmc.get("source")}
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "ArithmeticStark-shaped 2^20-row trace commits/sec (Goldilocks iNTT + coset LDE + "
-                      "Poseidon Merkle cap; BASELINE configs[1], the commit stage of segment STARK proofs/sec)",
-            "value": value,
-            "unit": "commits/s",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u64",
-            "data": "synthetic",
-            "config": {"workload": f"PolynomialBatch::from_values {a.cols} cols x 2^{a.log_n} rows, "
-                                   f"rate_bits 1, cap_height 4, hasher {'poseidon' if a.hasher == 0 else 'keccak25'}",
-                       "parallelism": f"{world} independent traces (one per GPU), no collective"},
-            "roofline": {"bound": "hbm", "kernel": "poseidon_hash_rows_kernel" if a.hasher == 0 else "keccak_hash_rows_kernel",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "ms_per_launch": dom_ms, "algorithmic_bytes": dom_bytes,
-                         "note": "kernel is integer-ALU bound (Poseidon), see DESIGN.md; "
-                                 "permutations/s = %.3e" % (perms / (dom_ms * 1e-3) if dom_ms else 0),
-                         "valu": valu},
-            "stages_ms": stage,
-            "ntt": {"achieved_GBs": ntt_bytes / (ntt_ms * 1e-3) / 1e9, "algorithmic_bytes": ntt_bytes,
-                    "frac_of_hbm_peak": ntt_bytes / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "commit": {"achieved_GBs": commit_bytes / (ms_per_step * 1e-3) / 1e9,
-                       "algorithmic_bytes": commit_bytes},
-        }
-        if a.proof_steps > 0 and a.cols == 116 and a.hasher == 0:
-            try:
-                out["table_proof"] = table_proof_bench(ctx, dev, a.log_n, a.proof_steps)
-            except Exception as e:
-                out["table_proof"] = {"error": repr(e)}
-        if not a.no_cpu_baseline and world == 1:
-            try:
-                out["cpu_baseline"] = cpu_baseline(a.cols, a.log_n, min(a.cpu_sample_log_n, a.log_n), a.hasher)
+                cb = cpu_baseline(116, 16, 16, a.hasher)
+                sample_cells = 116 << 16
+                sec = (1.0 / cb["value"]) * cells / sample_cells
+                out["cpu_baseline"] = {
+                    "value": 1.0 / sec, "unit": "segment proofs/s", "cores": cb["cores"], "kind": "port",
+                    "sample": cb["sample"].split(", scaled")[0] + f"; scaled by committed cells ({cells} / {sample_cells}) to "
+                              "the segment's 26 commitments -- COMMIT PHASE ONLY (the CPU quotient / FRI are not timed, the "
+                              "Python constraint oracle is not a performance port), so this is an upper bound on the CPU rate",
+                    "seconds_per_segment_est": sec}
             except Exception as e:  # the oracle is only a reported baseline; never fatal
                 out["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

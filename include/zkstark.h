@@ -77,6 +77,12 @@ int zk_ctx_set_abort_flag(zk_ctx *ctx, volatile const int *abort_flag);
 /* Per-stage device timings of the last commit on this ctx, in ms, keyed like the reference's
  * TimingTree scopes (prover.rs:92,99): [0]=ifft [1]=lde/coset-fft [2]=leaf hash [3]=tree. */
 int zk_ctx_last_timings(const zk_ctx *ctx, float out_ms[4]);
+/* Running totals of the same four HIP-event stage timings over every commit (from_values / from_coeffs) since the
+ * last reset, with the algorithmic work they cover: leaf-hash bytes (8*C*N read + 32*N written per commit),
+ * Poseidon permutations of the leaf hashing, NTT bytes (40*C*n per from_values, 24*C*n per from_coeffs).
+ * bench.py derives the leaf-hash kernel's roofline inside a timed multi-table proof from these. */
+int zk_ctx_commit_totals(zk_ctx *ctx, double out_ms[4], uint64_t *n_commits, double *leaf_hash_bytes,
+                         double *leaf_hash_perms, double *ntt_bytes, int reset);
 
 /* ---- PolynomialBatch::from_values / from_coeffs ------------------------------------------
  * Replaces plonky2 `PolynomialBatch::from_values(values, rate_bits, blinding=false, cap_height,

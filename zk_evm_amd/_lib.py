@@ -37,6 +37,8 @@ SIGNATURES = {
     "zk_last_error": (C.c_char_p, [vp]),
     "zk_ctx_set_abort_flag": (C.c_int, [vp, vp]),
     "zk_ctx_last_timings": (C.c_int, [vp, C.POINTER(C.c_float)]),
+    "zk_ctx_commit_totals": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
     "zk_commit_columns": (C.c_int, [vp, C.POINTER(ZkCfg), C.POINTER(vp), sz, ui, C.POINTER(vp)]),
     "zk_commit_columns_device": (C.c_int, [vp, C.POINTER(ZkCfg), u64p, sz, sz, ui, C.POINTER(vp)]),
     "zk_commit_coeffs_device": (C.c_int, [vp, C.POINTER(ZkCfg), u64p, sz, sz, ui, C.POINTER(vp)]),

@@ -60,6 +60,17 @@ class Context:
         self.check(self.lib.zk_ctx_last_timings(self.handle, arr))
         return dict(zip(("ifft", "lde", "leaf_hash", "tree"), [float(x) for x in arr]))
 
+    def commit_totals(self, reset: bool = False) -> dict:
+        """Accumulated stage timings (ms) and algorithmic work of every commit since the last reset."""
+        ms = (C.c_double * 4)()
+        n, lb, lp, nb = C.c_uint64(0), C.c_double(0), C.c_double(0), C.c_double(0)
+        self.check(self.lib.zk_ctx_commit_totals(self.handle, ms, C.byref(n), C.byref(lb), C.byref(lp), C.byref(nb),
+                                                 1 if reset else 0))
+        out = dict(zip(("ifft", "lde", "leaf_hash", "tree"), [float(x) for x in ms]))
+        out.update(commits=int(n.value), leaf_hash_bytes=float(lb.value), leaf_hash_perms=float(lp.value),
+                   ntt_bytes=float(nb.value))
+        return out
+
     def last_error(self) -> str:
         return self.lib.zk_last_error(self.handle).decode()
 

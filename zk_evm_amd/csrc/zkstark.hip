@@ -38,6 +38,10 @@ struct zk_ctx {
     std::map<std::pair<int, u64>, u64 *> coset_inv_tabs;    // (log_n, shift) -> n^-1 s^-bitrev(i)
     hipEvent_t ev[5] = {};
     float timings[4] = {0, 0, 0, 0};
+    // running totals over all commits since the last reset (zk_ctx_commit_totals)
+    double total_ms[4] = {0, 0, 0, 0};
+    double total_leaf_bytes = 0, total_leaf_perms = 0, total_ntt_bytes = 0;
+    uint64_t total_commits = 0;
     int cu_count = 0;
     std::set<zk_batch *> live_batches;  // freed by zk_ctx_destroy if the caller leaked them
     DevArena arena;                     // all batch + scratch HBM (arena.hpp)
@@ -190,6 +194,21 @@ extern "C" const char *zk_last_error(const zk_ctx *ctx) { return ctx ? ctx->err.
 extern "C" int zk_ctx_set_abort_flag(zk_ctx *ctx, volatile const int *abort_flag) {
     if (!ctx) return ZK_ERR_BAD_ARG;
     ctx->abort_flag = abort_flag;
+    return ZK_OK;
+}
+extern "C" int zk_ctx_commit_totals(zk_ctx *ctx, double out_ms[4], uint64_t *n_commits, double *leaf_hash_bytes,
+                                    double *leaf_hash_perms, double *ntt_bytes, int reset) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    if (out_ms) for (int i = 0; i < 4; ++i) out_ms[i] = ctx->total_ms[i];
+    if (n_commits) *n_commits = ctx->total_commits;
+    if (leaf_hash_bytes) *leaf_hash_bytes = ctx->total_leaf_bytes;
+    if (leaf_hash_perms) *leaf_hash_perms = ctx->total_leaf_perms;
+    if (ntt_bytes) *ntt_bytes = ctx->total_ntt_bytes;
+    if (reset) {
+        for (double &v : ctx->total_ms) v = 0;
+        ctx->total_leaf_bytes = ctx->total_leaf_perms = ctx->total_ntt_bytes = 0;
+        ctx->total_commits = 0;
+    }
     return ZK_OK;
 }
 extern "C" int zk_ctx_last_timings(const zk_ctx *ctx, float out_ms[4]) {
@@ -615,7 +634,15 @@ static int commit_impl(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t i
     B_HIP(hipMemcpyAsync(b->cap.data(), b->d_digests + 4 * (b->n_digests - ((size_t)1 << cfg->cap_height)),
                          b->cap.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     B_HIP(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 4; ++i) hipEventElapsedTime(&ctx->timings[i], ctx->ev[i], ctx->ev[i + 1]);
+    for (int i = 0; i < 4; ++i) {
+        hipEventElapsedTime(&ctx->timings[i], ctx->ev[i], ctx->ev[i + 1]);
+        ctx->total_ms[i] += ctx->timings[i];
+    }
+    // algorithmic bytes of the leaf-hash launch: read the LDE once, write N digests
+    ctx->total_leaf_bytes += 8.0 * (double)n_cols * (double)N + 32.0 * (double)N;
+    ctx->total_leaf_perms += n_cols > 4 ? (double)N * (double)((n_cols + 7) / 8) : 0.0;
+    ctx->total_ntt_bytes += (mode == COMMIT_VALUES ? 40.0 : 24.0) * (double)n_cols * (double)n;
+    ctx->total_commits += 1;
 #undef B_HIP
     *out = b;
     return ZK_OK;
