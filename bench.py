@@ -126,7 +126,7 @@ def table_proof_bench(ctx, dev, log_n, steps):
         for b, gm in chal:
             zd.append(zp.CtlZData(b, gm, ctl_entry, ctl_partial_sums(trace, ctl_entry, b, gm, 3, ctx=ctx)))
         t2 = time.perf_counter()
-        pr = zp.prove_with_commitment(zp.AIR_ARITHMETIC, cfg, trace, tb, [lookup], zd, chal, ch)
+        pr = zp.prove_single_table(zp.AIR_ARITHMETIC, cfg, trace, tb, [lookup], zd, chal, ch)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         tb.free()

@@ -263,6 +263,81 @@ int zk_quotient_polys(zk_ctx *ctx, const zk_cfg *cfg, uint32_t air_id, const uin
                       const uint64_t *ctl_program, size_t ctl_words, unsigned constraint_degree,
                       zk_batch **quotient_out);
 
+/* ---- one-call provers (compiled host driver, csrc/segment_host.inc) ---------------------------
+ * zk_prove_table replaces the reference's `prove_single_table` call (evm_arithmetization/src/prover.rs:301-341 ->
+ * starky `prove_with_commitment`, called with public_inputs = &[] and ctl data / challenges = Some): compact the
+ * challenger (-> init_challenger_state), logUp helper columns, auxiliary commitment, alphas, quotient polynomials
+ * and their commitment, zeta, openings, FRI proof.
+ *   lookup_program : as zk_quotient_polys (the table's `Stark::lookups()`), NULL if none
+ *   ctl_zdata      : as zk_quotient_polys `ctl_program` (this table's `CtlData::zs_columns`), NULL if none
+ *   d_ctl_cols     : device, column stride ctl_col_stride: for z-data i its n_helpers_i helper columns then its Z,
+ *                    z-data after z-data (the concatenated zk_ctl_partial_sums outputs)
+ *   ctl_challenges : beta, gamma per challenge (lookup challenges = the betas); NULL = draw lookup challenges
+ *   challenger     : advanced exactly as the reference advances it
+ * The result is host memory owned by the library until zk_table_proof_free. */
+typedef struct zk_table_proof zk_table_proof;
+typedef struct {
+    unsigned degree_bits;
+    size_t n_trace_cols, n_aux_cols, n_quotient_cols, n_ctl_zs;
+    size_t cap_digests;              /* 2^cap_height 32-byte digests per cap */
+    const uint64_t *trace_cap;       /* StarkProof.trace_cap */
+    const uint64_t *aux_cap;         /* StarkProof.auxiliary_polys_cap (NULL when the table has no auxiliary polys) */
+    const uint64_t *quotient_cap;    /* StarkProof.quotient_polys_cap */
+    const uint64_t *openings;        /* StarkOpeningSet, 2 u64 per value: at zeta (trace, aux, quotient chunks), at
+                                        g*zeta (trace, aux), at 1 (ctl_zs_first; present iff the table has CTL Zs) */
+    size_t n_openings;
+    const uint64_t *opening_proof;   /* flat FriProof (layout under zk_fri_prove_openings) */
+    size_t proof_words;
+    uint64_t init_challenger_state[12];   /* StarkProofWithMetadata.init_challenger_state (prover.rs:335-338) */
+} zk_table_proof_view;
+int zk_prove_table(zk_ctx *ctx, const zk_cfg *cfg, uint32_t air_id, const uint64_t *air_consts, size_t n_air_consts,
+                   const uint64_t *d_trace, size_t col_stride, const zk_batch *trace_commitment,
+                   const uint64_t *lookup_program, size_t lookup_words, const uint64_t *ctl_zdata, size_t ctl_words,
+                   const uint64_t *d_ctl_cols, size_t ctl_col_stride, const uint64_t *ctl_challenges,
+                   unsigned constraint_degree, int requires_ctls, zk_challenger *challenger, zk_table_proof **out);
+int zk_table_proof_get(const zk_table_proof *proof, zk_table_proof_view *view);
+void zk_table_proof_free(zk_table_proof *proof);
+
+/* zk_prove_segment replaces the reference's `prove_with_traces` (prover.rs:72-194; SURVEY 8(b) granularity B): one
+ * call per segment.  Tables are given in `Table::all()` order (all_stark.rs:133-146); every table's trace is
+ * committed and its cap observed (a zero cap for an optional table that is not in use, prover.rs:118-127), then the
+ * public-value elements (get_challenges.rs:195-218 order; the caller flattens `PublicValues`), then starky
+ * `get_ctl_data` and the per-table proofs in table order (prover.rs:251-259).
+ *   ctl_wiring := n_ctls, offset[n_ctls], per CTL: n_looking, (table, Entry) of the LOOKED table, then
+ *                 (table, Entry) x n_looking in `looking_tables` order   (`all_stark.cross_table_lookups`)
+ *   mem_before_table / mem_after_table: indices whose trace caps become PublicValues.mem_before / mem_after
+ *                 (prover.rs:261-271; mem_after is zeroed when that table is not in use), or -1.
+ * Cancellation: zk_ctx_set_abort_flag (polled between kernels and before every table -> ZK_ERR_ABORTED). */
+typedef struct {
+    const uint64_t *d_trace;         /* device, column-major: column c at d_trace + c*col_stride, 2^log_n rows */
+    size_t col_stride, n_cols;
+    unsigned log_n;
+    uint32_t air_id;                 /* zk_air */
+    const uint64_t *air_consts;
+    size_t n_air_consts;
+    const uint64_t *lookup_program;  /* the table's lookups (zk_quotient_polys lookup_program), NULL if none */
+    size_t lookup_words;
+    int in_use;                      /* `table_in_use` */
+    int optional;                    /* member of OPTIONAL_TABLE_INDICES (all_stark.rs:124-131) */
+} zk_table_in;
+typedef struct zk_segment_proof zk_segment_proof;
+int zk_prove_segment(zk_ctx *ctx, const zk_cfg *cfg, const zk_table_in *tables, size_t n_tables,
+                     const uint64_t *ctl_wiring, size_t wiring_words, const uint64_t *public_value_elements,
+                     size_t n_public_values, unsigned constraint_degree, int mem_before_table, int mem_after_table,
+                     zk_segment_proof **out);
+size_t zk_segment_proof_num_tables(const zk_segment_proof *proof);
+/* NULL for a table that was not in use; owned by the segment proof */
+const zk_table_proof *zk_segment_proof_table(const zk_segment_proof *proof, size_t table);
+/* (beta, gamma) x num_challenges; returns the number of words available */
+size_t zk_segment_proof_ctl_challenges(const zk_segment_proof *proof, uint64_t *out, size_t max_words);
+/* the two memory caps (cap_digests x 4 words each); returns the words per cap */
+size_t zk_segment_proof_mem_caps(const zk_segment_proof *proof, uint64_t *mem_before, uint64_t *mem_after,
+                                 size_t max_words);
+/* host wall-clock per stage in ms, the reference's TimingTree scopes: [0] "compute all trace commitments",
+ * [1] "compute CTL data", [2 + t] "prove <table t> STARK"; returns the number of entries */
+size_t zk_segment_proof_stage_ms(const zk_segment_proof *proof, double *out, size_t max);
+void zk_segment_proof_free(zk_segment_proof *proof);
+
 /* library / device info */
 const char *zk_version(void);
 int zk_device_info(int device, char *name_out, size_t name_len, int *cu_count, size_t *hbm_bytes);

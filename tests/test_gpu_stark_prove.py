@@ -69,16 +69,21 @@ def _run_case(oracle, air_id, n_cols, log_n, hasher, lookup_spec, ctl_spec, seed
             o_z.append(orc.CtlZData(orc.GrandProductChallenge(b, g), entries_for(orc, entries), 0))
             aux = prod.ctl_partial_sums(dev, entries_for(prod, entries), b, g, 3)
             p_z.append(zp.CtlZData(b, g, entries_for(prod, entries), aux))
+    # the product call is the reference's prove_single_table: it compacts the challenger first (prover.rs:318-320)
+    init = np.zeros(12, dtype=np.uint64)
+    L.orc_challenger_compact(C.byref(och), init)
     exp = oprover.prove_with_commitment(oracle, ol, cfg, oairs.AIRS[air_id][0], trace, tcommit, lookups_for(orc),
                                         o_z, ctl_challenges, och)
     scfg = zk.StarkConfig(hasher=hasher, num_challenges=nchal,
                           fri_config=zk.FriConfig(proof_of_work_bits=kw["pow_bits"], num_query_rounds=kw["queries"]))
-    got = zp.prove_with_commitment(air_id, scfg, dev, tbatch, lookups_for(prod), p_z, ctl_challenges, ch,
+    got = zp.prove_single_table(air_id, scfg, dev, tbatch, lookups_for(prod), p_z, ctl_challenges, ch,
                                    air_consts=air_consts)
     if exp["aux_cap"] is None:
         assert got.auxiliary_polys_cap is None
     else:
         assert np.array_equal(got.auxiliary_polys_cap, exp["aux_cap"])
+    assert np.array_equal(got.init_challenger_state, init)
+    assert np.array_equal(got.trace_cap, tcommit["cap"])
     assert np.array_equal(got.quotient_polys_cap, exp["quotient_cap"])
     assert np.array_equal(got.openings.reshape(-1), exp["openings"])
     assert np.array_equal(got.opening_proof, exp["fri"])

@@ -52,7 +52,9 @@ def _prove_and_verify(oracle, air_id, trace, hasher, ctl_entries_list, kw=None, 
                 for cols, table, freq, filts in lookup_spec]
     scfg = zk.StarkConfig(hasher=hasher, fri_config=zk.FriConfig(proof_of_work_bits=kw["pow_bits"],
                                                                  num_query_rounds=kw["queries"]))
-    pr = zp.prove_with_commitment(air_id, scfg, dev, tbatch, lookups_for(prod), p_z, ctl_challenges, ch)
+    pr = zp.prove_single_table(air_id, scfg, dev, tbatch, lookups_for(prod), p_z, ctl_challenges, ch)
+    # verifier side of prove_single_table's compact(): get_challenges.rs:298-300 compacts before each table too
+    oracle.lib.orc_challenger_compact(C.byref(och), np.zeros(12, dtype=np.uint64))
     proof = dict(trace_cap=tcap, aux_cap=pr.auxiliary_polys_cap, quotient_cap=pr.quotient_polys_cap,
                  openings=pr.openings, fri=pr.opening_proof)
     return overify.verify_stark_proof(oracle, ol, cfg, oairs.AIRS[air_id][0], n_cols, log_n, lookups_for(orc), o_z,

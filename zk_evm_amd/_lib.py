@@ -82,6 +82,18 @@ SIGNATURES = {
                                       C.POINTER(sz)]),
     "zk_quotient_polys": (C.c_int, [vp, C.POINTER(ZkCfg), u32, u64p, sz, vp, vp, u64p, u64p, sz, u64p, sz,
                                     u64p, sz, ui, C.POINTER(vp)]),
+    "zk_prove_table": (C.c_int, [vp, C.POINTER(ZkCfg), u32, u64p, sz, u64p, sz, vp, u64p, sz, u64p, sz, u64p, sz, u64p,
+                                 ui, C.c_int, vp, C.POINTER(vp)]),
+    "zk_table_proof_get": (C.c_int, [vp, vp]),
+    "zk_table_proof_free": (None, [vp]),
+    "zk_prove_segment": (C.c_int, [vp, C.POINTER(ZkCfg), vp, sz, u64p, sz, u64p, sz, ui, C.c_int, C.c_int,
+                                   C.POINTER(vp)]),
+    "zk_segment_proof_num_tables": (sz, [vp]),
+    "zk_segment_proof_table": (vp, [vp, sz]),
+    "zk_segment_proof_ctl_challenges": (sz, [vp, u64p, sz]),
+    "zk_segment_proof_mem_caps": (sz, [vp, u64p, u64p, sz]),
+    "zk_segment_proof_stage_ms": (sz, [vp, C.POINTER(C.c_double), sz]),
+    "zk_segment_proof_free": (None, [vp]),
     "zk_version": (C.c_char_p, []),
     "zk_device_info": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(sz)]),
 }

@@ -6,10 +6,12 @@
 // There is NO CPU fallback: every entry point either runs the HIP kernels or returns an error.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
 #include <utility>
@@ -761,3 +763,4 @@ extern "C" int zk_batch_merkle_path(const zk_batch *b, size_t leaf_index, uint64
 #include "fri_host.inc"
 #include "stark_host.inc"
 #include "quotient_host.inc"
+#include "segment_host.inc"

@@ -1,8 +1,7 @@
-"""Host mirror of starky's per-table prover (``starky::prover::prove_with_commitment``, [EXT]) as the
-reference drives it from ``prove_single_table`` (evm_arithmetization/src/prover.rs:301-341):
-lookup helper columns -> auxiliary commitment -> alphas -> quotient -> zeta -> openings -> FRI.
-Every arithmetic step is a C-ABI call into the HIP library; this file is sequencing only (what the
-Rust host keeps doing)."""
+"""Binding of the per-table prover: the reference's ``prove_single_table`` -> starky
+``prove_with_commitment`` (evm_arithmetization/src/prover.rs:301-341) is the C-ABI call ``zk_prove_table``
+(sequencing compiled in csrc/segment_host.inc); this file marshals the `Lookup` / `CtlZData` descriptions into
+the program encoding and copies the proof out.  ``quotient_polys`` exposes the K8/K9 step on its own."""
 import ctypes as C
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
@@ -12,9 +11,8 @@ import numpy as np
 from ._lib import ZkStarkError
 from .challenger import Challenger
 from .config import StarkConfig
-from .fri import fri_openings, prove_openings, stark_fri_instance
 from .polynomial_batch import PolynomialBatch
-from .stark import Column, Filter, Lookup, ctl_partial_sums, encode_program, lookup_helper_columns
+from .stark import Column, Filter, Lookup, encode_program
 
 AIR_NONE, AIR_MEM_CONTINUATION, AIR_LOGIC, AIR_MEMORY, AIR_BYTE_PACKING, AIR_ARITHMETIC = 0, 1, 2, 3, 4, 5
 AIR_KECCAK = 6
@@ -102,61 +100,75 @@ def quotient_polys(air_id: int, config: StarkConfig, trace: PolynomialBatch, aux
     return PolynomialBatch(ctx, h, trace.rate_bits, trace.cap_height, trace.hasher)
 
 
-def prove_with_commitment(air_id: int, config: StarkConfig, trace_values, trace_commitment: PolynomialBatch,
+class ZkTableProofView(C.Structure):
+    """include/zkstark.h zk_table_proof_view"""
+    _fields_ = [("degree_bits", C.c_uint), ("n_trace_cols", C.c_size_t), ("n_aux_cols", C.c_size_t),
+                ("n_quotient_cols", C.c_size_t), ("n_ctl_zs", C.c_size_t), ("cap_digests", C.c_size_t),
+                ("trace_cap", C.c_void_p), ("aux_cap", C.c_void_p), ("quotient_cap", C.c_void_p),
+                ("openings", C.c_void_p), ("n_openings", C.c_size_t), ("opening_proof", C.c_void_p),
+                ("proof_words", C.c_size_t), ("init_challenger_state", C.c_uint64 * 12)]
+
+
+def _copy_words(ptr, n_words, shape=None) -> np.ndarray:
+    a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(n_words,)).copy()
+    return a.reshape(shape) if shape else a
+
+
+def table_proof_from_handle(lib, handle) -> StarkProof:
+    """Copy a library-owned zk_table_proof into a StarkProof (the caller still frees the handle)."""
+    v = ZkTableProofView()
+    rc = lib.zk_table_proof_get(handle, C.byref(v))
+    if rc != 0:
+        raise ZkStarkError(rc, "zk_table_proof_get failed")
+    nd = v.cap_digests
+    return StarkProof(
+        trace_cap=_copy_words(v.trace_cap, 4 * nd, (nd, 4)),
+        auxiliary_polys_cap=_copy_words(v.aux_cap, 4 * nd, (nd, 4)) if v.aux_cap else None,
+        quotient_polys_cap=_copy_words(v.quotient_cap, 4 * nd, (nd, 4)),
+        openings=_copy_words(v.openings, 2 * v.n_openings, (v.n_openings, 2)),
+        opening_proof=_copy_words(v.opening_proof, v.proof_words),
+        init_challenger_state=np.array(list(v.init_challenger_state), dtype=np.uint64),
+        num_ctl_zs=int(v.n_ctl_zs), degree_bits=int(v.degree_bits))
+
+
+def prove_single_table(air_id: int, config: StarkConfig, trace_values, trace_commitment: PolynomialBatch,
                           lookups: Sequence[Lookup], ctl_zdatas: Sequence[CtlZData],
                           ctl_challenges: Optional[Sequence[Tuple[int, int]]], challenger: Challenger,
                           constraint_degree: int = 3, requires_ctls: bool = True,
                           air_consts: Sequence[int] = ()) -> StarkProof:
-    """trace_values: CUDA tensor (n_cols, n) (the same values trace_commitment was built from).
-    ctl_challenges: [(beta, gamma)] * num_challenges (lookup challenges = the betas, as starky does
-    when `ctl_challenges` is Some; otherwise drawn from the challenger)."""
+    """`prove_single_table` -> starky `prove_with_commitment` as ONE C-ABI call (zk_prove_table; the sequencing
+    lives in csrc/segment_host.inc).  The challenger is compacted first, exactly as prover.rs:318-320 does, and
+    its state is returned in `init_challenger_state`.
+    trace_values: CUDA tensor (n_cols, n) (the same values trace_commitment was built from).
+    ctl_challenges: [(beta, gamma)] * num_challenges (lookup challenges = the betas, as starky does when
+    `ctl_challenges` is Some; otherwise they are drawn from the challenger)."""
     import torch
-    nchal = config.num_challenges
-    # ---- lookup helper columns --------------------------------------------------------------
-    aux_parts = []
-    lookup_challenges: List[int] = []
-    if lookups:
-        lookup_challenges = [b for b, _ in ctl_challenges] if ctl_challenges is not None \
-            else challenger.get_n_challenges(nchal)
-        for l in lookups:
-            for ch in lookup_challenges:
-                aux_parts.append(lookup_helper_columns(l, trace_values, ch, constraint_degree, ctx=trace_commitment.ctx))
-    # get_ctl_auxiliary_polys: all helper polys of all z-data, then all Z polys
+    from .stark import _trace_args
+    ctx = trace_commitment.ctx
+    n_cols, n, log_n, stride = _trace_args(trace_values)
+    ctx.use_torch_current_stream()
+    cfg = config.to_c(rate_bits=trace_commitment.rate_bits, cap_height=trace_commitment.cap_height)
+    cfg.hasher = trace_commitment.hasher
+    lp = encode_lookup_set(lookups)
+    cp = encode_ctl_set(ctl_zdatas)
+    ctl_cols = None
     if ctl_zdatas:
-        for z in ctl_zdatas:
-            if z.n_helpers:
-                aux_parts.append(z.aux[:-1])
-        for z in ctl_zdatas:
-            aux_parts.append(z.aux[-1:])
-    aux = None
-    aux_cap = None
-    if aux_parts:
-        aux_values = torch.cat(aux_parts, dim=0).contiguous()
-        aux = PolynomialBatch.from_values(aux_values, trace_commitment.rate_bits, False, trace_commitment.cap_height,
-                                          hasher=trace_commitment.hasher, ctx=trace_commitment.ctx)
-        aux_cap = aux.merkle_tree.cap.elements
-        challenger.observe_cap(aux_cap)
-    alphas = challenger.get_n_challenges(nchal)
-    quotient = quotient_polys(air_id, config, trace_commitment, aux, alphas, lookups, lookup_challenges,
-                              ctl_zdatas, constraint_degree, air_consts)
-    q_cap = quotient.merkle_tree.cap.elements
-    challenger.observe_cap(q_cap)
-    zeta = challenger.get_extension_challenge()
-    # g = primitive_root_of_unity(degree_bits)
-    g = pow(7277203076849721926, 1 << (32 - trace_commitment.degree_log), P)
-    # (zeta^n == 1 would leak witness data; starky bails out.)
-    n_trace = trace_commitment.num_polys
-    n_aux = aux.num_polys if aux is not None else 0
-    n_ctl_zs = len(ctl_zdatas)
-    ctl_range = (n_aux - n_ctl_zs, n_aux) if (requires_ctls and n_ctl_zs) else None
-    g_zeta = (zeta[0] * g % P, zeta[1] * g % P)
-    inst = stark_fri_instance(zeta, g_zeta, n_trace, n_aux, quotient.num_polys, ctl_zs_range=ctl_range)
-    oracles = [trace_commitment] + ([aux] if aux is not None else []) + [quotient]
-    openings = fri_openings(inst, oracles)
-    challenger.observe_extension_elements(openings)
-    proof = prove_openings(inst, oracles, challenger, config, openings)
-    quotient.free()                    # release HBM now (the trace commitment belongs to the caller)
-    if aux is not None:
-        aux.free()
-    return StarkProof(trace_cap=trace_commitment.merkle_tree.cap.elements, auxiliary_polys_cap=aux_cap,
-                      quotient_polys_cap=q_cap, openings=openings, opening_proof=proof, num_ctl_zs=n_ctl_zs)
+        ctl_cols = torch.cat([z.aux for z in ctl_zdatas], dim=0).contiguous()
+    cc = None
+    if ctl_challenges is not None:
+        cc = np.array([x % (1 << 64) for bg in ctl_challenges for x in bg], dtype=np.uint64)
+    ac = np.array(list(air_consts), dtype=np.uint64)
+    h = C.c_void_p()
+    rc = ctx.lib.zk_prove_table(
+        ctx.handle, C.byref(cfg), air_id, ac.ctypes.data if ac.size else None, ac.size,
+        C.c_void_p(trace_values.data_ptr()), stride, trace_commitment.handle,
+        lp.ctypes.data if lp is not None else None, lp.size if lp is not None else 0,
+        cp.ctypes.data if cp is not None else None, cp.size if cp is not None else 0,
+        C.c_void_p(ctl_cols.data_ptr()) if ctl_cols is not None else None, n,
+        cc.ctypes.data if cc is not None else None, constraint_degree, 1 if requires_ctls else 0,
+        challenger.handle, C.byref(h))
+    ctx.check(rc)
+    try:
+        return table_proof_from_handle(ctx.lib, h)
+    finally:
+        ctx.lib.zk_table_proof_free(h)

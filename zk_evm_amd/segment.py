@@ -8,8 +8,11 @@
   * the output containers ``AllProof`` / ``MultiProof`` / ``StarkProofWithMetadata`` / ``MemCap`` (proof.rs:29-54,
     587-622).
 
-Sequencing and transcript bookkeeping only -- every column, commitment, quotient and FRI step is a C-ABI call
-into the HIP library (there is no CPU fallback: without the library / a GPU these functions raise)."""
+`prove_with_traces` is a binding of the compiled driver `zk_prove_segment` (csrc/segment_host.inc): this file
+flattens the public values and the table / CTL definitions and copies the proof out; `get_ctl_data` and
+`prove_single_table` expose the two inner steps for callers that keep their own loop.  There is no CPU fallback:
+without the library / a GPU these functions raise."""
+import ctypes as C
 from dataclasses import dataclass, field
 from itertools import groupby
 from typing import List, Optional, Sequence, Tuple
@@ -21,7 +24,7 @@ from .all_stark import NUM_TABLES, OPTIONAL_TABLE_INDICES, TABLE_NAMES, AllStark
 from .challenger import Challenger
 from .config import StarkConfig
 from .polynomial_batch import PolynomialBatch
-from .prover import CtlZData, StarkProof, prove_with_commitment
+from .prover import CtlZData, StarkProof
 from .stark import CrossTableLookup, ctl_partial_sums
 
 P = 0xFFFFFFFF00000001
@@ -236,79 +239,122 @@ def check_abort_signal(abort_signal) -> None:
 def prove_single_table(all_stark: AllStark, table: int, config: StarkConfig, trace_values, trace_commitment,
                        ctl_data: Sequence[CtlZData], ctl_challenges, challenger: Challenger,
                        abort_signal=None) -> StarkProofWithMetadata:
+    """prover.rs:301-341 for one table of `all_stark` (zk_prove_table: compact, then starky prove_with_commitment)."""
+    from .prover import prove_single_table as _prove
     check_abort_signal(abort_signal)
-    init_challenger_state = challenger.compact()          # "Clear buffered outputs."
-    proof = prove_with_commitment(all_stark.table_air[table], config, trace_values, trace_commitment,
-                                  all_stark.lookups[table], ctl_data, ctl_challenges, challenger,
-                                  constraint_degree=all_stark.constraint_degree,
-                                  air_consts=all_stark.air_consts[table])
-    proof.degree_bits = trace_commitment.degree_log
-    return StarkProofWithMetadata(proof, init_challenger_state)
+    proof = _prove(all_stark.table_air[table], config, trace_values, trace_commitment, all_stark.lookups[table],
+                   ctl_data, ctl_challenges, challenger, constraint_degree=all_stark.constraint_degree,
+                   air_consts=all_stark.air_consts[table])
+    return StarkProofWithMetadata(proof, proof.init_challenger_state)
 
 
-class _Timed:
-    """`timed!(timing, "label", ...)`: when the caller passes a dict, synchronise and accumulate wall seconds."""
+class ZkTableIn(C.Structure):
+    """include/zkstark.h zk_table_in"""
+    _fields_ = [("d_trace", C.c_void_p), ("col_stride", C.c_size_t), ("n_cols", C.c_size_t), ("log_n", C.c_uint),
+                ("air_id", C.c_uint32), ("air_consts", C.c_void_p), ("n_air_consts", C.c_size_t),
+                ("lookup_program", C.c_void_p), ("lookup_words", C.c_size_t), ("in_use", C.c_int),
+                ("optional", C.c_int)]
 
-    def __init__(self, timing, label):
-        self.timing, self.label = timing, label
 
-    def __enter__(self):
-        if self.timing is not None:
-            import time
-            import torch
-            torch.cuda.synchronize()
-            self.t0 = time.perf_counter()
+def encode_ctl_wiring(ctls: Sequence[CrossTableLookup]) -> np.ndarray:
+    """`all_stark.cross_table_lookups` in the flat wiring encoding of zk_prove_segment:
+    n_ctls, offset[n_ctls], per CTL: n_looking, (table, Entry) of the looked table, (table, Entry) x n_looking."""
+    head = 1 + len(ctls)
+    offs, payload = [], []
 
-    def __exit__(self, *exc):
-        if self.timing is not None:
-            import time
-            import torch
-            torch.cuda.synchronize()
-            self.timing[self.label] = self.timing.get(self.label, 0.0) + time.perf_counter() - self.t0
-        return False
+    def entry(t):
+        w = [t.table, len(t.columns)]
+        for c in t.columns:
+            w += c.encode()
+        return w + t.filter.encode()
+    for ctl in ctls:
+        offs.append(head + len(payload))
+        payload.append(len(ctl.looking_tables))
+        payload += entry(ctl.looked_table)
+        for t in ctl.looking_tables:
+            payload += entry(t)
+    return np.array([len(ctls)] + offs + payload, dtype=np.uint64)
 
 
 def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_values: Sequence,
                       table_in_use: Sequence[bool], public_values: PublicValues, abort_signal=None,
                       hasher: Optional[int] = None, ctx=None, timing: Optional[dict] = None) -> AllProof:
-    """prover.rs:72-194.  `trace_poly_values[t]`: CUDA int64/uint64 tensor (columns, 2^k) -- the column-major
-    `Vec<PolynomialValues<F>>` of table t (values may be non-canonical)."""
+    """prover.rs:72-194 as ONE C-ABI call (zk_prove_segment; the sequencing is compiled, csrc/segment_host.inc).
+    `trace_poly_values[t]`: CUDA int64/uint64 tensor (columns, 2^k) -- the column-major
+    `Vec<PolynomialValues<F>>` of table t (values may be non-canonical).  `abort_signal`: a ctypes c_int that
+    another thread may set (polled between kernels) or an object with `.is_set()` (checked on entry).
+    `timing`: optional dict receiving the reference's TimingTree scopes in seconds."""
+    from .context import default_context
+    from .prover import encode_lookup_set, table_proof_from_handle
+    from .stark import _trace_args
     if len(trace_poly_values) != NUM_TABLES or len(table_in_use) != NUM_TABLES:
         raise ZkStarkError(-1, "expected one trace and one in-use flag per table")
+    check_abort_signal(abort_signal)
     hasher = config.hasher if hasher is None else hasher
-    rate_bits, cap_height = config.fri_config.rate_bits, config.fri_config.cap_height
-    # trace commitments for every table, in use or not (prover.rs:90-111)
-    with _Timed(timing, "compute all trace commitments"):
-        trace_commitments = [PolynomialBatch.from_values(t, rate_bits, False, cap_height, hasher=hasher, ctx=ctx)
-                             for t in trace_poly_values]
-    challenger = Challenger(hasher)
-    for i, c in enumerate(trace_commitments):
-        cap = c.merkle_tree.cap.elements
-        if i in OPTIONAL_TABLE_INDICES and not table_in_use[i]:
-            challenger.observe_elements([0] * len(c.merkle_tree.cap.flatten()))   # zero cap, prover.rs:120-123
-        else:
-            challenger.observe_cap(cap)
-    observe_public_values(challenger, public_values)
-    with _Timed(timing, "compute CTL data"):
-        ctl_challenges, ctl_data_per_table = get_ctl_data(config, trace_poly_values, all_stark.cross_table_lookups,
-                                                          challenger, all_stark.constraint_degree, ctx=ctx)
-    stark_proofs: List[Optional[StarkProofWithMetadata]] = []
-    for t in Table.all():                                  # prove_with_commitments, prover.rs:251-259
-        if table_in_use[t]:
-            with _Timed(timing, "prove %s STARK" % TABLE_NAMES[t]):
-                stark_proofs.append(prove_single_table(all_stark, t, config, trace_poly_values[t],
-                                                       trace_commitments[t], ctl_data_per_table[t], ctl_challenges,
-                                                       challenger, abort_signal))
-        else:
-            stark_proofs.append(None)
-        ctl_data_per_table[t] = None       # drop this table's CTL columns
-        if t not in (Table.MemBefore, Table.MemAfter):
-            trace_commitments[t].free()    # (the two memory caps are read below)
-    public_values.mem_before = MemCap.from_merkle_cap(trace_commitments[Table.MemBefore].merkle_tree.cap.elements)
-    mem_after = MemCap.from_merkle_cap(trace_commitments[Table.MemAfter].merkle_tree.cap.elements)
-    if not table_in_use[Table.MemAfter]:
-        mem_after = MemCap([[0] * 4 for _ in mem_after.mem_cap])
-    public_values.mem_after = mem_after
-    for c in trace_commitments:
-        c.free()
+    ctx = ctx or default_context(trace_poly_values[0].device.index or 0)
+    ctx.use_torch_current_stream()
+    if isinstance(abort_signal, C.c_int):
+        ctx.set_abort_flag(abort_signal)
+    cfg = config.to_c()
+    cfg.hasher = hasher
+    pv = np.array(public_values_elements(public_values), dtype=np.uint64)      # may raise PublicValuesError
+    wiring = encode_ctl_wiring(all_stark.cross_table_lookups)
+    tables = (ZkTableIn * NUM_TABLES)()
+    keep = []
+    for t in Table.all():
+        tr = trace_poly_values[t]
+        n_cols, n, log_n, stride = _trace_args(tr)
+        if n_cols != all_stark.table_columns[t]:
+            raise ZkStarkError(-1, "table %s: expected %d columns, got %d" % (TABLE_NAMES[t], all_stark.table_columns[t], n_cols))
+        lp = encode_lookup_set(all_stark.lookups[t])
+        ac = np.array(list(all_stark.air_consts[t]), dtype=np.uint64)
+        keep += [lp, ac]
+        ti = tables[t]
+        ti.d_trace, ti.col_stride, ti.n_cols, ti.log_n = tr.data_ptr(), stride, n_cols, log_n
+        ti.air_id = all_stark.table_air[t]
+        ti.air_consts, ti.n_air_consts = (ac.ctypes.data if ac.size else None), ac.size
+        ti.lookup_program, ti.lookup_words = (lp.ctypes.data, lp.size) if lp is not None else (None, 0)
+        ti.in_use = 1 if table_in_use[t] else 0
+        ti.optional = 1 if t in OPTIONAL_TABLE_INDICES else 0
+    h = C.c_void_p()
+    try:
+        rc = ctx.lib.zk_prove_segment(ctx.handle, C.byref(cfg), C.cast(tables, C.c_void_p), NUM_TABLES,
+                                      wiring.ctypes.data, wiring.size, pv.ctypes.data, pv.size,
+                                      all_stark.constraint_degree, Table.MemBefore, Table.MemAfter, C.byref(h))
+        if rc == -4:
+            raise Aborted()
+        ctx.check(rc)
+    finally:
+        if isinstance(abort_signal, C.c_int):
+            ctx.set_abort_flag(None)
+    lib = ctx.lib
+    try:
+        nchal = config.num_challenges
+        cc = np.zeros(2 * nchal, dtype=np.uint64)
+        lib.zk_segment_proof_ctl_challenges(h, cc.ctypes.data, cc.size)
+        ctl_challenges = [(int(cc[2 * i]), int(cc[2 * i + 1])) for i in range(nchal)]
+        stark_proofs: List[Optional[StarkProofWithMetadata]] = []
+        for t in Table.all():
+            th = lib.zk_segment_proof_table(h, t)
+            if not th:
+                stark_proofs.append(None)
+                continue
+            p = table_proof_from_handle(lib, th)
+            stark_proofs.append(StarkProofWithMetadata(p, p.init_challenger_state))
+        nd = 1 << config.fri_config.cap_height
+        mb, ma = np.zeros(4 * nd, dtype=np.uint64), np.zeros(4 * nd, dtype=np.uint64)
+        lib.zk_segment_proof_mem_caps(h, mb.ctypes.data, ma.ctypes.data, 4 * nd)
+        public_values.mem_before = MemCap.from_merkle_cap(mb)
+        public_values.mem_after = MemCap.from_merkle_cap(ma)
+        if timing is not None:
+            ms = (C.c_double * (2 + NUM_TABLES))()
+            lib.zk_segment_proof_stage_ms(h, ms, 2 + NUM_TABLES)
+            timing["compute all trace commitments"] = timing.get("compute all trace commitments", 0.0) + ms[0] / 1e3
+            timing["compute CTL data"] = timing.get("compute CTL data", 0.0) + ms[1] / 1e3
+            for t in Table.all():
+                if table_in_use[t]:
+                    k = "prove %s STARK" % TABLE_NAMES[t]
+                    timing[k] = timing.get(k, 0.0) + ms[2 + t] / 1e3
+    finally:
+        lib.zk_segment_proof_free(h)
     return AllProof(MultiProof(stark_proofs, ctl_challenges), public_values, list(table_in_use))
