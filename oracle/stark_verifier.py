@@ -51,7 +51,7 @@ class Ext:
 
 
 def verify_stark_proof(o, fri_api, cfg, air_eval, n_cols, degree_bits, lookups, zdatas, ctl_challenges, proof, och,
-                       constraint_degree=3, requires_ctls=True):
+                       constraint_degree=3, requires_ctls=True, check_identity=True):
     """proof: dict(trace_cap, aux_cap, quotient_cap, openings (flat u64), fri).  zdatas: oracle CtlZData
     with n_helpers filled in.  och: challenger in the state `prove_with_commitment` started from.
     Returns (ok, reason)."""
@@ -93,12 +93,15 @@ def verify_stark_proof(o, fri_api, cfg, air_eval, n_cols, degree_bits, lookups, 
     l_last = z_h * n_inv * (zeta * g - 1).inv()
     cons = S.ConstraintConsumer(alphas, zeta - last, l_0, l_last)
     cons.accs = [Ext(0) for _ in alphas]
-    air_eval(local, nxt, cons)
-    if lookups:
-        S.eval_packed_lookups(lookups, lookup_challenges, local, nxt, aux_local, aux_next, cons, constraint_degree)
-    if zdatas:
-        S.eval_cross_table_lookup_checks(zdatas, local, nxt, aux_local, aux_next, n_lookup, cons, constraint_degree)
-    for i, acc in enumerate(cons.accs):
+    # check_identity=False: only the commitment / opening / FRI part (used for proofs of random, non-satisfying
+    # traces at full size, whose quotient is not a polynomial multiple of Z_H by construction)
+    if check_identity:
+        air_eval(local, nxt, cons)
+        if lookups:
+            S.eval_packed_lookups(lookups, lookup_challenges, local, nxt, aux_local, aux_next, cons, constraint_degree)
+        if zdatas:
+            S.eval_cross_table_lookup_checks(zdatas, local, nxt, aux_local, aux_next, n_lookup, cons, constraint_degree)
+    for i, acc in enumerate(cons.accs if check_identity else []):
         chunk = quot[i * qdf:(i + 1) * qdf]
         red = Ext(0)
         for c in reversed(chunk):

@@ -120,3 +120,59 @@ def test_segment_proof_matches_oracle(oracle, hasher, in_use):
     assert got.public_values.mem_after.mem_cap == [[int(x) for x in h] for h in exp["mem_after"]]
     if not in_use[8]:
         assert all(x == 0 for h in got.public_values.mem_after.mem_cap for x in h)
+
+
+def test_full_size_segment_openings_and_fri_verify(oracle):
+    """BASELINE configs[2] at FULL size (nine tables x 2^20 rows, standard_fast_config: 84 queries, 16 PoW bits)
+    through size-independent properties: the oracle replays the transcript (caps, public values, CTL challenges,
+    every table's init_challenger_state, alphas, zeta) and its FRI verifier accepts every table's opening proof --
+    Merkle paths of the trace / auxiliary / quotient oracles at all 84 query positions, the claimed openings, the
+    fold consistency, the final polynomial and the proof of work."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    from bench import synthetic_segment_traces
+    from oracle import all_stark as oas
+    from oracle import segment as oseg
+    from oracle import stark as orc
+    from oracle import stark_verifier as overify
+    from zk_evm_amd.all_stark import AllStark, TABLE_COLUMNS
+    ol.setup_fri_api(oracle)
+    L = oracle.lib
+    log_n = 20
+    dev = torch.device("cuda:0")
+    traces = synthetic_segment_traces([log_n] * 9, dev, seed=11)
+    scfg = zk.StarkConfig()                      # standard_fast_config
+    in_use = [True] * 9
+    pvd = make_pv(np.random.default_rng(5))
+    got = sg.prove_with_traces(AllStark((1, 2, 3, 4)), scfg, traces, in_use, to_public_values(pvd))
+    del traces
+    torch.cuda.empty_cache()
+    cfg = ol.make_cfg(hasher=0)                  # pow_bits 16, 84 queries
+    och = ol.new_challenger(oracle, 0)
+    for t in range(9):
+        cap = got.multi_proof.stark_proofs[t].proof.trace_cap
+        L.orc_challenger_observe_cap(C.byref(och), np.ascontiguousarray(cap), cap.shape[0])
+    e = np.array(oseg.pv_elements(pvd), dtype=np.uint64)
+    L.orc_challenger_observe(C.byref(och), e, e.size)
+    chal = [orc.GrandProductChallenge(L.orc_challenger_get(C.byref(och)), L.orc_challenger_get(C.byref(och)))
+            for _ in range(cfg.num_challenges)]
+    pairs = [(c.beta, c.gamma) for c in chal]
+    assert got.multi_proof.ctl_challenges == pairs
+    per_table = oseg.cross_table_lookup_data([None] * 9, oas.build_ctls(), chal, 3)
+    lookups = oas.build_lookups()
+    for t in range(9):
+        sp = got.multi_proof.stark_proofs[t]
+        st = np.zeros(12, dtype=np.uint64)
+        L.orc_challenger_compact(C.byref(och), st)
+        assert np.array_equal(sp.init_challenger_state, st), t
+        for z in per_table[t]:
+            k = len(z.columns_filters)
+            z.n_helpers = -(-k // 2) if k > 1 else 0
+        p = sp.proof
+        assert p.degree_bits == log_n
+        proof = dict(trace_cap=p.trace_cap, aux_cap=p.auxiliary_polys_cap, quotient_cap=p.quotient_polys_cap,
+                     openings=p.openings, fri=p.opening_proof)
+        ok, why = overify.verify_stark_proof(oracle, ol, cfg, None, TABLE_COLUMNS[t], log_n, lookups[t], per_table[t],
+                                             pairs, proof, och, check_identity=False)
+        assert ok, (t, why)
