@@ -108,6 +108,14 @@ def load_library():
     if not os.path.exists(path):
         raise ZkStarkError(-3, f"{path} not found: build it with `python -m zk_evm_amd.build` "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64, and this binding
+    # uses torch for device tensors and streams.  If libzkstark_hip.so (linked against /opt/rocm) were loaded
+    # first, a later `import torch` would bind to that copy and fail with "No HIP GPUs are available".  Loading
+    # torch first makes both share torch's runtime.  (A C / Rust caller without torch just links /opt/rocm.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
