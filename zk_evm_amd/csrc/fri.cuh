@@ -26,80 +26,7 @@ __device__ __forceinline__ gl2 gl2_inv_dev(gl2 x) {
     return gl2_make(gl_mul(x.a, ni), gl_mul(gl_neg(x.b), ni));
 }
 
-// W[p] = z^bitrev(p, log_n);  zpow[k] = z^(2^k) (ext), k < log_n
-struct ZPowers { u64 a[32], b[32]; };
-__global__ void ext_pow_bitrev_table_kernel(u64 *wa, u64 *wb, int log_n, ZPowers zp) {
-    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >> log_n) return;
-    u32 e = bitrev32(p, log_n);
-    gl2 acc = gl2_make(1, 0);
-    for (int k = 0; k < log_n; ++k)
-        if ((e >> k) & 1) acc = gl2_mul(acc, gl2_make(zp.a[k], zp.b[k]));
-    wa[p] = gl_canon(acc.a);
-    wb[p] = gl_canon(acc.b);
-}
-
-// partial[(col * gridDim.x + chunk) * 2 + {0,1}] = sum over the chunk of c[col][p] * W[p]
-__global__ void __launch_bounds__(256)
-eval_columns_partial_kernel(const u64 *__restrict__ coeffs, size_t col_stride, u32 n,
-                            const u64 *__restrict__ wa, const u64 *__restrict__ wb,
-                            u64 *__restrict__ partial) {
-    __shared__ u64 sa[256], sb[256];
-    const u64 *c = coeffs + (size_t)blockIdx.y * col_stride;
-    u32 per = (n + gridDim.x - 1) / gridDim.x;
-    u32 lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
-    gl2 acc = gl2_make(0, 0);
-    for (u32 p = lo + threadIdx.x; p < hi; p += blockDim.x) {
-        u64 v = c[p];
-        acc = gl2_add(acc, gl2_make(gl_mul(wa[p], v), gl_mul(wb[p], v)));
-    }
-    sa[threadIdx.x] = acc.a; sb[threadIdx.x] = acc.b;
-    __syncthreads();
-    for (u32 s = blockDim.x / 2; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            sa[threadIdx.x] = gl_add(sa[threadIdx.x], sa[threadIdx.x + s]);
-            sb[threadIdx.x] = gl_add(sb[threadIdx.x], sb[threadIdx.x + s]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        size_t o = ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2;
-        partial[o] = sa[0];
-        partial[o + 1] = sb[0];
-    }
-}
-__global__ void eval_columns_reduce_kernel(const u64 *partial, u32 chunks, u32 n_cols, u64 *out) {
-    u32 c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cols) return;
-    gl2 acc = gl2_make(0, 0);
-    for (u32 k = 0; k < chunks; ++k)
-        acc = gl2_add(acc, gl2_make(partial[((size_t)c * chunks + k) * 2], partial[((size_t)c * chunks + k) * 2 + 1]));
-    out[2 * c] = gl_canon(acc.a);
-    out[2 * c + 1] = gl_canon(acc.b);
-}
-
-// ---- value-domain batch combination ---------------------------------------------------------
-// V[j] = sum_b (prod of later shifts) * (sum_k alpha^k f_{b,k}(x_j) - y_b) / (x_j - z_b).
-// One lane per LDE point.  The loop runs over the DISTINCT columns (the zeta and g*zeta batches open the same
-// trace / auxiliary columns, so each value is loaded once and feeds every batch that opens it), and the
-// alpha-power dot products use delayed reduction: the four 32x32 partial products of coef * value are summed in
-// 96-bit accumulators (v_mad_u64_u32 + carry) and folded mod p once per point -- 8 VALU instructions per
-// (column, batch, component) instead of a 21-instruction field multiply plus an 8-instruction field add.
-#define ZK_FRI_MAX_BATCHES 4
-struct FriCombineArgs {
-    int n_batches;
-    int log_N;
-    const u64 *tw;                              // w_N^k, k < N/2
-    u64 coset_shift;                            // g
-    u32 n_cols;                                 // distinct columns
-    const u64 *const *cols;                     // device array [n_cols] of column base pointers (LDE, natural)
-    const u64 *coef;                            // device array [n_cols][n_batches][2]: alpha^pos (a, b); (0,0) = not opened
-    u64 y[ZK_FRI_MAX_BATCHES][2];               // reduced opening sum_k alpha^k f_k(z_b)
-    u64 z[ZK_FRI_MAX_BATCHES][2];               // opening point
-    u64 shift[ZK_FRI_MAX_BATCHES][2];           // alpha^(n_polys[b])
-    u64 *out_a, *out_b;                         // [N] each
-};
-
+// ---- delayed-reduction dot products --------------------------------------------------------------
 // sum of (scalar u64) * (vector u64) products, unreduced: value = s00 + s01 * 2^32 + s11 * 2^64
 struct DotAcc {
     u64 s00, s01, s11;     // low 64 bits of the three partial-product columns
@@ -129,6 +56,123 @@ __device__ __forceinline__ u64 dot_acc_reduce(const DotAcc &d) {
     // a + b * 2^32 + c * (2^32 - 1)
     return gl_add(a, gl_add(gl_mul(b, (u64)1 << 32), gl_mul(c, 0xFFFFFFFFULL)));
 }
+
+// same with per-lane (VGPR) coefficients
+__device__ __forceinline__ void dot_acc_mac_v(DotAcc &d, u64 c, u64 v) {
+    const u32 c0 = (u32)c, c1 = (u32)(c >> 32), v0 = (u32)v, v1 = (u32)(v >> 32);
+    asm("v_mad_u64_u32 %[s00], vcc, %[c0], %[v0], %[s00]\n\t"
+        "v_addc_co_u32 %[h00], vcc, 0, %[h00], vcc\n\t"
+        "v_mad_u64_u32 %[s01], vcc, %[c0], %[v1], %[s01]\n\t"
+        "v_addc_co_u32 %[h01], vcc, 0, %[h01], vcc\n\t"
+        "v_mad_u64_u32 %[s01], vcc, %[c1], %[v0], %[s01]\n\t"
+        "v_addc_co_u32 %[h01], vcc, 0, %[h01], vcc\n\t"
+        "v_mad_u64_u32 %[s11], vcc, %[c1], %[v1], %[s11]\n\t"
+        "v_addc_co_u32 %[h11], vcc, 0, %[h11], vcc"
+        : [s00] "+v"(d.s00), [s01] "+v"(d.s01), [s11] "+v"(d.s11), [h00] "+v"(d.h00), [h01] "+v"(d.h01),
+          [h11] "+v"(d.h11)
+        : [c0] "v"(c0), [c1] "v"(c1), [v0] "v"(v0), [v1] "v"(v1)
+        : "vcc");
+}
+
+// W[p] = z^bitrev(p, log_n);  zpow[k] = z^(2^k) (ext), k < log_n
+struct ZPowers { u64 a[32], b[32]; };
+__global__ void ext_pow_bitrev_table_kernel(u64 *wa, u64 *wb, int log_n, ZPowers zp) {
+    u32 p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >> log_n) return;
+    u32 e = bitrev32(p, log_n);
+    gl2 acc = gl2_make(1, 0);
+    for (int k = 0; k < log_n; ++k)
+        if ((e >> k) & 1) acc = gl2_mul(acc, gl2_make(zp.a[k], zp.b[k]));
+    wa[p] = gl_canon(acc.a);
+    wb[p] = gl_canon(acc.b);
+}
+
+// Openings: f_col(z_t) = sum_p c[col][p] * W_t[p] for up to ZK_EVAL_MAX_POINTS points in ONE pass over the
+// coefficients (zeta and g*zeta open the same columns).  Point t only covers columns [first[t], last[t]).
+// partial[((t * n_cols + col) * gridDim.x + chunk) * 2 + {0,1}] = sum over the chunk.
+#define ZK_EVAL_MAX_POINTS 3
+struct EvalPoints {
+    const u64 *wa[ZK_EVAL_MAX_POINTS], *wb[ZK_EVAL_MAX_POINTS];
+    u32 first[ZK_EVAL_MAX_POINTS], last[ZK_EVAL_MAX_POINTS];
+};
+template <int NP>
+__global__ void __launch_bounds__(256)
+eval_columns_partial_kernel(const u64 *__restrict__ coeffs, size_t col_stride, u32 n, u32 n_cols, u32 col0,
+                            EvalPoints P, u64 *__restrict__ partial) {
+    __shared__ u64 sa[256], sb[256];
+    const u32 col = col0 + blockIdx.y;
+    const u64 *c = coeffs + (size_t)col * col_stride;
+    u32 per = (n + gridDim.x - 1) / gridDim.x;
+    u32 lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    bool on[NP];
+    DotAcc acc[NP][2];
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+        on[t] = col >= P.first[t] && col < P.last[t];
+        dot_acc_init(acc[t][0]); dot_acc_init(acc[t][1]);
+    }
+    for (u32 p = lo + threadIdx.x; p < hi; p += blockDim.x) {
+        const u64 v = c[p];
+#pragma unroll
+        for (int t = 0; t < NP; ++t)
+            if (on[t]) {
+                dot_acc_mac_v(acc[t][0], P.wa[t][p], v);
+                dot_acc_mac_v(acc[t][1], P.wb[t][p], v);
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+        if (!on[t]) continue;          // uniform per block
+        sa[threadIdx.x] = dot_acc_reduce(acc[t][0]);
+        sb[threadIdx.x] = dot_acc_reduce(acc[t][1]);
+        __syncthreads();
+        for (u32 s = blockDim.x / 2; s > 0; s >>= 1) {
+            if (threadIdx.x < s) {
+                sa[threadIdx.x] = gl_add(sa[threadIdx.x], sa[threadIdx.x + s]);
+                sb[threadIdx.x] = gl_add(sb[threadIdx.x], sb[threadIdx.x + s]);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            size_t o = (((size_t)t * n_cols + col) * gridDim.x + blockIdx.x) * 2;
+            partial[o] = sa[0];
+            partial[o + 1] = sb[0];
+        }
+        __syncthreads();
+    }
+}
+// out[(t * n_cols + col) * 2 ..] = sum of the chunks (entries of points that skip the column stay 0)
+__global__ void eval_columns_reduce_kernel(const u64 *partial, u32 chunks, u32 n_entries, u64 *out) {
+    u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_entries) return;
+    gl2 acc = gl2_make(0, 0);
+    for (u32 k = 0; k < chunks; ++k)
+        acc = gl2_add(acc, gl2_make(partial[((size_t)c * chunks + k) * 2], partial[((size_t)c * chunks + k) * 2 + 1]));
+    out[2 * c] = gl_canon(acc.a);
+    out[2 * c + 1] = gl_canon(acc.b);
+}
+
+// ---- value-domain batch combination ---------------------------------------------------------
+// V[j] = sum_b (prod of later shifts) * (sum_k alpha^k f_{b,k}(x_j) - y_b) / (x_j - z_b).
+// One lane per LDE point.  The loop runs over the DISTINCT columns (the zeta and g*zeta batches open the same
+// trace / auxiliary columns, so each value is loaded once and feeds every batch that opens it), and the
+// alpha-power dot products use delayed reduction: the four 32x32 partial products of coef * value are summed in
+// 96-bit accumulators (v_mad_u64_u32 + carry) and folded mod p once per point -- 8 VALU instructions per
+// (column, batch, component) instead of a 21-instruction field multiply plus an 8-instruction field add.
+#define ZK_FRI_MAX_BATCHES 4
+struct FriCombineArgs {
+    int n_batches;
+    int log_N;
+    const u64 *tw;                              // w_N^k, k < N/2
+    u64 coset_shift;                            // g
+    u32 n_cols;                                 // distinct columns
+    const u64 *const *cols;                     // device array [n_cols] of column base pointers (LDE, natural)
+    const u64 *coef;                            // device array [n_cols][n_batches][2]: alpha^pos (a, b); (0,0) = not opened
+    u64 y[ZK_FRI_MAX_BATCHES][2];               // reduced opening sum_k alpha^k f_k(z_b)
+    u64 z[ZK_FRI_MAX_BATCHES][2];               // opening point
+    u64 shift[ZK_FRI_MAX_BATCHES][2];           // alpha^(n_polys[b])
+    u64 *out_a, *out_b;                         // [N] each
+};
 
 template <int NB>
 __global__ void __launch_bounds__(256) fri_combine_kernel(FriCombineArgs A) {
