@@ -8,14 +8,16 @@
 // no table constraints (lookup / CTL checks only) -- used by the generic-machinery tests
 struct AirNone {
     static constexpr u32 COLUMNS = 0;
-    __device__ static __forceinline__ void eval(const RowView &, const RowView &, Consumer &, const u64 *) {}
+    template <class CONS>
+    __device__ static __forceinline__ void eval(const RowView &, const RowView &, CONS &, const u64 *) {}
 };
 
 // MemoryContinuationStark (MemBefore / MemAfter): memory_continuation/memory_continuation_stark.rs:110-122,
 // columns memory_continuation/columns.rs:7-23 (FILTER = 0, 12 columns).
 struct AirMemContinuation {
     static constexpr u32 COLUMNS = 12;
-    __device__ static __forceinline__ void eval(const RowView &lv, const RowView &, Consumer &c, const u64 *) {
+    template <class CONS>
+    __device__ static __forceinline__ void eval(const RowView &lv, const RowView &, CONS &c, const u64 *) {
         Fe filter = lv[0];
         c.constraint(filter * (filter - FE_ONE));  // the filter must be binary
     }
@@ -25,7 +27,8 @@ struct AirMemContinuation {
 // input0 bits 3..258, input1 bits 259..514, result limbs 515..522 (8 x 32-bit).
 struct AirLogic {
     static constexpr u32 COLUMNS = 523;
-    __device__ static __forceinline__ void eval(const RowView &lv, const RowView &, Consumer &c, const u64 *) {
+    template <class CONS>
+    __device__ static __forceinline__ void eval(const RowView &lv, const RowView &, CONS &c, const u64 *) {
         constexpr u32 IN0 = 3, IN1 = 3 + 256, RES = 3 + 512;
         Fe is_and = lv[0], is_or = lv[1], is_xor = lv[2];
         c.constraint(is_and * (is_and - FE_ONE));
@@ -60,7 +63,8 @@ struct AirLogic {
 // mem_after_filter 26, range_check 27, counter 28, frequencies 29).
 struct AirMemory {
     static constexpr u32 COLUMNS = 30;
-    __device__ static __forceinline__ void eval(const RowView &lv, const RowView &nv, Consumer &c, const u64 *) {
+    template <class CONS>
+    __device__ static __forceinline__ void eval(const RowView &lv, const RowView &nv, CONS &c, const u64 *) {
         // Segment ids, unscaled (memory/segments.rs:14,41,79,81)
         constexpr u64 SEG_CODE = 0, SEG_TRIE_DATA = 12, SEG_ACCOUNTS_LL = 34, SEG_STORAGE_LL = 35;
         const Fe one = FE_ONE;
@@ -114,7 +118,8 @@ struct AirMemory {
 // value_bytes 37..68, range_counter 69, rc_frequencies 70).
 struct AirBytePacking {
     static constexpr u32 COLUMNS = 71;
-    __device__ static __forceinline__ void eval(const RowView &lv, const RowView &nv, Consumer &c, const u64 *) {
+    template <class CONS>
+    __device__ static __forceinline__ void eval(const RowView &lv, const RowView &nv, CONS &c, const u64 *) {
         constexpr u32 NUM_BYTES = 32, IDX = 1, VAL = 37;
         const Fe one = FE_ONE;
         Fe rc1 = lv[69], rc2 = nv[69];
@@ -158,7 +163,8 @@ struct AirArithmetic {
     }
 
     // addcy.rs:98-151
-    __device__ static __forceinline__ void addcy(Consumer &c, Fe filt, const Fe *x, const Fe *y, const Fe *z, const Fe *given_cy,
+    template <class CONS>
+    __device__ static __forceinline__ void addcy(CONS &c, Fe filt, const Fe *x, const Fe *y, const Fe *z, const Fe *given_cy,
                                  bool two_row) {
         Fe cy;
         for (u32 i = 0; i < NL; ++i) {
@@ -178,7 +184,8 @@ struct AirArithmetic {
     }
 
     // mul.rs:123-173 (eval_packed_generic_mul)
-    __device__ static __forceinline__ void mul(const RowView &lv, Consumer &c, Fe filt, const Fe *left, const Fe *right) {
+    template <class CONS>
+    __device__ static __forceinline__ void mul(const RowView &lv, CONS &c, Fe filt, const Fe *left, const Fe *right) {
         for (u32 d = 0; d < NL; ++d) {
             Fe cp;                                                     // pol_mul_lo
             for (u32 i = 0; i <= d; ++i) cp += left[i] * right[d - i];
@@ -197,7 +204,8 @@ struct AirArithmetic {
     }
 
     // modular.rs:419-501 (modular_constr_poly incl. check_reduced); cp_out has 2*NL entries
-    __device__ static __forceinline__ void modular_constr_poly(const RowView &lv, const RowView &nv, Consumer &c, Fe filt,
+    template <class CONS>
+    __device__ static __forceinline__ void modular_constr_poly(const RowView &lv, const RowView &nv, CONS &c, Fe filt,
                                                const Fe *output_in, const Fe *modulus_in, const Fe *quot, Fe *cp) {
         Fe output[NL], modulus[NL];
         for (u32 i = 0; i < NL; ++i) { output[i] = output_in[i]; modulus[i] = modulus_in[i]; }
@@ -241,7 +249,8 @@ struct AirArithmetic {
     }
 
     // divmod.rs:86-116 (eval_packed_divmod_helper)
-    __device__ static __forceinline__ void divmod_helper(const RowView &lv, const RowView &nv, Consumer &c, Fe filt, u32 num_s,
+    template <class CONS>
+    __device__ static __forceinline__ void divmod_helper(const RowView &lv, const RowView &nv, CONS &c, Fe filt, u32 num_s,
                                          u32 den_s, u32 quo_s, u32 rem_s) {
         c.constraint_last_row(filt);
         Fe den[NL], quo[2 * NL], rem[NL], cp[2 * NL];
@@ -256,7 +265,8 @@ struct AirArithmetic {
         }
     }
 
-    __device__ static __forceinline__ void eval(const RowView &lv, const RowView &nv, Consumer &c, const u64 *) {
+    template <class CONS>
+    __device__ static __forceinline__ void eval(const RowView &lv, const RowView &nv, CONS &c, const u64 *) {
         const Fe one = FE_ONE;
         Fe all_flags;
         for (u32 f = 0; f <= IS_RANGE_CHECK; ++f) { Fe fl = lv[f]; c.constraint(fl * (fl - one)); all_flags += fl; }
@@ -378,7 +388,8 @@ struct AirKeccak {
     __device__ static __forceinline__ Fe xor3_gen(Fe x, Fe y, Fe z) { return xor_gen(x, xor_gen(y, z)); }
     __device__ static __forceinline__ Fe andn_gen(Fe x, Fe y) { return (FE_ONE - x) * y; }
 
-    __device__ static void eval(const RowView &lv, const RowView &nv, Consumer &c, const u64 *) {
+    template <class CONS>
+    __device__ static void eval(const RowView &lv, const RowView &nv, CONS &c, const u64 *) {
         const Fe one = FE_ONE;
         // round_flags.rs
         Fe local_any, next_any;
@@ -470,7 +481,8 @@ struct AirKeccak {
 // rc_frequencies 437).
 struct AirKeccakSponge {
     static constexpr u32 COLUMNS = 438;
-    __device__ static void eval(const RowView &lv, const RowView &nv, Consumer &c, const u64 *) {
+    template <class CONS>
+    __device__ static void eval(const RowView &lv, const RowView &nv, CONS &c, const u64 *) {
         constexpr u32 RATE = 136, RATE_U32 = 34, CAP_U32 = 16, DIG_U32 = 8;
         constexpr u32 PAD = 6, ORATE = 142, OCAP = 176, BLOCK = 192, PARTIAL = 362, DIGEST = 404, RC = 436;
         const Fe one = FE_ONE;
@@ -537,7 +549,8 @@ struct AirCpu {
     __device__ static __forceinline__ u32 ch(u32 k) { return CH0 + 13 * k; }
 
     // stack.rs:173-282 (eval_packed_one)
-    __device__ static void stack_one(const RowView &lv, const RowView &nv, Consumer &c, Fe filt, u32 num_pops,
+    template <class CONS>
+    __device__ static void stack_one(const RowView &lv, const RowView &nv, CONS &c, Fe filt, u32 num_pops,
                                      bool pushes, bool disable) {
         const Fe one = FE_ONE;
         if (num_pops > 0) {
@@ -582,7 +595,8 @@ struct AirCpu {
         c.constraint_transition(filt * (nv[STACK_LEN] - (lv[STACK_LEN] - fe(num_pops) + fe(pushes ? 1 : 0))));
     }
 
-    __device__ static void eval(const RowView &lv, const RowView &nv, Consumer &c, const u64 *K) {
+    template <class CONS>
+    __device__ static void eval(const RowView &lv, const RowView &nv, CONS &c, const u64 *K) {
         const Fe one = FE_ONE;
         const Fe halt_pc(K[0]), start_pc(K[1]), syscall_jumptable(K[2]), exception_jumptable(K[3]);
         Fe b[8];

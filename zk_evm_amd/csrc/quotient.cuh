@@ -12,8 +12,10 @@
 #pragma once
 #include "gl.cuh"
 #include "stark.cuh"
+#include "fri.cuh"   // DotAcc (delayed-reduction dot products)
 
-#define ZK_MAX_CHALLENGES 4
+#define ZK_MAX_CHALLENGES 2   // num_challenges of every reference config is 1 (tests) or 2 (standard_fast_config)
+#define ZK_QUOTIENT_MAX_CONSTRAINTS (1u << 16)
 
 // ---- lazy field element with operators (AIR code reads like the Rust `P: PackedField` code) ----
 struct Fe {
@@ -40,20 +42,33 @@ struct RowView {
     __device__ __forceinline__ Fe operator[](u32 col) const { return Fe(base[(size_t)col * stride + row]); }
 };
 
-// starky `ConstraintConsumer`: acc_k <- acc_k * alpha_k + c, in yield order.
-struct Consumer {
-    u64 alpha[ZK_MAX_CHALLENGES];
-    u64 acc[ZK_MAX_CHALLENGES];
-    int nc;
+// starky `ConstraintConsumer`: acc_k <- acc_k * alpha_k + c in yield order, i.e. after K constraints
+// acc_k = sum_i c_i * alpha_k^(K-1-i).  Evaluated here as exactly that dot product with delayed reduction: K is
+// obtained once per (AIR, lookup / CTL shape) by instantiating the same AIR code with CountConsumer
+// (quotient_count_kernel), alpha_k^j comes from a per-proof table walked backwards with a uniform pointer (scalar
+// loads), and each constraint costs 8 VALU instructions per challenge (DotAcc) instead of a field multiply plus a
+// field add.  Both challenge slots are always computed (with num_challenges = 1 the second one mirrors the first).
+struct DotConsumer {
+    const u64 *ap0, *ap1;                 // one past the next coefficient: alpha_k^(left)
+    DotAcc d0, d1;
     Fe z_last, lagrange_first, lagrange_last;
     __device__ __forceinline__ void constraint(Fe c) {
-#pragma unroll
-        for (int k = 0; k < ZK_MAX_CHALLENGES; ++k)
-            if (k < nc) acc[k] = gl_add(gl_mul(acc[k], alpha[k]), c.v);
+        --ap0; --ap1;
+        const u64 a = *ap0, b = *ap1;
+        dot_acc_mac(d0, __builtin_amdgcn_readfirstlane((u32)a), __builtin_amdgcn_readfirstlane((u32)(a >> 32)), c.v);
+        dot_acc_mac(d1, __builtin_amdgcn_readfirstlane((u32)b), __builtin_amdgcn_readfirstlane((u32)(b >> 32)), c.v);
     }
     __device__ __forceinline__ void constraint_transition(Fe c) { constraint(c * z_last); }
     __device__ __forceinline__ void constraint_first_row(Fe c) { constraint(c * lagrange_first); }
     __device__ __forceinline__ void constraint_last_row(Fe c) { constraint(c * lagrange_last); }
+};
+// same interface, only counts (everything feeding the ignored values is dead code)
+struct CountConsumer {
+    u32 count;
+    __device__ __forceinline__ void constraint(Fe) { ++count; }
+    __device__ __forceinline__ void constraint_transition(Fe) { ++count; }
+    __device__ __forceinline__ void constraint_first_row(Fe) { ++count; }
+    __device__ __forceinline__ void constraint_last_row(Fe) { ++count; }
 };
 
 // ---- program evaluation on an evaluation frame (`Column::eval_with_next`, `Filter::eval_filter`) --
@@ -105,9 +120,10 @@ __device__ __forceinline__ void frame_eval_entry(const u64 *__restrict__ prog, u
 
 // starky `eval_helper_columns`: entries [0, n_entries) of the sub-program at prog+sub, helper h at
 // aux column h0 + h.
+template <class CONS>
 __device__ __forceinline__ void check_helper_columns(const u64 *__restrict__ prog, u32 sub, u32 n_entries, u32 chunk,
                                                      const RowView &lv, const RowView &nv, const RowView &aux_lv,
-                                                     u32 h0, u64 beta, u64 gamma, Consumer &cons) {
+                                                     u32 h0, u64 beta, u64 gamma, CONS &cons) {
     u32 h = 0;
     for (u32 e = 0; e < n_entries; e += chunk, ++h) {
         Fe hv = aux_lv[h0 + h];
@@ -145,45 +161,15 @@ struct QuotientArgs {
     u32 constraint_degree;
     const u64 *air_consts;
     u64 *out; size_t out_stride;  // [n_challenges][size] quotient VALUES on the coset
+    const u64 *alpha_pow[ZK_MAX_CHALLENGES];   // alpha_k^j, j < n_constraints
+    u32 n_constraints;    // K (from quotient_count_kernel)
+    u32 *count_out;       // quotient_count_kernel: receives K
+    int *err_flag;        // set to 3 when the number of constraints met differs from n_constraints
 };
 
-template <class Air>
-__device__ __forceinline__ void quotient_body(const QuotientArgs &A) {
-    const u32 size_log = A.log_n + A.qd_bits;
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >> size_log) return;
-    const u32 size = 1u << size_log, half = size >> 1;
-    // x = g * w_size^i
-    u64 w = A.tw[i & (half - 1)];
-    if (i & half) w = gl_neg(w);
-    const Fe x(gl_mul(w, A.coset_shift));
-    // Z_H(x) = x^n - 1 = g^n * (w_size^n)^i - 1, and w_size^n has order 2^qd_bits
-    u64 wn = 1;
-    {
-        const u32 k = i & ((1u << A.qd_bits) - 1);      // exponent of the 2^qd_bits-th root
-        if (k) {                                        // w_size^(n*k) = tw[k * n mod size]
-            u32 idx = k << A.log_n;
-            u64 t = A.tw[idx & (half - 1)];
-            wn = (idx & half) ? gl_neg(t) : t;
-        }
-    }
-    const Fe zh = Fe(gl_mul(A.g_pow_n, wn)) - FE_ONE;
-    const Fe xm1 = x - FE_ONE, xml = x - Fe(A.w_n_inv);
-    // one shared inversion for 1/zh, 1/(x-1), 1/(x-last)   (x is never in H: all non-zero)
-    Fe p01 = zh * xm1, p012 = p01 * xml;
-    Fe inv(gl_inv(p012.v));
-    Fe inv_xml = inv * p01;
-    Fe inv01 = inv * xml;
-    Fe inv_xm1 = inv01 * zh, inv_zh = inv01 * xm1;
-    Consumer cons;
-    cons.nc = A.n_challenges;
-#pragma unroll
-    for (int k = 0; k < ZK_MAX_CHALLENGES; ++k) { cons.alpha[k] = A.alphas[k]; cons.acc[k] = 0; }
-    cons.z_last = xml;
-    const Fe zh_over_n = zh * Fe(A.n_inv);
-    cons.lagrange_first = zh_over_n * inv_xm1;                    // L_0(x)     = Z_H(x) / (n (x - 1))
-    cons.lagrange_last = zh_over_n * Fe(A.w_n_inv) * inv_xml;     // L_{n-1}(x) = w^-1 Z_H(x) / (n (x - w^-1))
-
+// every constraint of the table at coset point i, in starky's order: AIR, lookups, CTLs
+template <class Air, class CONS>
+__device__ __forceinline__ void quotient_constraints(const QuotientArgs &A, u32 i, u32 size, CONS &cons) {
     const u32 row = i << A.step_log;
     const u32 row_next = ((i + (1u << A.qd_bits)) & (size - 1)) << A.step_log;
     RowView lv{A.trace, A.trace_stride, row}, nv{A.trace, A.trace_stride, row_next};
@@ -252,9 +238,48 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs &A) {
             start_index += n_help;
         }
     }
-#pragma unroll
-    for (int k = 0; k < ZK_MAX_CHALLENGES; ++k)
-        if (k < A.n_challenges) A.out[(size_t)k * A.out_stride + i] = gl_canon(gl_mul(cons.acc[k], inv_zh.v));
+}
+
+template <class Air>
+__device__ __forceinline__ void quotient_body(const QuotientArgs &A) {
+    const u32 size_log = A.log_n + A.qd_bits;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> size_log) return;
+    const u32 size = 1u << size_log, half = size >> 1;
+    // x = g * w_size^i
+    u64 w = A.tw[i & (half - 1)];
+    if (i & half) w = gl_neg(w);
+    const Fe x(gl_mul(w, A.coset_shift));
+    // Z_H(x) = x^n - 1 = g^n * (w_size^n)^i - 1, and w_size^n has order 2^qd_bits
+    u64 wn = 1;
+    {
+        const u32 k = i & ((1u << A.qd_bits) - 1);      // exponent of the 2^qd_bits-th root
+        if (k) {                                        // w_size^(n*k) = tw[k * n mod size]
+            u32 idx = k << A.log_n;
+            u64 t = A.tw[idx & (half - 1)];
+            wn = (idx & half) ? gl_neg(t) : t;
+        }
+    }
+    const Fe zh = Fe(gl_mul(A.g_pow_n, wn)) - FE_ONE;
+    const Fe xm1 = x - FE_ONE, xml = x - Fe(A.w_n_inv);
+    // one shared inversion for 1/zh, 1/(x-1), 1/(x-last)   (x is never in H: all non-zero)
+    Fe p01 = zh * xm1, p012 = p01 * xml;
+    Fe inv(gl_inv(p012.v));
+    Fe inv_xml = inv * p01;
+    Fe inv01 = inv * xml;
+    Fe inv_xm1 = inv01 * zh, inv_zh = inv01 * xm1;
+    DotConsumer cons;
+    cons.ap0 = A.alpha_pow[0] + A.n_constraints;
+    cons.ap1 = A.alpha_pow[1] + A.n_constraints;
+    dot_acc_init(cons.d0); dot_acc_init(cons.d1);
+    cons.z_last = xml;
+    const Fe zh_over_n = zh * Fe(A.n_inv);
+    cons.lagrange_first = zh_over_n * inv_xm1;                    // L_0(x)     = Z_H(x) / (n (x - 1))
+    cons.lagrange_last = zh_over_n * Fe(A.w_n_inv) * inv_xml;     // L_{n-1}(x) = w^-1 Z_H(x) / (n (x - w^-1))
+    quotient_constraints<Air>(A, i, size, cons);
+    if (cons.ap0 != A.alpha_pow[0] && i == 0) atomicExch(A.err_flag, 3);   // met fewer / more constraints than K
+    A.out[i] = gl_canon(gl_mul(dot_acc_reduce(cons.d0), inv_zh.v));
+    if (A.n_challenges > 1) A.out[A.out_stride + i] = gl_canon(gl_mul(dot_acc_reduce(cons.d1), inv_zh.v));
 }
 
 // Two launch-bound flavours of the same body: light AIRs keep their whole working set in VGPRs;
@@ -264,6 +289,22 @@ template <class Air>
 __global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs A) { quotient_body<Air>(A); }
 template <class Air>
 __global__ void __launch_bounds__(256, 4) quotient_kernel_heavy(QuotientArgs A) { quotient_body<Air>(A); }
+// K = number of constraints the table yields per point (depends only on the AIR and the lookup / CTL shapes)
+template <class Air>
+__global__ void quotient_count_kernel(QuotientArgs A) {
+    if (threadIdx.x || blockIdx.x) return;
+    CountConsumer cons;
+    cons.count = 0;
+    quotient_constraints<Air>(A, 0, 1u << (A.log_n + A.qd_bits), cons);
+    *A.count_out = cons.count;
+}
+// out[k * cap + j] = alpha_k^j
+__global__ void alpha_power_table_kernel(u64 *out, u32 cap, u32 count, u64 a0, u64 a1) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    out[j] = gl_canon(gl_pow(a0, j));
+    out[(size_t)cap + j] = gl_canon(gl_pow(a1, j));
+}
 
 // de-interleave the bit-reversed coefficients of a size-(n*Q) polynomial into its Q degree-n
 // chunks (chunk j = coefficients [j*n, (j+1)*n)): in bit-reversed order chunk j is the positions

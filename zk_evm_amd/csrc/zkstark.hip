@@ -47,6 +47,7 @@ struct zk_ctx {
     int cu_count = 0;
     std::set<zk_batch *> live_batches;  // freed by zk_ctx_destroy if the caller leaked them
     DevArena arena;                     // all batch + scratch HBM (arena.hpp)
+    std::map<std::vector<u64>, u32> constraint_counts;   // quotient: constraints yielded per (AIR, lookup/CTL shape)
 };
 
 struct zk_batch {
