@@ -12,6 +12,7 @@
 // three-kernel block scan over field addition.
 #pragma once
 #include "gl.cuh"
+#include "fri.cuh"   // DotAcc (delayed-reduction dot products)
 
 // ---- program interpreter ---------------------------------------------------------------------
 // Column  := n_local, n_next, constant, (idx, coef) * n_local, (idx, coef) * n_next
@@ -62,74 +63,142 @@ __device__ __forceinline__ u64 prog_eval_filter(const u64 *__restrict__ prog, u3
 // helpers[h][row] = sum over its entries of filter ? 1/(sum_j beta^j col_j + gamma) : 0.
 // extra_inv (optional): also writes 1/(gamma + table_col(row)) for the logUp table column, whose
 // Column program sits at prog[extra_pc].
+//
+// All `num_challenges` (beta, gamma) pairs are handled in ONE pass: the column values and the filter of an entry do
+// not depend on the challenge, only the combination sum_j beta_k^j col_j + gamma_k does.  Linear combinations
+// (`Column`) and the tuple combination are dot products with wave-uniform coefficients, accumulated unreduced
+// (DotAcc: 8 VALU instructions per term instead of a field multiply + add); beta_k^j comes precomputed.
 #define ZK_HELPER_BATCH 16
-// denominator and filter of entry e at `row`
+#define ZK_HELPER_MAX_CHALLENGES 2
+#define ZK_HELPER_MAX_TUPLE 64
+struct HelperChallenges {
+    u64 gamma[ZK_HELPER_MAX_CHALLENGES];
+    u64 bpow[ZK_HELPER_MAX_CHALLENGES][ZK_HELPER_MAX_TUPLE];   // beta_k^j
+};
+
+__device__ __forceinline__ void dot_acc_mac_u(DotAcc &d, u64 coef_uniform, u64 v) {
+    dot_acc_mac(d, __builtin_amdgcn_readfirstlane((u32)coef_uniform), __builtin_amdgcn_readfirstlane((u32)(coef_uniform >> 32)), v);
+}
+// Column at `row` ("table" semantics: the next-row part is dropped on the last row); lazy u64.
+__device__ __forceinline__ u64 prog_eval_column_dot(const u64 *__restrict__ prog, u32 &pc, const TraceView &t, u32 row) {
+    const u32 nl = (u32)prog[pc], nn = (u32)prog[pc + 1];
+    const u64 k = prog[pc + 2];
+    pc += 3;
+    const bool has_next = row + 1 < t.n;
+    if (nl == 1 && nn == 0 && k == 0 && prog[pc + 1] == 1) {       // Column::single, by far the most common
+        u64 v = t.base[(size_t)prog[pc] * t.stride + row];
+        pc += 2;
+        return v;
+    }
+    DotAcc a;
+    dot_acc_init(a);
+    for (u32 i = 0; i < nl; ++i, pc += 2) dot_acc_mac_u(a, prog[pc + 1], t.base[(size_t)prog[pc] * t.stride + row]);
+    for (u32 i = 0; i < nn; ++i, pc += 2)
+        if (has_next) dot_acc_mac_u(a, prog[pc + 1], t.base[(size_t)prog[pc] * t.stride + row + 1]);
+    return gl_add(dot_acc_reduce(a), k);
+}
+__device__ __forceinline__ u64 prog_eval_filter_dot(const u64 *__restrict__ prog, u32 &pc, const TraceView &t, u32 row) {
+    const u32 np = (u32)prog[pc], nc = (u32)prog[pc + 1];
+    pc += 2;
+    u64 acc = 0;
+    for (u32 i = 0; i < np; ++i) {
+        u64 a = prog_eval_column_dot(prog, pc, t, row);
+        u64 b = prog_eval_column_dot(prog, pc, t, row);
+        acc = gl_add(acc, gl_mul(a, b));
+    }
+    for (u32 i = 0; i < nc; ++i) acc = gl_add(acc, prog_eval_column_dot(prog, pc, t, row));
+    return gl_canon(acc);
+}
+// denominators (one per challenge) and filter of entry e at `row`
+template <int NCH>
 __device__ __forceinline__ void prog_eval_entry(const u64 *__restrict__ prog, u32 e, const TraceView &t, u32 row,
-                                                u64 beta, u64 gamma, u64 &denom, u64 &filt) {
+                                                const HelperChallenges &H, u64 (&denom)[NCH], u64 &filt) {
     u32 pc = (u32)prog[1 + e];
     const u32 ncols = (u32)prog[pc++];
-    u64 acc = 0, bp = 1;  // sum_j beta^j col_j  (== reduce_with_powers(evals, beta))
-    for (u32 j = 0; j < ncols; ++j) {
-        u64 c = prog_eval_column(prog, pc, t, row);
-        acc = gl_add(acc, j == 0 ? c : gl_mul(c, bp));
-        bp = j == 0 ? beta : gl_mul(bp, beta);
+    DotAcc acc[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) dot_acc_init(acc[k]);
+    for (u32 j = 0; j < ncols; ++j) {            // sum_j beta^j col_j  (== reduce_with_powers(evals, beta))
+        const u64 c = prog_eval_column_dot(prog, pc, t, row);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) dot_acc_mac_u(acc[k], H.bpow[k][j], c);
     }
-    denom = gl_canon(gl_add(acc, gamma));
-    filt = prog_eval_filter(prog, pc, t, row);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) denom[k] = gl_canon(gl_add(dot_acc_reduce(acc[k]), H.gamma[k]));
+    filt = prog_eval_filter_dot(prog, pc, t, row);
 }
 
+struct HelperOut {
+    u64 *helpers[ZK_HELPER_MAX_CHALLENGES];     // challenge k: helper column h at helpers[k] + h * helper_stride
+    u64 *extra_inv[ZK_HELPER_MAX_CHALLENGES];   // optional: 1 / (gamma_k + table column)
+};
+template <int NCH>
 __global__ void __launch_bounds__(256)
-helper_cols_kernel(const u64 *__restrict__ prog, TraceView t, u64 beta, u64 gamma, u32 chunk,
-                   u64 *__restrict__ helpers, size_t helper_stride, u32 extra_pc,
-                   u64 *__restrict__ extra_inv, int *__restrict__ err_flag) {
+helper_cols_kernel(const u64 *__restrict__ prog, TraceView t, HelperChallenges H, u32 chunk, HelperOut O,
+                   size_t helper_stride, u32 extra_pc, int *__restrict__ err_flag) {
     const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= t.n) return;
     const u32 n_entries = (u32)prog[0];
     // ZK_HELPER_BATCH is a multiple of chunk (1 or 2), so batches never split a helper group
     for (u32 e0 = 0; e0 < n_entries; e0 += ZK_HELPER_BATCH) {
-        u64 v[ZK_HELPER_BATCH], pre[ZK_HELPER_BATCH], flt[ZK_HELPER_BATCH];
-        u64 run = 1;
+        u64 v[NCH][ZK_HELPER_BATCH], pre[NCH][ZK_HELPER_BATCH], flt[ZK_HELPER_BATCH];
+        u64 run[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) run[k] = 1;
 #pragma unroll
         for (int i = 0; i < ZK_HELPER_BATCH; ++i) {
-            v[i] = 1; flt[i] = 0; pre[i] = 1;
+            flt[i] = 0;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) { v[k][i] = 1; pre[k][i] = 1; }
             if (e0 + i < n_entries) {
-                u64 d, f;
-                prog_eval_entry(prog, e0 + i, t, row, beta, gamma, d, f);
+                u64 d[NCH], f;
+                prog_eval_entry<NCH>(prog, e0 + i, t, row, H, d, f);
                 if (f > 1) atomicExch(err_flag, 1);          // "Non-binary filter?" (plonky2 asserts)
-                if (f == 1 && d == 0) { atomicExch(err_flag, 2); d = 1; }  // 1/0: plonky2 would panic
                 flt[i] = f;
-                v[i] = f == 1 ? d : 1;                       // dummy 1 where filtered out
-                pre[i] = run;
-                run = gl_mul(run, v[i]);
-            }
-        }
-        u64 inv = gl_inv(run);                               // ONE inversion for the whole batch
 #pragma unroll
-        for (int i = ZK_HELPER_BATCH - 1; i >= 0; --i) {
-            if (e0 + i < n_entries) {
-                u64 vi = v[i];
-                v[i] = flt[i] == 1 ? gl_mul(inv, pre[i]) : 0;
-                inv = gl_mul(inv, vi);
-            }
-        }
-        if (chunk == 1) {
-#pragma unroll
-            for (int i = 0; i < ZK_HELPER_BATCH; ++i)
-                if (e0 + i < n_entries) helpers[(size_t)(e0 + i) * helper_stride + row] = gl_canon(v[i]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < ZK_HELPER_BATCH; i += 2)
-                if (e0 + i < n_entries) {
-                    u64 s = e0 + i + 1 < n_entries ? gl_add(v[i], v[i + 1]) : v[i];
-                    helpers[(size_t)((e0 + i) >> 1) * helper_stride + row] = gl_canon(s);
+                for (int k = 0; k < NCH; ++k) {
+                    if (f == 1 && d[k] == 0) { atomicExch(err_flag, 2); d[k] = 1; }  // 1/0: plonky2 would panic
+                    v[k][i] = f == 1 ? d[k] : 1;             // dummy 1 where filtered out
+                    pre[k][i] = run[k];
+                    run[k] = gl_mul(run[k], v[k][i]);
                 }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            u64 inv = gl_inv(run[k]);                        // ONE inversion per challenge for the whole batch
+#pragma unroll
+            for (int i = ZK_HELPER_BATCH - 1; i >= 0; --i) {
+                if (e0 + i < n_entries) {
+                    u64 vi = v[k][i];
+                    v[k][i] = flt[i] == 1 ? gl_mul(inv, pre[k][i]) : 0;
+                    inv = gl_mul(inv, vi);
+                }
+            }
+            u64 *out = O.helpers[k];
+            if (chunk == 1) {
+#pragma unroll
+                for (int i = 0; i < ZK_HELPER_BATCH; ++i)
+                    if (e0 + i < n_entries) out[(size_t)(e0 + i) * helper_stride + row] = gl_canon(v[k][i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < ZK_HELPER_BATCH; i += 2)
+                    if (e0 + i < n_entries) {
+                        u64 s = e0 + i + 1 < n_entries ? gl_add(v[k][i], v[k][i + 1]) : v[k][i];
+                        out[(size_t)((e0 + i) >> 1) * helper_stride + row] = gl_canon(s);
+                    }
+            }
         }
     }
-    if (extra_inv) {  // logUp table column: 1 / (gamma + table(row))
+    if (O.extra_inv[0]) {  // logUp table column: 1 / (gamma + table(row))
         u32 pc = extra_pc;
-        u64 d = gl_canon(gl_add(prog_eval_column(prog, pc, t, row), gamma));
-        if (d == 0) { atomicExch(err_flag, 2); d = 1; }
-        extra_inv[row] = gl_canon(gl_inv(d));
+        const u64 tc = prog_eval_column_dot(prog, pc, t, row);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            u64 d = gl_canon(gl_add(tc, H.gamma[k]));
+            if (d == 0) { atomicExch(err_flag, 2); d = 1; }
+            O.extra_inv[k][row] = gl_canon(gl_inv(d));
+        }
     }
 }
 
