@@ -176,3 +176,76 @@ def test_full_size_segment_openings_and_fri_verify(oracle):
         ok, why = overify.verify_stark_proof(oracle, ol, cfg, None, TABLE_COLUMNS[t], log_n, lookups[t], per_table[t],
                                              pairs, proof, och, check_identity=False)
         assert ok, (t, why)
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_segment_matches_golden_fixture(idx):
+    """Committed self-golden digests (tests/golden/segment_proof.json, generated by tests/golden/gen_segment_proof.py
+    from the oracle): zk_prove_segment reproduces them with no oracle in the loop."""
+    import json
+    import os
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    from tests.golden.gen_segment_proof import KW, case_inputs, summarize
+    from zk_evm_amd.all_stark import AllStark
+    case = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "segment_proof.json")))["cases"][idx]
+    traces, pvd = case_inputs(case["hasher"], case["in_use"], case["seed"])
+    scfg = zk.StarkConfig(hasher=case["hasher"], fri_config=zk.FriConfig(proof_of_work_bits=KW["pow_bits"],
+                                                                           num_query_rounds=KW["queries"]))
+    dev = [torch.from_numpy(t.view(np.int64)).cuda() for t in traces]
+    got = sg.prove_with_traces(AllStark((31337, 4242, 777777, 888888)), scfg, dev, case["in_use"], to_public_values(pvd))
+    tables = [None if p is None else dict(init=p.init_challenger_state, aux_cap=p.proof.auxiliary_polys_cap,
+                                          quotient_cap=p.proof.quotient_polys_cap, openings=p.proof.openings,
+                                          fri=p.proof.opening_proof) for p in got.multi_proof.stark_proofs]
+    mb = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
+    ma = np.array(got.public_values.mem_after.mem_cap, dtype=np.uint64)
+    assert summarize(got.multi_proof.ctl_challenges, tables, mb, ma) == case["proof"]
+
+
+def test_segment_error_paths():
+    """zk_prove_segment fails loudly: wrong table width, out-of-range public values, a non-binary CTL filter
+    (starky's debug assertion), a raised abort flag (check_abort_signal, prover.rs:346-354), malformed C arguments."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    from zk_evm_amd._lib import ZkStarkError
+    from zk_evm_amd.all_stark import AllStark
+    rng = np.random.default_rng(3)
+    traces = make_traces(rng)
+    scfg = zk.StarkConfig(fri_config=zk.FriConfig(proof_of_work_bits=1, num_query_rounds=1))
+    alls = AllStark((1, 2, 3, 4))
+    dev = [torch.from_numpy(t.view(np.int64)).cuda() for t in traces]
+    in_use = [True] * 9
+    # baseline works
+    sg.prove_with_traces(alls, scfg, dev, in_use, sg.PublicValues())
+    # wrong width
+    bad = list(dev)
+    bad[0] = dev[0][:100].contiguous()
+    with pytest.raises(ZkStarkError):
+        sg.prove_with_traces(alls, scfg, bad, in_use, sg.PublicValues())
+    # public value out of range -> "Invalid conversion of public values."
+    pv = sg.PublicValues()
+    pv.block_metadata.block_gas_used = 1 << 40
+    with pytest.raises(sg.PublicValuesError):
+        sg.prove_with_traces(alls, scfg, dev, in_use, pv)
+    # non-binary filter: Logic op flags all set to 2
+    t5 = traces[5].copy()
+    t5[0:3] = 2
+    bad = list(dev)
+    bad[5] = torch.from_numpy(t5.view(np.int64)).cuda()
+    with pytest.raises(ZkStarkError, match="non-binary filter"):
+        sg.prove_with_traces(alls, scfg, bad, in_use, sg.PublicValues())
+    # abort flag raised before the call
+    flag = C.c_int(1)
+    with pytest.raises(sg.Aborted):
+        sg.prove_with_traces(alls, scfg, dev, in_use, sg.PublicValues(), abort_signal=flag)
+    # and the ctx is usable again afterwards
+    sg.prove_with_traces(alls, scfg, dev, in_use, sg.PublicValues())
+    # malformed C arguments: no tables, null output
+    ctx = zk.default_context(0)
+    cfg = scfg.to_c()
+    h = C.c_void_p()
+    assert ctx.lib.zk_prove_segment(ctx.handle, C.byref(cfg), None, 0, None, 0, None, 0, 3, -1, -1, C.byref(h)) != 0
+    assert "table" in ctx.last_error()
+    assert ctx.lib.zk_prove_segment(ctx.handle, C.byref(cfg), None, 9, None, 0, None, 0, 3, -1, -1, None) != 0
