@@ -150,6 +150,13 @@ struct AirBytePacking {
 // 116 columns: op flags 0..16, OPCODE 17, six 16-limb registers 18..113, RANGE_COUNTER 114,
 // RC_FREQUENCIES 115.  Constraints are yielded in exactly the reference's order.
 struct AirArithmetic {
+    // Register / memory discipline: this AIR multiplies 16/32-limb polynomials (five 32x16 and three 16x16
+    // schoolbook products per point).  Holding all operands in arrays costs 300+ VGPRs (scratch); re-reading them per
+    // term made the kernel L2-bandwidth bound (14k loads per wave, the two LDE rows of a wave do not fit L1).  So
+    // each product is a sliding-window convolution: the 16 limbs of one operand sit in registers, the other operand
+    // streams through a 16-entry register window (one load per output coefficient), the loop over the output
+    // coefficient is a real wave-uniform loop, and the 16-term inner product is an unrolled delayed-reduction dot
+    // product (DotAcc, 8 VALU instructions per term).  The order of the yielded constraints is exactly the reference's.
     static constexpr u32 COLUMNS = 116;
     static constexpr u32 NL = 16;
     enum { IS_ADD = 0, IS_MUL, IS_SUB, IS_DIV, IS_MOD, IS_ADDMOD, IS_MULMOD, IS_ADDFP254, IS_MULFP254,
@@ -158,111 +165,129 @@ struct AirArithmetic {
     static constexpr u64 BASE = 1ULL << 16, OFFSET = 1ULL << 20;
     static constexpr u64 OVERFLOW_INV = 18446462594437939201ULL;  // 2^-16 (addcy.rs:67)
 
-    __device__ static __forceinline__ void rd(const RowView &v, u32 start, Fe *out, u32 n = NL) {
-        for (u32 i = 0; i < n; ++i) out[i] = v[start + i];
+    // f(d, sum_j a(d - j) * m[j]) for d in [d_lo, d_hi); a(i) is read for 0 <= i < na and is 0 outside
+    template <class FA, class F>
+    __device__ static __forceinline__ void conv16(const Fe (&m)[NL], FA a, u32 na, u32 d_lo, u32 d_hi, F f) {
+        Fe win[NL];                                     // win[j] = a(d - j)
+#pragma unroll
+        for (u32 j = 0; j < NL; ++j) win[j] = (d_lo >= j && d_lo - j < na) ? a(d_lo - j) : Fe();
+#pragma unroll 1
+        for (u32 d = d_lo; d < d_hi; ++d) {
+            DotAcc p;
+            dot_acc_init(p);
+#pragma unroll
+            for (u32 j = 0; j < NL; ++j) dot_acc_mac_v(p, win[j].v, m[j].v);
+            f(d, Fe(dot_acc_reduce(p)));
+#pragma unroll
+            for (u32 j = NL - 1; j > 0; --j) win[j] = win[j - 1];
+            win[0] = d + 1 < na ? a(d + 1) : Fe();
+        }
     }
 
-    // addcy.rs:98-151
-    template <class CONS>
-    __device__ static __forceinline__ void addcy(CONS &c, Fe filt, const Fe *x, const Fe *y, const Fe *z, const Fe *given_cy,
-                                 bool two_row) {
+    // addcy.rs:98-151; x, y, z, given_cy: accessors i -> Fe
+    template <class CONS, class FX, class FY, class FZ, class FC>
+    __device__ static __forceinline__ void addcy(CONS &c, Fe filt, FX x, FY y, FZ z, FC given_cy, bool two_row) {
         Fe cy;
+#pragma unroll 1
         for (u32 i = 0; i < NL; ++i) {
-            Fe t = cy + x[i] + y[i] - z[i];
+            Fe t = cy + x(i) + y(i) - z(i);
             Fe v = filt * t * (fe(BASE) - t);
             if (two_row) c.constraint_transition(v); else c.constraint(v);
             cy = t * fe(OVERFLOW_INV);
         }
         if (two_row) {
-            c.constraint_transition(filt * (cy - given_cy[0]));
-            for (u32 i = 1; i < NL; ++i) c.constraint_transition(filt * given_cy[i]);
+            c.constraint_transition(filt * (cy - given_cy(0)));
+#pragma unroll 1
+            for (u32 i = 1; i < NL; ++i) c.constraint_transition(filt * given_cy(i));
         } else {
-            c.constraint(filt * given_cy[0] * (given_cy[0] - FE_ONE));
-            c.constraint(filt * (cy - given_cy[0]));
-            for (u32 i = 1; i < NL; ++i) c.constraint(filt * given_cy[i]);
+            Fe g0 = given_cy(0);
+            c.constraint(filt * g0 * (g0 - FE_ONE));
+            c.constraint(filt * (cy - g0));
+#pragma unroll 1
+            for (u32 i = 1; i < NL; ++i) c.constraint(filt * given_cy(i));
         }
     }
 
-    // mul.rs:123-173 (eval_packed_generic_mul)
-    template <class CONS>
-    __device__ static __forceinline__ void mul(const RowView &lv, CONS &c, Fe filt, const Fe *left, const Fe *right) {
-        for (u32 d = 0; d < NL; ++d) {
-            Fe cp;                                                     // pol_mul_lo
-            for (u32 i = 0; i <= d; ++i) cp += left[i] * right[d - i];
-            cp -= lv[OUT + d];
-            // (x - beta) * s(x), s = aux limbs with the 2^20 offset undone
-            Fe aux_d = lv[AUX0 + d] + lv[AUX1 + d] * fe(BASE) - fe(OFFSET);
-            Fe adj;
-            if (d == 0) adj = -(fe(BASE) * aux_d);
-            else {
-                Fe aux_p = lv[AUX0 + d - 1] + lv[AUX1 + d - 1] * fe(BASE) - fe(OFFSET);
-                adj = aux_p - fe(BASE) * aux_d;
-            }
-            cp -= adj;
+    // (x - beta) * s(x) coefficient d of the aux polynomial a(i) (pol_adjoin_root): a(d-1) - beta * a(d)
+    template <class FA>
+    __device__ static __forceinline__ Fe adjoin(FA a, u32 d) {
+        Fe aux_d = a(d);
+        if (d == 0) return -(fe(BASE) * aux_d);
+        return a(d - 1) - fe(BASE) * aux_d;
+    }
+
+    // mul.rs:123-173 (eval_packed_generic_mul); left: accessor, right_s: first column of the right operand
+    template <class CONS, class FL>
+    __device__ static __forceinline__ void mul(const RowView &lv, CONS &c, Fe filt, FL left, u32 right_s) {
+        auto aux = [&](u32 d) { return lv[AUX0 + d] + lv[AUX1 + d] * fe(BASE) - fe(OFFSET); };   // 2^20 offset undone
+        Fe r[NL];
+#pragma unroll
+        for (u32 i = 0; i < NL; ++i) r[i] = lv[right_s + i];
+        conv16(r, left, NL, 0, NL, [&](u32 d, Fe p) {                    // pol_mul_lo
+            Fe cp = p - lv[OUT + d];
+            cp -= adjoin(aux, d);
             c.constraint(filt * cp);
-        }
+        });
     }
 
-    // modular.rs:419-501 (modular_constr_poly incl. check_reduced); cp_out has 2*NL entries
-    template <class CONS>
-    __device__ static __forceinline__ void modular_constr_poly(const RowView &lv, const RowView &nv, CONS &c, Fe filt,
-                                               const Fe *output_in, const Fe *modulus_in, const Fe *quot, Fe *cp) {
-        Fe output[NL], modulus[NL];
-        for (u32 i = 0; i < NL; ++i) { output[i] = output_in[i]; modulus[i] = modulus_in[i]; }
+    // modular.rs:419-501 (modular_constr_poly incl. check_reduced), split in two: the constraints it yields
+    // itself (modular_checks), and the polynomial it returns, produced coefficient by coefficient (modular_cp).
+    //   output(i): 16 limbs; mod_s: first column of the modulus; quot(i): nq limbs (16 or 32)
+    __device__ static __forceinline__ void load_modulus(const RowView &lv, const RowView &nv, u32 mod_s, Fe (&m)[NL]) {
+#pragma unroll
+        for (u32 i = 0; i < NL; ++i) m[i] = lv[mod_s + i];
+        m[0] += nv[34];                                                 // + MODULAR_MOD_IS_ZERO
+    }
+    template <class CONS, class FO, class FQ>
+    __device__ static __forceinline__ void modular_checks(const RowView &lv, const RowView &nv, CONS &c, Fe filt, FO output,
+                                                          u32 mod_s, FQ quot, u32 nq) {
         Fe mod_is_zero = nv[34];                                        // MODULAR_MOD_IS_ZERO
         c.constraint_transition(filt * (mod_is_zero * mod_is_zero - mod_is_zero));
         Fe limb_sum;
-        for (u32 i = 0; i < NL; ++i) limb_sum += modulus[i];
+#pragma unroll 1
+        for (u32 i = 0; i < NL; ++i) limb_sum += lv[mod_s + i];
         c.constraint_transition(filt * limb_sum * mod_is_zero);
-        modulus[0] += mod_is_zero;
         Fe div_denom_is_zero = nv[97];                                  // MODULAR_DIV_DENOM_IS_ZERO
         Fe div_or_shr = lv[IS_DIV] + lv[IS_SHR];
         c.constraint_transition(filt * (mod_is_zero * div_or_shr - div_denom_is_zero));
-        output[0] += div_denom_is_zero;
-        {   // check_reduced (modular.rs:382-414)
-            Fe out_aux_red[NL], is_less_than[NL];
-            rd(nv, 18, out_aux_red);                                    // MODULAR_OUT_AUX_RED in nv
-            is_less_than[0] = FE_ONE - mod_is_zero * div_or_shr;
-            addcy(c, filt, modulus, out_aux_red, output, is_less_than, true);
+        {   // check_reduced (modular.rs:382-414): output[0] += div_denom_is_zero inside
+            Fe ilt0 = FE_ONE - mod_is_zero * div_or_shr;
+            addcy(c, filt, [&](u32 i) { return i == 0 ? lv[mod_s] + mod_is_zero : lv[mod_s + i]; },
+                  [&](u32 i) { return nv[18 + i]; },                    // MODULAR_OUT_AUX_RED in nv
+                  [&](u32 i) { return i == 0 ? output(0) + div_denom_is_zero : output(i); },
+                  [&](u32 i) { return i == 0 ? ilt0 : Fe(); }, true);
         }
-        output[0] -= div_denom_is_zero;
         // prod = q(x) * m(x)  (pol_mul_wide2): degrees 0 .. 3*NL-2; the top NL-1 must vanish
-        for (u32 d = 2 * NL; d < 3 * NL - 1; ++d) {
-            Fe p;
-            for (u32 j = 0; j < NL; ++j) { u32 i = d - j; if (i < 2 * NL) p += quot[i] * modulus[j]; }
-            c.constraint_transition(filt * p);
-        }
-        for (u32 d = 0; d < 2 * NL; ++d) {
-            Fe p;
-            for (u32 j = 0; j < NL && j <= d; ++j) p += quot[d - j] * modulus[j];
-            if (d < NL) p += output[d];
-            // + (x - beta) * s(x): aux[i] = nv[35+i] - 2^20 + 2^16 * nv[66+i] (i < 31), aux[31] = 0
-            Fe aux_d = d < 2 * NL - 1 ? nv[35 + d] - fe(OFFSET) + fe(BASE) * nv[66 + d] : Fe();
-            Fe adj;
-            if (d == 0) adj = -(fe(BASE) * aux_d);
-            else {
-                Fe aux_p = nv[35 + d - 1] - fe(OFFSET) + fe(BASE) * nv[66 + d - 1];
-                adj = aux_p - fe(BASE) * aux_d;
-            }
-            cp[d] = p + adj;
-        }
+        Fe m[NL];
+        load_modulus(lv, nv, mod_s, m);
+        conv16(m, quot, nq, 2 * NL, 3 * NL - 1, [&](u32, Fe p) { c.constraint_transition(filt * p); });
+    }
+    // f(d, coefficient d of  q*m + output + (x - beta) * s(x)) for d < 2*NL
+    template <class FO, class FQ, class F>
+    __device__ static __forceinline__ void modular_cp(const RowView &lv, const RowView &nv, FO output, u32 mod_s, FQ quot,
+                                                      u32 nq, F f) {
+        Fe m[NL];
+        load_modulus(lv, nv, mod_s, m);
+        // aux[i] = nv[35+i] - 2^20 + 2^16 * nv[66+i] (i < 31), aux[31] = 0
+        auto aux = [&](u32 i) { return i < 2 * NL - 1 ? nv[35 + i] - fe(OFFSET) + fe(BASE) * nv[66 + i] : Fe(); };
+        conv16(m, quot, nq, 0, 2 * NL, [&](u32 d, Fe p) {
+            if (d < NL) p += output(d);
+            f(d, p + adjoin(aux, d));
+        });
     }
 
-    // divmod.rs:86-116 (eval_packed_divmod_helper)
+    // divmod.rs:86-116 (eval_packed_divmod_helper): the quotient input has 16 limbs (upper half zero)
     template <class CONS>
     __device__ static __forceinline__ void divmod_helper(const RowView &lv, const RowView &nv, CONS &c, Fe filt, u32 num_s,
-                                         u32 den_s, u32 quo_s, u32 rem_s) {
+                                                         u32 den_s, u32 quo_s, u32 rem_s) {
         c.constraint_last_row(filt);
-        Fe den[NL], quo[2 * NL], rem[NL], cp[2 * NL];
-        rd(lv, den_s, den);
-        rd(lv, quo_s, quo);
-        for (u32 i = NL; i < 2 * NL; ++i) quo[i] = Fe();
-        rd(lv, rem_s, rem);
-        modular_constr_poly(lv, nv, c, filt, rem, den, quo, cp);
-        for (u32 i = 0; i < 2 * NL; ++i) {
-            Fe v = i < NL ? cp[i] - lv[num_s + i] : cp[i];
+        auto quo = [&](u32 i) { return lv[quo_s + i]; };
+        auto rem = [&](u32 i) { return lv[rem_s + i]; };
+        modular_checks(lv, nv, c, filt, rem, den_s, quo, NL);
+        modular_cp(lv, nv, rem, den_s, quo, NL, [&](u32 i, Fe cp) {
+            Fe v = i < NL ? cp - lv[num_s + i] : cp;
             c.constraint_transition(filt * v);
-        }
+        });
     }
 
     template <class CONS>
@@ -277,9 +302,12 @@ struct AirArithmetic {
         Fe incr = rc2 - rc1;
         c.constraint_transition(incr * incr - incr);
         c.constraint_last_row(rc1 - fe(65535));
-        Fe in0[NL], in1[NL], in2[NL], out[NL], aux[NL];
-        rd(lv, IN0, in0); rd(lv, IN1, in1); rd(lv, IN2, in2); rd(lv, OUT, out); rd(lv, AUX0, aux);
-        mul(lv, c, lv[IS_MUL], in0, in1);
+        auto in0 = [&](u32 i) { return lv[IN0 + i]; };
+        auto in1 = [&](u32 i) { return lv[IN1 + i]; };
+        auto in2 = [&](u32 i) { return lv[IN2 + i]; };
+        auto out = [&](u32 i) { return lv[OUT + i]; };
+        auto aux = [&](u32 i) { return lv[AUX0 + i]; };
+        mul(lv, c, lv[IS_MUL], in0, IN1);
         addcy(c, lv[IS_ADD], in0, in1, out, aux, false);
         addcy(c, lv[IS_SUB], in1, out, in0, aux, false);
         addcy(c, lv[IS_LT], in1, aux, in0, out, false);
@@ -292,76 +320,93 @@ struct AirArithmetic {
             Fe bn = lv[IS_ADDFP254] + lv[IS_MULFP254] + lv[IS_SUBFP254];
             Fe filt = lv[IS_ADDMOD] + lv[IS_SUBMOD] + lv[IS_MULMOD] + bn;
             c.constraint_last_row(filt);
-            for (u32 i = 0; i < NL; ++i) c.constraint_transition(bn * (in2[i] - fe((BN[i / 4] >> (16 * (i % 4))) & 0xFFFF)));
-            Fe quo_input[2 * NL];
-            rd(lv, AUX0, quo_input, 2 * NL);
+#pragma unroll
+            for (u32 i = 0; i < NL; ++i) c.constraint_transition(bn * (in2(i) - fe((BN[i / 4] >> (16 * (i % 4))) & 0xFFFF)));
+            auto quo_input = [&](u32 i) { return lv[AUX0 + i]; };      // 2 * NL limbs
             Fe add_f = lv[IS_ADDMOD] + lv[IS_ADDFP254], sub_f = lv[IS_SUBMOD] + lv[IS_SUBFP254];
             Fe mul_f = lv[IS_MULMOD] + lv[IS_MULFP254];
-            Fe sub_cp[2 * NL], mod_cp[2 * NL];
-            {   // submod_constr_poly (modular.rs:515-539)
-                Fe q[2 * NL];
-                Fe sign = quo_input[NL];
-                c.constraint(sub_f * sign * (sign - one));
-                for (u32 i = 0; i < NL; ++i) q[i] = quo_input[i] - fe(0xFFFF) * sign;
-                q[NL] = Fe();
-                for (u32 i = NL + 1; i < 2 * NL; ++i) q[i] = quo_input[i];
-                for (u32 i = NL; i < 2 * NL; ++i) c.constraint(sub_f * q[i]);
-                modular_constr_poly(lv, nv, c, sub_f, out, in2, q, sub_cp);
-            }
-            modular_constr_poly(lv, nv, c, add_f + mul_f, out, in2, quo_input, mod_cp);
-            for (u32 d = 0; d < 2 * NL; ++d)                      // add: input0 + input1
-                c.constraint_transition(add_f * (d < NL ? mod_cp[d] - (in0[d] + in1[d]) : mod_cp[d]));
-            for (u32 d = 0; d < 2 * NL; ++d)                      // sub: input0 - input1
-                c.constraint_transition(sub_f * (d < NL ? sub_cp[d] - (in0[d] - in1[d]) : sub_cp[d]));
-            for (u32 d = 0; d < 2 * NL; ++d) {                    // mul: pol_mul_wide(input0, input1)
-                Fe v = mod_cp[d];
-                if (d < 2 * NL - 1) {
-                    Fe p;
-                    for (u32 i = 0; i < NL; ++i) { u32 j = d - i; if (j < NL) p += in0[i] * in1[j]; }
-                    v -= p;
+            // submod_constr_poly (modular.rs:515-539): quotient with the sign limb folded in
+            Fe sign = quo_input(NL);
+            Fe sign_ffff = fe(0xFFFF) * sign;
+            auto q_sub = [&](u32 i) { return i < NL ? quo_input(i) - sign_ffff : (i == NL ? Fe() : quo_input(i)); };
+            c.constraint(sub_f * sign * (sign - one));
+#pragma unroll 1
+            for (u32 i = NL; i < 2 * NL; ++i) c.constraint(sub_f * q_sub(i));
+            modular_checks(lv, nv, c, sub_f, out, IN2, q_sub, 2 * NL);
+            modular_checks(lv, nv, c, add_f + mul_f, out, IN2, quo_input, 2 * NL);
+            modular_cp(lv, nv, out, IN2, quo_input, 2 * NL, [&](u32 d, Fe cp) {       // add: input0 + input1
+                c.constraint_transition(add_f * (d < NL ? cp - (in0(d) + in1(d)) : cp));
+            });
+            modular_cp(lv, nv, out, IN2, q_sub, 2 * NL, [&](u32 d, Fe cp) {           // sub: input0 - input1
+                c.constraint_transition(sub_f * (d < NL ? cp - (in0(d) - in1(d)) : cp));
+            });
+            {   // mul: pol_mul_wide(input0, input1), coefficient d < 2*NL - 1, subtracted from the same polynomial
+                Fe m[NL], r[NL];
+                load_modulus(lv, nv, IN2, m);
+#pragma unroll
+                for (u32 i = 0; i < NL; ++i) r[i] = lv[IN1 + i];
+                auto auxn = [&](u32 i) { return i < 2 * NL - 1 ? nv[35 + i] - fe(OFFSET) + fe(BASE) * nv[66 + i] : Fe(); };
+                Fe wq[NL], wi[NL];                        // two sliding windows: quotient limbs and input0 limbs
+#pragma unroll
+                for (u32 j = 0; j < NL; ++j) { wq[j] = j == 0 ? quo_input(0) : Fe(); wi[j] = j == 0 ? in0(0) : Fe(); }
+#pragma unroll 1
+                for (u32 d = 0; d < 2 * NL; ++d) {
+                    DotAcc p, q;
+                    dot_acc_init(p); dot_acc_init(q);
+#pragma unroll
+                    for (u32 j = 0; j < NL; ++j) { dot_acc_mac_v(p, wq[j].v, m[j].v); dot_acc_mac_v(q, wi[j].v, r[j].v); }
+                    Fe v(dot_acc_reduce(p));
+                    if (d < NL) v += out(d);
+                    v += adjoin(auxn, d);
+                    if (d < 2 * NL - 1) v -= Fe(dot_acc_reduce(q));
+                    c.constraint_transition(mul_f * v);
+#pragma unroll
+                    for (u32 j = NL - 1; j > 0; --j) { wq[j] = wq[j - 1]; wi[j] = wi[j - 1]; }
+                    wq[0] = d + 1 < 2 * NL ? quo_input(d + 1) : Fe();
+                    wi[0] = d + 1 < NL ? in0(d + 1) : Fe();
                 }
-                c.constraint_transition(mul_f * v);
             }
         }
         {   // byte.rs:201-296
             Fe is_byte = lv[IS_BYTE];
-            Fe tree[NL];
-            rd(lv, AUX1, tree);
+            Fe tree[NL], auxb[6];
+            for (u32 i = 0; i < NL; ++i) tree[i] = lv[AUX1 + i];
+            for (u32 i = 0; i < 6; ++i) auxb[i] = lv[AUX0 + i];
             Fe idx0_lo5;
             for (u32 i = 0; i < 5; ++i) {
-                Fe bit = aux[i];
+                Fe bit = auxb[i];
                 c.constraint(is_byte * (bit * bit - bit));
                 idx0_lo5 += bit * fe(1ULL << i);
             }
-            Fe idx0_hi = aux[5] * fe(32);
-            c.constraint(is_byte * (in0[0] - (idx0_lo5 + idx0_hi)));
-            Fe bit = aux[4];
-            for (u32 i = 0; i < 8; ++i) c.constraint(is_byte * (tree[i] - (bit * in1[i] + (one - bit) * in1[i + 8])));
-            bit = aux[3];
+            Fe idx0_hi = auxb[5] * fe(32);
+            c.constraint(is_byte * (in0(0) - (idx0_lo5 + idx0_hi)));
+            Fe bit = auxb[4];
+            for (u32 i = 0; i < 8; ++i) c.constraint(is_byte * (tree[i] - (bit * in1(i) + (one - bit) * in1(i + 8))));
+            bit = auxb[3];
             for (u32 i = 0; i < 4; ++i) c.constraint(is_byte * (tree[i + 8] - (bit * tree[i] + (one - bit) * tree[i + 4])));
-            bit = aux[2];
+            bit = auxb[2];
             for (u32 i = 0; i < 2; ++i) c.constraint(is_byte * (tree[i + 12] - (bit * tree[i + 8] + (one - bit) * tree[i + 10])));
-            bit = aux[1];
+            bit = auxb[1];
             Fe limb = bit * tree[12] + (one - bit) * tree[13];
             c.constraint(is_byte * (tree[14] - limb));
             const Fe base8 = fe(256);
             Fe lo_byte = lv[88], hi_byte = lv[89];
             c.constraint(is_byte * (lo_byte + base8 * (base8 * hi_byte - limb)));
-            bit = aux[0];
+            bit = auxb[0];
             Fe t = bit * lo_byte + (one - bit) * base8 * hi_byte;
             c.constraint(is_byte * (base8 * tree[15] - t));
             Fe hi_limb_sum = lv[87];
-            for (u32 i = 1; i < NL; ++i) hi_limb_sum += in0[i];
+            for (u32 i = 1; i < NL; ++i) hi_limb_sum += in0(i);
             Fe idx_is_large = lv[90];
             c.constraint(is_byte * (idx_is_large * idx_is_large - idx_is_large));
             c.constraint(is_byte * hi_limb_sum * (idx_is_large - one));
             Fe hi_inv = lv[91] + lv[92] * fe(1ULL << 16) + lv[93] * fe(1ULL << 32) + lv[94] * fe(1ULL << 48);
             c.constraint(is_byte * (hi_limb_sum * hi_inv - idx_is_large));
-            c.constraint(is_byte * (out[0] - (one - idx_is_large) * tree[15]));
-            for (u32 i = 1; i < NL; ++i) c.constraint(is_byte * out[i]);
+            c.constraint(is_byte * (out(0) - (one - idx_is_large) * tree[15]));
+            for (u32 i = 1; i < NL; ++i) c.constraint(is_byte * out(i));
         }
         // shift.rs:85-128: SHL = MUL on (IN1, IN2); SHR = DIV helper on (IN1, IN2, OUT, AUX0)
-        mul(lv, c, lv[IS_SHL], in1, in2);
+        mul(lv, c, lv[IS_SHL], in1, IN2);
         divmod_helper(lv, nv, c, lv[IS_SHR], IN1, IN2, OUT, AUX0);
     }
 };
