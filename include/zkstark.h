@@ -338,6 +338,14 @@ size_t zk_segment_proof_mem_caps(const zk_segment_proof *proof, uint64_t *mem_be
 size_t zk_segment_proof_stage_ms(const zk_segment_proof *proof, double *out, size_t max);
 void zk_segment_proof_free(zk_segment_proof *proof);
 
+/* ---- trace finalisation on the device -------------------------------------
+ * Keccak table: replaces `KeccakStark::generate_trace_rows` (evm_arithmetization/src/keccak/keccak_stark.rs:65-234):
+ * 24 rows x 2431 columns per permutation from its 25-word input (reference order input[y*5 + x]) and the timestamp
+ * that links it to the KeccakSponge table, zero rows up to 2^log_n.  inputs / timestamps are host memory; the
+ * trace is written column-major on the device (column c at d_out + c*col_stride), ready for zk_prove_segment. */
+int zk_keccak_generate_trace(zk_ctx *ctx, const uint64_t *inputs, const uint64_t *timestamps, size_t n_perms,
+                             unsigned log_n, uint64_t *d_out, size_t col_stride);
+
 /* library / device info */
 const char *zk_version(void);
 int zk_device_info(int device, char *name_out, size_t name_len, int *cu_count, size_t *hbm_bytes);

@@ -186,3 +186,38 @@ def test_arithmetic_valid_and_invalid(oracle):
         bad[115] += np.bincount(bad[col].astype(np.int64), minlength=1 << 16).astype(np.uint64)
     ok, why = _prove_and_verify(oracle, 5, bad, 0, [ctl], lookup_spec=[lk])
     assert not ok and why == "quotient identity", why
+
+
+def test_keccak_table_generated_on_device_verifies(oracle):
+    """The Keccak table end to end: witness rows generated ON THE DEVICE from permutation inputs
+    (zk_keccak_generate_trace = keccak_stark.rs:65-234) equal the oracle's restatement of the reference generator,
+    and the table proof of that (valid) trace -- with the table's two real CTL looked entries, all_stark.rs:226-255 --
+    is accepted by the oracle verifier including the quotient identity of the restated Keccak AIR; a trace with one
+    flipped A' bit is rejected."""
+    import torch
+    from oracle import keccak_trace as okt
+    from zk_evm_amd.tracegen import keccak_generate_trace
+    rng = np.random.default_rng(23)
+    inputs = [([int(v) for v in rng.integers(0, 1 << 64, size=25, dtype=np.uint64)], 5 + 3 * i) for i in range(2)]
+    dev = keccak_generate_trace(inputs, 16)
+    got = dev.cpu().numpy().view(np.uint64)
+    exp = okt.generate_trace_rows(inputs, 16)
+    assert got.shape == (2431, 64) and np.array_equal(got.T, exp)
+    from oracle import all_stark as oas
+    ctls = oas.build_ctls()
+    # CTL 3 (keccak_inputs) and 4 (keccak_outputs): the Keccak table is the looked table of both
+    def desc(col):
+        lc = col.linear_combination
+        return ("single", lc[0][0]) if (len(lc) == 1 and lc[0][1] == 1 and not col.next_row_linear_combination and col.constant == 0) \
+            else ("lc", list(lc), list(col.next_row_linear_combination), col.constant)
+    ctl_entries = []
+    for k in (3, 4):
+        lk = ctls[k].looked_table
+        ctl_entries.append([([desc(c) for c in lk.columns], ("simple", desc(lk.filter.constants[0])))])
+    t = np.ascontiguousarray(got)
+    ok, why = _prove_and_verify(oracle, 6, t, 0, ctl_entries)
+    assert ok, why
+    bad = t.copy()
+    bad[715 + 3 * 320 + 2 * 64 + 11, 29] ^= np.uint64(1)           # one A'[3, 2, 11] bit in row 29
+    ok, why = _prove_and_verify(oracle, 6, bad, 0, ctl_entries)
+    assert not ok and why == "quotient identity", why

@@ -1,0 +1,96 @@
+// Trace finalisation on the device, first table: the Keccak table.
+// Reference: evm_arithmetization/src/keccak/keccak_stark.rs:65-234 (`generate_trace_rows`): 24 rows of 2431
+// columns per permutation (467 kB of trace from 200 bytes of input), zero rows up to the padded height.
+//
+// MI355X mapping: one lane per ROW, so that for every column a wave writes 64 consecutive u64 (the trace is
+// column-major).  The lane recomputes the state entering its round from the permutation input (<= 23 rounds of
+// keccak-f on 25 registers: noise next to the 2431 stores) instead of chaining rows through memory.
+#pragma once
+#include "gl.cuh"
+
+#define ZK_KECCAK_COLUMNS 2431
+__device__ static const u64 ZK_KTRACE_RC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL, 0x000000000000808BULL,
+    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008AULL, 0x0000000000000088ULL,
+    0x0000000080008009ULL, 0x000000008000000AULL, 0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL,
+    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800AULL, 0x800000008000000AULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+// rotation offsets R[x][y] (keccak/columns.rs:43-49)
+__device__ static const unsigned char ZK_KTRACE_R[5][5] = {
+    {0, 36, 3, 41, 18}, {1, 44, 10, 45, 2}, {62, 6, 43, 15, 61}, {28, 55, 25, 21, 56}, {27, 20, 39, 8, 14}};
+
+__device__ __forceinline__ u64 rotl64(u64 v, unsigned r) { return r ? (v << r) | (v >> (64 - r)) : v; }
+
+// the intermediate values of one round, in the table's own terms (a[x][y] indexed as the reference's reg_a(x, y))
+struct KeccakRound {
+    u64 c[5], cp[5], ap[5][5], app[5][5];
+};
+__device__ __forceinline__ void keccak_round_parts(const u64 (&a)[5][5], KeccakRound &k) {
+#pragma unroll
+    for (int x = 0; x < 5; ++x) k.c[x] = a[x][0] ^ a[x][1] ^ a[x][2] ^ a[x][3] ^ a[x][4];
+#pragma unroll
+    for (int x = 0; x < 5; ++x) k.cp[x] = k.c[x] ^ k.c[(x + 4) % 5] ^ rotl64(k.c[(x + 1) % 5], 1);   // C[x+1, z-1]
+#pragma unroll
+    for (int x = 0; x < 5; ++x)
+#pragma unroll
+        for (int y = 0; y < 5; ++y) k.ap[x][y] = a[x][y] ^ k.c[x] ^ k.cp[x];
+    // B[x, y, z] = A'[(x + 3y) % 5, x, z - R]  (reg_b): B[x][y] = rotl(A'[a][b], R[a][b])
+#pragma unroll
+    for (int y = 0; y < 5; ++y) {
+        u64 b[5];
+#pragma unroll
+        for (int x = 0; x < 5; ++x) { const int aa = (x + 3 * y) % 5; b[x] = rotl64(k.ap[aa][x], ZK_KTRACE_R[aa][x]); }
+#pragma unroll
+        for (int x = 0; x < 5; ++x) k.app[x][y] = b[x] ^ (~b[(x + 1) % 5] & b[(x + 2) % 5]);
+    }
+}
+
+// inputs: [n_perms][25] (reference order: input[y * 5 + x]); out: column-major, column c at out + c * stride
+__global__ void __launch_bounds__(256)
+keccak_trace_kernel(const u64 *__restrict__ inputs, const u64 *__restrict__ timestamps, u32 n_perms, u32 n_rows,
+                    u64 *__restrict__ out, size_t stride) {
+    const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    auto put = [&](u32 col, u64 v) { out[(size_t)col * stride + row] = v; };
+    const u32 perm = row / 24, rnd = row % 24;
+    if (perm >= n_perms) {                              // padding rows are all zero
+        for (u32 c = 0; c < ZK_KECCAK_COLUMNS; ++c) put(c, 0);
+        return;
+    }
+    u64 a[5][5];
+#pragma unroll
+    for (int x = 0; x < 5; ++x)
+#pragma unroll
+        for (int y = 0; y < 5; ++y) a[x][y] = inputs[(size_t)perm * 25 + y * 5 + x];
+    KeccakRound k;
+    for (u32 r = 0; r < rnd; ++r) {                     // state entering this row's round
+        keccak_round_parts(a, k);
+#pragma unroll
+        for (int x = 0; x < 5; ++x)
+#pragma unroll
+            for (int y = 0; y < 5; ++y) a[x][y] = k.app[x][y];
+        a[0][0] ^= ZK_KTRACE_RC[r];
+    }
+    keccak_round_parts(a, k);
+    for (u32 s = 0; s < 24; ++s) put(s, s == rnd ? 1 : 0);                      // reg_step
+    put(24, timestamps[perm]);                                                   // TIMESTAMP
+    for (int x = 0; x < 5; ++x)
+        for (int y = 0; y < 5; ++y) {
+            const u32 ra = 25 + (x * 5 + y) * 2;                                 // reg_a
+            put(ra, a[x][y] & 0xFFFFFFFFULL);
+            put(ra + 1, a[x][y] >> 32);
+            const u32 rpp = 2315 + x * 10 + y * 2;                               // reg_a_prime_prime
+            put(rpp, k.app[x][y] & 0xFFFFFFFFULL);
+            put(rpp + 1, k.app[x][y] >> 32);
+            for (u32 z = 0; z < 64; ++z) put(715 + x * 320 + y * 64 + z, (k.ap[x][y] >> z) & 1);   // reg_a_prime
+        }
+    for (int x = 0; x < 5; ++x)
+        for (u32 z = 0; z < 64; ++z) {
+            put(75 + x * 64 + z, (k.c[x] >> z) & 1);                             // reg_c
+            put(395 + x * 64 + z, (k.cp[x] >> z) & 1);                           // reg_c_prime
+        }
+    for (u32 z = 0; z < 64; ++z) put(2365 + z, (k.app[0][0] >> z) & 1);          // reg_a_prime_prime_0_0_bit
+    const u64 appp = k.app[0][0] ^ ZK_KTRACE_RC[rnd];
+    put(2429, appp & 0xFFFFFFFFULL);                                             // reg_a_prime_prime_prime(0, 0)
+    put(2430, appp >> 32);
+}

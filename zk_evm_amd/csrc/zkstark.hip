@@ -26,6 +26,7 @@
 #include "stark.cuh"
 #include "quotient.cuh"
 #include "airs.cuh"
+#include "tracegen.cuh"
 #include "host_hash.hpp"
 
 // ------------------------------------------------------------------------------------------
@@ -765,3 +766,4 @@ extern "C" int zk_batch_merkle_path(const zk_batch *b, size_t leaf_index, uint64
 #include "stark_host.inc"
 #include "quotient_host.inc"
 #include "segment_host.inc"
+#include "tracegen_host.inc"

@@ -1,0 +1,34 @@
+"""Device trace generators.  `keccak_generate_trace` binds zk_keccak_generate_trace, the
+replacement of `KeccakStark::generate_trace` (evm_arithmetization/src/keccak/keccak_stark.rs:65-259)."""
+import ctypes as C
+from typing import Sequence, Tuple
+
+import numpy as np
+
+from ._lib import ZkStarkError
+from .context import Context, default_context
+
+NUM_ROUNDS = 24
+NUM_INPUTS = 25
+KECCAK_COLUMNS = 2431
+
+
+def keccak_generate_trace(inputs_and_timestamps: Sequence[Tuple[Sequence[int], int]], min_rows: int, device=0,
+                          ctx: Context = None):
+    """-> CUDA int64 tensor (2431, num_rows): the column-major `Vec<PolynomialValues<F>>` of the Keccak table;
+    num_rows = max(24 * len(inputs), min_rows).next_power_of_two() as in the reference."""
+    import torch
+    n_perms = len(inputs_and_timestamps)
+    n = max(n_perms * NUM_ROUNDS, min_rows, 1)
+    log_n = (n - 1).bit_length()
+    ctx = ctx or default_context(device)
+    ctx.use_torch_current_stream()
+    inp = np.array([[int(w) for w in i] for i, _ in inputs_and_timestamps], dtype=np.uint64).reshape(n_perms, NUM_INPUTS)
+    ts = np.array([int(t) for _, t in inputs_and_timestamps], dtype=np.uint64)
+    if inp.shape != (n_perms, NUM_INPUTS):
+        raise ZkStarkError(-1, "every Keccak input is 25 words")
+    out = torch.empty((KECCAK_COLUMNS, 1 << log_n), dtype=torch.int64, device=f"cuda:{device}")
+    ctx.check(ctx.lib.zk_keccak_generate_trace(ctx.handle, inp.ctypes.data if n_perms else None,
+                                               ts.ctypes.data if n_perms else None, n_perms, log_n,
+                                               C.c_void_p(out.data_ptr()), 1 << log_n))
+    return out
