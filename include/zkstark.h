@@ -346,6 +346,13 @@ void zk_segment_proof_free(zk_segment_proof *proof);
 int zk_keccak_generate_trace(zk_ctx *ctx, const uint64_t *inputs, const uint64_t *timestamps, size_t n_perms,
                              unsigned log_n, uint64_t *d_out, size_t col_stride);
 
+/* Range-check finalisation, in place on a device trace: `generate_range_checks` of the Arithmetic, BytePacking and
+ * KeccakSponge tables (arithmetic_stark.rs:130-156, byte_packing_stark.rs:254-283, keccak_sponge_stark.rs:503-533):
+ * counter_col[i] = min(i, range_max - 1); freq_col[x] = number of cells of columns [first_col, first_col + n_cols)
+ * equal to x (the column is overwritten).  A cell >= range_max is an error, as the reference asserts. */
+int zk_range_check_columns(zk_ctx *ctx, uint64_t *d_trace, size_t col_stride, size_t n_trace_cols, unsigned log_n,
+                           size_t first_col, size_t n_cols, size_t counter_col, size_t freq_col, uint64_t range_max);
+
 /* library / device info */
 const char *zk_version(void);
 int zk_device_info(int device, char *name_out, size_t name_len, int *cu_count, size_t *hbm_bytes);

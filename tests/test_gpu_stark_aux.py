@@ -138,3 +138,37 @@ def test_malformed_program_is_rejected():
     trace = torch.zeros((3, 16), dtype=torch.int64, device="cuda")
     with pytest.raises(zk.ZkStarkError):   # column index out of range
         prod.ctl_partial_sums(trace, [([prod.Column.single(7)], prod.Filter())], 3, 5, 3)
+
+
+@pytest.mark.parametrize("shape", [("arithmetic", 116, 17, 18, 96, 114, 115, 1 << 16),
+                                   ("byte_packing", 71, 10, 37, 32, 69, 70, 256),
+                                   ("keccak_sponge", 438, 9, 192, 136, 436, 437, 256)])
+def test_range_check_finalisation_on_device(shape):
+    """zk_range_check_columns == the reference's generate_range_checks (arithmetic_stark.rs:130-156,
+    byte_packing_stark.rs:254-283, keccak_sponge_stark.rs:503-533): counter = min(i, RANGE_MAX - 1), frequencies =
+    histogram of the range-checked columns; an out-of-range cell is an error (the reference asserts)."""
+    import torch
+    from zk_evm_amd._lib import ZkStarkError
+    from zk_evm_amd.tracegen import range_check_columns
+    name, n_cols, log_n, first, k, cc, fc, rmax = shape
+    rng = np.random.default_rng(len(name))
+    n = 1 << log_n
+    t = rng.integers(0, 1 << 64, size=(n_cols, n), dtype=np.uint64)
+    t[first:first + k] = rng.integers(0, rmax, size=(k, n), dtype=np.uint64)
+    t[first + 1, 5] = np.uint64(rmax - 1 + 0xFFFFFFFF00000001) if rmax < (1 << 31) else t[first + 1, 5]   # non-canonical rep
+    dev = torch.from_numpy(t.view(np.int64)).cuda()
+    range_check_columns(dev, first, k, cc, fc, rmax)
+    got = dev.cpu().numpy().view(np.uint64)
+    exp = t.copy()
+    exp[cc] = np.minimum(np.arange(n, dtype=np.uint64), np.uint64(rmax - 1))
+    vals = (t[first:first + k] % np.uint64(0xFFFFFFFF00000001)).astype(np.int64).reshape(-1)
+    exp[fc] = 0
+    exp[fc, :rmax] = np.bincount(vals, minlength=rmax).astype(np.uint64)
+    assert np.array_equal(got, exp)
+    bad = t.copy()
+    bad[first + 2, 3] = rmax
+    dev = torch.from_numpy(bad.view(np.int64)).cuda()
+    with pytest.raises(ZkStarkError, match="exceeds the max range"):
+        range_check_columns(dev, first, k, cc, fc, rmax)
+    with pytest.raises(ZkStarkError):
+        range_check_columns(dev, first, k, first + 1, fc, rmax)        # counter inside the checked range

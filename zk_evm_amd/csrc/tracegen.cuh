@@ -94,3 +94,39 @@ keccak_trace_kernel(const u64 *__restrict__ inputs, const u64 *__restrict__ time
     put(2429, appp & 0xFFFFFFFFULL);                                             // reg_a_prime_prime_prime(0, 0)
     put(2430, appp >> 32);
 }
+
+// ---- range-check finalisation ------------------------------------------------------------------------
+// `generate_range_checks` of the Arithmetic / BytePacking / KeccakSponge tables (arithmetic_stark.rs:130-156,
+// byte_packing_stark.rs:254-283, keccak_sponge_stark.rs:503-533 -- the same code three times):
+//   counter[i] = min(i, range_max - 1);  frequencies[x] = number of cells of the checked columns equal to x.
+__global__ void range_counter_kernel(u64 *__restrict__ counter, u64 *__restrict__ freq, u32 n, u32 range_max) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    counter[i] = i < range_max ? i : range_max - 1;
+    freq[i] = 0;
+}
+// grid: (row blocks, checked columns).  Small ranges (bytes) use a per-block LDS histogram, large ones global atomics.
+#define ZK_RC_LDS_BINS 4096
+__global__ void __launch_bounds__(256)
+range_histogram_kernel(const u64 *__restrict__ cols, size_t stride, u32 n, u32 rows_per_block, u32 range_max,
+                       unsigned long long *__restrict__ freq, int *__restrict__ err_flag) {
+    __shared__ u32 bins[ZK_RC_LDS_BINS];
+    const bool use_lds = range_max <= ZK_RC_LDS_BINS;
+    if (use_lds) {
+        for (u32 b = threadIdx.x; b < range_max; b += blockDim.x) bins[b] = 0;
+        __syncthreads();
+    }
+    const u64 *c = cols + (size_t)blockIdx.y * stride;
+    const u32 lo = blockIdx.x * rows_per_block, hi = lo + rows_per_block < n ? lo + rows_per_block : n;
+    for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const u64 x = gl_canon(c[i]);
+        if (x >= range_max) { atomicExch(err_flag, 1); continue; }   // the reference asserts
+        if (use_lds) atomicAdd(&bins[(u32)x], 1u);
+        else atomicAdd(&freq[x], 1ULL);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (u32 b = threadIdx.x; b < range_max; b += blockDim.x)
+            if (bins[b]) atomicAdd(&freq[b], (unsigned long long)bins[b]);
+    }
+}

@@ -32,3 +32,16 @@ def keccak_generate_trace(inputs_and_timestamps: Sequence[Tuple[Sequence[int], i
                                                ts.ctypes.data if n_perms else None, n_perms, log_n,
                                                C.c_void_p(out.data_ptr()), 1 << log_n))
     return out
+
+
+def range_check_columns(trace, first_col: int, n_cols: int, counter_col: int, freq_col: int, range_max: int,
+                        ctx: Context = None) -> None:
+    """In place on a CUDA (columns, 2^k) tensor: the `generate_range_checks` step of the Arithmetic (range 2^16,
+    columns 18..113 -> 114 / 115), BytePacking (256, 37..68 -> 69 / 70) and KeccakSponge (256, 192..327 -> 436 / 437)
+    tables."""
+    from .stark import _trace_args
+    n_trace_cols, n, log_n, stride = _trace_args(trace)
+    ctx = ctx or default_context(trace.device.index or 0)
+    ctx.use_torch_current_stream()
+    ctx.check(ctx.lib.zk_range_check_columns(ctx.handle, C.c_void_p(trace.data_ptr()), stride, n_trace_cols, log_n,
+                                             first_col, n_cols, counter_col, freq_col, range_max))
