@@ -346,6 +346,11 @@ void zk_segment_proof_free(zk_segment_proof *proof);
 int zk_keccak_generate_trace(zk_ctx *ctx, const uint64_t *inputs, const uint64_t *timestamps, size_t n_perms,
                              unsigned log_n, uint64_t *d_out, size_t col_stride);
 
+/* Logic table: replaces `LogicStark::generate_trace_rows` (evm_arithmetization/src/logic.rs:165-240).
+ * ops (host): n_ops x 9 words = operator (0 AND, 1 OR, 2 XOR), input0 as four 64-bit little-endian limbs, input1
+ * likewise; 523 columns are written column-major on the device, zero rows from n_ops to 2^log_n. */
+int zk_logic_generate_trace(zk_ctx *ctx, const uint64_t *ops, size_t n_ops, unsigned log_n, uint64_t *d_out,
+                            size_t col_stride);
 /* Range-check finalisation, in place on a device trace: `generate_range_checks` of the Arithmetic, BytePacking and
  * KeccakSponge tables (arithmetic_stark.rs:130-156, byte_packing_stark.rs:254-283, keccak_sponge_stark.rs:503-533):
  * counter_col[i] = min(i, range_max - 1); freq_col[x] = number of cells of columns [first_col, first_col + n_cols)

@@ -88,13 +88,15 @@ def test_mem_continuation_valid_and_invalid(oracle, hasher):
     assert ok, why
 
 
-def _logic_trace(rng, n_ops, n_padded):
+def _logic_trace(rng, n_ops, n_padded, ops_out=None):
     # logic.rs:165-188 (Operation::into_row): one-hot op flag, 2 x 256 input bits, 8 x 32-bit result limbs
     t = np.zeros((523, n_padded), dtype=np.uint64)
     for r in range(n_ops):
         op = int(rng.integers(0, 3))
         a = int.from_bytes(rng.bytes(32), "little")
         b = int.from_bytes(rng.bytes(32), "little")
+        if ops_out is not None:
+            ops_out.append((op, a, b))
         res = [a & b, a | b, a ^ b][op]
         t[op, r] = 1
         for i in range(256):
@@ -116,7 +118,13 @@ def _logic_ctl():
 
 def test_logic_valid_and_invalid(oracle):
     rng = np.random.default_rng(22)
-    t = _logic_trace(rng, 20, 32)
+    ops = []
+    t = _logic_trace(rng, 20, 32, ops)
+    # the device generator (zk_logic_generate_trace = logic.rs:165-240) produces the same table
+    from zk_evm_amd.tracegen import logic_generate_trace
+    dev = logic_generate_trace(ops, 32)
+    assert np.array_equal(dev.cpu().numpy().view(np.uint64), t)
+    assert not logic_generate_trace([], 16).cpu().numpy().any()
     ok, why = _prove_and_verify(oracle, 2, t, 0, [_logic_ctl()])
     assert ok, why
     bad = t.copy()

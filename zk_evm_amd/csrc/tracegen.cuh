@@ -130,3 +130,32 @@ range_histogram_kernel(const u64 *__restrict__ cols, size_t stride, u32 n, u32 r
             if (bins[b]) atomicAdd(&freq[b], (unsigned long long)bins[b]);
     }
 }
+
+// ---- Logic table ----------------------------------------------------------------------------------------
+// `LogicStark::generate_trace_rows` / `Operation::into_row` (evm_arithmetization/src/logic.rs:165-240): per
+// operation a one-hot flag (0 AND, 1 OR, 2 XOR), the 2 x 256 input bits and the 8 x 32-bit result limbs; zero rows up
+// to the padded height.  ops: [n_ops][9] = {operator, input0 limbs[4], input1 limbs[4]} (64-bit little-endian limbs,
+// `U256.0`).  One lane per row, 523 coalesced column stores.
+__global__ void __launch_bounds__(256)
+logic_trace_kernel(const u64 *__restrict__ ops, u32 n_ops, u32 n_rows, u64 *__restrict__ out, size_t stride) {
+    const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    auto put = [&](u32 col, u64 v) { out[(size_t)col * stride + row] = v; };
+    if (row >= n_ops) {
+        for (u32 c = 0; c < 523; ++c) put(c, 0);
+        return;
+    }
+    const u64 *o = ops + (size_t)row * 9;
+    const u32 op = (u32)o[0];
+    for (u32 k = 0; k < 3; ++k) put(k, k == op ? 1 : 0);
+    for (u32 l = 0; l < 4; ++l) {
+        const u64 a = o[1 + l], b = o[5 + l];
+        const u64 r = op == 0 ? (a & b) : (op == 1 ? (a | b) : (a ^ b));
+        for (u32 i = 0; i < 64; ++i) {
+            put(3 + 64 * l + i, (a >> i) & 1);
+            put(259 + 64 * l + i, (b >> i) & 1);
+        }
+        put(515 + 2 * l, r & 0xFFFFFFFFULL);
+        put(516 + 2 * l, r >> 32);
+    }
+}

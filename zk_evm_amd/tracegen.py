@@ -45,3 +45,28 @@ def range_check_columns(trace, first_col: int, n_cols: int, counter_col: int, fr
     ctx.use_torch_current_stream()
     ctx.check(ctx.lib.zk_range_check_columns(ctx.handle, C.c_void_p(trace.data_ptr()), stride, n_trace_cols, log_n,
                                              first_col, n_cols, counter_col, freq_col, range_max))
+
+
+LOGIC_COLUMNS = 523
+OP_AND, OP_OR, OP_XOR = 0, 1, 2
+
+
+def logic_generate_trace(operations: Sequence[Tuple[int, int, int]], min_rows: int, device=0, ctx: Context = None):
+    """`LogicStark::generate_trace` (logic.rs:189-240).  operations: (operator, input0, input1) with 256-bit ints;
+    -> CUDA int64 tensor (523, max(len, min_rows).next_power_of_two())."""
+    import torch
+    n_ops = len(operations)
+    n = max(n_ops, min_rows, 1)
+    log_n = (n - 1).bit_length()
+    ctx = ctx or default_context(device)
+    ctx.use_torch_current_stream()
+    m64 = (1 << 64) - 1
+    flat = np.zeros((n_ops, 9), dtype=np.uint64)
+    for r, (op, a, b) in enumerate(operations):
+        if not (0 <= a < (1 << 256) and 0 <= b < (1 << 256)):
+            raise ZkStarkError(-1, "logic inputs are U256")
+        flat[r] = [op] + [(a >> (64 * l)) & m64 for l in range(4)] + [(b >> (64 * l)) & m64 for l in range(4)]
+    out = torch.empty((LOGIC_COLUMNS, 1 << log_n), dtype=torch.int64, device=f"cuda:{device}")
+    ctx.check(ctx.lib.zk_logic_generate_trace(ctx.handle, flat.ctypes.data if n_ops else None, n_ops, log_n,
+                                              C.c_void_p(out.data_ptr()), 1 << log_n))
+    return out
