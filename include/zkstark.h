@@ -351,6 +351,17 @@ int zk_keccak_generate_trace(zk_ctx *ctx, const uint64_t *inputs, const uint64_t
  * likewise; 523 columns are written column-major on the device, zero rows from n_ops to 2^log_n. */
 int zk_logic_generate_trace(zk_ctx *ctx, const uint64_t *ops, size_t n_ops, unsigned log_n, uint64_t *d_out,
                             size_t col_stride);
+/* MemBefore / MemAfter table: `mem_before_values_to_rows` + `MemoryContinuationStark::generate_trace`
+ * (memory_continuation/memory_continuation_stark.rs:53-98).  entries (host): n x 7 words = context, segment, virt,
+ * value as four 64-bit little-endian limbs; 12 columns on the device, zero rows from n to 2^log_n (the reference pads
+ * to max(128, next_power_of_two(n)) -- the caller picks log_n accordingly). */
+int zk_memory_continuation_generate_trace(zk_ctx *ctx, const uint64_t *entries, size_t n, unsigned log_n,
+                                          uint64_t *d_out, size_t col_stride);
+/* `initial_memory_merkle_cap(rate_bits, cap_height)` (evm_arithmetization/src/verifier.rs:14-78):
+ * the cap of the MemBefore-shaped commitment of the kernel code bytes (segment Code) followed by the 256-entry shift
+ * table (segment ShiftTable), padded to the next power of two.  cap_out: 2^cap_height x 4 words. */
+int zk_initial_memory_merkle_cap(zk_ctx *ctx, const zk_cfg *cfg, const uint8_t *kernel_code, size_t code_len,
+                                 uint64_t *cap_out);
 /* Range-check finalisation, in place on a device trace: `generate_range_checks` of the Arithmetic, BytePacking and
  * KeccakSponge tables (arithmetic_stark.rs:130-156, byte_packing_stark.rs:254-283, keccak_sponge_stark.rs:503-533):
  * counter_col[i] = min(i, range_max - 1); freq_col[x] = number of cells of columns [first_col, first_col + n_cols)

@@ -229,3 +229,34 @@ def test_keccak_table_generated_on_device_verifies(oracle):
     bad[715 + 3 * 320 + 2 * 64 + 11, 29] ^= np.uint64(1)           # one A'[3, 2, 11] bit in row 29
     ok, why = _prove_and_verify(oracle, 6, bad, 0, ctl_entries)
     assert not ok and why == "quotient identity", why
+
+
+@pytest.mark.parametrize("hasher", [0, 1])
+def test_memory_continuation_generator_and_initial_memory_cap(oracle, hasher):
+    """MemBefore rows generated on the device (memory_continuation_stark.rs:53-98) and `initial_memory_merkle_cap`
+    (verifier.rs:14-78) for a synthetic kernel image, against a row-by-row restatement committed by the
+    oracle."""
+    from zk_evm_amd.tracegen import initial_memory_merkle_cap, memory_continuation_generate_trace
+    rng = np.random.default_rng(31 + hasher)
+    vals = [((int(rng.integers(0, 9)), int(rng.integers(0, 33)), int(rng.integers(0, 1 << 20))),
+             int.from_bytes(rng.bytes(32), "little")) for _ in range(200)]
+    got = memory_continuation_generate_trace(vals).cpu().numpy().view(np.uint64)
+    exp = np.zeros((12, 256), dtype=np.uint64)
+    for r, ((c, s, v), val) in enumerate(vals):
+        exp[0:4, r] = [1, c, s, v]
+        for j in range(8):
+            exp[4 + j, r] = (val >> (32 * j)) & 0xFFFFFFFF
+    assert np.array_equal(got, exp)
+    assert memory_continuation_generate_trace([]).shape == (12, 128)
+    code = rng.bytes(1000)                                # a stand-in for KERNEL.code
+    rows = []
+    for i, b in enumerate(code):
+        rows.append([1, 0, 0, i, b] + [0] * 7)
+    for i in range(256):
+        v = 1 << i
+        rows.append([1, 0, 13, i] + [(v >> (32 * j)) & 0xFFFFFFFF for j in range(8)])
+    n = 1 << (len(rows) - 1).bit_length()
+    t = np.zeros((12, n), dtype=np.uint64)
+    t[:, :len(rows)] = np.array(rows, dtype=np.uint64).T
+    ref = oracle.commit_values(t, rate_bits=1, cap_height=4, hasher=hasher, want_leaves=False)
+    assert np.array_equal(initial_memory_merkle_cap(code, 1, 4, hasher=hasher), ref["cap"])

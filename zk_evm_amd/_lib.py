@@ -97,6 +97,8 @@ SIGNATURES = {
     "zk_keccak_generate_trace": (C.c_int, [vp, u64p, u64p, sz, ui, u64p, sz]),
     "zk_range_check_columns": (C.c_int, [vp, u64p, sz, sz, ui, sz, sz, sz, sz, C.c_uint64]),
     "zk_logic_generate_trace": (C.c_int, [vp, u64p, sz, ui, u64p, sz]),
+    "zk_memory_continuation_generate_trace": (C.c_int, [vp, u64p, sz, ui, u64p, sz]),
+    "zk_initial_memory_merkle_cap": (C.c_int, [vp, C.POINTER(ZkCfg), vp, sz, u64p]),
     "zk_version": (C.c_char_p, []),
     "zk_device_info": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(sz)]),
 }

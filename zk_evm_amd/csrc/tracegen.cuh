@@ -159,3 +159,22 @@ logic_trace_kernel(const u64 *__restrict__ ops, u32 n_ops, u32 n_rows, u64 *__re
         put(516 + 2 * l, r >> 32);
     }
 }
+
+// ---- MemBefore / MemAfter table -----------------------------------------------------------------------------
+// `mem_before_values_to_rows` + `MemoryContinuationStark::generate_trace`
+// (memory_continuation/memory_continuation_stark.rs:53-98): FILTER = 1, (context, segment, virt), eight 32-bit value
+// limbs; zero rows up to the padded height.  entries: [n][7] = {context, segment, virt, value as 4 x 64-bit LE limbs}.
+__global__ void mem_continuation_trace_kernel(const u64 *__restrict__ entries, u32 n, u32 n_rows, u64 *__restrict__ out,
+                                              size_t stride) {
+    const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    const bool live = row < n;
+    const u64 *e = entries + (size_t)row * 7;
+    out[row] = live ? 1 : 0;
+    for (u32 k = 0; k < 3; ++k) out[(size_t)(1 + k) * stride + row] = live ? e[k] : 0;
+    for (u32 l = 0; l < 4; ++l) {
+        const u64 v = live ? e[3 + l] : 0;
+        out[(size_t)(4 + 2 * l) * stride + row] = v & 0xFFFFFFFFULL;
+        out[(size_t)(5 + 2 * l) * stride + row] = v >> 32;
+    }
+}

@@ -70,3 +70,41 @@ def logic_generate_trace(operations: Sequence[Tuple[int, int, int]], min_rows: i
     ctx.check(ctx.lib.zk_logic_generate_trace(ctx.handle, flat.ctypes.data if n_ops else None, n_ops, log_n,
                                               C.c_void_p(out.data_ptr()), 1 << log_n))
     return out
+
+
+MEM_CONTINUATION_COLUMNS = 12
+
+
+def memory_continuation_generate_trace(mem_values: Sequence[Tuple[Tuple[int, int, int], int]], device=0, ctx: Context = None):
+    """`mem_before_values_to_rows` + `MemoryContinuationStark::generate_trace`
+    (memory_continuation_stark.rs:53-98).  mem_values: ((context, segment, virt), value U256);
+    -> CUDA int64 tensor (12, max(128, len.next_power_of_two()))."""
+    import torch
+    n = len(mem_values)
+    rows = max(128, 1 << max(n - 1, 0).bit_length()) if n else 128
+    log_n = rows.bit_length() - 1
+    ctx = ctx or default_context(device)
+    ctx.use_torch_current_stream()
+    m64 = (1 << 64) - 1
+    flat = np.zeros((n, 7), dtype=np.uint64)
+    for r, ((c, s, v), val) in enumerate(mem_values):
+        flat[r] = [c, s, v] + [(val >> (64 * l)) & m64 for l in range(4)]
+    out = torch.empty((MEM_CONTINUATION_COLUMNS, rows), dtype=torch.int64, device=f"cuda:{device}")
+    ctx.check(ctx.lib.zk_memory_continuation_generate_trace(ctx.handle, flat.ctypes.data if n else None, n, log_n,
+                                                            C.c_void_p(out.data_ptr()), rows))
+    return out
+
+
+def initial_memory_merkle_cap(kernel_code: bytes, rate_bits: int, cap_height: int, hasher: int = 0, device=0,
+                              ctx: Context = None) -> np.ndarray:
+    """`initial_memory_merkle_cap::<F, C, D>(rate_bits, cap_height)` (verifier.rs:14-78) for a given kernel image
+    (the reference reads the global KERNEL.code).  -> (2^cap_height, 4) uint64."""
+    from .config import StarkConfig
+    ctx = ctx or default_context(device)
+    ctx.use_torch_current_stream()
+    cfg = StarkConfig(hasher=hasher).to_c(rate_bits=rate_bits, cap_height=cap_height)
+    code = np.frombuffer(bytes(kernel_code), dtype=np.uint8)
+    out = np.zeros((1 << cap_height, 4), dtype=np.uint64)
+    ctx.check(ctx.lib.zk_initial_memory_merkle_cap(ctx.handle, C.byref(cfg), code.ctypes.data if code.size else None,
+                                                   code.size, out.ctypes.data))
+    return out
