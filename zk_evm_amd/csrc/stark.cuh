@@ -202,6 +202,64 @@ helper_cols_kernel(const u64 *__restrict__ prog, TraceView t, HelperChallenges H
     }
 }
 
+// Fast path of helper_cols_kernel for logUp range checks whose entries are all `Column::single` with the default
+// filter (every lookup of the reference except Memory's: arithmetic_stark.rs:320-327, byte_packing_stark.rs:426-437,
+// keccak_sponge_stark.rs:946-953): no program interpretation, the 16 loads of a batch are independent.
+// cols[e] = trace column of entry e; table_col = the (single) table column.
+template <int NCH>
+__global__ void __launch_bounds__(256)
+lookup_singles_kernel(const u32 *__restrict__ cols, u32 n_entries, u32 table_col, TraceView t, HelperChallenges H, u32 chunk,
+                      HelperOut O, size_t helper_stride, int *__restrict__ err_flag) {
+    const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= t.n) return;
+    for (u32 e0 = 0; e0 < n_entries; e0 += ZK_HELPER_BATCH) {
+        u64 x[ZK_HELPER_BATCH];
+#pragma unroll
+        for (int i = 0; i < ZK_HELPER_BATCH; ++i) x[i] = e0 + i < n_entries ? t.base[(size_t)cols[e0 + i] * t.stride + row] : 0;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            u64 v[ZK_HELPER_BATCH], pre[ZK_HELPER_BATCH];
+            u64 run = 1;
+#pragma unroll
+            for (int i = 0; i < ZK_HELPER_BATCH; ++i) {
+                u64 d = gl_canon(gl_add(x[i], H.gamma[k]));
+                if (e0 + i >= n_entries) d = 1;
+                else if (d == 0) { atomicExch(err_flag, 2); d = 1; }     // 1/0: plonky2 would panic
+                v[i] = d;
+                pre[i] = run;
+                run = gl_mul(run, d);
+            }
+            u64 inv = gl_inv(run);
+#pragma unroll
+            for (int i = ZK_HELPER_BATCH - 1; i >= 0; --i) {
+                const u64 vi = v[i];
+                v[i] = gl_mul(inv, pre[i]);
+                inv = gl_mul(inv, vi);
+            }
+            u64 *out = O.helpers[k];
+            if (chunk == 1) {
+#pragma unroll
+                for (int i = 0; i < ZK_HELPER_BATCH; ++i)
+                    if (e0 + i < n_entries) out[(size_t)(e0 + i) * helper_stride + row] = gl_canon(v[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < ZK_HELPER_BATCH; i += 2)
+                    if (e0 + i < n_entries) {
+                        u64 s = e0 + i + 1 < n_entries ? gl_add(v[i], v[i + 1]) : v[i];
+                        out[(size_t)((e0 + i) >> 1) * helper_stride + row] = gl_canon(s);
+                    }
+            }
+        }
+    }
+    const u64 tc = t.base[(size_t)table_col * t.stride + row];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        u64 d = gl_canon(gl_add(tc, H.gamma[k]));
+        if (d == 0) { atomicExch(err_flag, 2); d = 1; }
+        O.extra_inv[k][row] = gl_canon(gl_inv(d));
+    }
+}
+
 // x[row] = sum_h helpers[h][row]  ( - freq(row) * table_inv[row]  when freq_pc != 0 )
 __global__ void helper_row_sums_kernel(const u64 *__restrict__ helpers, size_t helper_stride, u32 n_helpers,
                                        const u64 *__restrict__ prog, u32 freq_pc, TraceView t,
