@@ -109,6 +109,69 @@ __device__ __forceinline__ u64 prog_eval_filter_dot(const u64 *__restrict__ prog
     for (u32 i = 0; i < nc; ++i) acc = gl_add(acc, prog_eval_column_dot(prog, pc, t, row));
     return gl_canon(acc);
 }
+// ---- compiled entries ---------------------------------------------------------------------------------
+// Interpreting an Entry word by word is a chain of dependent scalar loads (count -> index -> value) and was latency
+// bound.  The host therefore flattens every entry once per call (stark_host.inc `compile_entries`): because the tuple
+// combination is linear, sum_j beta^j (sum_i c_ji v_ji + k_j) + gamma becomes ONE dot product over (column, row
+// offset) terms with coefficients beta^j c_ji (one array per challenge) plus a constant; filters become dot products
+// too.  All loop bounds and term descriptors are wave-uniform and independent of each other.
+//   blob := n_entries, lin_off, term_off, entry[n] {t0, t1, fp0, fp1, fc0, fc1, K_0, K_1},
+//           lin[] {t0, t1, constant}, term[] {col | next << 32, coef_0, coef_1}
+struct CBlob {
+    const u64 *w;
+    __device__ __forceinline__ u32 n_entries() const { return (u32)w[0]; }
+    __device__ __forceinline__ const u64 *entry(u32 e) const { return w + 3 + 8 * (size_t)e; }
+    __device__ __forceinline__ const u64 *lin(u32 l) const { return w + w[1] + 3 * (size_t)l; }
+    __device__ __forceinline__ const u64 *term(u32 t) const { return w + w[2] + 3 * (size_t)t; }
+};
+// LD(col, next) -> value, or skip the term when `next` is not available (last row of a table)
+template <int NCH, class LD>
+__device__ __forceinline__ void cterms_dot(const CBlob &B, u32 t0, u32 t1, LD ld, DotAcc (&d)[NCH]) {
+    u32 t = t0;
+    for (; t + 4 <= t1; t += 4) {                    // 4 independent descriptor + value loads in flight
+        u64 v[4];
+        bool ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const u64 w0 = B.term(t + i)[0]; ok[i] = ld((u32)w0, (u32)(w0 >> 32), v[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (ok[i]) {
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) dot_acc_mac_u(d[k], B.term(t + i)[1 + k], v[i]);
+            }
+    }
+    for (; t < t1; ++t) {
+        const u64 w0 = B.term(t)[0];
+        u64 v;
+        if (ld((u32)w0, (u32)(w0 >> 32), v)) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) dot_acc_mac_u(d[k], B.term(t)[1 + k], v);
+        }
+    }
+}
+template <class LD>
+__device__ __forceinline__ u64 clin_eval(const CBlob &B, u32 l, LD ld) {
+    const u64 *L = B.lin(l);
+    DotAcc d[1];
+    dot_acc_init(d[0]);
+    cterms_dot<1>(B, (u32)L[0], (u32)L[1], ld, d);
+    return gl_add(dot_acc_reduce(d[0]), L[2]);
+}
+template <int NCH, class LD>
+__device__ __forceinline__ void centry_eval(const CBlob &B, u32 e, LD ld, u64 (&denom)[NCH], u64 &filt) {
+    const u64 *E = B.entry(e);
+    DotAcc d[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) dot_acc_init(d[k]);
+    cterms_dot<NCH>(B, (u32)E[0], (u32)E[1], ld, d);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) denom[k] = gl_canon(gl_add(dot_acc_reduce(d[k]), E[6 + k]));
+    u64 acc = 0;
+    for (u32 p = (u32)E[2]; p < (u32)E[3]; ++p) acc = gl_add(acc, gl_mul(clin_eval(B, 2 * p, ld), clin_eval(B, 2 * p + 1, ld)));
+    for (u32 c = (u32)E[4]; c < (u32)E[5]; ++c) acc = gl_add(acc, clin_eval(B, c, ld));
+    filt = gl_canon(acc);
+}
+
 // denominators (one per challenge) and filter of entry e at `row`
 template <int NCH>
 __device__ __forceinline__ void prog_eval_entry(const u64 *__restrict__ prog, u32 e, const TraceView &t, u32 row,
@@ -134,11 +197,18 @@ struct HelperOut {
 };
 template <int NCH>
 __global__ void __launch_bounds__(256)
-helper_cols_kernel(const u64 *__restrict__ prog, TraceView t, HelperChallenges H, u32 chunk, HelperOut O,
-                   size_t helper_stride, u32 extra_pc, int *__restrict__ err_flag) {
+helper_cols_kernel(const u64 *__restrict__ prog, const u64 *__restrict__ compiled, TraceView t, HelperChallenges H,
+                   u32 chunk, HelperOut O, size_t helper_stride, u32 extra_pc, int *__restrict__ err_flag) {
     const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= t.n) return;
-    const u32 n_entries = (u32)prog[0];
+    const CBlob B{compiled};
+    const u32 n_entries = B.n_entries();
+    const bool has_next = row + 1 < t.n;       // "table" semantics: next-row terms are dropped on the last row
+    auto ld = [&](u32 col, u32 next, u64 &v) {
+        if (next && !has_next) return false;
+        v = t.base[(size_t)col * t.stride + row + next];
+        return true;
+    };
     // ZK_HELPER_BATCH is a multiple of chunk (1 or 2), so batches never split a helper group
     for (u32 e0 = 0; e0 < n_entries; e0 += ZK_HELPER_BATCH) {
         u64 v[NCH][ZK_HELPER_BATCH], pre[NCH][ZK_HELPER_BATCH], flt[ZK_HELPER_BATCH];
@@ -152,7 +222,7 @@ helper_cols_kernel(const u64 *__restrict__ prog, TraceView t, HelperChallenges H
             for (int k = 0; k < NCH; ++k) { v[k][i] = 1; pre[k][i] = 1; }
             if (e0 + i < n_entries) {
                 u64 d[NCH], f;
-                prog_eval_entry<NCH>(prog, e0 + i, t, row, H, d, f);
+                centry_eval<NCH>(B, e0 + i, ld, d, f);
                 if (f > 1) atomicExch(err_flag, 1);          // "Non-binary filter?" (plonky2 asserts)
                 flt[i] = f;
 #pragma unroll
