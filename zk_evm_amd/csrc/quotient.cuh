@@ -118,23 +118,22 @@ __device__ __forceinline__ void frame_eval_entry(const u64 *__restrict__ prog, u
     filt = frame_eval_filter(prog, pc, lv, nv);
 }
 
-// starky `eval_helper_columns`: entries [0, n_entries) of the sub-program at prog+sub, helper h at
-// aux column h0 + h.
-template <class CONS>
-__device__ __forceinline__ void check_helper_columns(const u64 *__restrict__ prog, u32 sub, u32 n_entries, u32 chunk,
-                                                     const RowView &lv, const RowView &nv, const RowView &aux_lv,
-                                                     u32 h0, u64 beta, u64 gamma, CONS &cons) {
+// starky `eval_helper_columns`: entries [0, n_entries) of a compiled blob (stark.cuh), helper h at aux column
+// h0 + h; `slot` selects the challenge the blob was compiled for.
+template <class CONS, class LD>
+__device__ __forceinline__ void check_helper_columns(const CBlob &B, u32 slot, u32 n_entries, u32 chunk, LD ld,
+                                                     const RowView &aux_lv, u32 h0, CONS &cons) {
     u32 h = 0;
     for (u32 e = 0; e < n_entries; e += chunk, ++h) {
         Fe hv = aux_lv[h0 + h];
-        Fe c0, f0;
-        frame_eval_entry(prog, sub + (u32)prog[sub + 1 + e], lv, nv, beta, gamma, c0, f0);
+        u64 c0, f0;
+        centry_eval_slot(B, e, slot, ld, c0, f0);
         if (chunk == 2 && e + 1 < n_entries) {
-            Fe c1, f1;
-            frame_eval_entry(prog, sub + (u32)prog[sub + 2 + e], lv, nv, beta, gamma, c1, f1);
-            cons.constraint(c1 * c0 * hv - f0 * c1 - f1 * c0);
+            u64 c1, f1;
+            centry_eval_slot(B, e + 1, slot, ld, c1, f1);
+            cons.constraint(Fe(c1) * Fe(c0) * hv - Fe(f0) * Fe(c1) - Fe(f1) * Fe(c0));
         } else {
-            cons.constraint(c0 * hv - f0);
+            cons.constraint(Fe(c0) * hv - Fe(f0));
         }
     }
 }
@@ -158,6 +157,9 @@ struct QuotientArgs {
     const u64 *lookup_prog; u32 n_lookup_challenges; u64 lookup_challenges[ZK_MAX_CHALLENGES];
     // ctl: program := n_zdata, off[n_zdata]; each := beta, gamma, n_helpers, helper program
     const u64 *ctl_prog; u32 num_lookup_columns; u32 total_ctl_helper_cols;
+    // compiled entries (stark.cuh): blob of lookup l (both lookup challenges as slots 0 / 1) at cblob + cblob[l],
+    // blob of CTL z-data z (slot 0) at cblob + cblob[n_lookups + z]
+    const u64 *cblob;
     u32 constraint_degree;
     const u64 *air_consts;
     u64 *out; size_t out_stride;  // [n_challenges][size] quotient VALUES on the coset
@@ -177,6 +179,7 @@ __device__ __forceinline__ void quotient_constraints(const QuotientArgs &A, u32 
 
     RowView alv{A.aux, A.aux_stride, row}, anv{A.aux, A.aux_stride, row_next};
     const u32 chunk = A.constraint_degree - 1;
+    auto ld = [&](u32 col, u32 next, u64 &v) { v = (next ? nv : lv)[col].v; return true; };   // `eval_with_next`
     // ---- starky eval_packed_lookups_generic ----
     if (A.lookup_prog) {
         const u64 *lp = A.lookup_prog;
@@ -186,9 +189,10 @@ __device__ __forceinline__ void quotient_constraints(const QuotientArgs &A, u32 
             const u32 sub = (u32)lp[1 + l];
             const u32 ne = (u32)lp[sub];
             const u32 n_help = (ne + chunk - 1) / chunk + 1;
+            const CBlob LB{A.cblob + A.cblob[l]};
             for (u32 c = 0; c < A.n_lookup_challenges; ++c) {
                 const u64 ch = A.lookup_challenges[c];
-                check_helper_columns(lp, sub, ne, chunk, lv, nv, alv, start, 1, ch, cons);
+                check_helper_columns(LB, c, ne, chunk, ld, alv, start, cons);
                 Fe z = alv[start + n_help - 1], next_z = anv[start + n_help - 1];
                 u32 pc = sub + (u32)lp[sub + 1 + ne];
                 Fe table = frame_eval_column(lp, pc, lv, nv, false) + Fe(ch);   // Column::eval: local row only
@@ -207,6 +211,7 @@ __device__ __forceinline__ void quotient_constraints(const QuotientArgs &A, u32 
     if (A.ctl_prog) {
         const u64 *cp = A.ctl_prog;
         const u32 n_z = (u32)cp[0];
+        const u32 n_lookups_total = A.lookup_prog ? (u32)A.lookup_prog[0] : 0;
         u32 start_index = 0;
         for (u32 zi = 0; zi < n_z; ++zi) {
             const u32 off = (u32)cp[1 + zi];
@@ -215,7 +220,8 @@ __device__ __forceinline__ void quotient_constraints(const QuotientArgs &A, u32 
             const u32 sub = off + 3;
             const u32 ne = (u32)cp[sub];
             const u32 h0 = A.num_lookup_columns + start_index;
-            if (n_help) check_helper_columns(cp, sub, ne, chunk, lv, nv, alv, h0, beta, gamma, cons);
+            const CBlob ZB{A.cblob + A.cblob[n_lookups_total + zi]};
+            if (n_help) check_helper_columns(ZB, 0, ne, chunk, ld, alv, h0, cons);
             const u32 zcol = A.num_lookup_columns + A.total_ctl_helper_cols + zi;
             Fe local_z = alv[zcol], next_z = anv[zcol];
             if (n_help) {
@@ -224,14 +230,16 @@ __device__ __forceinline__ void quotient_constraints(const QuotientArgs &A, u32 
                 cons.constraint_last_row(local_z - hs);
                 cons.constraint_transition(local_z - next_z - hs);
             } else if (ne > 1) {
-                Fe c0, f0, c1, f1;
-                frame_eval_entry(cp, sub + (u32)cp[sub + 1], lv, nv, beta, gamma, c0, f0);
-                frame_eval_entry(cp, sub + (u32)cp[sub + 2], lv, nv, beta, gamma, c1, f1);
+                u64 d0, g0, d1, g1;
+                centry_eval_slot(ZB, 0, 0, ld, d0, g0);
+                centry_eval_slot(ZB, 1, 0, ld, d1, g1);
+                const Fe c0(d0), f0(g0), c1(d1), f1(g1);
                 cons.constraint_last_row(c0 * c1 * local_z - f0 * c1 - f1 * c0);
                 cons.constraint_transition(c0 * c1 * (local_z - next_z) - f0 * c1 - f1 * c0);
             } else {
-                Fe c0, f0;
-                frame_eval_entry(cp, sub + (u32)cp[sub + 1], lv, nv, beta, gamma, c0, f0);
+                u64 d0, g0;
+                centry_eval_slot(ZB, 0, 0, ld, d0, g0);
+                const Fe c0(d0), f0(g0);
                 cons.constraint_last_row(c0 * local_z - f0);
                 cons.constraint_transition(c0 * (local_z - next_z) - f0);
             }

@@ -172,6 +172,38 @@ __device__ __forceinline__ void centry_eval(const CBlob &B, u32 e, LD ld, u64 (&
     filt = gl_canon(acc);
 }
 
+// one challenge, chosen at run time (wave-uniform slot 0 / 1): the quotient kernel walks lookups challenge by challenge
+template <class LD>
+__device__ __forceinline__ void cterms_dot_slot(const CBlob &B, u32 t0, u32 t1, u32 slot, LD ld, DotAcc &d) {
+    u32 t = t0;
+    for (; t + 4 <= t1; t += 4) {
+        u64 v[4];
+        bool ok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const u64 w0 = B.term(t + i)[0]; ok[i] = ld((u32)w0, (u32)(w0 >> 32), v[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (ok[i]) dot_acc_mac_u(d, B.term(t + i)[1 + slot], v[i]);
+    }
+    for (; t < t1; ++t) {
+        const u64 w0 = B.term(t)[0];
+        u64 v;
+        if (ld((u32)w0, (u32)(w0 >> 32), v)) dot_acc_mac_u(d, B.term(t)[1 + slot], v);
+    }
+}
+template <class LD>
+__device__ __forceinline__ void centry_eval_slot(const CBlob &B, u32 e, u32 slot, LD ld, u64 &denom, u64 &filt) {
+    const u64 *E = B.entry(e);
+    DotAcc d;
+    dot_acc_init(d);
+    cterms_dot_slot(B, (u32)E[0], (u32)E[1], slot, ld, d);
+    denom = gl_add(dot_acc_reduce(d), E[6 + slot]);
+    u64 acc = 0;
+    for (u32 p = (u32)E[2]; p < (u32)E[3]; ++p) acc = gl_add(acc, gl_mul(clin_eval(B, 2 * p, ld), clin_eval(B, 2 * p + 1, ld)));
+    for (u32 c = (u32)E[4]; c < (u32)E[5]; ++c) acc = gl_add(acc, clin_eval(B, c, ld));
+    filt = acc;
+}
+
 // denominators (one per challenge) and filter of entry e at `row`
 template <int NCH>
 __device__ __forceinline__ void prog_eval_entry(const u64 *__restrict__ prog, u32 e, const TraceView &t, u32 row,
