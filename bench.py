@@ -399,7 +399,7 @@ def main():
                              "ms_per_step": leaf_ms / a.steps, "share_of_step": leaf_ms / a.steps / ms_per_step,
                              "algorithmic_bytes": tot["leaf_hash_bytes"] / max(tot["commits"], 1),
                              "note": "summed over the %d leaf-hash launches of the timed region (one per commitment: "
-                                     "9 trace + 8 auxiliary + 9 quotient per segment); integer-VALU bound, not HBM bound "
+                                     "9 trace + 9 auxiliary + 9 quotient per segment); integer-VALU bound, not HBM bound "
                                      "(DESIGN.md): permutations/s = %.3e; per-launch PMC traffic for the 116-column "
                                      "launch is in commit_config1.roofline.traffic"
                                      % (tot["commits"], tot["leaf_hash_perms"] / (leaf_ms * 1e-3))},
@@ -430,7 +430,7 @@ def main():
                 out["cpu_baseline"] = {
                     "value": 1.0 / sec, "unit": "segment proofs/s", "cores": cb["cores"], "kind": "port",
                     "sample": cb["sample"].split(", scaled")[0] + f"; scaled by committed cells ({cells} / {sample_cells}) to "
-                              "the segment's 26 commitments -- COMMIT PHASE ONLY (the CPU quotient / FRI are not timed, the "
+                              "the segment's 27 commitments -- COMMIT PHASE ONLY (the CPU quotient / FRI are not timed, the "
                               "Python constraint oracle is not a performance port), so this is an upper bound on the CPU rate",
                     "seconds_per_segment_est": sec}
             except Exception as e:  # the oracle is only a reported baseline; never fatal
