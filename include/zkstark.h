@@ -362,6 +362,17 @@ int zk_memory_continuation_generate_trace(zk_ctx *ctx, const uint64_t *entries, 
  * table (segment ShiftTable), padded to the next power of two.  cap_out: 2^cap_height x 4 words. */
 int zk_initial_memory_merkle_cap(zk_ctx *ctx, const zk_cfg *cfg, const uint8_t *kernel_code, size_t code_len,
                                  uint64_t *cap_out);
+/* BytePacking table: replaces `BytePackingStark::generate_trace` (byte_packing/byte_packing_stark.rs:174-283) including
+ * its range-check columns.  ops (host): n_ops x 10 words = is_read, context, segment, virt, timestamp, length (1..32;
+ * the reference drops empty operations), the bytes as four 64-bit words (byte k at bits 8*(k%8) of word k/8).
+ * 71 columns, 2^log_n >= max(n_ops, 256) rows. */
+int zk_byte_packing_generate_trace(zk_ctx *ctx, const uint64_t *ops, size_t n_ops, unsigned log_n, uint64_t *d_out,
+                                   size_t col_stride);
+/* KeccakSponge table: replaces `KeccakSpongeStark::generate_trace` (keccak_sponge/keccak_sponge_stark.rs:252-533)
+ * including its range-check columns.  ops (host): n_ops x 5 words = context, segment, virt, timestamp, input length;
+ * inputs: the inputs concatenated.  Each operation yields length/136 + 1 rows; 438 columns, 2^log_n >= 256 rows. */
+int zk_keccak_sponge_generate_trace(zk_ctx *ctx, const uint64_t *ops, size_t n_ops, const uint8_t *inputs,
+                                    size_t input_bytes, unsigned log_n, uint64_t *d_out, size_t col_stride);
 /* Range-check finalisation, in place on a device trace: `generate_range_checks` of the Arithmetic, BytePacking and
  * KeccakSponge tables (arithmetic_stark.rs:130-156, byte_packing_stark.rs:254-283, keccak_sponge_stark.rs:503-533):
  * counter_col[i] = min(i, range_max - 1); freq_col[x] = number of cells of columns [first_col, first_col + n_cols)

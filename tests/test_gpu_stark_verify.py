@@ -260,3 +260,80 @@ def test_memory_continuation_generator_and_initial_memory_cap(oracle, hasher):
     t[:, :len(rows)] = np.array(rows, dtype=np.uint64).T
     ref = oracle.commit_values(t, rate_bits=1, cap_height=4, hasher=hasher, want_leaves=False)
     assert np.array_equal(initial_memory_merkle_cap(code, 1, 4, hasher=hasher), ref["cap"])
+
+
+def _registry_descs(table):
+    """(ctl_entries_list, lookup_spec) of one table in the descriptor form of _prove_and_verify, taken from the real
+    registry (oracle/all_stark.py): one z-data per CTL run of looking entries of this table / per looked role."""
+    from oracle import all_stark as oas
+
+    def desc(col):
+        lc = col.linear_combination
+        if len(lc) == 1 and lc[0][1] == 1 and not col.next_row_linear_combination and col.constant == 0:
+            return ("single", lc[0][0])
+        return ("lc", list(lc), list(col.next_row_linear_combination), col.constant)
+
+    def fdesc(f):
+        return ("full", [(desc(a), desc(b)) for a, b in f.products], [desc(c) for c in f.constants])
+    zlist = []
+    for ctl in oas.build_ctls():
+        mine = [t for t in ctl.looking_tables if t.table == table]
+        if mine:
+            zlist.append([([desc(c) for c in t.columns], fdesc(t.filter)) for t in mine])
+        if ctl.looked_table.table == table:
+            lk = ctl.looked_table
+            zlist.append([([desc(c) for c in lk.columns], fdesc(lk.filter))])
+    lookups = [([desc(c) for c in l.columns], desc(l.table_column), desc(l.frequencies_column),
+                [None if (not f.products and len(f.constants) == 1 and f.constants[0].constant == 1
+                          and not f.constants[0].linear_combination) else fdesc(f) for f in l.filter_columns])
+               for l in oas.build_lookups()[table]]
+    return zlist, lookups
+
+
+def test_byte_packing_table_generated_on_device_verifies(oracle):
+    """BytePacking end to end with its REAL lookups and CTL entries (looked by the Cpu, 32 lookers into Memory):
+    device-generated rows == the restated reference generator, and the proof of that valid trace is accepted by the
+    oracle verifier (quotient identity included); a flipped byte is rejected."""
+    from oracle import tracegen as otg
+    from tests.test_oracle_tracegen import sample_byte_packing_ops
+    from zk_evm_amd.tracegen import byte_packing_generate_trace
+    rng = np.random.default_rng(41)
+    ops = sample_byte_packing_ops(rng, 60)
+    got = byte_packing_generate_trace(ops, 16).cpu().numpy().view(np.uint64)
+    exp = otg.byte_packing_generate_trace(ops, 16)
+    assert np.array_equal(got, exp)
+    zlist, lookups = _registry_descs(1)
+    assert [len(z) for z in zlist] == [1, 32] and len(lookups) == 1
+    t = np.ascontiguousarray(got)
+    ok, why = _prove_and_verify(oracle, 4, t, 0, zlist, lookup_spec=lookups)
+    assert ok, why
+    bad = t.copy()
+    bad[37 + 2, 7] = 256                                    # a "byte" out of range: the logUp range check fails
+    ok, why = _prove_and_verify(oracle, 4, bad, 0, zlist, lookup_spec=lookups)
+    assert not ok, why
+
+
+def test_keccak_sponge_table_generated_on_device_verifies(oracle):
+    """KeccakSponge end to end with its real 136-column range check and all its CTL roles (looked by the Cpu, looking
+    into Keccak inputs / outputs, 5 Logic lookers, 136 Memory lookers): device rows == restated generator, valid
+    trace accepted by the oracle verifier, a wrong already_absorbed_bytes rejected."""
+    from oracle import tracegen as otg
+    from tests.test_oracle_tracegen import _keccak_f, sample_sponge_ops
+    from zk_evm_amd.tracegen import keccak_sponge_generate_trace
+    rng = np.random.default_rng(43)
+    ops = sample_sponge_ops(rng)
+    got = keccak_sponge_generate_trace(ops, 16).cpu().numpy().view(np.uint64)
+    exp = otg.keccak_sponge_generate_trace(ops, 16, _keccak_f(oracle))
+    assert np.array_equal(got, exp)
+    zlist, lookups = _registry_descs(4)
+    assert [len(z) for z in zlist] == [1, 1, 1, 5, 136] and len(lookups) == 1
+    t = np.ascontiguousarray(got)
+    ok, why = _prove_and_verify(oracle, 7, t, 0, zlist, lookup_spec=lookups)
+    assert ok, why
+    bad = t.copy()
+    # (the updated state of a final row is only tied to the Keccak table through a CTL, so corrupt something the
+    # table itself constrains: already_absorbed_bytes of the second row of the 136-byte input, rows 4-5)
+    assert bad[0, 4] == 1 and bad[5, 5] == 136
+    bad[5, 5] += np.uint64(1)
+    ok, why = _prove_and_verify(oracle, 7, bad, 0, zlist, lookup_spec=lookups)
+    assert not ok, why

@@ -1,0 +1,71 @@
+"""CPU: the oracle's BytePacking / KeccakSponge generators (oracle/tracegen.py) against the restated AIRs -- the
+reference's own generate<->eval test style: every constraint vanishes on every generated row --
+and the sponge digest against keccak256."""
+import numpy as np
+
+from oracle import airs as oairs
+from oracle import tracegen as otg
+
+P = 0xFFFFFFFF00000001
+
+
+def _check_air(air, t):
+    n = t.shape[1]
+
+    class Cons:
+        def __init__(self, i): self.i, self.bad = i, 0
+        def constraint(self, c): self.bad += 1 if c % P else 0
+        def constraint_transition(self, c): self.bad += 1 if (self.i != n - 1 and c % P) else 0
+        def constraint_first_row(self, c): self.bad += 1 if (self.i == 0 and c % P) else 0
+        def constraint_last_row(self, c): self.bad += 1 if (self.i == n - 1 and c % P) else 0
+    rows = t.T
+    for i in range(n):
+        c = Cons(i)
+        air([int(v) for v in rows[i]], [int(v) for v in rows[(i + 1) % n]], c)
+        assert c.bad == 0, (i, c.bad)
+
+
+def _keccak_f(oracle):
+    def f(words):
+        a = np.array(words, dtype=np.uint64)
+        oracle.lib.orc_keccak_f1600(a)
+        return [int(x) for x in a]
+    return f
+
+
+def sample_byte_packing_ops(rng, n):
+    ops = []
+    for _ in range(n):
+        ln = int(rng.integers(1, 33))
+        ops.append((bool(rng.integers(0, 2)), (int(rng.integers(0, 5)), int(rng.integers(0, 30)), int(rng.integers(0, 1 << 20))),
+                    int(rng.integers(1, 1 << 20)), rng.bytes(ln)))
+    ops.insert(3, (True, (0, 0, 0), 9, b""))            # an empty op produces no row (byte_packing_stark.rs:209-213)
+    return ops
+
+
+def sample_sponge_ops(rng):
+    lens = [0, 1, 55, 135, 136, 137, 272, 300]
+    return [((int(rng.integers(0, 5)), int(rng.integers(0, 30)), int(rng.integers(0, 1 << 20))), int(rng.integers(1, 1 << 20)),
+             rng.bytes(ln)) for ln in lens]
+
+
+def test_byte_packing_rows_satisfy_the_air():
+    rng = np.random.default_rng(1)
+    t = otg.byte_packing_generate_trace(sample_byte_packing_ops(rng, 40), 16)
+    assert t.shape == (71, 256)
+    _check_air(oairs.eval_byte_packing, t)
+    assert int(t[70].sum()) == 32 * 256 and np.array_equal(t[69], np.arange(256, dtype=np.uint64))
+
+
+def test_keccak_sponge_rows_satisfy_the_air_and_hash(oracle):
+    rng = np.random.default_rng(2)
+    ops = sample_sponge_ops(rng)
+    t = otg.keccak_sponge_generate_trace(ops, 16, _keccak_f(oracle))
+    assert t.shape == (438, 256)
+    _check_air(oairs.eval_keccak_sponge, t)
+    r = 0
+    for _, _, data in ops:                               # final row of each op holds keccak256(input)
+        r += len(data) // 136
+        digest = bytes(int(t[404 + i, r]) for i in range(32))
+        assert digest == oracle.keccak256(data)
+        r += 1

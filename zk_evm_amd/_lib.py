@@ -99,6 +99,8 @@ SIGNATURES = {
     "zk_logic_generate_trace": (C.c_int, [vp, u64p, sz, ui, u64p, sz]),
     "zk_memory_continuation_generate_trace": (C.c_int, [vp, u64p, sz, ui, u64p, sz]),
     "zk_initial_memory_merkle_cap": (C.c_int, [vp, C.POINTER(ZkCfg), vp, sz, u64p]),
+    "zk_byte_packing_generate_trace": (C.c_int, [vp, u64p, sz, ui, u64p, sz]),
+    "zk_keccak_sponge_generate_trace": (C.c_int, [vp, u64p, sz, vp, sz, ui, u64p, sz]),
     "zk_version": (C.c_char_p, []),
     "zk_device_info": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(sz)]),
 }

@@ -178,3 +178,102 @@ __global__ void mem_continuation_trace_kernel(const u64 *__restrict__ entries, u
         out[(size_t)(5 + 2 * l) * stride + row] = v >> 32;
     }
 }
+
+// ---- BytePacking table --------------------------------------------------------------------------------------
+// `BytePackingStark::generate_trace_rows` / `generate_row_for_op` (byte_packing/byte_packing_stark.rs:194-251); the
+// range-check columns are added afterwards by range_counter_kernel / range_histogram_kernel.
+// ops: [n][10] = {is_read, context, segment, virt, timestamp, len (1..32), bytes as 4 x u64 (byte k of the sequence
+// at bits 8*(k%8) of word k/8)}.  value_bytes[i] = bytes[len - 1 - i].
+__global__ void byte_packing_trace_kernel(const u64 *__restrict__ ops, u32 n_ops, u32 n_rows, u64 *__restrict__ out,
+                                          size_t stride) {
+    const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n_rows) return;
+    auto put = [&](u32 col, u64 v) { out[(size_t)col * stride + row] = v; };
+    if (row >= n_ops) {
+        for (u32 c = 0; c < 71; ++c) put(c, 0);
+        return;
+    }
+    const u64 *o = ops + (size_t)row * 10;
+    const u32 len = (u32)o[5];
+    put(0, o[0]);
+    for (u32 i = 0; i < 32; ++i) put(1 + i, i + 1 == len ? 1 : 0);        // index_len
+    put(33, o[1]); put(34, o[2]); put(35, o[3]); put(36, o[4]);
+    for (u32 i = 0; i < 32; ++i) {
+        u64 b = 0;
+        if (i < len) { const u32 k = len - 1 - i; b = (o[6 + k / 8] >> (8 * (k % 8))) & 0xFF; }
+        put(37 + i, b);
+    }
+    put(69, 0); put(70, 0);
+}
+
+// ---- KeccakSponge table ---------------------------------------------------------------------------------------
+// `KeccakSpongeStark::generate_rows_for_op` / `generate_common_fields` (keccak_sponge/keccak_sponge_stark.rs:298-494).
+// The blocks of one input are chained through the sponge state, so one lane walks one operation and writes its
+// len/136 + 1 rows (the table is small: <= 2^13 rows in production, scripts/prove_stdio.rs:94); padding rows and the
+// range-check columns come from a memset and the range kernels.
+// ops: [n][7] = {context, segment, virt, timestamp, input length, byte offset into `data`, first row}.
+__device__ __forceinline__ void keccakf_trace(u64 (&st)[25]) {      // plain keccak-f[1600] on the standard lane order
+    u64 a[5][5];
+#pragma unroll
+    for (int x = 0; x < 5; ++x)
+#pragma unroll
+        for (int y = 0; y < 5; ++y) a[x][y] = st[y * 5 + x];
+    KeccakRound k;
+    for (u32 r = 0; r < 24; ++r) {
+        keccak_round_parts(a, k);
+#pragma unroll
+        for (int x = 0; x < 5; ++x)
+#pragma unroll
+            for (int y = 0; y < 5; ++y) a[x][y] = k.app[x][y];
+        a[0][0] ^= ZK_KTRACE_RC[r];
+    }
+#pragma unroll
+    for (int x = 0; x < 5; ++x)
+#pragma unroll
+        for (int y = 0; y < 5; ++y) st[y * 5 + x] = a[x][y];
+}
+__global__ void keccak_sponge_trace_kernel(const u64 *__restrict__ ops, const unsigned char *__restrict__ data, u32 n_ops,
+                                           u64 *__restrict__ out, size_t stride) {
+    const u32 op = blockIdx.x * blockDim.x + threadIdx.x;
+    if (op >= n_ops) return;
+    const u64 *o = ops + (size_t)op * 7;
+    const u64 len = o[4];
+    const unsigned char *in = data + o[5];
+    u32 row = (u32)o[6];
+    auto put = [&](u32 col, u64 v) { out[(size_t)col * stride + row] = v; };
+    u64 st[25];
+    for (int i = 0; i < 25; ++i) st[i] = 0;
+    for (u64 absorbed = 0;; absorbed += 136, ++row) {
+        const u64 left = len - absorbed;
+        const bool full = left >= 136;
+        put(0, full ? 1 : 0);
+        put(1, o[0]); put(2, o[1]); put(3, o[2]); put(4, o[3]); put(5, absorbed);
+        unsigned char blk[136];
+        for (u32 i = 0; i < 136; ++i) {
+            unsigned char b = i < left ? in[absorbed + i] : 0;
+            if (!full) {                                              // pad10*1
+                if (i == left) b = left == 135 ? 0x81 : 0x01;
+                else if (i == 135) b = 0x80;
+            }
+            blk[i] = b;
+            put(192 + i, b);                                          // block_bytes
+            put(6 + i, (!full && i >= left) ? 1 : 0);                 // is_padding_byte
+        }
+        for (u32 i = 0; i < 50; ++i) {                                // original rate / capacity u32s
+            const u64 w = (st[i / 2] >> (32 * (i % 2))) & 0xFFFFFFFFULL;
+            put(i < 34 ? 142 + i : 176 + (i - 34), w);
+        }
+        for (u32 i = 0; i < 17; ++i) {                                // xor the block into the rate
+            u64 w = 0;
+            for (u32 j = 0; j < 8; ++j) w |= (u64)blk[8 * i + j] << (8 * j);
+            st[i] ^= w;
+            put(328 + 2 * i, st[i] & 0xFFFFFFFFULL);                  // xored_rate_u32s
+            put(329 + 2 * i, st[i] >> 32);
+        }
+        keccakf_trace(st);
+        for (u32 i = 8; i < 50; ++i) put(362 + (i - 8), (st[i / 2] >> (32 * (i % 2))) & 0xFFFFFFFFULL);   // partial_updated_state
+        for (u32 i = 0; i < 32; ++i) put(404 + i, (st[i / 8] >> (8 * (i % 8))) & 0xFF);                  // updated_digest_state_bytes
+        put(436, 0); put(437, 0);
+        if (!full) break;
+    }
+}

@@ -108,3 +108,48 @@ def initial_memory_merkle_cap(kernel_code: bytes, rate_bits: int, cap_height: in
     ctx.check(ctx.lib.zk_initial_memory_merkle_cap(ctx.handle, C.byref(cfg), code.ctypes.data if code.size else None,
                                                    code.size, out.ctypes.data))
     return out
+
+
+BYTE_PACKING_COLUMNS, KECCAK_SPONGE_COLUMNS, BYTE_RANGE_MAX, KECCAK_RATE_BYTES = 71, 438, 256, 136
+
+
+def _pow2_log(n: int) -> int:
+    return max(n - 1, 0).bit_length()
+
+
+def byte_packing_generate_trace(ops, min_rows: int, device=0, ctx: Context = None):
+    """`BytePackingStark::generate_trace` (byte_packing_stark.rs:174-283).  ops: (is_read, (context, segment, virt),
+    timestamp, bytes); -> CUDA int64 tensor (71, max(len(ops), 256, min_rows).next_power_of_two())."""
+    import torch
+    log_n = _pow2_log(max(len(ops), BYTE_RANGE_MAX, min_rows))
+    live = [op for op in ops if len(op[3])]
+    flat = np.zeros((len(live), 10), dtype=np.uint64)
+    for r, (is_read, (c, s, v), ts, data) in enumerate(live):
+        data = bytes(data)
+        if len(data) > 32:
+            raise ZkStarkError(-1, "byte sequences are at most 32 bytes")
+        words = [int.from_bytes(data[8 * k:8 * k + 8].ljust(8, b"\0"), "little") for k in range(4)]
+        flat[r] = [1 if is_read else 0, c, s, v, ts, len(data)] + words
+    ctx = ctx or default_context(device)
+    ctx.use_torch_current_stream()
+    out = torch.empty((BYTE_PACKING_COLUMNS, 1 << log_n), dtype=torch.int64, device=f"cuda:{device}")
+    ctx.check(ctx.lib.zk_byte_packing_generate_trace(ctx.handle, flat.ctypes.data if len(live) else None, len(live), log_n,
+                                                     C.c_void_p(out.data_ptr()), 1 << log_n))
+    return out
+
+
+def keccak_sponge_generate_trace(ops, min_rows: int, device=0, ctx: Context = None):
+    """`KeccakSpongeStark::generate_trace` (keccak_sponge_stark.rs:252-533).  ops: ((context, segment, virt), timestamp,
+    input bytes); -> CUDA int64 tensor (438, max(rows, 256, min_rows).next_power_of_two())."""
+    import torch
+    rows = sum(len(bytes(d)) // KECCAK_RATE_BYTES + 1 for _, _, d in ops)
+    log_n = _pow2_log(max(rows, BYTE_RANGE_MAX, min_rows))
+    flat = np.array([[c, s, v, ts, len(bytes(d))] for (c, s, v), ts, d in ops], dtype=np.uint64).reshape(len(ops), 5)
+    blob = np.frombuffer(b"".join(bytes(d) for _, _, d in ops), dtype=np.uint8)
+    ctx = ctx or default_context(device)
+    ctx.use_torch_current_stream()
+    out = torch.empty((KECCAK_SPONGE_COLUMNS, 1 << log_n), dtype=torch.int64, device=f"cuda:{device}")
+    ctx.check(ctx.lib.zk_keccak_sponge_generate_trace(ctx.handle, flat.ctypes.data if len(ops) else None, len(ops),
+                                                      blob.ctypes.data if blob.size else None, blob.size, log_n,
+                                                      C.c_void_p(out.data_ptr()), 1 << log_n))
+    return out
