@@ -69,3 +69,43 @@ def test_keccak_sponge_rows_satisfy_the_air_and_hash(oracle):
         digest = bytes(int(t[404 + i, r]) for i in range(32))
         assert digest == oracle.keccak256(data)
         r += 1
+
+
+def sample_arith_ops(rng):
+    from oracle import arith_trace as at
+    def r256(): return int.from_bytes(rng.bytes(32), "little")
+    ops = []
+    for f in (at.IS_ADD, at.IS_SUB, at.IS_LT, at.IS_GT, at.IS_MUL, at.IS_DIV, at.IS_MOD):
+        ops += [("bin", f, r256(), r256()), ("bin", f, r256(), r256() >> 200)]
+    ops += [("bin", at.IS_DIV, r256(), 0), ("bin", at.IS_MOD, r256(), 0), ("bin", at.IS_MUL, 0, r256())]
+    for f in (at.IS_ADDMOD, at.IS_SUBMOD, at.IS_MULMOD):
+        ops += [("ter", f, r256(), r256(), r256()), ("ter", f, r256(), r256(), r256() >> 100), ("ter", f, r256(), r256(), 0)]
+    ops += [("ter", at.IS_SUBMOD, 5, 7, 1000), ("ter", at.IS_SUBMOD, 7, 5, 1000)]
+    for f in (at.IS_ADDFP254, at.IS_MULFP254, at.IS_SUBFP254):
+        ops += [("bin", f, r256() % at.BN_BASE, r256() % at.BN_BASE), ("bin", f, 3, at.BN_BASE - 1)]
+    for sh in (0, 1, 17, 255, 256, 1 << 40):
+        ops += [("bin", at.IS_SHL, sh, r256()), ("bin", at.IS_SHR, sh, r256())]
+    for idx in (0, 1, 13, 30, 31, 32, 77, 1 << 100):
+        ops.append(("bin", at.IS_BYTE, idx, r256()))
+    ops.append(("range_check", r256(), r256(), r256(), 0x49, r256()))
+    return ops
+
+
+def test_arithmetic_rows_satisfy_the_air():
+    from oracle import arith_trace as at
+    rng = np.random.default_rng(3)
+    t, n_rows = at.generate_trace(sample_arith_ops(rng))
+    assert t.shape == (116, 1 << 16) and n_rows > 80
+    n = t.shape[1]
+
+    class Cons:
+        def __init__(self, i): self.i, self.bad = i, 0
+        def constraint(self, c): self.bad += 1 if c % P else 0
+        def constraint_transition(self, c): self.bad += 1 if (self.i != n - 1 and c % P) else 0
+        def constraint_first_row(self, c): self.bad += 1 if (self.i == 0 and c % P) else 0
+        def constraint_last_row(self, c): self.bad += 1 if (self.i == n - 1 and c % P) else 0
+    rows = t.T
+    for i in list(range(n_rows + 2)) + [65534, 65535]:     # the operation rows, the first padding rows, the wrap-around
+        c = Cons(i)
+        oairs.eval_arithmetic([int(v) for v in rows[i]], [int(v) for v in rows[(i + 1) % n]], c)
+        assert c.bad == 0, (i, c.bad)
