@@ -365,3 +365,24 @@ def test_arithmetic_all_operations_verify(oracle):
     bad[115, :1 << 16] = np.bincount(bad[18:114].astype(np.int64).reshape(-1), minlength=1 << 16).astype(np.uint64)
     ok, why = _prove_and_verify(oracle, 5, bad, 0, zlist, lookup_spec=lookups)
     assert not ok and why == "quotient identity", why
+
+
+def test_memory_table_valid_trace_verifies(oracle):
+    """The Memory table: a consistent operation log run through the restated reference pipeline (sort, fill_gaps,
+    padding, first-change flags, range-check / stale-context frequencies: oracle/mem_trace.py = memory_stark.rs:104-455),
+    proven on the GPU with the table's two real lookups (one filtered, one using a next-row column) and its four CTL
+    roles, accepted by the oracle verifier; breaking the address ordering is rejected."""
+    from oracle import mem_trace as mt
+    from tests.test_oracle_tracegen import sample_memory_ops
+    rng = np.random.default_rng(61)
+    ops, before, stale = sample_memory_ops(rng, 60)
+    t, _ = mt.generate_trace(ops, before, stale)
+    zlist, lookups = _registry_descs(6)
+    assert [len(z) for z in zlist] == [1, 1, 1, 1] and len(lookups) == 2
+    ok, why = _prove_and_verify(oracle, 3, t, 0, zlist, lookup_spec=lookups)
+    assert ok, why
+    bad = t.copy()
+    i = next(r for r in range(5, t.shape[1] - 2) if t[mt.VIRT_FIRST, r] == 1)
+    bad[mt.VIRT, i + 1], bad[mt.VIRT, i] = t[mt.VIRT, i], t[mt.VIRT, i + 1]      # two rows out of address order
+    ok, why = _prove_and_verify(oracle, 3, bad, 0, zlist, lookup_spec=lookups)
+    assert not ok, why

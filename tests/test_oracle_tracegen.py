@@ -109,3 +109,35 @@ def test_arithmetic_rows_satisfy_the_air():
         c = Cons(i)
         oairs.eval_arithmetic([int(v) for v in rows[i]], [int(v) for v in rows[(i + 1) % n]], c)
         assert c.bad == 0, (i, c.bad)
+
+
+def sample_memory_ops(rng, n_addr=40):
+    """A consistent log: per address a run of writes / reads at increasing timestamps (reads return the last value, a
+    read before any write returns 0), some addresses preloaded through mem_before, one context marked stale."""
+    ops, before = [], []
+    ts = 1
+    for _ in range(n_addr):
+        addr = (int(rng.integers(0, 4)), int(rng.integers(1, 12)), int(rng.integers(0, 60)))
+        val = 0
+        if rng.random() < 0.25 and not any(a == addr for a, _ in before):
+            val = int.from_bytes(rng.bytes(32), "little")
+            before.append((addr, val))
+        elif any(a == addr for a, _ in before) or any((o["ctx"], o["seg"], o["virt"]) == addr for o in ops):
+            continue
+        for _ in range(int(rng.integers(1, 5))):
+            ts += int(rng.integers(1, 4))
+            if rng.random() < 0.5:
+                val = int.from_bytes(rng.bytes(32), "little")
+                ops.append(dict(filter=True, timestamp=ts, ctx=addr[0], seg=addr[1], virt=addr[2], is_read=False, value=val))
+            else:
+                ops.append(dict(filter=True, timestamp=ts, ctx=addr[0], seg=addr[1], virt=addr[2], is_read=True, value=val))
+    return ops, before, [2]
+
+
+def test_memory_rows_satisfy_the_air():
+    from oracle import mem_trace as mt
+    rng = np.random.default_rng(4)
+    ops, before, stale = sample_memory_ops(rng)
+    t, mem_after = mt.generate_trace(ops, before, stale)
+    assert t.shape[0] == 30 and t.shape[1] & (t.shape[1] - 1) == 0 and len(mem_after) > 0
+    _check_air(oairs.eval_memory, t)
