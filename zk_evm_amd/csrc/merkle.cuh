@@ -70,6 +70,17 @@ poseidon_merkle_level_kernel(const u64 *__restrict__ child, u64 *__restrict__ pa
     o[1] = make_ulonglong2(gl_canon(s[2]), gl_canon(s[3]));
 }
 
+// two_to_one for the small levels near the cap: one parent per 16-lane group (poseidon.cuh, cooperative permutation)
+__global__ void __launch_bounds__(256)
+poseidon_merkle_level_coop_kernel(const u64 *__restrict__ child, u64 *__restrict__ parent, u32 n_parent) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 node = t >> 4, e = t & 15;
+    if (node >= n_parent) return;                      // whole groups leave together
+    u64 s = e < 8 ? child[(size_t)8 * node + e] : 0;
+    s = poseidon_permute_coop(s, e, threadIdx.x & 63);
+    if (e < 4) parent[(size_t)4 * node + e] = gl_canon(s);
+}
+
 __global__ void poseidon_permute_states_kernel(u64 *states, size_t n_states) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_states) return;

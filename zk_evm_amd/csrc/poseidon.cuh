@@ -154,3 +154,37 @@ __device__ __forceinline__ void poseidon_permute(u64 (&s)[12]) {
     pos_mds<false>(s, nullptr);
 }
 
+
+// ---- lane-cooperative permutation ---------------------------------------------------------------------
+// For the top of a Merkle tree there are fewer states than lanes, and a level costs one full permutation latency
+// (20.5 k dependent-issue instructions, ~37 us) however few nodes it has.  Here ONE state is spread over a group of 16
+// lanes (element e = lane % 16, 12 active): every lane runs one S-box and one MDS row, the row's twelve inputs arrive
+// through ds_bpermute ("wavefront shuffles for the round state"), ~140 instructions per round instead of ~700, so a
+// level's latency drops ~5x.  Throughput per lane is 16x worse: only used where lanes would idle anyway.
+__device__ __forceinline__ u64 poseidon_permute_coop(u64 s, u32 e, u32 lane) {
+    constexpr u32 C[12] = ZK_POSEIDON_MDS_CIRC_INIT;
+    const u32 gbase = lane & ~15u;
+    const bool act = e < 12;
+    const u32 ec = act ? e : 0;
+    s = gl_add_canon(s, act ? ZK_RC[ec] : 0);
+    int round = 0;
+    auto mds = [&](bool has_rc) {
+        const u32 lo = (u32)s, hi = (u32)(s >> 32);
+        u64 al = has_rc ? ZK_RCS[round * 12 + ec].lo : 0, ah = has_rc ? ZK_RCS[round * 12 + ec].hi : 0;
+#pragma unroll
+        for (u32 j = 0; j < 12; ++j) {
+            const u32 src = gbase + (ec + j >= 12 ? ec + j - 12 : ec + j);
+            const u32 xl = (u32)__shfl((int)lo, (int)src, 64), xh = (u32)__shfl((int)hi, (int)src, 64);
+            al += (u64)xl * C[j];
+            ah += (u64)xh * C[j];
+        }
+        if (e == 0) { al += (u64)lo * 8; ah += (u64)hi * 8; }      // MDS_MATRIX_DIAG = (8, 0, .., 0)
+        s = pos_fold(al, ah);
+    };
+    for (int k = 0; k < ZK_POSEIDON_HALF_FULL_ROUNDS; ++k) { s = pos_sbox(s); ++round; mds(true); }
+    for (int k = 0; k < ZK_POSEIDON_PARTIAL_ROUNDS; ++k) { if (e == 0) s = pos_sbox(s); ++round; mds(true); }
+    for (int k = 0; k < ZK_POSEIDON_HALF_FULL_ROUNDS - 1; ++k) { s = pos_sbox(s); ++round; mds(true); }
+    s = pos_sbox(s);
+    mds(false);
+    return s;
+}

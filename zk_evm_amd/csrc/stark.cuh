@@ -414,12 +414,23 @@ scan_block_kernel(const u64 *__restrict__ x, u32 n, int mode, u64 *__restrict__ 
     }
     if (threadIdx.x == ZK_SCAN_THREADS - 1) totals[blockIdx.x] = sh[threadIdx.x];
 }
-// single block: exclusive scan of the block totals (n_blocks <= 2^31 / 2048, handled in a loop)
-__global__ void scan_totals_kernel(u64 *totals, u32 n_blocks) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        u64 run = 0;
-        for (u32 i = 0; i < n_blocks; ++i) { u64 v = totals[i]; totals[i] = run; run = gl_add(run, v); }
+// single block: exclusive scan of the block totals, 256 lanes each owning a contiguous chunk
+__global__ void __launch_bounds__(256) scan_totals_kernel(u64 *totals, u32 n_blocks) {
+    __shared__ u64 sh[256];
+    const u32 per = (n_blocks + 255) / 256;
+    const u32 lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    u64 run = 0;
+    for (u32 i = lo; i < hi; ++i) run = gl_add(run, totals[i]);
+    sh[threadIdx.x] = run;
+    __syncthreads();
+    for (u32 off = 1; off < 256; off <<= 1) {
+        u64 add = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] = gl_add(sh[threadIdx.x], add);
+        __syncthreads();
     }
+    run = threadIdx.x ? sh[threadIdx.x - 1] : 0;
+    for (u32 i = lo; i < hi; ++i) { u64 v = totals[i]; totals[i] = run; run = gl_add(run, v); }
 }
 __global__ void scan_finish_kernel(const u64 *__restrict__ incl, const u64 *__restrict__ totals, u32 n,
                                    int mode, u64 *__restrict__ out) {
