@@ -535,7 +535,7 @@ static int merkle_levels(zk_ctx *ctx, uint32_t hasher, u64 *digests, unsigned lo
         size_t cnt = (size_t)1 << l;
         u64 *parent = child + 4 * (cnt * 2);
         unsigned blocks = (unsigned)((cnt + 255) / 256);
-        if (hasher == ZK_HASH_POSEIDON && cnt <= ((size_t)1 << 13) && env_int("ZK_MERKLE_COOP", 1))
+        if (hasher == ZK_HASH_POSEIDON && cnt <= ((size_t)1 << env_int("ZK_MERKLE_COOP_LOG", 13)))
             poseidon_merkle_level_coop_kernel<<<(unsigned)((cnt * 16 + 255) / 256), 256, 0, ctx->stream>>>(child, parent, (u32)cnt);
         else if (hasher == ZK_HASH_POSEIDON)
             poseidon_merkle_level_kernel<<<blocks, 256, 0, ctx->stream>>>(child, parent, cnt);
