@@ -90,6 +90,24 @@ static int set_err(zk_ctx *ctx, int code, const char *fmt, ...) {
         if (rc_ != ZK_OK) return rc_; \
     } while (0)
 
+// Scoped device scratch from the ctx arena: every block is returned on scope exit, on error paths too.
+struct DevBuf {
+    zk_ctx *ctx;
+    std::vector<void *> ptrs;
+    explicit DevBuf(zk_ctx *c) : ctx(c) {}
+    ~DevBuf() { for (void *p : ptrs) ctx->arena.free(p); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    template <class T> int alloc(T **out, size_t count) {
+        void *p = nullptr;
+        hipError_t e = ctx->arena.alloc(&p, count * sizeof(T) ? count * sizeof(T) : 8);
+        if (e != hipSuccess) return set_err(ctx, e == hipErrorOutOfMemory ? ZK_ERR_OOM : ZK_ERR_HIP, "device arena: %s", hipGetErrorString(e));
+        ptrs.push_back(p);
+        *out = (T *)p;
+        return ZK_OK;
+    }
+};
+
 static int check_abort(zk_ctx *ctx) {
     if (ctx->abort_flag && *ctx->abort_flag) return set_err(ctx, ZK_ERR_ABORTED, "aborted");
     return ZK_OK;
@@ -444,7 +462,8 @@ extern "C" int zk_lde(zk_ctx *ctx, const uint64_t *d_coeffs, size_t in_stride, u
     if (!n_cols) return ZK_OK;
     size_t n = (size_t)1 << log_n;
     u64 *tmp = nullptr;
-    HIP_TRY(ctx, ctx->arena.alloc((void **)&tmp, n_cols * n * sizeof(u64)));
+    DevBuf scratch(ctx);
+    ZK_TRY(scratch.alloc(&tmp, n_cols * n));
     HIP_TRY(ctx, hipMemcpy2DAsync(tmp, n * 8, d_coeffs, in_stride * 8, n * 8, n_cols,
                                   hipMemcpyDeviceToDevice, ctx->stream));
     int rc = bitrev_columns(ctx, tmp, n, n_cols, log_n);
@@ -452,7 +471,6 @@ extern "C" int zk_lde(zk_ctx *ctx, const uint64_t *d_coeffs, size_t in_stride, u
     if (rc == ZK_OK) rc = get_coset_table(ctx, log_n, GL_GENERATOR, false, &tab);
     if (rc == ZK_OK)
         rc = ntt_coeffs_to_values(ctx, tmp, n, (u64 *)d_out, out_stride, n_cols, log_n, rate_bits, tab);
-    ctx->arena.free(tmp);
     return rc;
 }
 
