@@ -381,6 +381,21 @@ def main():
             timing = {}
             step(timing)                     # one extra, synchronised, untimed proof for the stage breakdown
             trace_bytes = 8.0 * sum(c << l for c, l in zip(TABLE_COLUMNS, log_ns))
+            # HBM bytes per leaf-hash launch (mean over the 27 launches of a segment) from the rocprofv3 --pmc passes
+            # on this same workload, summarised in profiles/pmc_latest.json["segment"]; only valid for the default shape
+            seg_traffic, seg_valu = None, None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get("segment")
+                if pm and a.log_n == 20 and a.hasher == 0:
+                    seg_traffic = pm["leaf_hash_hbm_bytes_per_launch"]
+                    ach = pm["leaf_hash_valu_wave_insts_per_launch"] / (leaf_ms / max(tot["commits"], 1) * 1e-3)
+                    seg_valu = {"wave_insts_per_launch": pm["leaf_hash_valu_wave_insts_per_launch"],
+                                "achieved_wave_insts_per_s": ach, "peak_wave_insts_per_s": 1024 * 2.4e9 / 4.0,
+                                "frac": ach / (1024 * 2.4e9 / 4.0),
+                                "assumes": "1024 SIMDs x 2.4 GHz / 4 cycles per integer VALU wave-instruction",
+                                "source": pm["source"]}
+            except Exception:
+                pass
             cells = segment_committed_cells(log_ns)
             out = {
                 "metric": "segment STARK proofs/sec (2^20-row traces, all nine AllStark tables)",
@@ -394,14 +409,15 @@ def main():
                            "committed_cells": cells, "proof_words": proof_words},
                 "roofline": {"bound": "hbm", "kernel": "poseidon_hash_rows_kernel" if a.hasher == 0 else "keccak_hash_rows_kernel",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                             "traffic": None,
+                             "traffic": seg_traffic,
                              "launches": tot["commits"], "ms_per_launch": leaf_ms / max(tot["commits"], 1),
                              "ms_per_step": leaf_ms / a.steps, "share_of_step": leaf_ms / a.steps / ms_per_step,
                              "algorithmic_bytes": tot["leaf_hash_bytes"] / max(tot["commits"], 1),
+                             "valu": seg_valu,
                              "note": "summed over the %d leaf-hash launches of the timed region (one per commitment: "
                                      "9 trace + 9 auxiliary + 9 quotient per segment); integer-VALU bound, not HBM bound "
-                                     "(DESIGN.md): permutations/s = %.3e; per-launch PMC traffic for the 116-column "
-                                     "launch is in commit_config1.roofline.traffic"
+                                     "(DESIGN.md): permutations/s = %.3e; traffic / valu from the --pmc passes on this workload "
+                                     "(profiles/pmc_latest.json)"
                                      % (tot["commits"], tot["leaf_hash_perms"] / (leaf_ms * 1e-3))},
                 "commit_stages_ms_per_step": {k: tot[k] / a.steps for k in ("ifft", "lde", "leaf_hash", "tree")},
                 "ntt": {"achieved_GBs": tot["ntt_bytes"] / (ntt_ms * 1e-3) / 1e9,
