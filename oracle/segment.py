@@ -131,3 +131,114 @@ def verify_cross_table_lookups(ctls, ctl_zs_first, extra_looking_sums, num_chall
         if next(i, None) is not None:
             return False, "unconsumed Z openings"
     return True, ""
+
+
+# ---- verifier.rs:184-312 `verify_proof` and :319-512 `get_memory_extra_looking_sum` / `add_data_write` ----
+SEG_GLOBAL_METADATA, SEG_GLOBAL_BLOCK_BLOOM, SEG_BLOCK_HASHES, SEG_REGISTERS_STATES = 5, 24, 32, 33   # segments.rs:25-77
+# GlobalMetadata ordinals (cpu/kernel/constants/global_metadata.rs:7-77, `unscale()`d)
+GM = dict(StateTrieRootDigestBefore=6, TransactionTrieRootDigestBefore=7, ReceiptTrieRootDigestBefore=8,
+          StateTrieRootDigestAfter=9, TransactionTrieRootDigestAfter=10, ReceiptTrieRootDigestAfter=11,
+          BlockBeneficiary=12, BlockTimestamp=13, BlockNumber=14, BlockDifficulty=15, BlockRandom=16,
+          BlockGasLimit=17, BlockChainId=18, BlockBaseFee=19, BlockBlobGasUsed=20, BlockExcessBlobGas=21,
+          BlockGasUsed=22, BlockGasUsedBefore=23, BlockGasUsedAfter=24, BlockCurrentHash=25,
+          ParentBeaconBlockRoot=26, TxnNumberBefore=42, TxnNumberAfter=43, KernelHash=45, KernelLen=46)
+REGISTER_FIELDS = ("program_counter", "is_kernel", "stack_len", "stack_top", "context", "gas_used")
+MEMORY_CTL_IDX = 6                                                                     # all_stark.rs:146
+
+
+def public_memory_writes(pv: dict, kernel_hash: int, kernel_len: int):
+    """The (segment, index, U256 value) list `get_memory_extra_looking_sum` turns into Memory writes
+    (verifier.rs:330-494, eth_mainnet feature set).  `KERNEL.code_hash` / `KERNEL.code.len()` are parameters: the
+    assembled kernel is outside this path's scope.  pv as in `pv_elements`, plus optional registers_before/after
+    dicts keyed by REGISTER_FIELDS (default 0)."""
+    be = lambda b: int.from_bytes(b, "big")
+    rb, ra, rc = pv["roots_before"], pv["roots_after"], None
+    fields = [("BlockBeneficiary", be(pv["beneficiary"])), ("BlockTimestamp", pv["timestamp"]),
+              ("BlockNumber", pv["number"]), ("BlockRandom", be(pv["random"])), ("BlockDifficulty", pv["difficulty"]),
+              ("BlockGasLimit", pv["gaslimit"]), ("BlockChainId", pv["chain_id"]), ("BlockBaseFee", pv["base_fee"]),
+              ("ParentBeaconBlockRoot", be(pv["parent_beacon_root"])), ("BlockCurrentHash", be(pv["cur_hash"])),
+              ("BlockGasUsed", pv["gas_used"]), ("BlockBlobGasUsed", pv["blob_gas_used"]),
+              ("BlockExcessBlobGas", pv["excess_blob_gas"]), ("TxnNumberBefore", pv["txn_before"]),
+              ("TxnNumberAfter", pv["txn_after"]), ("BlockGasUsedBefore", pv["gas_before"]),
+              ("BlockGasUsedAfter", pv["gas_after"]),
+              ("StateTrieRootDigestBefore", be(rb[0])), ("TransactionTrieRootDigestBefore", be(rb[1])),
+              ("ReceiptTrieRootDigestBefore", be(rb[2])), ("StateTrieRootDigestAfter", be(ra[0])),
+              ("TransactionTrieRootDigestAfter", be(ra[1])), ("ReceiptTrieRootDigestAfter", be(ra[2])),
+              ("KernelHash", kernel_hash), ("KernelLen", kernel_len)]
+    w = [(SEG_GLOBAL_METADATA, GM[k], v) for k, v in fields]
+    w += [(SEG_GLOBAL_BLOCK_BLOOM, i, pv["bloom"][i]) for i in range(8)]
+    w += [(SEG_BLOCK_HASHES, i, be(pv["prev_hashes"][i])) for i in range(256)]
+    for base, key in ((0, "registers_before"), (len(REGISTER_FIELDS), "registers_after")):
+        regs = pv.get(key, {})
+        w += [(SEG_REGISTERS_STATES, base + i, regs.get(f, 0)) for i, f in enumerate(REGISTER_FIELDS)]
+    return w
+
+
+def get_memory_extra_looking_sum(pv, challenge, kernel_hash, kernel_len):
+    """verifier.rs:319-512: sum over the public-value writes of 1 / combine(is_read=0, ctx=0, segment, index,
+    value limbs[8], timestamp=2)."""
+    total = 0
+    for seg, idx, val in public_memory_writes(pv, kernel_hash, kernel_len):
+        row = [0, 0, seg, idx] + [(val >> (32 * j)) & 0xFFFFFFFF for j in range(8)] + [2]
+        total = (total + S.inv(challenge.combine(row))) % P
+    return total
+
+
+def verify_proof(o, fri_api, cfg, stark_proofs, table_in_use, pv, cpu_air_consts, kernel_hash, kernel_len,
+                 is_initial=False, initial_mem_cap=None, mem_before_cap=None, ctls=None, lookups=None):
+    """verifier.rs:184-312 (+ get_challenges.rs:270-312).  stark_proofs[t]: None or dict(trace_cap, aux_cap,
+    quotient_cap, openings, fri, degree_bits).  -> (ok, reason).  `initial_mem_cap` stands for
+    initial_memory_merkle_cap (verifier.rs:14-78) of the kernel image in use; compared with `mem_before_cap`
+    (public_values.mem_before.mem_cap) when is_initial."""
+    from . import airs
+    L = o.lib
+    ctls = ctls if ctls is not None else A.build_ctls()
+    lookups = lookups if lookups is not None else A.build_lookups()
+    och = fri_api.new_challenger(o, cfg.hasher)
+    for t, sp in enumerate(stark_proofs):
+        if sp is not None:
+            cap = np.ascontiguousarray(sp["trace_cap"])
+            L.orc_challenger_observe_cap(C.byref(och), cap, cap.shape[0])
+        else:
+            if t not in A.OPTIONAL_TABLES or table_in_use[t]:
+                return False, "missing stark_proof for table %d" % t
+            z = np.zeros((1 << cfg.cap_height) * 4, dtype=np.uint64)
+            L.orc_challenger_observe(C.byref(och), z, z.size)
+    try:
+        e = np.array(pv_elements(pv), dtype=np.uint64)
+    except AssertionError:
+        return False, "Invalid sampling of proof challenges."
+    L.orc_challenger_observe(C.byref(och), e, e.size)
+    chal = [S.GrandProductChallenge(L.orc_challenger_get(C.byref(och)), L.orc_challenger_get(C.byref(och)))
+            for _ in range(cfg.num_challenges)]
+    pairs = [(c.beta, c.gamma) for c in chal]
+    per_table = cross_table_lookup_data([None] * A.NUM_TABLES, ctls, chal, 3)
+    from . import stark_verifier as V
+    zs_first = []
+    for t, sp in enumerate(stark_proofs):
+        zd = per_table[t]
+        for z in zd:                                     # num_ctl_helpers_zs_all: ceil(k / (degree - 1)) helpers, k > 1
+            k = len(z.columns_filters)
+            z.n_helpers = -(-k // 2) if k > 1 else 0
+        if sp is None:
+            zs_first.append([0] * len(zd))
+            continue
+        st = np.zeros(12, dtype=np.uint64)
+        L.orc_challenger_compact(C.byref(och), st)
+        air = airs.AIRS[A.TABLE_AIR[t]][0] if t != A.CPU else airs.make_eval_cpu(*cpu_air_consts)
+        ok, why = V.verify_stark_proof(o, fri_api, cfg, air, A.TABLE_COLUMNS[t], sp["degree_bits"], lookups[t], zd,
+                                       pairs, sp, och)
+        if not ok:
+            return False, "table %d: %s" % (t, why)
+        opn = np.ascontiguousarray(sp["openings"], dtype=np.uint64).reshape(-1)
+        first = opn[opn.size - 2 * len(zd):].reshape(-1, 2) if zd else np.zeros((0, 2), dtype=np.uint64)
+        if any(int(b) for _, b in first):
+            return False, "table %d: ctl_zs_first outside the base field" % t
+        zs_first.append([int(a) for a, _ in first])      # ctl_zs_first: base-field openings at 1
+    if is_initial:
+        if initial_mem_cap is None or mem_before_cap is None or not np.array_equal(
+                np.asarray(initial_mem_cap, dtype=np.uint64), np.asarray(mem_before_cap, dtype=np.uint64)):
+            return False, "Invalid initial MemBefore Merkle cap."
+    extra = [[0] * cfg.num_challenges for _ in ctls]
+    extra[MEMORY_CTL_IDX] = [get_memory_extra_looking_sum(pv, c, kernel_hash, kernel_len) for c in chal]
+    return verify_cross_table_lookups(ctls, zs_first, extra, cfg.num_challenges)

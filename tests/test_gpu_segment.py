@@ -249,3 +249,80 @@ def test_segment_error_paths():
     assert ctx.lib.zk_prove_segment(ctx.handle, C.byref(cfg), None, 0, None, 0, None, 0, 3, -1, -1, C.byref(h)) != 0
     assert "table" in ctx.last_error()
     assert ctx.lib.zk_prove_segment(ctx.handle, C.byref(cfg), None, 9, None, 0, None, 0, 3, -1, -1, None) != 0
+
+
+def _proof_dicts(got):
+    out = []
+    for sp in got.multi_proof.stark_proofs:
+        if sp is None:
+            out.append(None)
+            continue
+        p = sp.proof
+        out.append(dict(trace_cap=p.trace_cap, aux_cap=p.auxiliary_polys_cap, quotient_cap=p.quotient_polys_cap,
+                        openings=p.openings, fri=p.opening_proof, degree_bits=p.degree_bits))
+    return out
+
+
+@pytest.mark.parametrize("in_use", [[True, False, True, True, True, True, True, True, True],
+                                    [True, False, True, False, False, False, True, True, True]])
+def test_consistent_segment_accepted_by_verify_proof(oracle, in_use):
+    """The reference's own acceptance criterion, end to end (verifier.rs:184-312 restated in oracle/segment.py):
+    a complete consistent segment (tests/consistent_segment.py: halting Cpu, Memory holding the initial memory and
+    every public-value write, MemBefore = kernel image + shift table, MemAfter = final memory, the other tables
+    empty) proven by `zk_prove_segment` under standard_fast_config; the oracle re-derives every challenge from the
+    transcript, checks each table's constraint identity at zeta (AIR + range-check lookups + CTL partial sums), its
+    FRI proof, the initial-memory cap, and `verify_cross_table_lookups` with `get_memory_extra_looking_sum`.
+    BytePacking is off in both cases: its AIR pins the first row's filter to 1 (byte_packing_stark.rs:311), so a
+    segment without byte-packing operations cannot carry the table -- which is why the reference makes it optional.
+    Second case: the other optional empty tables are switched off too (their Z values default to zero).  Then three ways to be
+    rejected: a changed public value, a changed Memory cell, a wrong initial-memory cap."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    from oracle import airs as oairs
+    from oracle import segment as oseg
+    from tests import consistent_segment as cs
+    from zk_evm_amd.all_stark import AllStark
+    from zk_evm_amd.tracegen import initial_memory_merkle_cap
+    ol.setup_fri_api(oracle)
+    rng = np.random.default_rng(77)
+    code = rng.bytes(700)                                  # stand-in for KERNEL.code
+    kh = int.from_bytes(rng.bytes(32), "big")
+    consts = oairs.CPU_TEST_CONSTS
+    traces, pvd, _ = cs.build(rng, consts[0], code, kh)
+    scfg = zk.StarkConfig()
+    cfg = ol.make_cfg(hasher=0)
+
+    def prove(trs, pv_dict):
+        dev = [torch.from_numpy(np.ascontiguousarray(t).view(np.int64)).cuda() for t in trs]
+        return sg.prove_with_traces(AllStark(consts), scfg, dev, in_use, to_public_values(pv_dict))
+
+    def verify(got, pv_dict, init_cap):
+        before_cap = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
+        return oseg.verify_proof(oracle, ol, cfg, _proof_dicts(got), in_use, pv_dict, consts, kh, len(code),
+                                 is_initial=True, initial_mem_cap=init_cap, mem_before_cap=before_cap)
+
+    init_cap = initial_memory_merkle_cap(code, 1, 4, hasher=0)
+    got = prove(traces, pvd)
+    assert [p is not None for p in got.multi_proof.stark_proofs] == in_use
+    ok, why = verify(got, pvd, init_cap)
+    assert ok, why
+    # the same proof against other public values: the transcript (hence every challenge) changes -> rejected
+    pv2 = dict(pvd, gas_after=pvd["gas_after"] ^ 1)
+    ok, why = verify(got, pv2, init_cap)
+    assert not ok
+    # a proof made FOR the other public values, from the unchanged Memory table: every table verifies on its own,
+    # only the Memory CTL (extra looking sum) fails
+    got2 = prove(traces, pv2)
+    ok, why = verify(got2, pv2, init_cap)
+    assert not ok and why == "CTL 6 challenge 0", why
+    # a wrong kernel image
+    ok, why = verify(got, pvd, initial_memory_merkle_cap(code[:-1] + b"\x00\x01", 1, 4, hasher=0))
+    assert not ok and "initial MemBefore" in why
+    # one Memory value limb changed (a public-value write): Memory's own AIR still holds, CTL 6 and MemAfter break
+    from oracle import mem_trace as mt
+    bad = [t.copy() for t in traces]
+    r = next(i for i in range(bad[6].shape[1]) if bad[6][mt.SEG, i] == 32 and bad[6][mt.FILTER, i] == 1)
+    bad[6][mt.VALUE, r] ^= 1
+    ok, why = verify(prove(bad, pvd), pvd, init_cap)
+    assert not ok and why.startswith("CTL"), why
