@@ -380,6 +380,37 @@ int zk_keccak_sponge_generate_trace(zk_ctx *ctx, const uint64_t *ops, size_t n_o
 int zk_range_check_columns(zk_ctx *ctx, uint64_t *d_trace, size_t col_stride, size_t n_trace_cols, unsigned log_n,
                            size_t first_col, size_t n_cols, size_t counter_col, size_t freq_col, uint64_t range_max);
 
+/* Memory table: replaces `MemoryStark::generate_trace` (evm_arithmetization/src/memory/memory_stark.rs:405-455 and
+ * everything it calls, :104-403) -- the sort by (context, segment, virt, timestamp), `fill_gaps`, `pad_memory_ops`,
+ * `into_row`, the first-change flags / range_check / frequencies / stale-context columns and the extraction of the
+ * final memory (the next segment's mem_before) -- on the device.  Two steps, because the height of the table is only
+ * known after fill_gaps:
+ *   zk_memory_trace_begin   ops (host): n_ops x 9 words = flags (bit 0 is_read, bit 1 filter), timestamp, context,
+ *                           segment (unscaled), virt, value as four 64-bit little-endian limbs; mem_before (host):
+ *                           n_before x 7 words = context, segment, virt, value limbs (each becomes a filtered write at
+ *                           timestamp 0).  timestamp / context / segment / virt < 2^32.  Operations with equal keys
+ *                           keep their input order (ops first, then mem_before), as the reference's stable sort does.
+ *   zk_memory_gen_log_n / _unpadded_length   the padded height 2^log_n and the reference's third return value
+ *   zk_memory_trace_finish  writes the 30 columns column-major on the device (column c at d_out + c*col_stride) and
+ *                           reports the number of final-memory entries; stale_contexts (host) must be unique and
+ *                           smaller than the height.  An operation log the reference would panic on ("Range check
+ *                           ... is too large", a context beyond the height) is ZK_ERR_BAD_ARG.
+ *   zk_memory_gen_final_values     the reference's `final_values` in row order, n x 7 words like mem_before (host)
+ *   zk_memory_gen_mem_after_trace  the MemAfter table (12 columns, zero rows up to 2^log_n) straight from the device
+ *                                  copy of those entries */
+typedef struct zk_memory_gen zk_memory_gen;
+int zk_memory_trace_begin(zk_ctx *ctx, const uint64_t *ops, size_t n_ops, const uint64_t *mem_before, size_t n_before,
+                          zk_memory_gen **out);
+size_t zk_memory_gen_unpadded_length(const zk_memory_gen *gen);
+unsigned zk_memory_gen_log_n(const zk_memory_gen *gen);
+int zk_memory_trace_finish(zk_ctx *ctx, zk_memory_gen *gen, const uint64_t *stale_contexts, size_t n_stale,
+                           uint64_t *d_out, size_t col_stride, size_t *n_mem_after);
+size_t zk_memory_gen_num_mem_after(const zk_memory_gen *gen);
+int zk_memory_gen_final_values(zk_ctx *ctx, const zk_memory_gen *gen, uint64_t *entries_out);
+int zk_memory_gen_mem_after_trace(zk_ctx *ctx, const zk_memory_gen *gen, unsigned log_n, uint64_t *d_out,
+                                  size_t col_stride);
+void zk_memory_gen_free(zk_memory_gen *gen);
+
 /* library / device info */
 const char *zk_version(void);
 int zk_device_info(int device, char *name_out, size_t name_len, int *cu_count, size_t *hbm_bytes);

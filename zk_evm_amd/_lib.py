@@ -97,6 +97,14 @@ SIGNATURES = {
     "zk_keccak_generate_trace": (C.c_int, [vp, u64p, u64p, sz, ui, u64p, sz]),
     "zk_range_check_columns": (C.c_int, [vp, u64p, sz, sz, ui, sz, sz, sz, sz, C.c_uint64]),
     "zk_logic_generate_trace": (C.c_int, [vp, u64p, sz, ui, u64p, sz]),
+    "zk_memory_trace_begin": (C.c_int, [vp, u64p, sz, u64p, sz, C.POINTER(vp)]),
+    "zk_memory_gen_unpadded_length": (sz, [vp]),
+    "zk_memory_gen_log_n": (ui, [vp]),
+    "zk_memory_trace_finish": (C.c_int, [vp, vp, u64p, sz, u64p, sz, C.POINTER(sz)]),
+    "zk_memory_gen_num_mem_after": (sz, [vp]),
+    "zk_memory_gen_final_values": (C.c_int, [vp, vp, u64p]),
+    "zk_memory_gen_mem_after_trace": (C.c_int, [vp, vp, ui, u64p, sz]),
+    "zk_memory_gen_free": (None, [vp]),
     "zk_memory_continuation_generate_trace": (C.c_int, [vp, u64p, sz, ui, u64p, sz]),
     "zk_initial_memory_merkle_cap": (C.c_int, [vp, C.POINTER(ZkCfg), vp, sz, u64p]),
     "zk_byte_packing_generate_trace": (C.c_int, [vp, u64p, sz, ui, u64p, sz]),

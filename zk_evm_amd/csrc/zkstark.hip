@@ -17,6 +17,8 @@
 #include <utility>
 #include <vector>
 
+#include <rocprim/rocprim.hpp>   // radix sort + scans of the Memory-table generator (memtrace_host.inc)
+
 #include "../../include/zkstark.h"
 #include "arena.hpp"
 #include "gl.cuh"
@@ -27,6 +29,7 @@
 #include "quotient.cuh"
 #include "airs.cuh"
 #include "tracegen.cuh"
+#include "memtrace.cuh"
 #include "host_hash.hpp"
 
 // ------------------------------------------------------------------------------------------
@@ -787,3 +790,4 @@ extern "C" int zk_batch_merkle_path(const zk_batch *b, size_t leaf_index, uint64
 #include "quotient_host.inc"
 #include "segment_host.inc"
 #include "tracegen_host.inc"
+#include "memtrace_host.inc"

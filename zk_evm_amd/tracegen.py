@@ -95,6 +95,50 @@ def memory_continuation_generate_trace(mem_values: Sequence[Tuple[Tuple[int, int
     return out
 
 
+MEMORY_COLUMNS = 30
+
+
+def memory_generate_trace(memory_ops, mem_before_values=(), stale_contexts=(), device=0, ctx: Context = None):
+    """`MemoryStark::generate_trace(memory_ops, mem_before_values, stale_contexts)` (memory/memory_stark.rs:405-455)
+    on the device: sort, fill_gaps, padding, flags, range-check / frequency / stale-context columns, final memory.
+    memory_ops: (filter, timestamp, (context, segment, virt), is_read, value U256); mem_before_values: ((context,
+    segment, virt), value).  -> (trace: CUDA int64 (30, 2^k), mem_after: CUDA int64 (12, max(128, pow2)) MemAfter
+    table, final_values: [((context, segment, virt), value)] in row order, unpadded_length)."""
+    import torch
+    ctx = ctx or default_context(device)
+    ctx.use_torch_current_stream()
+    m64 = (1 << 64) - 1
+    n_ops, n_before = len(memory_ops), len(mem_before_values)
+    ops = np.zeros((n_ops, 9), dtype=np.uint64)
+    for r, (filt, ts, (c, s, v), is_read, val) in enumerate(memory_ops):
+        ops[r] = [(1 if is_read else 0) | (2 if filt else 0), ts, c, s, v] + [(val >> (64 * l)) & m64 for l in range(4)]
+    before = np.zeros((n_before, 7), dtype=np.uint64)
+    for r, ((c, s, v), val) in enumerate(mem_before_values):
+        before[r] = [c, s, v] + [(val >> (64 * l)) & m64 for l in range(4)]
+    stale = np.array([int(x) for x in stale_contexts], dtype=np.uint64)
+    gen = C.c_void_p()
+    ctx.check(ctx.lib.zk_memory_trace_begin(ctx.handle, ops.ctypes.data if n_ops else None, n_ops,
+                                            before.ctypes.data if n_before else None, n_before, C.byref(gen)))
+    try:
+        log_n = ctx.lib.zk_memory_gen_log_n(gen)
+        unpadded = ctx.lib.zk_memory_gen_unpadded_length(gen)
+        trace = torch.empty((MEMORY_COLUMNS, 1 << log_n), dtype=torch.int64, device=f"cuda:{device}")
+        n_after = C.c_size_t()
+        ctx.check(ctx.lib.zk_memory_trace_finish(ctx.handle, gen, stale.ctypes.data if stale.size else None, stale.size,
+                                                 C.c_void_p(trace.data_ptr()), 1 << log_n, C.byref(n_after)))
+        k = n_after.value
+        flat = np.zeros((k, 7), dtype=np.uint64)
+        ctx.check(ctx.lib.zk_memory_gen_final_values(ctx.handle, gen, flat.ctypes.data if k else None))
+        rows = max(128, 1 << max(k - 1, 0).bit_length())
+        after = torch.empty((MEM_CONTINUATION_COLUMNS, rows), dtype=torch.int64, device=f"cuda:{device}")
+        ctx.check(ctx.lib.zk_memory_gen_mem_after_trace(ctx.handle, gen, rows.bit_length() - 1,
+                                                        C.c_void_p(after.data_ptr()), rows))
+    finally:
+        ctx.lib.zk_memory_gen_free(gen)
+    final = [((int(e[0]), int(e[1]), int(e[2])), sum(int(e[3 + l]) << (64 * l) for l in range(4))) for e in flat]
+    return trace, after, final, unpadded
+
+
 def initial_memory_merkle_cap(kernel_code: bytes, rate_bits: int, cap_height: int, hasher: int = 0, device=0,
                               ctx: Context = None) -> np.ndarray:
     """`initial_memory_merkle_cap::<F, C, D>(rate_bits, cap_height)` (verifier.rs:14-78) for a given kernel image
