@@ -380,6 +380,17 @@ int zk_keccak_sponge_generate_trace(zk_ctx *ctx, const uint64_t *ops, size_t n_o
 int zk_range_check_columns(zk_ctx *ctx, uint64_t *d_trace, size_t col_stride, size_t n_trace_cols, unsigned log_n,
                            size_t first_col, size_t n_cols, size_t counter_col, size_t freq_col, uint64_t range_max);
 
+/* Arithmetic table: replaces `ArithmeticStark::generate_trace` (arithmetic/arithmetic_stark.rs:158-190) and
+ * `Operation::to_rows` (arithmetic/mod.rs:253-359: addcy.rs, mul.rs, modular.rs, divmod.rs, shift.rs, byte.rs).
+ * ops (host): n_ops x 18 words = code, opcode, input0, input1, input2, result (four 64-bit little-endian limbs each).
+ * code is the operation's flag column: 0 ADD, 1 MUL, 2 SUB, 3 DIV, 4 MOD, 5 ADDMOD, 6 MULMOD, 7 ADDFP254, 8 MULFP254,
+ * 9 SUBFP254, 10 SUBMOD, 11 LT, 12 GT, 13 BYTE (input0 = index), 14 SHL, 15 SHR (input0 = shift, input1 = value),
+ * 16 = RangeCheckOperation (opcode and result are only read for this one; every other result is recomputed).
+ * DIV, MOD, SHR and the modular operations take two rows.  116 columns column-major on the device, zero rows up to
+ * 2^log_n >= max(rows, 2^16), range-check columns included; *n_rows_out = rows used by operations. */
+int zk_arithmetic_generate_trace(zk_ctx *ctx, const uint64_t *ops, size_t n_ops, unsigned log_n, uint64_t *d_out,
+                                 size_t col_stride, size_t *n_rows_out);
+
 /* Memory table: replaces `MemoryStark::generate_trace` (evm_arithmetization/src/memory/memory_stark.rs:405-455 and
  * everything it calls, :104-403) -- the sort by (context, segment, virt, timestamp), `fill_gaps`, `pad_memory_ops`,
  * `into_row`, the first-change flags / range_check / frequencies / stale-context columns and the extraction of the

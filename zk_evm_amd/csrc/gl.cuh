@@ -12,6 +12,7 @@
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
+typedef long long i64;
 
 #define GL_P 0xFFFFFFFF00000001ULL
 #define GL_EPS 0xFFFFFFFFULL

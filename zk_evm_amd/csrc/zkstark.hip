@@ -30,6 +30,7 @@
 #include "airs.cuh"
 #include "tracegen.cuh"
 #include "memtrace.cuh"
+#include "arithtrace.cuh"
 #include "host_hash.hpp"
 
 // ------------------------------------------------------------------------------------------

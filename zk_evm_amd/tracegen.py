@@ -95,6 +95,48 @@ def memory_continuation_generate_trace(mem_values: Sequence[Tuple[Tuple[int, int
     return out
 
 
+ARITHMETIC_COLUMNS = 116
+# the operation's flag column (arithmetic/columns.rs:25-45); 16 = RangeCheckOperation
+(ARITH_ADD, ARITH_MUL, ARITH_SUB, ARITH_DIV, ARITH_MOD, ARITH_ADDMOD, ARITH_MULMOD, ARITH_ADDFP254, ARITH_MULFP254,
+ ARITH_SUBFP254, ARITH_SUBMOD, ARITH_LT, ARITH_GT, ARITH_BYTE, ARITH_SHL, ARITH_SHR, ARITH_RANGE_CHECK) = range(17)
+_ARITH_TWO_ROWS = (ARITH_DIV, ARITH_MOD, ARITH_SHR, ARITH_ADDMOD, ARITH_MULMOD, ARITH_SUBMOD, ARITH_ADDFP254,
+                   ARITH_MULFP254, ARITH_SUBFP254)
+
+
+def arithmetic_generate_trace(operations, device=0, ctx: Context = None):
+    """`ArithmeticStark::generate_trace(operations)` (arithmetic_stark.rs:158-190) on the device.  operations:
+    (code, input0, input1) for binary operations (BYTE: index, value; SHL / SHR: shift, value; FP254: two inputs),
+    (code, input0, input1, input2) for ADDMOD / MULMOD / SUBMOD, (ARITH_RANGE_CHECK, input0, input1, input2, opcode,
+    result) for range-check rows.  -> (CUDA int64 (116, max(2^16, pow2(rows))), rows used)."""
+    import torch
+    ctx = ctx or default_context(device)
+    ctx.use_torch_current_stream()
+    m64 = (1 << 64) - 1
+    n_ops = len(operations)
+    flat = np.zeros((n_ops, 18), dtype=np.uint64)
+    rows = 0
+    for r, op in enumerate(operations):
+        code = int(op[0])
+        if code == ARITH_RANGE_CHECK:
+            _, a, b, c, opcode, res = op
+        else:
+            a, b = op[1], op[2]
+            c = op[3] if len(op) > 3 else 0
+            opcode, res = 0, 0
+        flat[r, 0], flat[r, 1] = code, opcode
+        for k, v in enumerate((a, b, c, res)):
+            if not 0 <= v < 1 << 256:
+                raise ZkStarkError(-1, "operands are U256")
+            flat[r, 2 + 4 * k:6 + 4 * k] = [(v >> (64 * l)) & m64 for l in range(4)]
+        rows += 2 if code in _ARITH_TWO_ROWS else 1
+    n = max(1 << max(rows - 1, 0).bit_length(), 1 << 16)
+    out = torch.empty((ARITHMETIC_COLUMNS, n), dtype=torch.int64, device=f"cuda:{device}")
+    used = C.c_size_t()
+    ctx.check(ctx.lib.zk_arithmetic_generate_trace(ctx.handle, flat.ctypes.data if n_ops else None, n_ops,
+                                                   n.bit_length() - 1, C.c_void_p(out.data_ptr()), n, C.byref(used)))
+    return out, used.value
+
+
 MEMORY_COLUMNS = 30
 
 
