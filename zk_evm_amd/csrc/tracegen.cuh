@@ -105,30 +105,32 @@ __global__ void range_counter_kernel(u64 *__restrict__ counter, u64 *__restrict_
     counter[i] = i < range_max ? i : range_max - 1;
     freq[i] = 0;
 }
-// grid: (row blocks, checked columns).  Small ranges (bytes) use a per-block LDS histogram, large ones global atomics.
+// grid: (row blocks, checked columns).  Values below ZK_RC_LDS_BINS go through a per-block LDS histogram -- that is all
+// of a byte range, and for the 16-bit range of the Arithmetic table it takes the hot cells (0, 1, the 15 / 16 of the
+// offset auxiliary limbs), which as same-address global atomics would serialise in L2; the rest are spread over the
+// range and go to global atomics directly.
 #define ZK_RC_LDS_BINS 4096
 __global__ void __launch_bounds__(256)
 range_histogram_kernel(const u64 *__restrict__ cols, size_t stride, u32 n, u32 rows_per_block, u32 range_max,
                        unsigned long long *__restrict__ freq, int *__restrict__ err_flag) {
     __shared__ u32 bins[ZK_RC_LDS_BINS];
-    const bool use_lds = range_max <= ZK_RC_LDS_BINS;
-    if (use_lds) {
-        for (u32 b = threadIdx.x; b < range_max; b += blockDim.x) bins[b] = 0;
-        __syncthreads();
-    }
+    const u32 lds_bins = range_max < ZK_RC_LDS_BINS ? range_max : ZK_RC_LDS_BINS;
+    for (u32 b = threadIdx.x; b < lds_bins; b += blockDim.x) bins[b] = 0;
+    __syncthreads();
     const u64 *c = cols + (size_t)blockIdx.y * stride;
     const u32 lo = blockIdx.x * rows_per_block, hi = lo + rows_per_block < n ? lo + rows_per_block : n;
+    u32 zeros = 0;
     for (u32 i = lo + threadIdx.x; i < hi; i += blockDim.x) {
         const u64 x = gl_canon(c[i]);
         if (x >= range_max) { atomicExch(err_flag, 1); continue; }   // the reference asserts
-        if (use_lds) atomicAdd(&bins[(u32)x], 1u);
+        if (x == 0) ++zeros;
+        else if (x < lds_bins) atomicAdd(&bins[(u32)x], 1u);
         else atomicAdd(&freq[x], 1ULL);
     }
-    if (use_lds) {
-        __syncthreads();
-        for (u32 b = threadIdx.x; b < range_max; b += blockDim.x)
-            if (bins[b]) atomicAdd(&freq[b], (unsigned long long)bins[b]);
-    }
+    if (zeros) atomicAdd(&bins[0], zeros);
+    __syncthreads();
+    for (u32 b = threadIdx.x; b < lds_bins; b += blockDim.x)
+        if (bins[b]) atomicAdd(&freq[b], (unsigned long long)bins[b]);
 }
 
 // ---- Logic table ----------------------------------------------------------------------------------------
