@@ -48,11 +48,18 @@ def parse():
     ap.add_argument("--cols", type=int, default=116)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--hasher", type=int, default=0)
+    ap.add_argument("--log-ns", type=str, default="",
+                    help="nine comma-separated table heights (log2) instead of --log-n for all; 'realistic' = the upper "
+                         "ends of the per-table ranges of the reference's scripts/prove_stdio.rs:89-101")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=16)
     ap.add_argument("--proof-steps", type=int, default=0,
                     help="also time N full ArithmeticStark table proofs (0 disables)")
     return ap.parse_args()
+
+
+# Arithmetic, BytePacking, Cpu, Keccak, KeccakSponge, Logic, Memory, MemBefore, MemAfter (scripts/prove_stdio.rs:89-101)
+REALISTIC_LOG_NS = [17, 14, 19, 17, 13, 16, 21, 19, 19]
 
 
 def cpu_baseline(cols, log_n, sample_log_n, hasher):
@@ -352,6 +359,10 @@ def main():
         import zk_evm_amd.segment as sg
         from zk_evm_amd.all_stark import TABLE_COLUMNS, TABLE_NAMES, AllStark
         log_ns = [a.log_n] * 9
+        if a.log_ns:
+            log_ns = REALISTIC_LOG_NS if a.log_ns == "realistic" else [int(x) for x in a.log_ns.split(",")]
+            assert len(log_ns) == 9, "--log-ns takes nine heights"
+        uniform = len(set(log_ns)) == 1
         traces = synthetic_segment_traces(log_ns, dev, seed=1 + rank)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
@@ -386,7 +397,7 @@ def main():
             seg_traffic, seg_valu = None, None
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get("segment")
-                if pm and a.log_n == 20 and a.hasher == 0:
+                if pm and log_ns == [20] * 9 and a.hasher == 0:
                     seg_traffic = pm["leaf_hash_hbm_bytes_per_launch"]
                     ach = pm["leaf_hash_valu_wave_insts_per_launch"] / (leaf_ms / max(tot["commits"], 1) * 1e-3)
                     seg_valu = {"wave_insts_per_launch": pm["leaf_hash_valu_wave_insts_per_launch"],
@@ -398,12 +409,13 @@ def main():
                 pass
             cells = segment_committed_cells(log_ns)
             out = {
-                "metric": "segment STARK proofs/sec (2^20-row traces, all nine AllStark tables)",
+                "metric": "segment STARK proofs/sec (2^20-row traces, all nine AllStark tables)" if log_ns == [20] * 9 else
+                          "segment STARK proofs/sec (table heights 2^%s)" % ",".join(map(str, log_ns)),
                 "value": world * a.steps / elapsed, "unit": "segment proofs/s", "n_gpus": world, "steps": a.steps,
                 "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                 "config": {"workload": f"prove_with_traces: full AllStark segment proof (BASELINE configs[2]), 9 tables x "
-                                       f"2^{a.log_n} rows ({sum(TABLE_COLUMNS)} trace columns, {trace_bytes / 1e9:.1f} GB), "
+                                       f"2^{log_ns[0] if uniform else log_ns} rows ({sum(TABLE_COLUMNS)} trace columns, {trace_bytes / 1e9:.1f} GB), "
                                        f"10 CTLs + lookups, standard_fast_config, hasher {hname}",
                            "parallelism": f"{world} independent segments (one per GPU), no collective",
                            "committed_cells": cells, "proof_words": proof_words},
