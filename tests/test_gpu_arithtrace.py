@@ -94,3 +94,23 @@ def test_error_paths():
         arithmetic_generate_trace([(17, 1, 2)])
     with pytest.raises(ZkStarkError):
         arithmetic_generate_trace([(0, 1 << 256, 2)])
+
+
+def test_packed_array_is_passed_through():
+    import torch
+    from tests.test_oracle_tracegen import sample_arith_ops
+    from zk_evm_amd.tracegen import arithmetic_generate_trace
+    ops = _to_product(sample_arith_ops(np.random.default_rng(5)))
+    m64 = (1 << 64) - 1
+    flat = np.zeros((len(ops), 18), dtype=np.uint64)
+    for r, op in enumerate(ops):
+        if op[0] == 16:
+            _, a, b, c, opcode, res = op
+        else:
+            a, b, c, opcode, res = op[1], op[2], (op[3] if len(op) > 3 else 0), 0, 0
+        flat[r, 0], flat[r, 1] = op[0], opcode
+        for k, v in enumerate((a, b, c, res)):
+            flat[r, 2 + 4 * k:6 + 4 * k] = [(v >> (64 * l)) & m64 for l in range(4)]
+    t1, u1 = arithmetic_generate_trace(ops)
+    t2, u2 = arithmetic_generate_trace(flat)
+    assert torch.equal(t1, t2) and u1 == u2

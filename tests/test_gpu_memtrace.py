@@ -114,3 +114,19 @@ def test_error_paths():
         memory_generate_trace([(True, 1, (900, 0, 0), False, 5)], [], [])   # context beyond the trace height
     with pytest.raises(ZkStarkError):                                # 2^31 virt gap over a 2-operation log
         memory_generate_trace([op, (True, 2, (0, 0, 1 << 31), False, 5), (True, 3, (0, 0, (1 << 32) - 1), False, 5)], [], [])
+
+
+def test_packed_arrays_are_passed_through():
+    """(n, 9) / (n, 7) uint64 arrays in the C ABI's record layout give the same table as the tuple form."""
+    import torch
+    from tests.test_oracle_tracegen import sample_memory_ops
+    from zk_evm_amd.tracegen import memory_generate_trace
+    ops, before, stale = sample_memory_ops(np.random.default_rng(21), 50)
+    pops, pbefore = _to_product(ops, before)
+    m64 = (1 << 64) - 1
+    a = np.array([[(1 if r else 0) | (2 if f else 0), ts, c, s, v] + [(val >> (64 * l)) & m64 for l in range(4)]
+                  for f, ts, (c, s, v), r, val in pops], dtype=np.uint64)
+    b = np.array([[c, s, v] + [(val >> (64 * l)) & m64 for l in range(4)] for (c, s, v), val in pbefore], dtype=np.uint64)
+    t1, a1, f1, u1 = memory_generate_trace(pops, pbefore, stale)
+    t2, a2, f2, u2 = memory_generate_trace(a, b, stale)
+    assert torch.equal(t1, t2) and torch.equal(a1, a2) and f1 == f2 and u1 == u2

@@ -113,9 +113,16 @@ def arithmetic_generate_trace(operations, device=0, ctx: Context = None):
     ctx.use_torch_current_stream()
     m64 = (1 << 64) - 1
     n_ops = len(operations)
-    flat = np.zeros((n_ops, 18), dtype=np.uint64)
-    rows = 0
-    for r, op in enumerate(operations):
+    packed = isinstance(operations, np.ndarray)          # the C ABI's own record layout: (n_ops, 18) uint64
+    if packed:
+        if operations.dtype != np.uint64 or operations.ndim != 2 or operations.shape[1] != 18:
+            raise ZkStarkError(-1, "packed operations are a (n, 18) uint64 array (include/zkstark.h)")
+        flat = np.ascontiguousarray(operations)
+        rows = int(np.isin(flat[:, 0], _ARITH_TWO_ROWS).sum()) + n_ops
+    else:
+        flat = np.zeros((n_ops, 18), dtype=np.uint64)
+        rows = 0
+    for r, op in enumerate(() if packed else operations):
         code = int(op[0])
         if code == ARITH_RANGE_CHECK:
             _, a, b, c, opcode, res = op
@@ -151,12 +158,23 @@ def memory_generate_trace(memory_ops, mem_before_values=(), stale_contexts=(), d
     ctx.use_torch_current_stream()
     m64 = (1 << 64) - 1
     n_ops, n_before = len(memory_ops), len(mem_before_values)
-    ops = np.zeros((n_ops, 9), dtype=np.uint64)
-    for r, (filt, ts, (c, s, v), is_read, val) in enumerate(memory_ops):
-        ops[r] = [(1 if is_read else 0) | (2 if filt else 0), ts, c, s, v] + [(val >> (64 * l)) & m64 for l in range(4)]
-    before = np.zeros((n_before, 7), dtype=np.uint64)
-    for r, ((c, s, v), val) in enumerate(mem_before_values):
-        before[r] = [c, s, v] + [(val >> (64 * l)) & m64 for l in range(4)]
+    # numpy arrays in the C ABI's record layout ((n, 9) / (n, 7) uint64, include/zkstark.h) are passed through
+    if isinstance(memory_ops, np.ndarray):
+        if memory_ops.dtype != np.uint64 or memory_ops.ndim != 2 or memory_ops.shape[1] != 9:
+            raise ZkStarkError(-1, "packed memory operations are a (n, 9) uint64 array")
+        ops = np.ascontiguousarray(memory_ops)
+    else:
+        ops = np.zeros((n_ops, 9), dtype=np.uint64)
+        for r, (filt, ts, (c, s, v), is_read, val) in enumerate(memory_ops):
+            ops[r] = [(1 if is_read else 0) | (2 if filt else 0), ts, c, s, v] + [(val >> (64 * l)) & m64 for l in range(4)]
+    if isinstance(mem_before_values, np.ndarray):
+        if mem_before_values.dtype != np.uint64 or mem_before_values.ndim != 2 or mem_before_values.shape[1] != 7:
+            raise ZkStarkError(-1, "packed mem_before values are a (n, 7) uint64 array")
+        before = np.ascontiguousarray(mem_before_values)
+    else:
+        before = np.zeros((n_before, 7), dtype=np.uint64)
+        for r, ((c, s, v), val) in enumerate(mem_before_values):
+            before[r] = [c, s, v] + [(val >> (64 * l)) & m64 for l in range(4)]
     stale = np.array([int(x) for x in stale_contexts], dtype=np.uint64)
     gen = C.c_void_p()
     ctx.check(ctx.lib.zk_memory_trace_begin(ctx.handle, ops.ctypes.data if n_ops else None, n_ops,
