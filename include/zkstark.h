@@ -243,6 +243,7 @@ typedef enum {
                                     cpu/syscalls_exceptions.rs:68,73) */
     ZK_AIR_KECCAK_SPONGE = 7,    /* keccak_sponge/keccak_sponge_stark.rs:546-715 */
     ZK_AIR_KECCAK = 6,           /* keccak/keccak_stark.rs:266-426 + keccak/round_flags.rs:14-60 */
+    ZK_AIR_POSEIDON = 9,         /* `cdk_erigon` only: poseidon/poseidon_stark.rs:445-690 (322 columns) */
     ZK_AIR_ARITHMETIC = 5,       /* arithmetic/arithmetic_stark.rs:203-252 + mul/addcy/divmod/modular/byte/shift */
 } zk_air;
 /* starky `compute_quotient_polys` + chunk split + `PolynomialBatch::from_coeffs`:
@@ -390,6 +391,15 @@ int zk_range_check_columns(zk_ctx *ctx, uint64_t *d_trace, size_t col_stride, si
  * 2^log_n >= max(rows, 2^16), range-check columns included; *n_rows_out = rows used by operations. */
 int zk_arithmetic_generate_trace(zk_ctx *ctx, const uint64_t *ops, size_t n_ops, unsigned log_n, uint64_t *d_out,
                                  size_t col_stride, size_t *n_rows_out);
+
+/* Poseidon table (`cdk_erigon`): replaces `PoseidonStark::generate_trace` (poseidon/poseidon_stark.rs:183-425).
+ * ops (host): n_ops x 13 words.  word 0 = kind: 0 = PoseidonSimpleOp, words 1..12 = the permutation input (field
+ * elements); 1 = PoseidonGeneralOp, words 1..6 = context, segment, virt, timestamp, len, number of input bytes -- the
+ * (already padded) input is the next `bytes` bytes of `inputs`, a multiple of 56 = FELT_MAX_BYTES * SPONGE_RATE, one
+ * row per 56-byte block; the reference indexes `is_final_input_len` with len % 56, so len % 56 < 8 is required.
+ * 322 columns column-major on the device; rows after the operations hold the permutation of the zero state. */
+int zk_poseidon_generate_trace(zk_ctx *ctx, const uint64_t *ops, size_t n_ops, const uint8_t *inputs, size_t input_bytes,
+                               unsigned log_n, uint64_t *d_out, size_t col_stride);
 
 /* Memory table: replaces `MemoryStark::generate_trace` (evm_arithmetization/src/memory/memory_stark.rs:405-455 and
  * everything it calls, :104-403) -- the sort by (context, segment, virt, timestamp), `fill_gaps`, `pad_memory_ops`,

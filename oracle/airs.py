@@ -953,3 +953,8 @@ def make_eval_cpu(halt_pc, start_pc, syscall_jumptable, exception_jumptable):
 
 CPU_TEST_CONSTS = (31337, 4242, 777777, 888888)
 AIRS.update({8: (make_eval_cpu(*CPU_TEST_CONSTS), 85)})
+
+
+# ---- cdk_erigon Poseidon table (oracle/poseidon_table.py) ----
+from .poseidon_table import eval_poseidon  # noqa: E402
+AIRS.update({9: (eval_poseidon, 322)})

@@ -233,3 +233,53 @@ def generate_trace(operations, min_rows):
     generate_perm(pad, [0] * WIDTH)
     rows += [pad] * (n - len(rows))
     return np.array(rows, dtype=np.uint64).T.copy()
+
+
+# ---- CTL roles (poseidon_stark.rs:35-137); Table::Poseidon = 9 ----
+POSEIDON_TABLE = 9
+
+
+def _h():
+    from . import all_stark as A
+    return A
+
+
+def ctl_looked_simple_op():
+    A = _h()
+    cols = [A.S(INPUT + i) for i in range(WIDTH)] + [A.S(DIGEST_COL + i) for i in range(2 * DIGEST)]
+    return A.TWC(POSEIDON_TABLE, cols, A.simple(A.S(IS_SIMPLE_OP)))
+
+
+def ctl_looked_general_output():
+    A = _h()
+    cols = [A.S(DIGEST_COL + i) for i in range(2 * DIGEST)] + [A.S(TIMESTAMP)]
+    filt = A.prod(A.LC([(IS_FINAL_INPUT_LEN + i, 1) for i in range(RATE)]), A.LC([(IS_SIMPLE_OP, -1)], 1))
+    return A.TWC(POSEIDON_TABLE, cols, filt)
+
+
+def ctl_looked_general_input():
+    A = _h()
+    return A.TWC(POSEIDON_TABLE, [A.S(CONTEXT), A.S(SEGMENT), A.S(VIRT), A.S(LEN), A.S(TIMESTAMP)],
+                 A.simple(A.S(IS_FIRST_ROW_GENERAL_OP)))
+
+
+def ctl_looking_memory(i):
+    """Byte i of the 56-byte block: (is_read = 1, context, segment, virt + already_absorbed + i, byte, 0 x 7,
+    timestamp); the first byte of each 7-byte element is input - sum_j input_bytes[j] * 256^(j+1)."""
+    A = _h()
+    from .stark import Column
+    e, j = divmod(i, FELT_MAX_BYTES)
+    if j == 0:
+        byte = A.LC([(INPUT + e, 1)] + [(INPUT_BYTES + 6 * e + k, -(1 << (8 * (k + 1)))) for k in range(FELT_MAX_BYTES - 1)])
+    else:
+        byte = A.S(INPUT_BYTES + 6 * e + j - 1)
+    cols = [A.K(1), A.S(CONTEXT), A.S(SEGMENT), A.LC([(VIRT, 1), (ALREADY_ABSORBED, 1)], i), byte]
+    cols += [Column() for _ in range(7)] + [A.S(TIMESTAMP)]
+    return A.TWC(POSEIDON_TABLE, cols, A.prod(A.S(NOT_PADDING), A.LC([(IS_SIMPLE_OP, -1)], 1)))
+
+
+def ctl_roles():
+    """z-data of the table in `cross_table_lookup_data` order under cdk_erigon: the 56 Memory lookers (CTL 6), then
+    looked in poseidon_simple (10), general_input (11), general_output (12) -- all_stark.rs:153-172."""
+    return [[ctl_looking_memory(i) for i in range(BLOCK_BYTES)], [ctl_looked_simple_op()], [ctl_looked_general_input()],
+            [ctl_looked_general_output()]]

@@ -97,6 +97,7 @@ SIGNATURES = {
     "zk_keccak_generate_trace": (C.c_int, [vp, u64p, u64p, sz, ui, u64p, sz]),
     "zk_range_check_columns": (C.c_int, [vp, u64p, sz, sz, ui, sz, sz, sz, sz, C.c_uint64]),
     "zk_logic_generate_trace": (C.c_int, [vp, u64p, sz, ui, u64p, sz]),
+    "zk_poseidon_generate_trace": (C.c_int, [vp, u64p, sz, vp, sz, ui, u64p, sz]),
     "zk_arithmetic_generate_trace": (C.c_int, [vp, u64p, sz, ui, u64p, sz, C.POINTER(sz)]),
     "zk_memory_trace_begin": (C.c_int, [vp, u64p, sz, u64p, sz, C.POINTER(vp)]),
     "zk_memory_gen_unpadded_length": (sz, [vp]),

@@ -4,6 +4,7 @@
 // Column indices follow the reference's `#[repr(C)]` column structs.
 #pragma once
 #include "quotient.cuh"
+#include "poseidon.cuh"
 
 // no table constraints (lookup / CTL checks only) -- used by the generic-machinery tests
 struct AirNone {
@@ -1005,5 +1006,100 @@ struct AirCpu {
             c.constraint(fex * (exc_code - stop) * nv[CH0 + VAL + 1]);
             for (u32 i = 2; i < 6; ++i) c.constraint(tf * nv[CH0 + VAL + i]);
         }
+    }
+};
+
+// PoseidonStark (`cdk_erigon` feature): poseidon/poseidon_stark.rs:445-690, columns poseidon/columns.rs:14-94.
+// The reference evaluates the partial rounds through plonky2's sparse "fast" factorisation; the plain round function
+// used here (constant vector, S-box on word 0, full MDS) yields the identical constraint polynomials -- between two
+// S-boxes both forms are the same affine map of (state after the first full rounds, S-box outputs so far), see
+// oracle/poseidon_table.py -- and on this chip the plain MDS layer (24 v_mad_u64_u32 per row with inline constants,
+// next round's constants as the accumulators' start values: pos_mds) is also the cheaper one.
+struct AirPoseidon {
+    static constexpr u32 COLUMNS = 322;
+    enum : u32 { CONTEXT = 0, SEGMENT, VIRT, TIMESTAMP, LEN, ALREADY_ABSORBED, IS_FINAL_INPUT_LEN = 6, IS_FULL_INPUT_BLOCK = 14,
+                 INPUT = 15, CUBED_FULL = 27, CUBED_PARTIAL = 123, FULL_SBOX_0 = 145, PARTIAL_SBOX = 181, FULL_SBOX_1 = 203,
+                 DIGEST = 251, OUTPUT_PARTIAL = 259, PINV = 267, INPUT_BYTES = 271, IS_SIMPLE_OP = 319,
+                 IS_FIRST_ROW_GENERAL_OP = 320, NOT_PADDING = 321 };
+    template <class CONS>
+    __device__ static __forceinline__ void eval(const RowView &lv, const RowView &nv, CONS &c, const u64 *) {
+        constexpr u32 W = 12, RATE = 8, DG = 4;
+        const Fe one = FE_ONE;
+        Fe is_full = lv[IS_FULL_INPUT_BLOCK];
+        c.constraint(is_full * (is_full - one));
+        Fe is_final;
+        for (u32 i = 0; i < RATE; ++i) is_final += lv[IS_FINAL_INPUT_LEN + i];
+        c.constraint(is_final * (is_final - one));
+        for (u32 i = 0; i < RATE; ++i) { Fe f = lv[IS_FINAL_INPUT_LEN + i]; c.constraint(f * (f - one)); }
+        Fe first_general = lv[IS_FIRST_ROW_GENERAL_OP];
+        c.constraint(first_general * (first_general - one));
+        c.constraint(is_final * is_full);
+        Fe absorbed = lv[ALREADY_ABSORBED], len = lv[LEN];
+        c.constraint_first_row(absorbed);
+        for (u32 i = RATE; i < W; ++i) c.constraint_first_row(len * lv[INPUT + i]);
+        c.constraint_transition(is_final * nv[ALREADY_ABSORBED]);
+        Fe nlen = nv[LEN];
+        for (u32 i = RATE; i < W; ++i) c.constraint_transition(nlen * is_final * nv[INPUT + i]);
+        for (u32 col = CONTEXT; col <= TIMESTAMP; ++col) c.constraint_transition(is_full * (lv[col] - nv[col]));
+        c.constraint_transition(is_full * (absorbed + fe(56) - nv[ALREADY_ABSORBED]));   // FELT_MAX_BYTES * RATE
+        for (u32 i = 0; i < W - RATE; ++i)
+            c.constraint_transition(is_full * (lv[DIGEST + 2 * i] + lv[DIGEST + 2 * i + 1] * fe(1ull << 32) - nv[INPUT + RATE + i]));
+        Fe is_dummy = one - is_full - is_final;
+        Fe next_is_final;
+        for (u32 i = 0; i < RATE; ++i) next_is_final += nv[IS_FINAL_INPUT_LEN + i];
+        c.constraint_transition(is_dummy * (nv[IS_FULL_INPUT_BLOCK] + next_is_final));
+        Fe offset = len - absorbed;
+        for (u32 i = 0; i < RATE; ++i) c.constraint(len * lv[IS_FINAL_INPUT_LEN + i] * (offset - fe(56 - i)));
+
+        // ---- the permutation, plain rounds ----
+        u64 s[12];
+#pragma unroll
+        for (u32 i = 0; i < W; ++i) s[i] = gl_add(lv[INPUT + i].v, ZK_RC[i]);
+        int round = 0;
+#pragma unroll 1
+        for (u32 r = 0; r < 4; ++r) {
+#pragma unroll
+            for (u32 i = 0; i < W; ++i) {
+                if (r != 0) {
+                    Fe sbox_in = lv[FULL_SBOX_0 + W * (r - 1) + i];
+                    c.constraint(Fe(s[i]) - sbox_in);
+                    s[i] = sbox_in.v;
+                }
+                Fe cube = lv[CUBED_FULL + W * r + i];
+                c.constraint(Fe(gl_mul(gl_sqr(s[i]), s[i])) - cube);
+                s[i] = gl_mul(s[i], gl_sqr(cube.v));
+            }
+            ++round;
+            pos_mds<true>(s, &ZK_RCS[round * 12]);
+        }
+#pragma unroll 1
+        for (u32 r = 0; r < 22; ++r) {
+            Fe sbox_in = lv[PARTIAL_SBOX + r];
+            c.constraint(Fe(s[0]) - sbox_in);
+            Fe cube = lv[CUBED_PARTIAL + r];
+            c.constraint(Fe(gl_mul(gl_sqr(sbox_in.v), sbox_in.v)) - cube);
+            s[0] = gl_mul(gl_sqr(cube.v), sbox_in.v);
+            ++round;
+            pos_mds<true>(s, &ZK_RCS[round * 12]);
+        }
+#pragma unroll 1
+        for (u32 r = 0; r < 4; ++r) {
+#pragma unroll
+            for (u32 i = 0; i < W; ++i) {
+                Fe sbox_in = lv[FULL_SBOX_1 + W * r + i];
+                c.constraint(Fe(s[i]) - sbox_in);
+                Fe cube = lv[CUBED_FULL + W * (4 + r) + i];
+                c.constraint(Fe(gl_mul(gl_sqr(sbox_in.v), sbox_in.v)) - cube);
+                s[i] = gl_mul(sbox_in.v, gl_sqr(cube.v));
+            }
+            ++round;
+            if (r < 3) pos_mds<true>(s, &ZK_RCS[round * 12]);
+            else pos_mds<false>(s, nullptr);
+        }
+        for (u32 i = 0; i < DG; ++i)
+            c.constraint(Fe(s[i]) - (lv[DIGEST + 2 * i] + lv[DIGEST + 2 * i + 1] * fe(1ull << 32)));
+        for (u32 i = DG; i < W; ++i) c.constraint(Fe(s[i]) - lv[OUTPUT_PARTIAL + i - DG]);
+        for (u32 i = 0; i < DG; ++i)
+            c.constraint(((lv[DIGEST + 2 * i + 1] - fe(0xFFFFFFFFull)) * lv[PINV + i] - one) * lv[DIGEST + 2 * i]);
     }
 };

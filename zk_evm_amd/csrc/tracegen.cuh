@@ -7,6 +7,7 @@
 // keccak-f on 25 registers: noise next to the 2431 stores) instead of chaining rows through memory.
 #pragma once
 #include "gl.cuh"
+#include "poseidon.cuh"
 
 #define ZK_KECCAK_COLUMNS 2431
 __device__ static const u64 ZK_KTRACE_RC[24] = {
@@ -278,4 +279,122 @@ __global__ void keccak_sponge_trace_kernel(const u64 *__restrict__ ops, const un
         put(436, 0); put(437, 0);
         if (!full) break;
     }
+}
+
+// ---- Poseidon table (`cdk_erigon`) -----------------------------------------------------------------------------
+// `PoseidonStark::generate_trace_rows` / `generate_perm` (poseidon/poseidon_stark.rs:183-405).  One lane per unit: an
+// operation (a general operation walks its 56-byte blocks in sequence: the digest of one row is the capacity of the
+// next) or one padding row (the permutation of the zero state).  The table is zero-filled beforehand.
+// tab: [n_ops][16] = {kind, a1..a12 (simple: the 12 inputs; general: context, segment, virt, timestamp, len, bytes),
+//                     byte offset into `data`, first row, unused}
+__device__ inline void poseidon_table_perm_row(u64 *__restrict__ out, size_t cs, u32 row, u64 (&s)[12]) {
+    enum : u32 { INPUT = 15, CUBED_FULL = 27, CUBED_PARTIAL = 123, FULL_SBOX_0 = 145, PARTIAL_SBOX = 181, FULL_SBOX_1 = 203,
+                 DIGEST = 251, OUTPUT_PARTIAL = 259, PINV = 267 };
+    auto put = [&](u32 col, u64 v) { out[(size_t)col * cs + row] = v; };
+#pragma unroll
+    for (u32 i = 0; i < 12; ++i) { s[i] = gl_canon(s[i]); put(INPUT + i, s[i]); s[i] = gl_add(s[i], ZK_RC[i]); }
+    int round = 0;
+#pragma unroll 1
+    for (u32 r = 0; r < 4; ++r) {
+#pragma unroll
+        for (u32 i = 0; i < 12; ++i) {
+            const u64 x = gl_canon(s[i]);
+            if (r != 0) put(FULL_SBOX_0 + 12 * (r - 1) + i, x);
+            const u64 cube = gl_canon(gl_mul(gl_sqr(x), x));
+            put(CUBED_FULL + 12 * r + i, cube);
+            s[i] = gl_mul(x, gl_sqr(cube));
+        }
+        ++round;
+        pos_mds<true>(s, &ZK_RCS[round * 12]);
+    }
+#pragma unroll 1
+    for (u32 r = 0; r < 22; ++r) {
+        const u64 x = gl_canon(s[0]);
+        put(PARTIAL_SBOX + r, x);
+        const u64 cube = gl_canon(gl_mul(gl_sqr(x), x));
+        put(CUBED_PARTIAL + r, cube);
+        s[0] = gl_mul(x, gl_sqr(cube));
+        ++round;
+        pos_mds<true>(s, &ZK_RCS[round * 12]);
+    }
+#pragma unroll 1
+    for (u32 r = 0; r < 4; ++r) {
+#pragma unroll
+        for (u32 i = 0; i < 12; ++i) {
+            const u64 x = gl_canon(s[i]);
+            put(FULL_SBOX_1 + 12 * r + i, x);
+            const u64 cube = gl_canon(gl_mul(gl_sqr(x), x));
+            put(CUBED_FULL + 12 * (4 + r) + i, cube);
+            s[i] = gl_mul(x, gl_sqr(cube));
+        }
+        ++round;
+        if (r < 3) pos_mds<true>(s, &ZK_RCS[round * 12]);
+        else pos_mds<false>(s, nullptr);
+    }
+#pragma unroll
+    for (u32 i = 0; i < 12; ++i) s[i] = gl_canon(s[i]);
+    for (u32 i = 0; i < 4; ++i) {
+        const u64 lo = s[i] & 0xFFFFFFFFull, hi = s[i] >> 32;
+        const u64 d = gl_canon(gl_sub(hi, 0xFFFFFFFFull));
+        put(PINV + i, d ? gl_canon(gl_inv(d)) : 0);
+        put(DIGEST + 2 * i, lo);
+        put(DIGEST + 2 * i + 1, hi);
+    }
+    for (u32 i = 4; i < 12; ++i) put(OUTPUT_PARTIAL + i - 4, s[i]);
+}
+
+__global__ void __launch_bounds__(64)
+poseidon_table_trace_kernel(const u64 *__restrict__ tab, const unsigned char *__restrict__ data, u32 n_ops, u32 rows_used, u32 n_rows,
+                            u64 *__restrict__ out, size_t cs) {
+    enum : u32 { CONTEXT = 0, SEGMENT, VIRT, TIMESTAMP, LEN, ALREADY_ABSORBED, IS_FINAL_INPUT_LEN = 6, IS_FULL_INPUT_BLOCK = 14,
+                 INPUT_BYTES = 271, IS_SIMPLE_OP = 319, IS_FIRST_ROW_GENERAL_OP = 320, NOT_PADDING = 321 };
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 n_pad = n_rows - rows_used;
+    if (t >= n_ops + n_pad) return;
+    auto put = [&](u32 col, u32 row, u64 v) { out[(size_t)col * cs + row] = v; };
+    u64 s[12];
+    if (t >= n_ops) {                                            // padding row
+#pragma unroll
+        for (u32 i = 0; i < 12; ++i) s[i] = 0;
+        poseidon_table_perm_row(out, cs, rows_used + (t - n_ops), s);
+        return;
+    }
+    const u64 *o = tab + (size_t)t * 16;
+    const u32 row0 = (u32)o[14];
+    if (o[0] == 0) {                                             // generate_row_for_simple_op
+#pragma unroll
+        for (u32 i = 0; i < 12; ++i) s[i] = o[1 + i];
+        poseidon_table_perm_row(out, cs, row0, s);
+        put(IS_FINAL_INPUT_LEN + 7, row0, 1);
+        put(NOT_PADDING, row0, 1);
+        put(IS_SIMPLE_OP, row0, 1);
+        return;
+    }
+    const u64 len = o[5];
+    const u32 n_blocks = (u32)(o[6] / 56), last_non_padding = (u32)(len % 56);
+    const unsigned char *in = data + o[13];
+    u64 cap[4] = {0, 0, 0, 0}, absorbed = 0;
+    for (u32 k = 0; k < n_blocks; ++k) {                         // generate_rows_for_general_op
+        const u32 row = row0 + k;
+        const unsigned char *blk = in + (size_t)k * 56;
+        for (u32 i = 0; i < 8; ++i) {
+            u64 v = 0;
+            for (u32 j = 0; j < 7; ++j) v |= (u64)blk[7 * i + j] << (8 * j);
+            s[i] = v;
+            for (u32 j = 0; j < 6; ++j) put(INPUT_BYTES + 6 * i + j, row, blk[7 * i + 1 + j]);
+        }
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) s[8 + i] = cap[i];
+        const bool is_last = k + 1 == n_blocks;
+        if (is_last) put(IS_FINAL_INPUT_LEN + last_non_padding, row, 1);
+        else put(IS_FULL_INPUT_BLOCK, row, 1);
+        put(CONTEXT, row, o[1]); put(SEGMENT, row, o[2]); put(VIRT, row, o[3]); put(TIMESTAMP, row, o[4]);
+        put(LEN, row, len); put(ALREADY_ABSORBED, row, absorbed);
+        put(NOT_PADDING, row, 1);
+        poseidon_table_perm_row(out, cs, row, s);
+        absorbed += is_last ? last_non_padding : 56;
+#pragma unroll
+        for (u32 i = 0; i < 4; ++i) cap[i] = s[i];              // digest limbs recombined = the canonical word
+    }
+    put(IS_FIRST_ROW_GENERAL_OP, row0, 1);
 }

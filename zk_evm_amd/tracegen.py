@@ -95,6 +95,42 @@ def memory_continuation_generate_trace(mem_values: Sequence[Tuple[Tuple[int, int
     return out
 
 
+POSEIDON_COLUMNS = 322
+GOLDILOCKS_P = 0xFFFFFFFF00000001
+
+
+def poseidon_generate_trace(operations, min_rows: int, device=0, ctx: Context = None):
+    """`PoseidonStark::generate_trace(operations, min_rows)` (poseidon/poseidon_stark.rs:407-425; `cdk_erigon`).
+    operations: ("simple", [12 field elements]) for PoseidonSimpleOp, ("general", (context, segment, virt), timestamp,
+    padded input bytes, len) for PoseidonGeneralOp.  -> CUDA int64 (322, max(rows, min_rows).next_power_of_two())."""
+    import torch
+    ctx = ctx or default_context(device)
+    ctx.use_torch_current_stream()
+    n_ops = len(operations)
+    flat = np.zeros((n_ops, 13), dtype=np.uint64)
+    data = bytearray()
+    rows = 0
+    for r, op in enumerate(operations):
+        if op[0] == "simple":
+            if len(op[1]) != 12 or any(not 0 <= int(x) < GOLDILOCKS_P for x in op[1]):
+                raise ZkStarkError(-1, "a simple operation takes 12 canonical field elements")
+            flat[r, 1:13] = [int(x) for x in op[1]]
+            rows += 1
+        else:
+            _, (c, s, v), ts, inp, length = op
+            inp = bytes(inp)
+            flat[r, 0:7] = [1, c, s, v, ts, length, len(inp)]
+            data += inp
+            rows += len(inp) // 56
+    log_n = _pow2_log(max(rows, min_rows, 1))
+    out = torch.empty((POSEIDON_COLUMNS, 1 << log_n), dtype=torch.int64, device=f"cuda:{device}")
+    buf = np.frombuffer(bytes(data), dtype=np.uint8) if data else np.zeros(0, dtype=np.uint8)
+    ctx.check(ctx.lib.zk_poseidon_generate_trace(ctx.handle, flat.ctypes.data if n_ops else None, n_ops,
+                                                 buf.ctypes.data if buf.size else None, buf.size, log_n,
+                                                 C.c_void_p(out.data_ptr()), 1 << log_n))
+    return out
+
+
 ARITHMETIC_COLUMNS = 116
 # the operation's flag column (arithmetic/columns.rs:25-45); 16 = RangeCheckOperation
 (ARITH_ADD, ARITH_MUL, ARITH_SUB, ARITH_DIV, ARITH_MOD, ARITH_ADDMOD, ARITH_MULMOD, ARITH_ADDFP254, ARITH_MULFP254,
