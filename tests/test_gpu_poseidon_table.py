@@ -60,3 +60,18 @@ def test_error_paths():
         poseidon_generate_trace([("general", (0, 0, 0), 1, bytes(112), 70)], 4)      # len % 56 >= 8
     with pytest.raises(ZkStarkError):
         poseidon_generate_trace([("simple", [pt.P] * 12)], 4)
+
+
+def test_random_trace_proof_matches_oracle_prover_word_for_word(oracle):
+    """As for the nine eth_mainnet tables (tests/test_gpu_stark_prove.py): on a RANDOM (non-satisfying) 322-column
+    trace the GPU table proof -- auxiliary / quotient caps, openings, FRI proof -- equals the oracle prover's, i.e.
+    the device AIR is the oracle's constraint polynomial system in the same order."""
+    from tests.test_gpu_stark_prove import _run_case
+    role = _descs()
+
+    def fix(trace, rng):                                   # filters must be binary: one-hot is_final_input_len
+        pick = rng.integers(0, 9, size=trace.shape[1])
+        for i in range(8):
+            trace[pt.IS_FINAL_INPUT_LEN + i] = (pick == i).astype(np.uint64)
+    _run_case(oracle, 9, 322, 5, 0, [], [role[1], role[3]], seed=23, trace_fix=fix,
+              binary_cols=(pt.IS_SIMPLE_OP, pt.IS_FIRST_ROW_GENERAL_OP, pt.NOT_PADDING))
