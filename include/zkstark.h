@@ -243,6 +243,8 @@ typedef enum {
                                     cpu/syscalls_exceptions.rs:68,73) */
     ZK_AIR_KECCAK_SPONGE = 7,    /* keccak_sponge/keccak_sponge_stark.rs:546-715 */
     ZK_AIR_KECCAK = 6,           /* keccak/keccak_stark.rs:266-426 + keccak/round_flags.rs:14-60 */
+    ZK_AIR_CPU_ERIGON = 10,      /* the Cpu table of a `cdk_erigon` build: 86 columns (`poseidon` flag after
+                                  * jumpdest_keccak_general), no JUMPDEST-bit read; air_consts as for ZK_AIR_CPU */
     ZK_AIR_POSEIDON = 9,         /* `cdk_erigon` only: poseidon/poseidon_stark.rs:445-690 (322 columns) */
     ZK_AIR_ARITHMETIC = 5,       /* arithmetic/arithmetic_stark.rs:203-252 + mul/addcy/divmod/modular/byte/shift */
 } zk_air;

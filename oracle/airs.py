@@ -478,6 +478,8 @@ C_OPS = ["binary_op", "ternary_op", "fp254_op", "eq_iszero", "logic_op", "not_po
          "exit_kernel", "m_op_general", "pc_push0", "syscall", "exception"]
 C_OP = {name: 6 + i for i, name in enumerate(C_OPS)}
 C_BITS, C_GEN, C_CLOCK = 24, 32, 40
+# `cdk_erigon`: one more flag after jumpdest_keccak_general (cpu/columns/ops.rs:22-25); every later column moves by one
+C_OPS_ERIGON = C_OPS[:8] + ["poseidon"] + C_OPS[8:]
 SEG_STACK, SEG_SHIFT_TABLE, SEG_JUMPDEST_BITS, SEG_CODE_ = 1, 13, 14, 0
 
 
@@ -488,17 +490,19 @@ class _Chan:
 
 
 class _CpuRow:
-    def __init__(self, v):
+    def __init__(self, v, erigon=False):
         self.v = v
+        names = C_OPS_ERIGON if erigon else C_OPS
+        x = 1 if erigon else 0
         self.context, self.code_context, self.program_counter = v[0], v[1], v[2]
         self.stack_len, self.is_kernel_mode, self.gas = v[3], v[4], v[5]
-        self.op = {name: v[C_OP[name]] for name in C_OPS}
-        self.ops = [v[6 + i] for i in range(18)]          # struct field order
-        self.opcode_bits = list(v[24:32])
-        self.g = list(v[32:40])
-        self.clock = v[40]
-        self.mem_channels = [_Chan(v, 41 + 13 * k) for k in range(3)]
-        self.partial_channel = _Chan(v, 80, True)
+        self.op = {name: v[6 + i] for i, name in enumerate(names)}
+        self.ops = [v[6 + i] for i in range(len(names))]  # struct field order
+        self.opcode_bits = list(v[24 + x:32 + x])
+        self.g = list(v[32 + x:40 + x])
+        self.clock = v[40 + x]
+        self.mem_channels = [_Chan(v, 41 + x + 13 * k) for k in range(3)]
+        self.partial_channel = _Chan(v, 80 + x, True)
     # general (union) views
     @property
     def exc_code_bits(self): return self.g[0:3]
@@ -580,9 +584,15 @@ def _stack_eval_one(lv, nv, filt, sb, c):
     c.constraint_transition(filt * (nv.stack_len - (lv.stack_len - num_pops + (1 if pushes else 0))))
 
 
-def make_eval_cpu(halt_pc, start_pc, syscall_jumptable, exception_jumptable):
+def make_eval_cpu(halt_pc, start_pc, syscall_jumptable, exception_jumptable, cdk_erigon=False):
+    """cdk_erigon=True: the 86-column variant (`poseidon` flag): contextops.rs:26-27, control_flow.rs:11-23,
+    decode.rs:10,41-42, gas.rs:30-31, jumps.rs:124-150 (no JUMPDEST-bit read), stack.rs:106-119,353-369."""
+    C_OPS = C_OPS_ERIGON if cdk_erigon else globals()["C_OPS"]
+    _SB = dict(globals()["_SB"], poseidon=None)
+    _GAS = dict(globals()["_GAS"], **({"poseidon": 0} if cdk_erigon else {}))
+
     def eval_cpu(lv_raw, nv_raw, c):
-        lv, nv = _CpuRow(lv_raw), _CpuRow(nv_raw)
+        lv, nv = _CpuRow(lv_raw, cdk_erigon), _CpuRow(nv_raw, cdk_erigon)
         b = lv.opcode_bits
         # byte_unpacking.rs
         filt = lv.op["m_op_32bytes"] * (b[5] - 1)
@@ -645,8 +655,8 @@ def make_eval_cpu(halt_pc, start_pc, syscall_jumptable, exception_jumptable):
         next_halt = 1 - is_cpu_next
         c.constraint_transition(is_cpu * (is_cpu_next + next_halt - 1))
         native = sum(lv.op[k] for k in ("binary_op", "ternary_op", "fp254_op", "eq_iszero", "logic_op", "not_pop",
-                                        "shift", "jumpdest_keccak_general", "pc_push0", "dup_swap", "context_op",
-                                        "m_op_general"))
+                                        "shift", "jumpdest_keccak_general") + (("poseidon",) if cdk_erigon else ()) +
+                     ("pc_push0", "dup_swap", "context_op", "m_op_general"))
         c.constraint_transition(native * (lv.program_counter - nv.program_counter + 1))
         c.constraint_transition(native * (lv.is_kernel_mode - nv.is_kernel_mode))
         is_pi = lv.op["push_prover_input"] * b[7]
@@ -662,7 +672,8 @@ def make_eval_cpu(halt_pc, start_pc, syscall_jumptable, exception_jumptable):
         c.constraint(km * (km - 1))
         for bit in b:
             c.constraint(bit * (bit - 1))
-        OPCODES = [(0x14, 1, False, "eq_iszero"), (0x56, 1, False, "jumps"), (0x80, 5, False, "dup_swap"),
+        OPCODES = [(0x14, 1, False, "eq_iszero")] + ([(0x22, 1, True, "poseidon")] if cdk_erigon else []) + \
+                  [(0x56, 1, False, "jumps"), (0x80, 5, False, "dup_swap"),
                    (0xf6, 1, True, "context_op"), (0xf9, 0, True, "exit_kernel")]
         COMBINED = ["logic_op", "fp254_op", "binary_op", "ternary_op", "shift", "m_op_general",
                     "jumpdest_keccak_general", "not_pop", "pc_push0", "m_op_32bytes", "push_prover_input"]
@@ -778,13 +789,14 @@ def make_eval_cpu(halt_pc, start_pc, syscall_jumptable, exception_jumptable):
         c.constraint(f * (sj - 1) * cond_sum)
         c.constraint(f * (lv.cond_sum_pinv * cond_sum - sj))
         c.constraint(f * sj * sum(dst[1:]))
-        jd = lv.mem_channels[2]
-        c.constraint(f * (jd.value[0] - 1))
-        c.constraint(f * (jd.used - sj * (1 - lv.is_kernel_mode)))
-        c.constraint(f * (jd.is_read - 1))
-        c.constraint(f * (jd.addr_context - lv.context))
-        c.constraint(f * (jd.addr_segment - SEG_JUMPDEST_BITS))
-        c.constraint(f * (jd.addr_virtual - dst[0]))
+        if not cdk_erigon:                                   # "We skip jump destinations verification with cdk_erigon"
+            jd = lv.mem_channels[2]
+            c.constraint(f * (jd.value[0] - 1))
+            c.constraint(f * (jd.used - sj * (1 - lv.is_kernel_mode)))
+            c.constraint(f * (jd.is_read - 1))
+            c.constraint(f * (jd.addr_context - lv.context))
+            c.constraint(f * (jd.addr_segment - SEG_JUMPDEST_BITS))
+            c.constraint(f * (jd.addr_virtual - dst[0]))
         c.constraint(f * lv.partial_channel.used)
         c.constraint(is_jump * lv.mem_channels[1].used)
         c.constraint_transition(is_jump * (nv.stack_len - lv.stack_len + 1))
@@ -897,6 +909,9 @@ def make_eval_cpu(halt_pc, start_pc, syscall_jumptable, exception_jumptable):
                 c.constraint_transition(lv.op[name] * (diff * lv.stack_len_bounds_aux - (1 - nv.is_kernel_mode)))
         _stack_eval_one(lv, nv, lv.op["jumpdest_keccak_general"] * b[1], (0, False, True), c)
         _stack_eval_one(lv, nv, lv.op["jumpdest_keccak_general"] * (1 - b[1]), (2, True, True), c)
+        if cdk_erigon:                                           # POSEIDON (3 pops) / POSEIDON_GENERAL (2 pops)
+            _stack_eval_one(lv, nv, lv.op["poseidon"] * (1 - b[0]), (3, True, True), c)
+            _stack_eval_one(lv, nv, lv.op["poseidon"] * b[0], (2, True, True), c)
         npop = lv.op["not_pop"]
         c.constraint(npop * ((lv.stack_len - 1) * lv.stack_inv - lv.stack_inv_aux))
         trc = nv.mem_channels[0]
@@ -952,7 +967,7 @@ def make_eval_cpu(halt_pc, start_pc, syscall_jumptable, exception_jumptable):
 
 
 CPU_TEST_CONSTS = (31337, 4242, 777777, 888888)
-AIRS.update({8: (make_eval_cpu(*CPU_TEST_CONSTS), 85)})
+AIRS.update({8: (make_eval_cpu(*CPU_TEST_CONSTS), 85), 10: (make_eval_cpu(*CPU_TEST_CONSTS, cdk_erigon=True), 86)})
 
 
 # ---- cdk_erigon Poseidon table (oracle/poseidon_table.py) ----

@@ -245,3 +245,26 @@ def test_cpu_table(oracle):
             trace[c] = rng.integers(0, 2, size=n, dtype=np.uint64)
     _run_case(oracle, 8, 85, 5, 0, [], [ctl_mem, ctl_logic], seed=17, trace_fix=fix,
               air_consts=oairs.CPU_TEST_CONSTS)
+
+
+def test_cpu_table_cdk_erigon(oracle):
+    # The 86-column Cpu table of a `cdk_erigon` build (AIR id 10: `poseidon` flag at column 14, everything after it one
+    # further; contextops / control_flow / decode / gas / stack gain their poseidon terms, jumps loses the
+    # JUMPDEST-bit read).  CTLs: the three looking shapes this feature adds, cpu_stark.rs:465-544.
+    from oracle import airs as oairs
+    ch = lambda k: 42 + 13 * k
+    pos_flag, bit0, clock = 14, 25, 41
+    simple_cols = [("lc", [(ch(k) + 5 + 2 * i, 1), (ch(k) + 5 + 2 * i + 1, 1 << 32)], [], 0) for k in range(3) for i in range(4)] + \
+                  [("next", ch(0) + 5 + i) for i in range(8)]
+    f_simple = ("full", [(("single", pos_flag), ("lc", [(bit0, 0xFFFFFFFF00000001 - 1)], [], 1))], [])
+    f_general = ("full", [(("single", pos_flag), ("single", bit0))], [])
+    general_in = [("single", ch(0) + 5 + 2), ("single", ch(0) + 5 + 1), ("single", ch(0) + 5), ("single", ch(1) + 5),
+                  ("lc", [(clock, 5)], [], 0)]
+    general_out = [("next", ch(0) + 5 + i) for i in range(8)] + [("lc", [(clock, 5)], [], 0)]
+
+    def fix(trace, rng):
+        n = trace.shape[1]
+        for c in list(range(6, 25)) + [ch(0), 4] + list(range(25, 33)):
+            trace[c] = rng.integers(0, 2, size=n, dtype=np.uint64)
+    _run_case(oracle, 10, 86, 5, 0, [], [[(simple_cols, f_simple)], [(general_in, f_general)], [(general_out, f_general)]],
+              seed=19, trace_fix=fix, air_consts=oairs.CPU_TEST_CONSTS)

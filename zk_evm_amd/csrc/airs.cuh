@@ -582,15 +582,22 @@ struct AirKeccakSponge {
 // opcode_bits 24..31, general union 32..39, clock 40, mem_channels[3] 41..79, partial_channel 80..84.
 // air_consts = { halt_final pc, init pc, syscall_jumptable, exception_jumptable } -- kernel labels that
 // only the reference's assembler can produce (cpu/control_flow.rs:37-47, syscalls_exceptions.rs:68,73).
-struct AirCpu {
-    static constexpr u32 COLUMNS = 85;
+// ERIGON = true is the `cdk_erigon` build of the table: one more operation flag, `poseidon`, after
+// jumpdest_keccak_general (cpu/columns/ops.rs:22-25) -- every later column moves by one (86 columns) -- and the
+// differences of contextops.rs:26-27, control_flow.rs:11-23, decode.rs:10,41-42, gas.rs:30-31, jumps.rs:124-150 (no
+// JUMPDEST-bit read), stack.rs:106-119,353-369.
+template <bool ERIGON>
+struct AirCpuT {
+    static constexpr u32 X = ERIGON ? 1 : 0;
+    static constexpr u32 COLUMNS = 85 + X;
+    static constexpr u32 N_OPS = 18 + X;
     enum { CTX = 0, CODE_CTX, PC, STACK_LEN, KERNEL, GAS };
-    enum { BINARY_OP = 6, TERNARY_OP, FP254_OP, EQ_ISZERO, LOGIC_OP, NOT_POP, SHIFT, JUMPDEST_KECCAK_GENERAL, JUMPS,
-           PUSH_PROVER_INPUT, DUP_SWAP, CONTEXT_OP, M_OP_32BYTES, EXIT_KERNEL, M_OP_GENERAL, PC_PUSH0, SYSCALL,
-           EXCEPTION };
-    enum { BITS = 24, GEN = 32, CLOCK = 40, CH0 = 41, CH1 = 54, CH2 = 67, PARTIAL = 80 };
+    enum { BINARY_OP = 6, TERNARY_OP, FP254_OP, EQ_ISZERO, LOGIC_OP, NOT_POP, SHIFT, JUMPDEST_KECCAK_GENERAL,
+           POSEIDON = 14 /* only when ERIGON */, JUMPS = 14 + X, PUSH_PROVER_INPUT, DUP_SWAP, CONTEXT_OP, M_OP_32BYTES,
+           EXIT_KERNEL, M_OP_GENERAL, PC_PUSH0, SYSCALL, EXCEPTION };
+    enum { BITS = 24 + X, GEN = 32 + X, CLOCK = 40 + X, CH0 = 41 + X, CH1 = 54 + X, CH2 = 67 + X, PARTIAL = 80 + X };
     enum { USED = 0, IS_READ = 1, ACTX = 2, ASEG = 3, AVIRT = 4, VAL = 5 };
-    enum { STACK_INV = 36, STACK_INV_AUX = 37, STACK_INV_AUX_2 = 38, STACK_LEN_BOUNDS_AUX = 39 };
+    enum { STACK_INV = 36 + X, STACK_INV_AUX = 37 + X, STACK_INV_AUX_2 = 38 + X, STACK_LEN_BOUNDS_AUX = 39 + X };
     static constexpr u64 SEG_STACK = 1, SEG_SHIFT_TABLE = 13, SEG_JUMPDEST_BITS = 14, SEG_CODE = 0;
     __device__ static __forceinline__ u32 ch(u32 k) { return CH0 + 13 * k; }
 
@@ -703,8 +710,9 @@ struct AirCpu {
         {
             c.constraint_transition(is_cpu * (is_cpu_next + next_halt - one));
             Fe native = lv[BINARY_OP] + lv[TERNARY_OP] + lv[FP254_OP] + lv[EQ_ISZERO] + lv[LOGIC_OP] + lv[NOT_POP] +
-                        lv[SHIFT] + lv[JUMPDEST_KECCAK_GENERAL] + lv[PC_PUSH0] + lv[DUP_SWAP] + lv[CONTEXT_OP] +
-                        lv[M_OP_GENERAL];
+                        lv[SHIFT] + lv[JUMPDEST_KECCAK_GENERAL];
+            if (ERIGON) native += lv[POSEIDON];
+            native = native + lv[PC_PUSH0] + lv[DUP_SWAP] + lv[CONTEXT_OP] + lv[M_OP_GENERAL];
             Fe dpc = lv[PC] - nv[PC] + one, dk = lv[KERNEL] - nv[KERNEL];
             c.constraint_transition(native * dpc);
             c.constraint_transition(native * dk);
@@ -723,17 +731,23 @@ struct AirCpu {
             c.constraint(km * (km - one));
             for (u32 i = 0; i < 8; ++i) c.constraint(b[i] * (b[i] - one));
             // OPCODES: (opcode, block_length, kernel_only, flag column)
-            constexpr u32 OC[5] = {0x14, 0x56, 0x80, 0xf6, 0xf9};
-            constexpr u32 BL[5] = {1, 1, 5, 1, 0};
-            constexpr bool KO[5] = {false, false, false, true, true};
-            constexpr u32 COL[5] = {EQ_ISZERO, JUMPS, DUP_SWAP, CONTEXT_OP, EXIT_KERNEL};
+            // (the cdk_erigon POSEIDON block 0x22-0x23 sits second in the list; without the feature its slot is skipped)
+            constexpr u32 NOC = 6;
+            constexpr u32 OC[NOC] = {0x14, 0x22, 0x56, 0x80, 0xf6, 0xf9};
+            constexpr u32 BL[NOC] = {1, 1, 1, 5, 1, 0};
+            constexpr bool KO[NOC] = {false, true, false, false, true, true};
+            constexpr u32 COL[NOC] = {EQ_ISZERO, POSEIDON, JUMPS, DUP_SWAP, CONTEXT_OP, EXIT_KERNEL};
             constexpr u32 COMBINED[11] = {LOGIC_OP, FP254_OP, BINARY_OP, TERNARY_OP, SHIFT, M_OP_GENERAL,
                                           JUMPDEST_KECCAK_GENERAL, NOT_POP, PC_PUSH0, M_OP_32BYTES, PUSH_PROVER_INPUT};
             Fe flag_sum;
-            for (u32 k = 0; k < 5; ++k) { Fe f = lv[COL[k]]; c.constraint(f * (f - one)); flag_sum += f; }
+            for (u32 k = 0; k < NOC; ++k) {
+                if (k == 1 && !ERIGON) continue;
+                Fe f = lv[COL[k]]; c.constraint(f * (f - one)); flag_sum += f;
+            }
             for (u32 k = 0; k < 11; ++k) { Fe f = lv[COMBINED[k]]; c.constraint(f * (f - one)); flag_sum += f; }
             c.constraint(flag_sum * (flag_sum - one));
-            for (u32 k = 0; k < 5; ++k) {
+            for (u32 k = 0; k < NOC; ++k) {
+                if (k == 1 && !ERIGON) continue;
                 Fe unavailable = KO[k] ? one - km : Fe();
                 Fe mismatch;
                 for (int i = 7; i >= (int)BL[k]; --i) mismatch += ((OC[k] >> i) & 1) ? one - b[i] : b[i];
@@ -784,13 +798,20 @@ struct AirCpu {
         // ---- gas.rs ----
         {
             // SIMPLE_OPCODES in struct field order: (column, cost)
-            constexpr u32 GC[9] = {FP254_OP, EQ_ISZERO, LOGIC_OP, SHIFT, DUP_SWAP, CONTEXT_OP, M_OP_32BYTES, M_OP_GENERAL, PC_PUSH0};
-            constexpr u64 GV[9] = {0, 3, 3, 3, 3, 0, 0, 0, 2};
+            constexpr u32 NG = 10;                      // slot 4 = poseidon (KERNEL_ONLY_INSTR = 0), cdk_erigon only
+            constexpr u32 GC[NG] = {FP254_OP, EQ_ISZERO, LOGIC_OP, SHIFT, POSEIDON, DUP_SWAP, CONTEXT_OP, M_OP_32BYTES, M_OP_GENERAL, PC_PUSH0};
+            constexpr u64 GV[NG] = {0, 3, 3, 3, 0, 3, 0, 0, 0, 2};
             Fe gfilt, gas_used;
-            for (u32 k = 0; k < 9; ++k) { Fe f = lv[GC[k]]; gfilt += f; gas_used += fe(GV[k]) * f; }
+            for (u32 k = 0; k < NG; ++k) {
+                if (k == 4 && !ERIGON) continue;
+                Fe f = lv[GC[k]]; gfilt += f; gas_used += fe(GV[k]) * f;
+            }
             c.constraint_transition(gfilt * (nv[GAS] - (lv[GAS] + gas_used)));
             Fe gas_diff = nv[GAS] - lv[GAS];
-            for (u32 k = 0; k < 9; ++k) c.constraint_transition(lv[GC[k]] * (gas_diff - fe(GV[k])));
+            for (u32 k = 0; k < NG; ++k) {
+                if (k == 4 && !ERIGON) continue;
+                c.constraint_transition(lv[GC[k]] * (gas_diff - fe(GV[k])));
+            }
             c.constraint_transition(lv[JUMPS] * (gas_diff - (fe(8) + b[0] * fe(2))));
             Fe cost_filter = b[0] + b[4] - b[0] * b[4];
             c.constraint_transition(lv[BINARY_OP] * (gas_diff - (fe(5) + cost_filter * (fe(3) - fe(5)))));
@@ -838,12 +859,14 @@ struct AirCpu {
             c.constraint(f * (sj - one) * cond_sum);
             c.constraint(f * (cond_sum_pinv * cond_sum - sj));
             c.constraint(f * sj * dst_hi_sum);
-            c.constraint(f * (lv[CH2 + VAL] - one));
-            c.constraint(f * (lv[CH2 + USED] - sj * (one - lv[KERNEL])));
-            c.constraint(f * (lv[CH2 + IS_READ] - one));
-            c.constraint(f * (lv[CH2 + ACTX] - lv[CTX]));
-            c.constraint(f * (lv[CH2 + ASEG] - fe(SEG_JUMPDEST_BITS)));
-            c.constraint(f * (lv[CH2 + AVIRT] - lv[CH0 + VAL]));
+            if (!ERIGON) {                                  // "We skip jump destinations verification with cdk_erigon"
+                c.constraint(f * (lv[CH2 + VAL] - one));
+                c.constraint(f * (lv[CH2 + USED] - sj * (one - lv[KERNEL])));
+                c.constraint(f * (lv[CH2 + IS_READ] - one));
+                c.constraint(f * (lv[CH2 + ACTX] - lv[CTX]));
+                c.constraint(f * (lv[CH2 + ASEG] - fe(SEG_JUMPDEST_BITS)));
+                c.constraint(f * (lv[CH2 + AVIRT] - lv[CH0 + VAL]));
+            }
             c.constraint(f * lv[PARTIAL + USED]);
             c.constraint(is_jump * lv[CH1 + USED]);
             c.constraint_transition(is_jump * (nv[STACK_LEN] - lv[STACK_LEN] + one));
@@ -946,8 +969,8 @@ struct AirCpu {
             constexpr bool PU[18] = {1, 1, 1, 0, 1, 0, 1, 0, 0, 1, 0, 0, 1, 0, 0, 1, 1, 1};
             constexpr bool DI[18] = {1, 1, 1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 1, 0, 1, 0, 0};
             constexpr bool OV[18] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
-            for (u32 k = 0; k < 18; ++k) {
-                Fe op = lv[BINARY_OP + k];
+            for (u32 k = 0; k < 18; ++k) {                       // (cdk_erigon's poseidon flag: None / false, no term)
+                Fe op = lv[BINARY_OP + k + (k >= 8 ? X : 0)];
                 if (NP[k] >= 0) stack_one(lv, nv, c, op, (u32)NP[k], PU[k], DI[k]);
                 if (OV[k]) {
                     Fe diff = nv[STACK_LEN] - fe(1025);
@@ -956,6 +979,10 @@ struct AirCpu {
             }
             stack_one(lv, nv, c, lv[JUMPDEST_KECCAK_GENERAL] * b[1], 0, false, true);          // JUMPDEST_OP
             stack_one(lv, nv, c, lv[JUMPDEST_KECCAK_GENERAL] * (one - b[1]), 2, true, true);   // KECCAK_GENERAL_OP
+            if (ERIGON) {
+                stack_one(lv, nv, c, lv[POSEIDON] * (one - b[0]), 3, true, true);               // POSEIDON_OP
+                stack_one(lv, nv, c, lv[POSEIDON] * b[0], 2, true, true);                       // POSEIDON_GENERAL_OP
+            }
             Fe npop = lv[NOT_POP];
             c.constraint(npop * ((lv[STACK_LEN] - one) * lv[STACK_INV] - lv[STACK_INV_AUX]));
             Fe is_top_read = lv[STACK_INV_AUX] * (one - b[0]);
@@ -1008,6 +1035,9 @@ struct AirCpu {
         }
     }
 };
+
+using AirCpu = AirCpuT<false>;
+using AirCpuErigon = AirCpuT<true>;
 
 // PoseidonStark (`cdk_erigon` feature): poseidon/poseidon_stark.rs:445-690, columns poseidon/columns.rs:14-94.
 // The reference evaluates the partial rounds through plonky2's sparse "fast" factorisation; the plain round function
