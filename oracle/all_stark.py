@@ -64,7 +64,46 @@ def cpu_keccak_sponge_cols():
     return [S(v0[2]), S(v0[1]), S(v0[0]), S(CHV(1)[0]), _ts()] + [N(c) for c in v0]
 
 
-def build_ctls():
+def _erigon_cpu(col):
+    """Cpu column number of the eth_mainnet layout -> `cdk_erigon` layout (`poseidon` flag inserted at 14)."""
+    return col + 1 if col >= 14 else col
+
+
+def _remap_column(c, f):
+    return Column([(f(i), k) for i, k in c.linear_combination], [(f(i), k) for i, k in c.next_row_linear_combination], c.constant)
+
+
+def _remap_twc(t, f):
+    filt = Filter([(_remap_column(a, f), _remap_column(b, f)) for a, b in t.filter.products],
+                  [_remap_column(c, f) for c in t.filter.constants])
+    return TWC(t.table, [_remap_column(c, f) for c in t.columns], filt)
+
+
+def build_ctls(cdk_erigon=False):
+    """cdk_erigon=True (all_stark.rs:103-172,344-366,419-441): every Cpu entry re-numbered for the 86-column table,
+    the code-read filter extended by the new flag (it sums ALL operation flags), 56 Poseidon-table byte reads appended
+    to the Memory CTL, and CTLs 10-12 (Poseidon simple / general input / general output)."""
+    if cdk_erigon:
+        from . import poseidon_table as PT
+        ctls = build_ctls(False)
+        for ctl in ctls:
+            ctl.looking_tables = [_remap_twc(t, _erigon_cpu) if t.table == CPU else t for t in ctl.looking_tables]
+            if ctl.looked_table.table == CPU:
+                ctl.looked_table = _remap_twc(ctl.looked_table, _erigon_cpu)
+        code_read = ctls[6].looking_tables[0]
+        code_read.filter = simple(LC([(c, 1) for c in range(6, 25)]))              # COL_MAP.op.iter(): 19 flags
+        ctls[6].looking_tables += [PT.ctl_looking_memory(i) for i in range(56)]
+        e = lambda k: 42 + 13 * k + 5                                               # mem_channels[k].value[0], 86-col layout
+        pos, bit0, clock = 14, 25, 41
+        simple_cols = [LC([(e(k) + 2 * i, 1), (e(k) + 2 * i + 1, 1 << 32)]) for k in range(3) for i in range(4)] + \
+                      [N(e(0) + i) for i in range(8)]
+        f_simple, f_general = prod(S(pos), LC([(bit0, -1)], 1)), prod(S(pos), S(bit0))
+        ctls.append(CTL([TWC(CPU, simple_cols, f_simple)], PT.ctl_looked_simple_op()))
+        ctls.append(CTL([TWC(CPU, [S(e(0) + 2), S(e(0) + 1), S(e(0)), S(e(1)), LC([(clock, NCH)])], f_general)],
+                        PT.ctl_looked_general_input()))
+        ctls.append(CTL([TWC(CPU, [N(e(0) + i) for i in range(8)] + [LC([(clock, NCH)])], prod(S(pos), S(bit0)))],
+                        PT.ctl_looked_general_output()))
+        return ctls
     v0, v1, v2 = CHV(0), CHV(1), CHV(2)
     one_minus = lambda c: LC([(c, -1)], 1)
     ctls = []
@@ -156,13 +195,26 @@ def build_ctls():
     return ctls
 
 
-def build_lookups():
+def build_lookups(cdk_erigon=False):
     """Stark::lookups() per table (arithmetic_stark.rs:320, byte_packing_stark.rs:426, keccak_sponge_stark.rs:946,
-    memory_stark.rs:858)."""
-    out = [[] for _ in range(NUM_TABLES)]
+    memory_stark.rs:858); the cdk_erigon Poseidon table has none."""
+    out = [[] for _ in range(NUM_TABLES + (1 if cdk_erigon else 0))]
     out[ARITHMETIC] = [Lookup([S(18 + i) for i in range(96)], S(114), S(115), [Filter() for _ in range(96)])]
     out[BYTE_PACKING] = [Lookup([S(37 + i) for i in range(32)], S(69), S(70), [Filter() for _ in range(32)])]
     out[KECCAK_SPONGE] = [Lookup([S(192 + i) for i in range(136)], S(436), S(437), [Filter() for _ in range(136)])]
     out[MEMORY] = [Lookup([S(27), N(6)], S(28), S(29), [Filter(), simple(LC([(15, 1), (16, 1)]))]),
                    Lookup([LC([(4, 1)], 1)], S(21), S(23), [simple(S(24))])]
     return out
+
+
+class Registry:
+    """The per-feature-set table list: eth_mainnet (9 tables, 10 CTLs) or cdk_erigon (10 tables, 13 CTLs)."""
+
+    def __init__(self, cdk_erigon=False):
+        self.cdk_erigon = cdk_erigon
+        self.NUM_TABLES = NUM_TABLES + (1 if cdk_erigon else 0)
+        self.OPTIONAL_TABLES = OPTIONAL_TABLES + ((9,) if cdk_erigon else ())
+        self.TABLE_COLUMNS = (116, 71, 86, 2431, 438, 523, 30, 12, 12, 322) if cdk_erigon else TABLE_COLUMNS
+        self.TABLE_AIR = (5, 4, 10, 6, 7, 2, 3, 1, 1, 9) if cdk_erigon else TABLE_AIR
+        self.ctls = build_ctls(cdk_erigon)
+        self.lookups = build_lookups(cdk_erigon)

@@ -35,7 +35,8 @@ def pv_elements(pv: dict):
     e += limbs(int.from_bytes(pv["beneficiary"], "big"))[:5]
     e += u32(pv["timestamp"]) + u32(pv["number"]) + u32(pv["difficulty"]) + h(pv["random"])
     e += u32(pv["gaslimit"]) + u32(pv["chain_id"]) + u64(pv["base_fee"]) + u32(pv["gas_used"])
-    e += u64(pv["blob_gas_used"]) + u64(pv["excess_blob_gas"]) + h(pv["parent_beacon_root"])
+    if pv.get("burn_addr") is None:                           # #[cfg(feature = "eth_mainnet")], get_challenges.rs:66-74
+        e += u64(pv["blob_gas_used"]) + u64(pv["excess_blob_gas"]) + h(pv["parent_beacon_root"])
     for b in pv["bloom"]:
         e += limbs(b)
     assert len(pv["prev_hashes"]) == 256
@@ -43,6 +44,8 @@ def pv_elements(pv: dict):
         e += h(b)
     e += h(pv["cur_hash"]) + h(pv["checkpoint_root"]) + [x % P for x in pv["checkpoint_hash"]]
     e += u32(pv["txn_before"]) + u32(pv["txn_after"]) + u32(pv["gas_before"]) + u32(pv["gas_after"])
+    if pv.get("burn_addr") is not None:                       # observe_burn_addr, cdk_erigon (get_challenges.rs:146-154)
+        e += limbs(pv["burn_addr"])
     return e
 
 
@@ -67,17 +70,18 @@ def cross_table_lookup_data(traces, ctls, challenges, constraint_degree):
     return per_table
 
 
-def prove_with_traces(o, fri_api, cfg, traces, table_in_use, pv, cpu_air_consts, ctls=None, lookups=None):
-    """traces: list of 9 (C_t, n_t) uint64 arrays.  Returns dict(ctl_challenges, proofs[9] (None if unused),
-    init_states[9], mem_before, mem_after, trace_caps)."""
+def prove_with_traces(o, fri_api, cfg, traces, table_in_use, pv, cpu_air_consts, ctls=None, lookups=None, reg=None):
+    """traces: list of 9 (C_t, n_t) uint64 arrays (10 with reg = A.Registry(cdk_erigon=True)).  Returns
+    dict(ctl_challenges, proofs (None if unused), init_states, mem_before, mem_after, trace_caps)."""
     from . import airs
     L = o.lib
-    ctls = ctls if ctls is not None else A.build_ctls()
-    lookups = lookups if lookups is not None else A.build_lookups()
+    reg = reg or A.Registry(False)
+    ctls = ctls if ctls is not None else reg.ctls
+    lookups = lookups if lookups is not None else reg.lookups
     commits = [o.commit_values(t, rate_bits=cfg.rate_bits, cap_height=cfg.cap_height, hasher=cfg.hasher) for t in traces]
     och = fri_api.new_challenger(o, cfg.hasher)
     for i, c in enumerate(commits):
-        if i in A.OPTIONAL_TABLES and not table_in_use[i]:
+        if i in reg.OPTIONAL_TABLES and not table_in_use[i]:
             z = np.zeros(c["cap"].size, dtype=np.uint64)
             L.orc_challenger_observe(C.byref(och), z, z.size)
         else:
@@ -92,7 +96,7 @@ def prove_with_traces(o, fri_api, cfg, traces, table_in_use, pv, cpu_air_consts,
     ctl_pairs = [(c.beta, c.gamma) for c in challenges]
     per_table = cross_table_lookup_data(traces, ctls, challenges, 3)
     proofs, inits = [], []
-    for t in range(A.NUM_TABLES):
+    for t in range(reg.NUM_TABLES):
         if not table_in_use[t]:
             proofs.append(None)
             inits.append(None)
@@ -100,7 +104,7 @@ def prove_with_traces(o, fri_api, cfg, traces, table_in_use, pv, cpu_air_consts,
         st = np.zeros(12, dtype=np.uint64)
         L.orc_challenger_compact(C.byref(och), st)
         inits.append(st)
-        air = airs.AIRS[A.TABLE_AIR[t]][0] if t != A.CPU else airs.make_eval_cpu(*cpu_air_consts)
+        air = airs.AIRS[reg.TABLE_AIR[t]][0] if t != A.CPU else airs.make_eval_cpu(*cpu_air_consts, cdk_erigon=reg.cdk_erigon)
         proofs.append(SP.prove_with_commitment(o, fri_api, cfg, air, traces[t], commits[t], lookups[t], per_table[t],
                                                ctl_pairs, och))
     mem_after = commits[A.MEM_AFTER]["cap"].copy()
@@ -141,7 +145,7 @@ GM = dict(StateTrieRootDigestBefore=6, TransactionTrieRootDigestBefore=7, Receip
           BlockBeneficiary=12, BlockTimestamp=13, BlockNumber=14, BlockDifficulty=15, BlockRandom=16,
           BlockGasLimit=17, BlockChainId=18, BlockBaseFee=19, BlockBlobGasUsed=20, BlockExcessBlobGas=21,
           BlockGasUsed=22, BlockGasUsedBefore=23, BlockGasUsedAfter=24, BlockCurrentHash=25,
-          ParentBeaconBlockRoot=26, TxnNumberBefore=42, TxnNumberAfter=43, KernelHash=45, KernelLen=46)
+          ParentBeaconBlockRoot=26, TxnNumberBefore=42, TxnNumberAfter=43, KernelHash=45, KernelLen=46, BurnAddr=53)
 REGISTER_FIELDS = ("program_counter", "is_kernel", "stack_len", "stack_top", "context", "gas_used")
 MEMORY_CTL_IDX = 6                                                                     # all_stark.rs:146
 
@@ -158,14 +162,17 @@ def public_memory_writes(pv: dict, kernel_hash: int, kernel_len: int):
               ("BlockGasLimit", pv["gaslimit"]), ("BlockChainId", pv["chain_id"]), ("BlockBaseFee", pv["base_fee"]),
               ("ParentBeaconBlockRoot", be(pv["parent_beacon_root"])), ("BlockCurrentHash", be(pv["cur_hash"])),
               ("BlockGasUsed", pv["gas_used"]), ("BlockBlobGasUsed", pv["blob_gas_used"]),
-              ("BlockExcessBlobGas", pv["excess_blob_gas"]), ("TxnNumberBefore", pv["txn_before"]),
+              ("BlockExcessBlobGas", pv["excess_blob_gas"]), ("BurnAddr", pv.get("burn_addr")),
+              ("TxnNumberBefore", pv["txn_before"]),
               ("TxnNumberAfter", pv["txn_after"]), ("BlockGasUsedBefore", pv["gas_before"]),
               ("BlockGasUsedAfter", pv["gas_after"]),
               ("StateTrieRootDigestBefore", be(rb[0])), ("TransactionTrieRootDigestBefore", be(rb[1])),
               ("ReceiptTrieRootDigestBefore", be(rb[2])), ("StateTrieRootDigestAfter", be(ra[0])),
               ("TransactionTrieRootDigestAfter", be(ra[1])), ("ReceiptTrieRootDigestAfter", be(ra[2])),
               ("KernelHash", kernel_hash), ("KernelLen", kernel_len)]
-    w = [(SEG_GLOBAL_METADATA, GM[k], v) for k, v in fields]
+    erigon = pv.get("burn_addr") is not None                  # verifier.rs:334-340 (cdk_erigon) vs :370-385 (eth_mainnet)
+    skip = ("ParentBeaconBlockRoot", "BlockBlobGasUsed", "BlockExcessBlobGas") if erigon else ("BurnAddr",)
+    w = [(SEG_GLOBAL_METADATA, GM[k], v) for k, v in fields if k not in skip]
     w += [(SEG_GLOBAL_BLOCK_BLOOM, i, pv["bloom"][i]) for i in range(8)]
     w += [(SEG_BLOCK_HASHES, i, be(pv["prev_hashes"][i])) for i in range(256)]
     for base, key in ((0, "registers_before"), (len(REGISTER_FIELDS), "registers_after")):
@@ -185,22 +192,23 @@ def get_memory_extra_looking_sum(pv, challenge, kernel_hash, kernel_len):
 
 
 def verify_proof(o, fri_api, cfg, stark_proofs, table_in_use, pv, cpu_air_consts, kernel_hash, kernel_len,
-                 is_initial=False, initial_mem_cap=None, mem_before_cap=None, ctls=None, lookups=None):
+                 is_initial=False, initial_mem_cap=None, mem_before_cap=None, ctls=None, lookups=None, reg=None):
     """verifier.rs:184-312 (+ get_challenges.rs:270-312).  stark_proofs[t]: None or dict(trace_cap, aux_cap,
     quotient_cap, openings, fri, degree_bits).  -> (ok, reason).  `initial_mem_cap` stands for
     initial_memory_merkle_cap (verifier.rs:14-78) of the kernel image in use; compared with `mem_before_cap`
     (public_values.mem_before.mem_cap) when is_initial."""
     from . import airs
     L = o.lib
-    ctls = ctls if ctls is not None else A.build_ctls()
-    lookups = lookups if lookups is not None else A.build_lookups()
+    reg = reg or A.Registry(False)
+    ctls = ctls if ctls is not None else reg.ctls
+    lookups = lookups if lookups is not None else reg.lookups
     och = fri_api.new_challenger(o, cfg.hasher)
     for t, sp in enumerate(stark_proofs):
         if sp is not None:
             cap = np.ascontiguousarray(sp["trace_cap"])
             L.orc_challenger_observe_cap(C.byref(och), cap, cap.shape[0])
         else:
-            if t not in A.OPTIONAL_TABLES or table_in_use[t]:
+            if t not in reg.OPTIONAL_TABLES or table_in_use[t]:
                 return False, "missing stark_proof for table %d" % t
             z = np.zeros((1 << cfg.cap_height) * 4, dtype=np.uint64)
             L.orc_challenger_observe(C.byref(och), z, z.size)
@@ -212,7 +220,7 @@ def verify_proof(o, fri_api, cfg, stark_proofs, table_in_use, pv, cpu_air_consts
     chal = [S.GrandProductChallenge(L.orc_challenger_get(C.byref(och)), L.orc_challenger_get(C.byref(och)))
             for _ in range(cfg.num_challenges)]
     pairs = [(c.beta, c.gamma) for c in chal]
-    per_table = cross_table_lookup_data([None] * A.NUM_TABLES, ctls, chal, 3)
+    per_table = cross_table_lookup_data([None] * reg.NUM_TABLES, ctls, chal, 3)
     from . import stark_verifier as V
     zs_first = []
     for t, sp in enumerate(stark_proofs):
@@ -225,8 +233,8 @@ def verify_proof(o, fri_api, cfg, stark_proofs, table_in_use, pv, cpu_air_consts
             continue
         st = np.zeros(12, dtype=np.uint64)
         L.orc_challenger_compact(C.byref(och), st)
-        air = airs.AIRS[A.TABLE_AIR[t]][0] if t != A.CPU else airs.make_eval_cpu(*cpu_air_consts)
-        ok, why = V.verify_stark_proof(o, fri_api, cfg, air, A.TABLE_COLUMNS[t], sp["degree_bits"], lookups[t], zd,
+        air = airs.AIRS[reg.TABLE_AIR[t]][0] if t != A.CPU else airs.make_eval_cpu(*cpu_air_consts, cdk_erigon=reg.cdk_erigon)
+        ok, why = V.verify_stark_proof(o, fri_api, cfg, air, reg.TABLE_COLUMNS[t], sp["degree_bits"], lookups[t], zd,
                                        pairs, sp, och)
         if not ok:
             return False, "table %d: %s" % (t, why)

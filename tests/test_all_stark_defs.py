@@ -25,9 +25,11 @@ def _enc(cols, filt):
     return w
 
 
-def test_ctl_definitions_agree():
-    prod, orc = pas.all_cross_table_lookups(), oas.build_ctls()
-    assert len(prod) == len(orc) == pas.NUM_CTLS == 10
+@pytest.mark.parametrize("cdk_erigon", [False, True])
+def test_ctl_definitions_agree(cdk_erigon):
+    prod, orc = pas.all_cross_table_lookups(cdk_erigon), oas.build_ctls(cdk_erigon)
+    assert len(prod) == len(orc) == (13 if cdk_erigon else pas.NUM_CTLS)       # all_stark.rs:148
+    assert pas._C.num_columns == 85                                               # the column map swap is scoped
     for i, (a, b) in enumerate(zip(prod, orc)):
         assert len(a.looking_tables) == len(b.looking_tables), i
         for j, (x, y) in enumerate(zip(a.looking_tables + [a.looked_table], b.looking_tables + [b.looked_table])):
@@ -69,6 +71,48 @@ def test_counts_match_survey():
             for col in t.columns:
                 for idx, _ in col.linear_combination + col.next_row_linear_combination:
                     assert 0 <= idx < pas.TABLE_COLUMNS[t.table]
+
+
+def test_cdk_erigon_counts():
+    """all_stark.rs:103-172,344-366,419-441: ten tables, 13 CTLs, 176 + 56 Memory lookers; tuple widths of the
+    three Poseidon CTLs (12 inputs + 8 digest limbs; 5; 8 + timestamp); every referenced column inside its table."""
+    st = pas.AllStark((1, 2, 3, 4), cdk_erigon=True)
+    reg = oas.Registry(True)
+    ctls = st.cross_table_lookups
+    assert st.num_tables == reg.NUM_TABLES == 10 and len(ctls) == 13
+    assert st.table_columns == list(reg.TABLE_COLUMNS) and st.table_air == list(reg.TABLE_AIR)
+    assert st.optional_table_indices == list(reg.OPTIONAL_TABLES)
+    assert len(ctls[pas.MEMORY_CTL_IDX].looking_tables) == 176 + 56
+    assert [len(c.looked_table.columns) for c in ctls[10:]] == [20, 5, 9]
+    assert [c.looked_table.table for c in ctls[10:]] == [9, 9, 9] and all(c.looking_tables[0].table == pas.Table.Cpu for c in ctls[10:])
+    for c in ctls:
+        for t in c.looking_tables + [c.looked_table]:
+            assert len(t.columns) == len(c.looked_table.columns)
+            for col in t.columns + [x for pr in t.filter.products for x in pr] + t.filter.constants:
+                for idx, _ in col.linear_combination + col.next_row_linear_combination:
+                    assert 0 <= idx < st.table_columns[t.table]
+    # the code-read filter sums all 19 operation flags, the new one included
+    assert sorted(i for i, _ in ctls[6].looking_tables[0].filter.constants[0].linear_combination) == list(range(6, 25))
+    from zk_evm_amd.segment import num_ctl_helpers_zs_all
+    aux = [sum(num_ctl_helpers_zs_all(ctls, t, 2, 3)[:2]) for t in range(10)]
+    assert aux == [2, 36, 24 + 6, 4, 152, 2, 8, 4, 2, 28 * 2 + 2 + 6]
+
+
+def test_cdk_erigon_public_values():
+    """get_challenges.rs:66-74,146-154,211-219: no eth_mainnet block-metadata fields, the burn address appended."""
+    import zk_evm_amd.segment as sg
+    from oracle import segment as oseg
+    from tests.consistent_segment import make_public_values
+    from tests.test_gpu_segment import to_public_values
+    d = make_public_values(np.random.default_rng(3))
+    d.update(burn_addr=(1 << 160) - 12345, blob_gas_used=0, excess_blob_gas=0, parent_beacon_root=bytes(32))
+    pv = to_public_values(d)
+    pv.burn_addr = d["burn_addr"]
+    e = sg.public_values_elements(pv)
+    assert e == oseg.pv_elements(d) and len(e) == 2217 - 12 + 8
+    pv.block_metadata.block_blob_gas_used = 1
+    with pytest.raises(sg.ZkStarkError):
+        sg.public_values_elements(pv)
 
 
 def test_public_values_range_errors():

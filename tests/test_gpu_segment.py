@@ -371,3 +371,72 @@ def test_device_generated_witness_segment_accepted_by_verify_proof(oracle):
                                 is_initial=True, initial_mem_cap=tg.initial_memory_merkle_cap(code, 1, 4, hasher=0),
                                 mem_before_cap=before_cap)
     assert ok, why
+
+
+def make_traces_cdk_erigon(rng):
+    """Ten random traces for the cdk_erigon feature set: the Cpu table gets its `poseidon` flag column (14) as part
+    of the one-hot operation flags, the Poseidon table (322 columns) binary / one-hot filter columns."""
+    from oracle import poseidon_table as pt
+    tr = make_traces(rng)
+    cpu = np.insert(tr[2], 14, 0, axis=0)                        # every later column one further
+    _one_hot(cpu, list(range(6, 25)), rng)
+    tr[2] = cpu
+    p = rng.integers(0, 1 << 64, size=(322, 16), dtype=np.uint64)
+    _one_hot(p, list(range(pt.IS_FINAL_INPUT_LEN, pt.IS_FINAL_INPUT_LEN + 8)), rng, 0.4)
+    for c in (pt.IS_SIMPLE_OP, pt.IS_FIRST_ROW_GENERAL_OP, pt.NOT_PADDING):
+        p[c] = rng.integers(0, 2, size=16, dtype=np.uint64)
+    return tr + [p]
+
+
+@pytest.mark.parametrize("in_use", [[True] * 10, [True, False, True, True, False, True, True, True, True, False]])
+def test_cdk_erigon_segment_proof_matches_oracle(oracle, in_use):
+    """The `cdk_erigon` feature set end to end (all_stark.rs:103-172: ten tables -- 86-column Cpu, Poseidon -- and 13
+    CTLs, the Poseidon table's 56 byte reads in the Memory CTL; public values without the eth_mainnet fields and with
+    the burn address): zk_prove_segment == the oracle restatement, word for word; second case with the optional
+    Poseidon table (and two others) unused."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    from oracle import airs as oairs
+    from oracle import all_stark as oas
+    from oracle import segment as oseg
+    from zk_evm_amd.all_stark import AllStark
+    ol.setup_fri_api(oracle)
+    rng = np.random.default_rng(4096)
+    traces = make_traces_cdk_erigon(rng)
+    for t, used in enumerate(in_use):
+        if not used:
+            traces[t] = np.zeros((traces[t].shape[0], 16), dtype=np.uint64)
+    pvd = make_pv(rng)
+    pvd.update(burn_addr=int(rng.integers(1, 1 << 62)) << 90, blob_gas_used=0, excess_blob_gas=0, parent_beacon_root=bytes(32))
+    kw = dict(pow_bits=3, queries=2)
+    cfg = ol.make_cfg(hasher=0, **kw)
+    reg = oas.Registry(True)
+    exp = oseg.prove_with_traces(oracle, ol, cfg, traces, in_use, pvd, oairs.CPU_TEST_CONSTS, reg=reg)
+    scfg = zk.StarkConfig(hasher=0, num_challenges=cfg.num_challenges,
+                          fri_config=zk.FriConfig(proof_of_work_bits=kw["pow_bits"], num_query_rounds=kw["queries"]))
+    dev = [torch.from_numpy(t.view(np.int64)).cuda() for t in traces]
+    pv = to_public_values(pvd)
+    pv.burn_addr = pvd["burn_addr"]
+    assert sg.public_values_elements(pv) == oseg.pv_elements(pvd)
+    st = AllStark(oairs.CPU_TEST_CONSTS, cdk_erigon=True)
+    got = sg.prove_with_traces(st, scfg, dev, in_use, pv)
+    assert got.multi_proof.ctl_challenges == exp["ctl_challenges"]
+    assert len(got.multi_proof.stark_proofs) == 10
+    for t in range(10):
+        sp, ep = got.multi_proof.stark_proofs[t], exp["proofs"][t]
+        if not in_use[t]:
+            assert sp is None and ep is None
+            continue
+        assert np.array_equal(sp.init_challenger_state, exp["init_states"][t]), t
+        assert np.array_equal(sp.proof.trace_cap, exp["trace_caps"][t]), t
+        assert np.array_equal(sp.proof.auxiliary_polys_cap, ep["aux_cap"]), t
+        assert np.array_equal(sp.proof.quotient_polys_cap, ep["quotient_cap"]), t
+        assert np.array_equal(sp.proof.openings.reshape(-1), ep["openings"]), t
+        assert np.array_equal(sp.proof.opening_proof, ep["fri"]), t
+    assert got.public_values.mem_before.mem_cap == [[int(x) for x in h] for h in exp["mem_before"]]
+    # an eth_mainnet AllStark refuses ten tables; a cdk_erigon one refuses public values without a burn address
+    with pytest.raises(zk.ZkStarkError):
+        sg.prove_with_traces(AllStark(oairs.CPU_TEST_CONSTS), scfg, dev, in_use, pv)
+    with pytest.raises(zk.ZkStarkError):
+        sg.prove_with_traces(st, scfg, dev, in_use, to_public_values(pvd))

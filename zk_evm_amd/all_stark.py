@@ -132,20 +132,30 @@ class _MemChannel:
         self.value = list(range(base + 5, base + 13))
 
 
-class _C:
-    """cpu/columns/mod.rs:56-97, ops.rs:6-47 (eth_mainnet), general.rs (8-wide union at 32)."""
-    context, code_context, program_counter, stack_len, is_kernel_mode, gas = range(6)
-    OPS = ["binary_op", "ternary_op", "fp254_op", "eq_iszero", "logic_op", "not_pop", "shift",
-           "jumpdest_keccak_general", "jumps", "push_prover_input", "dup_swap", "context_op", "m_op_32bytes",
-           "exit_kernel", "m_op_general", "pc_push0", "syscall", "exception"]
-    op = {name: 6 + i for i, name in enumerate(OPS)}
-    opcode_bits = list(range(24, 32))
-    general = list(range(32, 40))
-    push_is_not_kernel = 32           # general.push().is_not_kernel
-    context_pruning_flag = 32         # general.context_pruning().pruning_flag
-    clock = 40
-    mem_channels = [_MemChannel(41 + 13 * k) for k in range(NUM_GP_CHANNELS)]
-    partial_channel = _MemChannel(80)   # used, is_read, addr_* only (5 columns)
+class _CpuColumns:
+    """cpu/columns/mod.rs:56-97, ops.rs:6-47, general.rs (8-wide union after the opcode bits).  `cdk_erigon` adds the
+    `poseidon` flag after jumpdest_keccak_general (ops.rs:22-25): every later column moves by one."""
+
+    def __init__(self, cdk_erigon=False):
+        x = 1 if cdk_erigon else 0
+        self.context, self.code_context, self.program_counter, self.stack_len, self.is_kernel_mode, self.gas = range(6)
+        self.OPS = ["binary_op", "ternary_op", "fp254_op", "eq_iszero", "logic_op", "not_pop", "shift",
+                    "jumpdest_keccak_general"] + (["poseidon"] if cdk_erigon else []) + \
+                   ["jumps", "push_prover_input", "dup_swap", "context_op", "m_op_32bytes",
+                    "exit_kernel", "m_op_general", "pc_push0", "syscall", "exception"]
+        self.op = {name: 6 + i for i, name in enumerate(self.OPS)}
+        self.opcode_bits = list(range(24 + x, 32 + x))
+        self.general = list(range(32 + x, 40 + x))
+        self.push_is_not_kernel = 32 + x           # general.push().is_not_kernel
+        self.context_pruning_flag = 32 + x         # general.context_pruning().pruning_flag
+        self.clock = 40 + x
+        self.mem_channels = [_MemChannel(41 + x + 13 * k) for k in range(NUM_GP_CHANNELS)]
+        self.partial_channel = _MemChannel(80 + x)   # used, is_read, addr_* only (5 columns)
+        self.num_columns = 85 + x
+
+
+# the column map the cpu_ctl_* functions below read; `all_cross_table_lookups(cdk_erigon=True)` swaps it while it runs
+_C = _CpuColumns(False)
 
 
 MEM_CODE_CHANNEL_IDX = 0
@@ -602,10 +612,111 @@ def ctl_mem_after() -> CrossTableLookup:
         TableWithColumns(Table.MemAfter, memory_continuation_ctl_data(), memory_continuation_ctl_filter()))
 
 
-def all_cross_table_lookups() -> List[CrossTableLookup]:
-    """all_stark.rs:153-172 (order is part of the protocol: CTL z-data are appended per table in it)."""
-    return [ctl_arithmetic(), ctl_byte_packing(), ctl_keccak_sponge(), ctl_keccak_inputs(), ctl_keccak_outputs(),
-            ctl_logic(), ctl_memory(), ctl_mem_before(), ctl_mem_after(), ctl_context_pruning()]
+# ============================ Poseidon (cdk_erigon) ===========================================
+class _P:
+    """poseidon/columns.rs:14-94"""
+    context, segment, virt, timestamp, len, already_absorbed_elements = range(6)
+    is_final_input_len = list(range(6, 14))
+    is_full_input_block = 14
+    input = list(range(15, 27))
+    digest = list(range(251, 259))
+    input_bytes = [[271 + 6 * i + j for j in range(6)] for i in range(8)]
+    is_simple_op, is_first_row_general_op, not_padding = 319, 320, 321
+    NUM_COLUMNS = 322
+    FELT_MAX_BYTES, SPONGE_RATE = 7, 8
+
+
+POSEIDON_TABLE = 9     # Table::Poseidon (all_stark.rs:96-97)
+
+
+def poseidon_ctl_looked_simple_op() -> TableWithColumns:                    # poseidon_stark.rs:35-43
+    return TableWithColumns(POSEIDON_TABLE, Column.singles(_P.input) + Column.singles(_P.digest),
+                            Filter.new_simple(Column.single(_P.is_simple_op)))
+
+
+def poseidon_ctl_looked_general_output() -> TableWithColumns:               # poseidon_stark.rs:45-63
+    cols = Column.singles(_P.digest) + [Column.single(_P.timestamp)]
+    filt = Filter.new([(Column.sum(_P.is_final_input_len),
+                        Column.linear_combination_with_constant([(_P.is_simple_op, -1)], 1))], [])
+    return TableWithColumns(POSEIDON_TABLE, cols, filt)
+
+
+def poseidon_ctl_looked_general_input() -> TableWithColumns:                # poseidon_stark.rs:65-79
+    return TableWithColumns(POSEIDON_TABLE, Column.singles([_P.context, _P.segment, _P.virt, _P.len, _P.timestamp]),
+                            Filter.new_simple(Column.single(_P.is_first_row_general_op)))
+
+
+def poseidon_ctl_looking_memory(i: int) -> List[Column]:                    # poseidon_stark.rs:81-124
+    res = [Column.constant_col(1)] + Column.singles([_P.context, _P.segment])
+    res.append(Column.linear_combination_with_constant([(_P.virt, 1), (_P.already_absorbed_elements, 1)], i))
+    e, j = divmod(i, _P.FELT_MAX_BYTES)
+    if j == 0:
+        res.append(Column.linear_combination([(_P.input[e], 1)] +
+                                             [(_P.input_bytes[e][k], -(1 << (8 * (k + 1)))) for k in range(_P.FELT_MAX_BYTES - 1)]))
+    else:
+        res.append(Column.single(_P.input_bytes[e][j - 1]))
+    res += [Column.zero() for _ in range(1, 8)]
+    res.append(Column.single(_P.timestamp))
+    return res
+
+
+def poseidon_ctl_looking_memory_filter() -> Filter:                         # poseidon_stark.rs:126-137
+    return Filter.new([(Column.single(_P.not_padding),
+                        Column.linear_combination_with_constant([(_P.is_simple_op, -1)], 1))], [])
+
+
+def cpu_ctl_poseidon_simple_filter() -> Filter:                             # cpu_stark.rs:510-521
+    return Filter.new([(Column.single(_C.op["poseidon"]),
+                        Column.linear_combination_with_constant([(_C.opcode_bits[0], -1)], 1))], [])
+
+
+def cpu_ctl_poseidon_general_filter() -> Filter:                            # cpu_stark.rs:523-534
+    return Filter.new([(Column.single(_C.op["poseidon"]), Column.single(_C.opcode_bits[0]))], [])
+
+
+def cpu_ctl_poseidon_simple_op() -> TableWithColumns:                       # cpu_stark.rs:465-487
+    cols = []
+    for channel in range(3):
+        v = _C.mem_channels[channel].value
+        cols += [Column.linear_combination([(v[2 * i], 1), (v[2 * i + 1], 1 << 32)]) for i in range(VALUE_LIMBS // 2)]
+    cols += Column.singles_next_row(_C.mem_channels[0].value)
+    return TableWithColumns(Table.Cpu, cols, cpu_ctl_poseidon_simple_filter())
+
+
+def cpu_ctl_poseidon_general_input() -> TableWithColumns:                   # cpu_stark.rs:489-508
+    context, segment, virt = _get_addr(0)
+    cols = Column.singles([context, segment, virt, _C.mem_channels[1].value[0]])
+    cols.append(Column.linear_combination([(_C.clock, NUM_CHANNELS)]))
+    return TableWithColumns(Table.Cpu, cols, cpu_ctl_poseidon_general_filter())
+
+
+def cpu_ctl_poseidon_general_output() -> TableWithColumns:                  # cpu_stark.rs:536-544
+    cols = Column.singles_next_row(_C.mem_channels[0].value) + [Column.linear_combination([(_C.clock, NUM_CHANNELS)])]
+    return TableWithColumns(Table.Cpu, cols, cpu_ctl_poseidon_general_filter())
+
+
+def all_cross_table_lookups(cdk_erigon: bool = False) -> List[CrossTableLookup]:
+    """all_stark.rs:153-172 (order is part of the protocol: CTL z-data are appended per table in it).  With
+    `cdk_erigon`: the Cpu columns of that build, 56 more Memory lookers (the Poseidon table's byte reads,
+    all_stark.rs:344-366) and the three Poseidon CTLs (:419-441)."""
+    global _C
+    saved = _C
+    _C = _CpuColumns(cdk_erigon)
+    try:
+        memory = ctl_memory()
+        if cdk_erigon:
+            memory.looking_tables += [TableWithColumns(POSEIDON_TABLE, poseidon_ctl_looking_memory(i),
+                                                       poseidon_ctl_looking_memory_filter())
+                                      for i in range(_P.FELT_MAX_BYTES * _P.SPONGE_RATE)]
+        ctls = [ctl_arithmetic(), ctl_byte_packing(), ctl_keccak_sponge(), ctl_keccak_inputs(), ctl_keccak_outputs(),
+                ctl_logic(), memory, ctl_mem_before(), ctl_mem_after(), ctl_context_pruning()]
+        if cdk_erigon:
+            ctls += [CrossTableLookup([cpu_ctl_poseidon_simple_op()], poseidon_ctl_looked_simple_op()),
+                     CrossTableLookup([cpu_ctl_poseidon_general_input()], poseidon_ctl_looked_general_input()),
+                     CrossTableLookup([cpu_ctl_poseidon_general_output()], poseidon_ctl_looked_general_output())]
+        return ctls
+    finally:
+        _C = saved
 
 
 def table_lookups(table: int) -> List[Lookup]:
@@ -615,13 +726,25 @@ def table_lookups(table: int) -> List[Lookup]:
 
 
 class AllStark:
-    """all_stark.rs:34-76: the nine tables (by AIR id and width) plus the CTL list; `air_consts` carries the four
-    kernel labels the Cpu AIR needs (include/zkstark.h ZK_AIR_CPU)."""
+    """all_stark.rs:34-76: the tables (by AIR id and width) plus the CTL list; `air_consts` carries the four kernel
+    labels the Cpu AIR needs (include/zkstark.h ZK_AIR_CPU).  cdk_erigon=True is the ten-table feature set: the
+    86-column Cpu table (ZK_AIR_CPU_ERIGON), the Poseidon table (ZK_AIR_POSEIDON, optional) and 13 CTLs."""
 
-    def __init__(self, cpu_air_consts=(0, 0, 0, 0)):
-        self.cross_table_lookups = all_cross_table_lookups()
+    def __init__(self, cpu_air_consts=(0, 0, 0, 0), cdk_erigon: bool = False):
+        self.cdk_erigon = bool(cdk_erigon)
+        self.cross_table_lookups = all_cross_table_lookups(cdk_erigon)
         self.table_air = list(TABLE_AIR)
         self.table_columns = list(TABLE_COLUMNS)
-        self.lookups = [table_lookups(t) for t in Table.all()]
-        self.air_consts = [tuple(cpu_air_consts) if t == Table.Cpu else () for t in Table.all()]
+        self.table_names = list(TABLE_NAMES)
+        self.optional_table_indices = list(OPTIONAL_TABLE_INDICES)
+        if cdk_erigon:
+            self.table_air[Table.Cpu] = 10
+            self.table_columns[Table.Cpu] = 86
+            self.table_air.append(9)
+            self.table_columns.append(_P.NUM_COLUMNS)
+            self.table_names.append("Poseidon")
+            self.optional_table_indices.append(POSEIDON_TABLE)
+        self.num_tables = len(self.table_air)
+        self.lookups = [table_lookups(t) for t in range(self.num_tables)]
+        self.air_consts = [tuple(cpu_air_consts) if t == Table.Cpu else () for t in range(self.num_tables)]
         self.constraint_degree = 3

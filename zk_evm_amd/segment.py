@@ -90,6 +90,9 @@ class PublicValues:
     extra_block_data: ExtraBlockData = field(default_factory=ExtraBlockData)
     mem_before: MemCap = field(default_factory=MemCap)
     mem_after: MemCap = field(default_factory=MemCap)
+    # proof.rs:73-78: "Address to store the base fee to be burnt: only used when `cdk_erigon` is active" (a U256);
+    # None = eth_mainnet.  Observed after extra_block_data (get_challenges.rs:146-154,211-219).
+    burn_addr: Optional[int] = None
 
 
 class PublicValuesError(ZkStarkError):
@@ -124,8 +127,11 @@ def u256_to_u64(v: int) -> Tuple[int, int]:
 
 
 def public_values_elements(pv: PublicValues) -> List[int]:
-    """The exact element sequence `observe_public_values` feeds the transcript (get_challenges.rs:195-218,
-    eth_mainnet feature set)."""
+    """The exact element sequence `observe_public_values` feeds the transcript (get_challenges.rs:195-218).
+    `pv.burn_addr is None` = the eth_mainnet feature set; a `burn_addr` = the cdk_erigon build, where the three
+    `#[cfg(feature = "eth_mainnet")]` block-metadata fields are not observed (:66-74; `features_check`,
+    prover.rs:356-368, requires them to be zero) and the burn address is appended (:146-154)."""
+    erigon = pv.burn_addr is not None
     out: List[int] = []
     for roots in (pv.trie_roots_before, pv.trie_roots_after):          # :21-29
         for r in (roots.state_root, roots.transactions_root, roots.receipts_root):
@@ -137,9 +143,12 @@ def public_values_elements(pv: PublicValues) -> List[int]:
     out += [u256_to_u32(m.block_gaslimit), u256_to_u32(m.block_chain_id)]
     out += list(u256_to_u64(m.block_base_fee))
     out.append(u256_to_u32(m.block_gas_used))
-    out += list(u256_to_u64(m.block_blob_gas_used))
-    out += list(u256_to_u64(m.block_excess_blob_gas))
-    out += h256_limbs(m.parent_beacon_block_root)
+    if not erigon:
+        out += list(u256_to_u64(m.block_blob_gas_used))
+        out += list(u256_to_u64(m.block_excess_blob_gas))
+        out += h256_limbs(m.parent_beacon_block_root)
+    elif m.block_blob_gas_used or m.block_excess_blob_gas or any(m.parent_beacon_block_root):
+        raise ZkStarkError(-1, "features_check: the eth_mainnet block-metadata fields must be zero in a cdk_erigon proof")
     for i in range(8):
         out += u256_limbs(m.block_bloom[i])
     if len(pv.block_hashes.prev_hashes) != 256:                         # :170-180
@@ -152,6 +161,10 @@ def public_values_elements(pv: PublicValues) -> List[int]:
     out += [int(x) % P for x in e.checkpoint_consolidated_hash]
     out += [u256_to_u32(e.txn_number_before), u256_to_u32(e.txn_number_after), u256_to_u32(e.gas_used_before),
             u256_to_u32(e.gas_used_after)]
+    if pv.burn_addr is not None:                                        # observe_burn_addr (cdk_erigon)
+        if not 0 <= pv.burn_addr < 1 << 256:
+            raise PublicValuesError()
+        out += u256_limbs(pv.burn_addr)
     return out
 
 
@@ -287,8 +300,12 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
     from .context import default_context
     from .prover import encode_lookup_set, table_proof_from_handle
     from .stark import _trace_args
+    NUM_TABLES, TABLE_NAMES = all_stark.num_tables, all_stark.table_names
+    OPTIONAL_TABLE_INDICES = all_stark.optional_table_indices
     if len(trace_poly_values) != NUM_TABLES or len(table_in_use) != NUM_TABLES:
         raise ZkStarkError(-1, "expected one trace and one in-use flag per table")
+    if all_stark.cdk_erigon and public_values.burn_addr is None:
+        raise ZkStarkError(-1, "There should be an address set in cdk_erigon.")      # get_challenges.rs:216-218
     check_abort_signal(abort_signal)
     hasher = config.hasher if hasher is None else hasher
     ctx = ctx or default_context(trace_poly_values[0].device.index or 0)
@@ -301,7 +318,7 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
     wiring = encode_ctl_wiring(all_stark.cross_table_lookups)
     tables = (ZkTableIn * NUM_TABLES)()
     keep = []
-    for t in Table.all():
+    for t in range(NUM_TABLES):
         tr = trace_poly_values[t]
         n_cols, n, log_n, stride = _trace_args(tr)
         if n_cols != all_stark.table_columns[t]:
@@ -334,7 +351,7 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
         lib.zk_segment_proof_ctl_challenges(h, cc.ctypes.data, cc.size)
         ctl_challenges = [(int(cc[2 * i]), int(cc[2 * i + 1])) for i in range(nchal)]
         stark_proofs: List[Optional[StarkProofWithMetadata]] = []
-        for t in Table.all():
+        for t in range(NUM_TABLES):
             th = lib.zk_segment_proof_table(h, t)
             if not th:
                 stark_proofs.append(None)
@@ -351,7 +368,7 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
             lib.zk_segment_proof_stage_ms(h, ms, 2 + NUM_TABLES)
             timing["compute all trace commitments"] = timing.get("compute all trace commitments", 0.0) + ms[0] / 1e3
             timing["compute CTL data"] = timing.get("compute CTL data", 0.0) + ms[1] / 1e3
-            for t in Table.all():
+            for t in range(NUM_TABLES):
                 if table_in_use[t]:
                     k = "prove %s STARK" % TABLE_NAMES[t]
                     timing[k] = timing.get(k, 0.0) + ms[2 + t] / 1e3
