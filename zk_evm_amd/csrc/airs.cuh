@@ -1042,8 +1042,9 @@ using AirCpuErigon = AirCpuT<true>;
 // PoseidonStark (`cdk_erigon` feature): poseidon/poseidon_stark.rs:445-690, columns poseidon/columns.rs:14-94.
 // The reference evaluates the partial rounds through plonky2's sparse "fast" factorisation; the plain round function
 // used here (constant vector, S-box on word 0, full MDS) yields the identical constraint polynomials -- between two
-// S-boxes both forms are the same affine map of (state after the first full rounds, S-box outputs so far), see
-// oracle/poseidon_table.py -- and on this chip the plain MDS layer (24 v_mad_u64_u32 per row with inline constants,
+// S-boxes both forms are the same affine map of (state after the first full rounds, S-box outputs so far): the fast
+// form is a rewriting of the plain one valid for ANY function on word 0, hence also with the S-box outputs as free
+// symbols -- and on this chip the plain MDS layer (24 v_mad_u64_u32 per row with inline constants,
 // next round's constants as the accumulators' start values: pos_mds) is also the cheaper one.
 struct AirPoseidon {
     static constexpr u32 COLUMNS = 322;
