@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--cols", type=int, default=116)
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--hasher", type=int, default=0)
+    ap.add_argument("--cdk-erigon", action="store_true",
+                    help="the ten-table cdk_erigon feature set (86-column Cpu, Poseidon table, 13 CTLs) instead of eth_mainnet")
     ap.add_argument("--log-ns", type=str, default="",
                     help="nine comma-separated table heights (log2) instead of --log-n for all; 'realistic' = the upper "
                          "ends of the per-table ranges of the reference's scripts/prove_stdio.rs:89-101")
@@ -147,16 +149,18 @@ def table_proof_bench(ctx, dev, log_n, steps):
             "proof_words": int(pr.opening_proof.size)}
 
 
-def synthetic_segment_traces(log_ns, dev, seed=1):
+def synthetic_segment_traces(log_ns, dev, seed=1, cdk_erigon=False):
     """Random traces in HBM for the nine tables with every CTL / lookup *filter* column binary (one-hot op
     flags etc.): the helper-column kernels reject non-binary filters exactly like starky's debug assert.  Values are
-    otherwise uniform 64-bit patterns (non-canonical representatives included)."""
+    otherwise uniform 64-bit patterns (non-canonical representatives included).  cdk_erigon: ten tables (86-column
+    Cpu, Poseidon)."""
     import torch
-    from zk_evm_amd.all_stark import TABLE_COLUMNS
+    from zk_evm_amd.all_stark import AllStark
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
     out = []
-    for t, (c, l) in enumerate(zip(TABLE_COLUMNS, log_ns)):
+    x = 1 if cdk_erigon else 0
+    for t, (c, l) in enumerate(zip(AllStark((0, 0, 0, 0), cdk_erigon).table_columns, log_ns)):
         n = 1 << l
         tr = torch.randint(-(1 << 63), (1 << 63) - 1, (c, n), dtype=torch.int64, device=dev, generator=g)
 
@@ -173,8 +177,8 @@ def synthetic_segment_traces(log_ns, dev, seed=1):
         elif t == 1:
             one_hot(list(range(1, 33)))                   # BytePacking index_len
         elif t == 2:
-            one_hot(list(range(6, 24)))                   # Cpu op flags
-            binary(list(range(24, 33)) + [41, 54, 67, 80])
+            one_hot(list(range(6, 24 + x)))               # Cpu op flags
+            binary(list(range(24 + x, 33 + x)) + [41 + x, 54 + x, 67 + x, 80 + x])
         elif t == 3:
             binary([0, 23])                               # Keccak first / last round flags
         elif t == 4:                                      # KeccakSponge: none / full block / final block of length ln
@@ -191,21 +195,25 @@ def synthetic_segment_traces(log_ns, dev, seed=1):
             f = torch.randint(0, 2, (n,), dtype=torch.int64, device=dev, generator=g)
             tr[1] = f                                     # timestamp = timestamp_inv in {0,1}: mem_before filter binary
             tr[2] = f
+        elif t == 9:                                      # Poseidon (cdk_erigon)
+            one_hot(list(range(6, 14)))
+            binary([319, 320, 321])
         else:
             binary([0])                                   # MemBefore / MemAfter filter
         out.append(tr)
     return out
 
 
-def segment_committed_cells(log_ns):
+def segment_committed_cells(log_ns, cdk_erigon=False):
     """(columns x rows) the segment commits: trace + auxiliary (lookup + CTL) + 4 quotient chunks per table."""
     from zk_evm_amd import all_stark as A
     from zk_evm_amd.segment import num_ctl_helpers_zs_all
-    ctls = A.all_cross_table_lookups()
+    st = A.AllStark((0, 0, 0, 0), cdk_erigon)
+    ctls = st.cross_table_lookups
     cells = 0
-    for t in A.Table.all():
+    for t in range(st.num_tables):
         aux = sum(num_ctl_helpers_zs_all(ctls, t, 2, 3)[:2]) + 2 * sum(l.num_helper_columns(3) for l in A.table_lookups(t))
-        cells += (A.TABLE_COLUMNS[t] + aux + 4) << log_ns[t]
+        cells += (st.table_columns[t] + aux + 4) << log_ns[t]
     return cells
 
 
@@ -358,20 +366,23 @@ def main():
     else:
         import zk_evm_amd.segment as sg
         from zk_evm_amd.all_stark import TABLE_COLUMNS, TABLE_NAMES, AllStark
-        log_ns = [a.log_n] * 9
+        n_tab = 10 if a.cdk_erigon else 9
+        log_ns = [a.log_n] * n_tab
         if a.log_ns:
-            log_ns = REALISTIC_LOG_NS if a.log_ns == "realistic" else [int(x) for x in a.log_ns.split(",")]
-            assert len(log_ns) == 9, "--log-ns takes nine heights"
+            log_ns = (REALISTIC_LOG_NS + [14] * (n_tab - 9)) if a.log_ns == "realistic" else [int(x) for x in a.log_ns.split(",")]
+            assert len(log_ns) == n_tab, "--log-ns takes one height per table"
         uniform = len(set(log_ns)) == 1
-        traces = synthetic_segment_traces(log_ns, dev, seed=1 + rank)
+        traces = synthetic_segment_traces(log_ns, dev, seed=1 + rank, cdk_erigon=a.cdk_erigon)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         cfg = zk_evm_amd.StarkConfig(hasher=a.hasher)   # == standard_fast_config() with the chosen hasher
-        all_stark = AllStark((1, 2, 3, 4))   # kernel-label constants of the Cpu AIR: arbitrary for timing
-        in_use = [True] * 9
+        all_stark = AllStark((1, 2, 3, 4), a.cdk_erigon)   # kernel-label constants of the Cpu AIR: arbitrary for timing
+        in_use = [True] * n_tab
+        TABLE_COLUMNS = all_stark.table_columns
 
         def step(timing=None):
-            return sg.prove_with_traces(all_stark, cfg, traces, in_use, sg.PublicValues(), ctx=ctx, timing=timing)
+            return sg.prove_with_traces(all_stark, cfg, traces, in_use, sg.PublicValues(burn_addr=1 if a.cdk_erigon else None),
+                                        ctx=ctx, timing=timing)
         for _ in range(a.warmup):
             step()
         barrier()
@@ -407,10 +418,10 @@ def main():
                                 "source": pm["source"]}
             except Exception:
                 pass
-            cells = segment_committed_cells(log_ns)
+            cells = segment_committed_cells(log_ns, a.cdk_erigon)
             out = {
                 "metric": "segment STARK proofs/sec (2^20-row traces, all nine AllStark tables)" if log_ns == [20] * 9 else
-                          "segment STARK proofs/sec (table heights 2^%s)" % ",".join(map(str, log_ns)),
+                          "segment STARK proofs/sec (table heights 2^%s%s)" % (",".join(map(str, log_ns)), ", cdk_erigon" if a.cdk_erigon else ""),
                 "value": world * a.steps / elapsed, "unit": "segment proofs/s", "n_gpus": world, "steps": a.steps,
                 "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "u64", "data": "synthetic",
