@@ -80,6 +80,97 @@ def build(rng, halt_pc, kernel_code=b"", kernel_hash=0, cpu_rows=32):
     return traces, pv, before_rows
 
 
+# ---- a segment whose Cpu table really executes instructions ---------------------------------------------------------
+CPU_PROGRAM = bytes([0x58, 0x58, 0x58, 0x01, 0x50, 0x50])        # PC PC PC ADD POP POP, then halt at pc = 6
+CPU_PROGRAM_CONSTS = (len(CPU_PROGRAM), 0, 777777, 888888)       # halt_final, init, syscall / exception jumptables
+
+
+def cpu_program_trace(n=16):
+    """The Cpu rows of the kernel-mode run of CPU_PROGRAM (cpu/columns/mod.rs:56-97 layout), with the memory-bus
+    operations and Arithmetic operations it performs.  Stack discipline as the reference's witness generator keeps
+    it: the top of the stack lives in mem_channels[0].value; a push writes the old top through the partial channel
+    (stack.rs:173-282), ADD reads its second operand through GP channel 1, a POP that leaves a non-empty stack makes
+    the NEXT row read the new top through channel 0 (stack.rs:371-410); timestamps = (clock - 1) * 5 + 1 + channel."""
+    from oracle import airs
+    ops = airs.C_OPS
+    col = lambda name: 6 + ops.index(name)
+    bits, gen, clock, partial = 24, 32, 40, 80
+    ch = lambda k: 41 + 13 * k
+    limbs = lambda v: [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
+    t = np.zeros((85, n), dtype=np.uint64)
+    stack, gas, mem_ops, arith, top_read = [], 0, [], [], False
+    for r in range(n):
+        t[clock, r], t[4, r], t[3, r], t[5, r] = r + 1, 1, len(stack), gas
+        base = r * 5 + 1
+        if r >= len(CPU_PROGRAM):
+            t[2, r] = len(CPU_PROGRAM)                                # halting rows
+            continue
+        op = CPU_PROGRAM[r]
+        t[2, r] = r
+        for i in range(8):
+            t[bits + i, r] = (op >> i) & 1
+        mem_ops.append(dict(filter=True, timestamp=base, ctx=0, seg=0, virt=r, is_read=True, value=op))   # code read
+        sl, top = len(stack), (stack[-1] if stack else 0)
+        t[ch(0) + 5:ch(0) + 13, r] = limbs(top)
+        if top_read:
+            t[ch(0):ch(0) + 5, r] = [1, 1, 0, 1, sl - 1]
+            mem_ops.append(dict(filter=True, timestamp=base + 1, ctx=0, seg=1, virt=sl - 1, is_read=True, value=top))
+            top_read = False
+        if op == 0x58:                                                # PC: push the program counter
+            t[col("pc_push0"), r] = 1
+            if sl:
+                t[gen + 4, r], t[gen + 5, r] = pow(sl, P_FIELD - 2, P_FIELD), 1      # stack_inv, stack_inv_aux
+                t[partial:partial + 5, r] = [1, 0, 0, 1, sl - 1]
+                mem_ops.append(dict(filter=True, timestamp=base + 4, ctx=0, seg=1, virt=sl - 1, is_read=False, value=top))
+            stack.append(r)
+            gas += 2
+        elif op == 0x01:                                              # ADD
+            t[col("binary_op"), r] = 1
+            a, b = stack[-1], stack[-2]
+            t[ch(1):ch(1) + 5, r] = [1, 1, 0, 1, sl - 2]
+            t[ch(1) + 5:ch(1) + 13, r] = limbs(b)
+            mem_ops.append(dict(filter=True, timestamp=base + 2, ctx=0, seg=1, virt=sl - 2, is_read=True, value=b))
+            arith.append(("bin", 0, a, b))                            # IS_ADD
+            stack[-2:] = [(a + b) % (1 << 256)]
+            gas += 3
+        else:                                                         # POP
+            t[col("not_pop"), r] = 1
+            if sl - 1:
+                t[gen + 4, r], t[gen + 5, r], t[gen + 6, r] = pow(sl - 1, P_FIELD - 2, P_FIELD), 1, 1
+                top_read = True
+            stack.pop()
+            gas += 2
+    return t, mem_ops, arith
+
+
+def build_with_cpu_program(rng, kernel_hash=0):
+    """Like `build`, but the kernel image IS CPU_PROGRAM and the Cpu table executes it: six code reads, two stack
+    writes and two stack reads join the Memory table, one ADD row the Arithmetic table."""
+    pv = make_public_values(rng)
+    code = CPU_PROGRAM
+    cpu, cpu_mem_ops, arith_ops = cpu_program_trace()
+    before = [((0, SEG_CODE, i), b) for i, b in enumerate(code)]
+    before += [((0, SEG_SHIFT_TABLE, i), 1 << i) for i in range(256)]
+    ops = [dict(filter=True, timestamp=2, ctx=0, seg=seg, virt=idx, is_read=False, value=val)
+           for seg, idx, val in oseg.public_memory_writes(pv, kernel_hash, len(code))] + cpu_mem_ops
+    memory, mem_after = mem_trace.generate_trace(ops, before, [])
+    before_rows = [[1, c, s, v] + [(val >> (32 * j)) & 0xFFFFFFFF for j in range(8)] for (c, s, v), val in before]
+    traces = [None] * 9
+    traces[0] = arith_trace.generate_trace(arith_ops)[0]
+    traces[1] = otg.byte_packing_generate_trace([], 0)
+    traces[2] = cpu
+    traces[3] = np.ascontiguousarray(keccak_trace.generate_trace_rows([], 32).T)
+    traces[4] = otg.keccak_sponge_generate_trace([], 0, None)
+    traces[5] = np.zeros((523, 32), dtype=np.uint64)
+    traces[6] = memory
+    traces[7] = continuation_table(before_rows)
+    traces[8] = continuation_table(mem_after)
+    return traces, pv, code
+
+
+P_FIELD = 0xFFFFFFFF00000001
+
+
 def ctl_first_values(traces, ctls, challenges):
     """Z(first row) of every CtlZData straight from the rows: sum_r filter(r) / combine(columns(r)), in the
     z-data order `verify_cross_table_lookups` consumes (one value per looking run / looked table, per challenge)."""

@@ -440,3 +440,43 @@ def test_cdk_erigon_segment_proof_matches_oracle(oracle, in_use):
         sg.prove_with_traces(AllStark(oairs.CPU_TEST_CONSTS), scfg, dev, in_use, pv)
     with pytest.raises(zk.ZkStarkError):
         sg.prove_with_traces(st, scfg, dev, in_use, to_public_values(pvd))
+
+
+def test_segment_with_executing_cpu_accepted_by_verify_proof(oracle):
+    """`verify_proof` (verifier.rs:184-312) on a segment whose Cpu table executes a six-instruction kernel
+    (tests/consistent_segment.py: PC PC PC ADD POP POP, halt): the kernel image is the MemBefore content (so
+    `verify_initial_memory` uses it too), the Cpu rows look up their code bytes, stack writes / reads and the ADD in
+    Memory and Arithmetic.  Proven by zk_prove_segment under standard_fast_config, accepted; with one Cpu cell
+    changed (the sum the ADD leaves on the stack) rejected at the Arithmetic CTL."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    from oracle import segment as oseg
+    from tests import consistent_segment as cs
+    from zk_evm_amd.all_stark import AllStark
+    from zk_evm_amd.tracegen import initial_memory_merkle_cap
+    ol.setup_fri_api(oracle)
+    rng = np.random.default_rng(79)
+    kh = int.from_bytes(rng.bytes(32), "big")
+    traces, pvd, code = cs.build_with_cpu_program(rng, kh)
+    consts = cs.CPU_PROGRAM_CONSTS
+    in_use = [True, False, True, True, True, True, True, True, True]
+    cfg = ol.make_cfg(hasher=0)
+    init_cap = initial_memory_merkle_cap(code, 1, 4, hasher=0)
+
+    def run(trs):
+        dev = [torch.from_numpy(np.ascontiguousarray(t).view(np.int64)).cuda() for t in trs]
+        got = sg.prove_with_traces(AllStark(consts), zk.StarkConfig(), dev, in_use, to_public_values(pvd))
+        before_cap = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
+        return oseg.verify_proof(oracle, ol, cfg, _proof_dicts(got), in_use, pvd, consts, kh, len(code), is_initial=True,
+                                 initial_mem_cap=init_cap, mem_before_cap=before_cap)
+    ok, why = run(traces)
+    assert ok, why
+    bad = [t.copy() for t in traces]
+    bad[2][41 + 5, 4] = 4                                           # 2 + 1 = 4
+    ok, why = run(bad)
+    assert not ok and why.startswith("CTL 0"), why
+    bad = [t.copy() for t in traces]
+    bad[2][5, 5] += np.uint64(1)                                    # one unit of gas too many: the Cpu AIR itself
+    ok, why = run(bad)
+    assert not ok and why == "table 2: quotient identity", why

@@ -2,6 +2,7 @@
 reference's top-level verifier pieces -- `get_memory_extra_looking_sum` (verifier.rs:319-512) and
 `verify_cross_table_lookups` -- without proving anything: the CTL sums are taken straight from the rows."""
 import numpy as np
+import pytest
 
 from oracle import airs as oairs
 from oracle import all_stark as A
@@ -47,3 +48,41 @@ def test_consistent_segment_rows_and_ctls_balance():
     extra[oseg.MEMORY_CTL_IDX] = [oseg.get_memory_extra_looking_sum(pv2, c, KH, len(code)) for c in ch]
     ok, why = oseg.verify_cross_table_lookups(ctls, zf, extra, 2)
     assert not ok and why.startswith("CTL 6")
+
+
+def test_segment_with_an_executing_cpu_table():
+    """A Cpu table that really runs instructions (PC PC PC ADD POP POP in kernel mode, then halts): its rows satisfy
+    all 514 constraints of the restated Cpu AIR, and its bus traffic -- six code reads of the kernel image, two stack
+    writes through the partial channel, two stack reads, one ADD -- balances the Memory, MemBefore, MemAfter and
+    Arithmetic CTLs of the real wiring.  A wrong gas charge or stack pointer breaks the AIR; a wrong sum breaks
+    exactly the Arithmetic CTL; executing a byte that is not in the kernel image breaks the Memory CTL."""
+    rng = np.random.default_rng(2)
+    traces, pv, code = cs.build_with_cpu_program(rng, KH)
+    air = oairs.make_eval_cpu(*cs.CPU_PROGRAM_CONSTS)
+    _check_air(air, traces[A.CPU])
+    _check_air(oairs.eval_memory, traces[A.MEMORY])
+    assert int(traces[A.ARITHMETIC][0].sum()) == 1 and int(traces[A.CPU][6:24].sum()) == 6
+    ctls = A.build_ctls()
+    ch = [S.GrandProductChallenge(1234567, 7654321), S.GrandProductChallenge(99, 101)]
+
+    def balance(trs):
+        zf = cs.ctl_first_values(trs, ctls, ch)
+        extra = [[0, 0] for _ in ctls]
+        extra[oseg.MEMORY_CTL_IDX] = [oseg.get_memory_extra_looking_sum(pv, c, KH, len(code)) for c in ch]
+        return oseg.verify_cross_table_lookups(ctls, zf, extra, 2), zf
+    (ok, why), zf = balance(traces)
+    assert ok, why
+    assert all(z != 0 for z in zf[A.CPU][0:2]) and any(zf[A.CPU][2:])        # arithmetic and memory lookups are live
+    for col, row in ((5, 4), (3, 2), (40, 7)):                                # gas, stack_len, clock
+        bad = traces[A.CPU].copy()
+        bad[col, row] += np.uint64(1)
+        with pytest.raises(AssertionError):
+            _check_air(air, bad)
+    bad = [t.copy() for t in traces]
+    bad[A.CPU][41 + 5, 4] = 4                                                 # the sum seen by the row after ADD: 2 + 1 = 4
+    (ok, why), _ = balance(bad)
+    assert not ok and why.startswith("CTL 0"), why
+    bad = [t.copy() for t in traces]
+    bad[A.CPU][24, 0] ^= np.uint64(1)                                         # row 0 claims opcode 0x59 at pc 0
+    (ok, why), _ = balance(bad)
+    assert not ok and why.startswith("CTL 6"), why
