@@ -81,7 +81,7 @@ def build(rng, halt_pc, kernel_code=b"", kernel_hash=0, cpu_rows=32):
 
 
 # ---- a segment whose Cpu table really executes instructions ---------------------------------------------------------
-CPU_PROGRAM = bytes([0x58, 0x58, 0x58, 0x01, 0x50, 0x50])        # PC PC PC ADD POP POP, then halt at pc = 6
+CPU_PROGRAM = bytes([0x58, 0x58, 0x58, 0x01, 0x18, 0x50])        # PC PC PC ADD XOR POP, then halt at pc = 6
 CPU_PROGRAM_CONSTS = (len(CPU_PROGRAM), 0, 777777, 888888)       # halt_final, init, syscall / exception jumptables
 
 
@@ -89,7 +89,7 @@ def cpu_program_trace(n=16):
     """The Cpu rows of the kernel-mode run of CPU_PROGRAM (cpu/columns/mod.rs:56-97 layout), with the memory-bus
     operations and Arithmetic operations it performs.  Stack discipline as the reference's witness generator keeps
     it: the top of the stack lives in mem_channels[0].value; a push writes the old top through the partial channel
-    (stack.rs:173-282), ADD reads its second operand through GP channel 1, a POP that leaves a non-empty stack makes
+    (stack.rs:173-282), ADD reads its second operand (as XOR) through GP channel 1, a POP that leaves a non-empty stack makes
     the NEXT row read the new top through channel 0 (stack.rs:371-410); timestamps = (clock - 1) * 5 + 1 + channel."""
     from oracle import airs
     ops = airs.C_OPS
@@ -98,7 +98,7 @@ def cpu_program_trace(n=16):
     ch = lambda k: 41 + 13 * k
     limbs = lambda v: [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
     t = np.zeros((85, n), dtype=np.uint64)
-    stack, gas, mem_ops, arith, top_read = [], 0, [], [], False
+    stack, gas, mem_ops, arith, logic, top_read = [], 0, [], [], [], False
     for r in range(n):
         t[clock, r], t[4, r], t[3, r], t[5, r] = r + 1, 1, len(stack), gas
         base = r * 5 + 1
@@ -124,14 +124,18 @@ def cpu_program_trace(n=16):
                 mem_ops.append(dict(filter=True, timestamp=base + 4, ctx=0, seg=1, virt=sl - 1, is_read=False, value=top))
             stack.append(r)
             gas += 2
-        elif op == 0x01:                                              # ADD
-            t[col("binary_op"), r] = 1
+        elif op in (0x01, 0x18):                                      # ADD (Arithmetic CTL) / XOR (Logic CTL)
+            t[col("binary_op" if op == 0x01 else "logic_op"), r] = 1
             a, b = stack[-1], stack[-2]
             t[ch(1):ch(1) + 5, r] = [1, 1, 0, 1, sl - 2]
             t[ch(1) + 5:ch(1) + 13, r] = limbs(b)
             mem_ops.append(dict(filter=True, timestamp=base + 2, ctx=0, seg=1, virt=sl - 2, is_read=True, value=b))
-            arith.append(("bin", 0, a, b))                            # IS_ADD
-            stack[-2:] = [(a + b) % (1 << 256)]
+            if op == 0x01:
+                arith.append(("bin", 0, a, b))                        # IS_ADD
+                stack[-2:] = [(a + b) % (1 << 256)]
+            else:
+                logic.append((2, a, b))                               # is_xor
+                stack[-2:] = [a ^ b]
             gas += 3
         else:                                                         # POP
             t[col("not_pop"), r] = 1
@@ -140,15 +144,28 @@ def cpu_program_trace(n=16):
                 top_read = True
             stack.pop()
             gas += 2
-    return t, mem_ops, arith
+    return t, mem_ops, arith, logic
+
+
+def logic_table(ops, n=32):
+    """`LogicStark::generate_trace` rows (logic.rs:165-240): one-hot {and, or, xor}, 2 x 256 input bits, 8 result limbs."""
+    t = np.zeros((523, n), dtype=np.uint64)
+    for r, (kind, a, b) in enumerate(ops):
+        t[kind, r] = 1
+        for i in range(256):
+            t[3 + i, r], t[259 + i, r] = (a >> i) & 1, (b >> i) & 1
+        res = (a & b, a | b, a ^ b)[kind]
+        for i in range(8):
+            t[515 + i, r] = (res >> (32 * i)) & 0xFFFFFFFF
+    return t
 
 
 def build_with_cpu_program(rng, kernel_hash=0):
     """Like `build`, but the kernel image IS CPU_PROGRAM and the Cpu table executes it: six code reads, two stack
-    writes and two stack reads join the Memory table, one ADD row the Arithmetic table."""
+    writes and two stack reads join the Memory table, one ADD row the Arithmetic table, one XOR row the Logic table."""
     pv = make_public_values(rng)
     code = CPU_PROGRAM
-    cpu, cpu_mem_ops, arith_ops = cpu_program_trace()
+    cpu, cpu_mem_ops, arith_ops, logic_ops = cpu_program_trace()
     before = [((0, SEG_CODE, i), b) for i, b in enumerate(code)]
     before += [((0, SEG_SHIFT_TABLE, i), 1 << i) for i in range(256)]
     ops = [dict(filter=True, timestamp=2, ctx=0, seg=seg, virt=idx, is_read=False, value=val)
@@ -161,7 +178,7 @@ def build_with_cpu_program(rng, kernel_hash=0):
     traces[2] = cpu
     traces[3] = np.ascontiguousarray(keccak_trace.generate_trace_rows([], 32).T)
     traces[4] = otg.keccak_sponge_generate_trace([], 0, None)
-    traces[5] = np.zeros((523, 32), dtype=np.uint64)
+    traces[5] = logic_table(logic_ops)
     traces[6] = memory
     traces[7] = continuation_table(before_rows)
     traces[8] = continuation_table(mem_after)

@@ -444,9 +444,9 @@ def test_cdk_erigon_segment_proof_matches_oracle(oracle, in_use):
 
 def test_segment_with_executing_cpu_accepted_by_verify_proof(oracle):
     """`verify_proof` (verifier.rs:184-312) on a segment whose Cpu table executes a six-instruction kernel
-    (tests/consistent_segment.py: PC PC PC ADD POP POP, halt): the kernel image is the MemBefore content (so
-    `verify_initial_memory` uses it too), the Cpu rows look up their code bytes, stack writes / reads and the ADD in
-    Memory and Arithmetic.  Proven by zk_prove_segment under standard_fast_config, accepted; with one Cpu cell
+    (tests/consistent_segment.py: PC PC PC ADD XOR POP, halt): the kernel image is the MemBefore content (so
+    `verify_initial_memory` uses it too), the Cpu rows look up their code bytes, stack writes / reads, the ADD and the
+    XOR in Memory, Arithmetic and Logic.  Proven by zk_prove_segment under standard_fast_config, accepted; with one Cpu cell
     changed (the sum the ADD leaves on the stack) rejected at the Arithmetic CTL."""
     import torch
     import zk_evm_amd as zk

@@ -51,17 +51,18 @@ def test_consistent_segment_rows_and_ctls_balance():
 
 
 def test_segment_with_an_executing_cpu_table():
-    """A Cpu table that really runs instructions (PC PC PC ADD POP POP in kernel mode, then halts): its rows satisfy
+    """A Cpu table that really runs instructions (PC PC PC ADD XOR POP in kernel mode, then halts): its rows satisfy
     all 514 constraints of the restated Cpu AIR, and its bus traffic -- six code reads of the kernel image, two stack
-    writes through the partial channel, two stack reads, one ADD -- balances the Memory, MemBefore, MemAfter and
-    Arithmetic CTLs of the real wiring.  A wrong gas charge or stack pointer breaks the AIR; a wrong sum breaks
+    writes through the partial channel, two stack reads, one ADD, one XOR -- balances the Memory, MemBefore, MemAfter,
+    Arithmetic and Logic CTLs of the real wiring.  A wrong gas charge or stack pointer breaks the AIR; a wrong sum breaks
     exactly the Arithmetic CTL; executing a byte that is not in the kernel image breaks the Memory CTL."""
     rng = np.random.default_rng(2)
     traces, pv, code = cs.build_with_cpu_program(rng, KH)
     air = oairs.make_eval_cpu(*cs.CPU_PROGRAM_CONSTS)
     _check_air(air, traces[A.CPU])
     _check_air(oairs.eval_memory, traces[A.MEMORY])
-    assert int(traces[A.ARITHMETIC][0].sum()) == 1 and int(traces[A.CPU][6:24].sum()) == 6
+    _check_air(oairs.AIRS[2][0], traces[A.LOGIC])
+    assert int(traces[A.ARITHMETIC][0].sum()) == 1 and int(traces[A.CPU][6:24].sum()) == 6 and int(traces[A.LOGIC][2].sum()) == 1
     ctls = A.build_ctls()
     ch = [S.GrandProductChallenge(1234567, 7654321), S.GrandProductChallenge(99, 101)]
 
@@ -82,6 +83,10 @@ def test_segment_with_an_executing_cpu_table():
     bad[A.CPU][41 + 5, 4] = 4                                                 # the sum seen by the row after ADD: 2 + 1 = 4
     (ok, why), _ = balance(bad)
     assert not ok and why.startswith("CTL 0"), why
+    bad = [t.copy() for t in traces]
+    bad[A.LOGIC][515, 0] ^= np.uint64(4)                                      # the Logic table claims another XOR result
+    (ok, why), _ = balance(bad)
+    assert not ok and why.startswith("CTL 5"), why
     bad = [t.copy() for t in traces]
     bad[A.CPU][24, 0] ^= np.uint64(1)                                         # row 0 claims opcode 0x59 at pc 0
     (ok, why), _ = balance(bad)
