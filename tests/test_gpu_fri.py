@@ -56,20 +56,25 @@ def test_challenger_matches_oracle(oracle, hasher):
     (10, 7, 0, 2, False, dict(pow_bits=3, queries=4)),
     (13, 9, 5, 4, True, dict(pow_bits=10, queries=12)),
     (16, 6, 2, 4, True, dict(pow_bits=16, queries=84)),   # production FRI parameters
+    # the FRI shape of the recursion layer (`standard_recursion_config`, rate_bits 3, 28 queries)
+    (12, 7, 3, 2, True, dict(pow_bits=16, queries=28, rate_bits=3)),
+    (13, 4, 0, 8, False, dict(pow_bits=8, queries=9, rate_bits=2)),
 ])
 def test_prove_openings_matches_oracle(oracle, hasher, degree_bits, n_trace, n_aux, n_quot, with_ctl, kw):
     import zk_evm_amd as zk
     setup_fri_api(oracle)
     L = oracle.lib
     n = 1 << degree_bits
-    cfg = make_cfg(hasher=hasher, **kw)
+    kw = dict(kw)
+    rate_bits = kw.pop("rate_bits", 1)
+    cfg = make_cfg(hasher=hasher, rate_bits=rate_bits, **kw)
     seed = 11
     mats = []
     for k, c in enumerate([n_trace, n_aux, n_quot]):
         if c:
             mats.append(np.stack([splitmix64(seed * 100 + k * 1000 + j, n) for j in range(c)]))
-    commits = [oracle.commit_values(m, rate_bits=1, cap_height=4, hasher=hasher) for m in mats]
-    batches = [zk.PolynomialBatch.from_values(m, 1, False, 4, hasher=hasher) for m in mats]
+    commits = [oracle.commit_values(m, rate_bits=rate_bits, cap_height=4, hasher=hasher) for m in mats]
+    batches = [zk.PolynomialBatch.from_values(m, rate_bits, False, 4, hasher=hasher) for m in mats]
     for r, b in zip(commits, batches):
         assert np.array_equal(b.merkle_tree.cap.elements, r["cap"])
     # transcript up to zeta, both sides
@@ -93,7 +98,7 @@ def test_prove_openings_matches_oracle(oracle, hasher, degree_bits, n_trace, n_a
     g_open = zk.fri_openings(inst, batches)
     assert np.array_equal(g_open.reshape(-1), o_open)
     ch.observe_extension_elements(g_open)
-    scfg = zk.StarkConfig(hasher=hasher, fri_config=zk.FriConfig(proof_of_work_bits=kw["pow_bits"],
+    scfg = zk.StarkConfig(hasher=hasher, fri_config=zk.FriConfig(rate_bits=rate_bits, proof_of_work_bits=kw["pow_bits"],
                                                                  num_query_rounds=kw["queries"]))
     g_proof = zk.prove_openings(inst, batches, ch, scfg, g_open)
     assert g_proof.shape == o_proof.shape
