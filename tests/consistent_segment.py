@@ -81,16 +81,20 @@ def build(rng, halt_pc, kernel_code=b"", kernel_hash=0, cpu_rows=32):
 
 
 # ---- a segment whose Cpu table really executes instructions ---------------------------------------------------------
-CPU_PROGRAM = bytes([0x58, 0x58, 0x58, 0x01, 0x18, 0x50])        # PC PC PC ADD XOR POP, then halt at pc = 6
-CPU_PROGRAM_CONSTS = (len(CPU_PROGRAM), 0, 777777, 888888)       # halt_final, init, syscall / exception jumptables
+# PC PC PC ADD XOR PC PC ADD KECCAK_GENERAL POP, halt at pc = 10; bytes 10..15 are data (the hashed range is 11..13)
+CPU_PROGRAM = bytes([0x58, 0x58, 0x58, 0x01, 0x18, 0x58, 0x58, 0x01, 0x21, 0x50, 0xA1, 0xB2, 0xC3, 0xD4, 0xE5, 0xF6])
+CPU_EXECUTED = 10
+CPU_PROGRAM_CONSTS = (CPU_EXECUTED, 0, 777777, 888888)           # halt_final, init, syscall / exception jumptables
 
 
-def cpu_program_trace(n=16):
-    """The Cpu rows of the kernel-mode run of CPU_PROGRAM (cpu/columns/mod.rs:56-97 layout), with the memory-bus
-    operations and Arithmetic operations it performs.  Stack discipline as the reference's witness generator keeps
-    it: the top of the stack lives in mem_channels[0].value; a push writes the old top through the partial channel
-    (stack.rs:173-282), ADD reads its second operand (as XOR) through GP channel 1, a POP that leaves a non-empty stack makes
-    the NEXT row read the new top through channel 0 (stack.rs:371-410); timestamps = (clock - 1) * 5 + 1 + channel."""
+def cpu_program_trace(keccak256, n=16):
+    """The Cpu rows of the kernel-mode run of CPU_PROGRAM (cpu/columns/mod.rs:56-97 layout), with the memory-bus,
+    Arithmetic, Logic and KeccakSponge operations it performs.  Stack discipline as the reference's witness generator
+    keeps it: the top of the stack lives in mem_channels[0].value; a push writes the old top through the partial
+    channel (stack.rs:173-282); ADD / XOR / KECCAK_GENERAL read their second operand through GP channel 1;
+    KECCAK_GENERAL(addr, len) pushes keccak256(mem[addr .. addr + len]) (the word read big-endian); a POP that leaves
+    a non-empty stack makes the NEXT row read the new top through channel 0 (stack.rs:371-410); timestamps =
+    (clock - 1) * 5 + 1 + channel."""
     from oracle import airs
     ops = airs.C_OPS
     col = lambda name: 6 + ops.index(name)
@@ -98,12 +102,12 @@ def cpu_program_trace(n=16):
     ch = lambda k: 41 + 13 * k
     limbs = lambda v: [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
     t = np.zeros((85, n), dtype=np.uint64)
-    stack, gas, mem_ops, arith, logic, top_read = [], 0, [], [], [], False
+    stack, gas, mem_ops, arith, logic, sponge, top_read = [], 0, [], [], [], [], False
     for r in range(n):
         t[clock, r], t[4, r], t[3, r], t[5, r] = r + 1, 1, len(stack), gas
         base = r * 5 + 1
-        if r >= len(CPU_PROGRAM):
-            t[2, r] = len(CPU_PROGRAM)                                # halting rows
+        if r >= CPU_EXECUTED:
+            t[2, r] = CPU_EXECUTED                                    # halting rows
             continue
         op = CPU_PROGRAM[r]
         t[2, r] = r
@@ -124,8 +128,8 @@ def cpu_program_trace(n=16):
                 mem_ops.append(dict(filter=True, timestamp=base + 4, ctx=0, seg=1, virt=sl - 1, is_read=False, value=top))
             stack.append(r)
             gas += 2
-        elif op in (0x01, 0x18):                                      # ADD (Arithmetic CTL) / XOR (Logic CTL)
-            t[col("binary_op" if op == 0x01 else "logic_op"), r] = 1
+        elif op in (0x01, 0x18, 0x21):            # ADD (Arithmetic CTL) / XOR (Logic CTL) / KECCAK_GENERAL (sponge CTL)
+            t[col({0x01: "binary_op", 0x18: "logic_op", 0x21: "jumpdest_keccak_general"}[op]), r] = 1
             a, b = stack[-1], stack[-2]
             t[ch(1):ch(1) + 5, r] = [1, 1, 0, 1, sl - 2]
             t[ch(1) + 5:ch(1) + 13, r] = limbs(b)
@@ -133,10 +137,19 @@ def cpu_program_trace(n=16):
             if op == 0x01:
                 arith.append(("bin", 0, a, b))                        # IS_ADD
                 stack[-2:] = [(a + b) % (1 << 256)]
-            else:
+                gas += 3
+            elif op == 0x18:
                 logic.append((2, a, b))                               # is_xor
                 stack[-2:] = [a ^ b]
-            gas += 3
+                gas += 3
+            else:                                                     # a = address word (virt | seg << 32 | ctx << 64)
+                virt, seg, ctx = a & 0xFFFFFFFF, (a >> 32) & 0xFFFFFFFF, (a >> 64) & 0xFFFFFFFF
+                assert (ctx, seg) == (0, 0) and virt + b <= len(CPU_PROGRAM), "this run hashes a slice of the kernel image"
+                data = CPU_PROGRAM[virt:virt + b]
+                sponge.append(((ctx, seg, virt), base, data))
+                mem_ops += [dict(filter=True, timestamp=base, ctx=ctx, seg=seg, virt=virt + i, is_read=True, value=x)
+                            for i, x in enumerate(data)]
+                stack[-2:] = [int.from_bytes(keccak256(data), "big")]
         else:                                                         # POP
             t[col("not_pop"), r] = 1
             if sl - 1:
@@ -144,7 +157,7 @@ def cpu_program_trace(n=16):
                 top_read = True
             stack.pop()
             gas += 2
-    return t, mem_ops, arith, logic
+    return t, mem_ops, arith, logic, sponge
 
 
 def logic_table(ops, n=32):
@@ -160,12 +173,36 @@ def logic_table(ops, n=32):
     return t
 
 
-def build_with_cpu_program(rng, kernel_hash=0):
-    """Like `build`, but the kernel image IS CPU_PROGRAM and the Cpu table executes it: six code reads, two stack
-    writes and two stack reads join the Memory table, one ADD row the Arithmetic table, one XOR row the Logic table."""
+def sponge_side_effects(ks):
+    """What the KeccakSponge rows ask of the Keccak and Logic tables (keccak_sponge_stark.rs: every absorbing row XORs
+    its 136-byte block into the rate -- five 256-bit Logic XORs, `ctl_looking_logic` -- and sends the xored state
+    through one Keccak-f permutation tagged with the operation's timestamp)."""
+    perms, xors = [], []
+    for r in range(ks.shape[1]):
+        row = [int(v) for v in ks[:, r]]
+        if not (row[0] or row[6 + 135]):                              # is_full_input_block + is_final (padding byte 135 set)
+            continue
+        words = row[328:362] + row[176:192]                           # xored rate + original capacity: 50 u32
+        perms.append(([words[2 * j] | (words[2 * j + 1] << 32) for j in range(25)], row[4]))
+        for i in range(5):
+            rate = (row[142 + 8 * i:142 + min(8 * i + 8, 34)] + [0] * 8)[:8]
+            blk = [sum(row[192 + k + b] << (8 * b) for b in range(min(4, 136 - k))) for k in range(32 * i, min(32 * i + 32, 136), 4)]
+            blk = (blk + [0] * 8)[:8]
+            word = lambda ls: sum(v << (32 * j) for j, v in enumerate(ls))
+            xors.append((2, word(rate), word(blk)))
+    return perms, xors
+
+
+def build_with_cpu_program(rng, oracle, kernel_hash=0):
+    """Like `build`, but the kernel image IS CPU_PROGRAM and the Cpu table executes it: code reads, stack writes /
+    reads and the hashed bytes join the Memory table, two ADD rows the Arithmetic table, the XOR and the sponge's
+    block XORs the Logic table, one KECCAK_GENERAL the KeccakSponge table and its permutation the Keccak table."""
+    from tests.test_oracle_tracegen import _keccak_f
     pv = make_public_values(rng)
     code = CPU_PROGRAM
-    cpu, cpu_mem_ops, arith_ops, logic_ops = cpu_program_trace()
+    cpu, cpu_mem_ops, arith_ops, logic_ops, sponge_ops = cpu_program_trace(oracle.keccak256)
+    sponge = otg.keccak_sponge_generate_trace(sponge_ops, 0, _keccak_f(oracle))
+    perms, sponge_xors = sponge_side_effects(sponge)
     before = [((0, SEG_CODE, i), b) for i, b in enumerate(code)]
     before += [((0, SEG_SHIFT_TABLE, i), 1 << i) for i in range(256)]
     ops = [dict(filter=True, timestamp=2, ctx=0, seg=seg, virt=idx, is_read=False, value=val)
@@ -176,9 +213,9 @@ def build_with_cpu_program(rng, kernel_hash=0):
     traces[0] = arith_trace.generate_trace(arith_ops)[0]
     traces[1] = otg.byte_packing_generate_trace([], 0)
     traces[2] = cpu
-    traces[3] = np.ascontiguousarray(keccak_trace.generate_trace_rows([], 32).T)
-    traces[4] = otg.keccak_sponge_generate_trace([], 0, None)
-    traces[5] = logic_table(logic_ops)
+    traces[3] = np.ascontiguousarray(keccak_trace.generate_trace_rows(perms, 32).T)
+    traces[4] = sponge
+    traces[5] = logic_table(logic_ops + sponge_xors)
     traces[6] = memory
     traces[7] = continuation_table(before_rows)
     traces[8] = continuation_table(mem_after)

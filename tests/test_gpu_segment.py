@@ -443,11 +443,14 @@ def test_cdk_erigon_segment_proof_matches_oracle(oracle, in_use):
 
 
 def test_segment_with_executing_cpu_accepted_by_verify_proof(oracle):
-    """`verify_proof` (verifier.rs:184-312) on a segment whose Cpu table executes a six-instruction kernel
-    (tests/consistent_segment.py: PC PC PC ADD XOR POP, halt): the kernel image is the MemBefore content (so
-    `verify_initial_memory` uses it too), the Cpu rows look up their code bytes, stack writes / reads, the ADD and the
-    XOR in Memory, Arithmetic and Logic.  Proven by zk_prove_segment under standard_fast_config, accepted; with one Cpu cell
-    changed (the sum the ADD leaves on the stack) rejected at the Arithmetic CTL."""
+    """`verify_proof` (verifier.rs:184-312) on a segment whose Cpu table executes a ten-instruction kernel
+    (tests/consistent_segment.py: PC PC PC ADD XOR PC PC ADD KECCAK_GENERAL POP, halt): the kernel image is the
+    MemBefore content (so `verify_initial_memory` uses it too); the Cpu rows look up their code bytes, stack writes /
+    reads, the ADDs, the XOR and the KECCAK_GENERAL in Memory, Arithmetic, Logic and KeccakSponge, the sponge in turn
+    its permutation in Keccak, its block XORs in Logic and its input bytes in Memory -- eight live tables, all ten
+    CTLs carrying traffic.  Proven by zk_prove_segment under standard_fast_config, accepted; rejected with one Cpu
+    cell changed (the sum an ADD leaves on the stack: Arithmetic CTL; the digest: KeccakSponge CTL; one unit of gas:
+    the Cpu AIR itself)."""
     import torch
     import zk_evm_amd as zk
     import zk_evm_amd.segment as sg
@@ -458,7 +461,7 @@ def test_segment_with_executing_cpu_accepted_by_verify_proof(oracle):
     ol.setup_fri_api(oracle)
     rng = np.random.default_rng(79)
     kh = int.from_bytes(rng.bytes(32), "big")
-    traces, pvd, code = cs.build_with_cpu_program(rng, kh)
+    traces, pvd, code = cs.build_with_cpu_program(rng, oracle, kh)
     consts = cs.CPU_PROGRAM_CONSTS
     in_use = [True, False, True, True, True, True, True, True, True]
     cfg = ol.make_cfg(hasher=0)
@@ -476,6 +479,10 @@ def test_segment_with_executing_cpu_accepted_by_verify_proof(oracle):
     bad[2][41 + 5, 4] = 4                                           # 2 + 1 = 4
     ok, why = run(bad)
     assert not ok and why.startswith("CTL 0"), why
+    bad = [t.copy() for t in traces]
+    bad[2][41 + 5, 9] ^= np.uint64(1)                               # the digest KECCAK_GENERAL pushed
+    ok, why = run(bad)
+    assert not ok and why.startswith("CTL 2"), why
     bad = [t.copy() for t in traces]
     bad[2][5, 5] += np.uint64(1)                                    # one unit of gas too many: the Cpu AIR itself
     ok, why = run(bad)

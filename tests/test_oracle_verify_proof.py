@@ -50,19 +50,27 @@ def test_consistent_segment_rows_and_ctls_balance():
     assert not ok and why.startswith("CTL 6")
 
 
-def test_segment_with_an_executing_cpu_table():
-    """A Cpu table that really runs instructions (PC PC PC ADD XOR POP in kernel mode, then halts): its rows satisfy
-    all 514 constraints of the restated Cpu AIR, and its bus traffic -- six code reads of the kernel image, two stack
-    writes through the partial channel, two stack reads, one ADD, one XOR -- balances the Memory, MemBefore, MemAfter,
-    Arithmetic and Logic CTLs of the real wiring.  A wrong gas charge or stack pointer breaks the AIR; a wrong sum breaks
-    exactly the Arithmetic CTL; executing a byte that is not in the kernel image breaks the Memory CTL."""
+def test_segment_with_an_executing_cpu_table(oracle):
+    """A Cpu table that really runs instructions (PC PC PC ADD XOR PC PC ADD KECCAK_GENERAL POP in kernel mode, then
+    halts): its rows satisfy all 514 constraints of the restated Cpu AIR, and its bus traffic -- ten code reads of the
+    kernel image, stack writes through the partial channel, stack reads, two ADDs, one XOR, one KECCAK_GENERAL over
+    three bytes of the kernel image (a KeccakSponge row, its Keccak-f permutation, its five block XORs, its byte
+    reads) -- balances all ten CTLs of the real wiring across eight live tables.  A wrong gas charge or stack pointer
+    breaks the AIR; a wrong sum breaks exactly the Arithmetic CTL, a wrong XOR the Logic CTL, a wrong digest the
+    KeccakSponge CTL; executing a byte that is not in the kernel image breaks the Memory CTL."""
     rng = np.random.default_rng(2)
-    traces, pv, code = cs.build_with_cpu_program(rng, KH)
+    traces, pv, code = cs.build_with_cpu_program(rng, oracle, KH)
     air = oairs.make_eval_cpu(*cs.CPU_PROGRAM_CONSTS)
     _check_air(air, traces[A.CPU])
     _check_air(oairs.eval_memory, traces[A.MEMORY])
     _check_air(oairs.AIRS[2][0], traces[A.LOGIC])
-    assert int(traces[A.ARITHMETIC][0].sum()) == 1 and int(traces[A.CPU][6:24].sum()) == 6 and int(traces[A.LOGIC][2].sum()) == 1
+    _check_air(oairs.eval_keccak_sponge, traces[A.KECCAK_SPONGE])
+    _check_air(oairs.AIRS[6][0], traces[A.KECCAK])
+    assert int(traces[A.ARITHMETIC][0].sum()) == 2 and int(traces[A.CPU][6:24].sum()) == cs.CPU_EXECUTED
+    assert int(traces[A.LOGIC][2].sum()) == 1 + 5 and int(traces[A.KECCAK][0].sum()) == 1
+    # the digest the Cpu pushed is keccak256 of the three hashed bytes, read big-endian
+    digest = sum(int(traces[A.CPU][41 + 5 + i, 9]) << (32 * i) for i in range(8))
+    assert digest == int.from_bytes(oracle.keccak256(code[11:14]), "big")
     ctls = A.build_ctls()
     ch = [S.GrandProductChallenge(1234567, 7654321), S.GrandProductChallenge(99, 101)]
 
@@ -73,21 +81,19 @@ def test_segment_with_an_executing_cpu_table():
         return oseg.verify_cross_table_lookups(ctls, zf, extra, 2), zf
     (ok, why), zf = balance(traces)
     assert ok, why
-    assert all(z != 0 for z in zf[A.CPU][0:2]) and any(zf[A.CPU][2:])        # arithmetic and memory lookups are live
+    assert all(z != 0 for z in zf[A.CPU][0:2]) and all(z != 0 for z in zf[A.KECCAK_SPONGE][0:2]) and all(zf[A.KECCAK])
     for col, row in ((5, 4), (3, 2), (40, 7)):                                # gas, stack_len, clock
         bad = traces[A.CPU].copy()
         bad[col, row] += np.uint64(1)
         with pytest.raises(AssertionError):
             _check_air(air, bad)
-    bad = [t.copy() for t in traces]
-    bad[A.CPU][41 + 5, 4] = 4                                                 # the sum seen by the row after ADD: 2 + 1 = 4
-    (ok, why), _ = balance(bad)
-    assert not ok and why.startswith("CTL 0"), why
-    bad = [t.copy() for t in traces]
-    bad[A.LOGIC][515, 0] ^= np.uint64(4)                                      # the Logic table claims another XOR result
-    (ok, why), _ = balance(bad)
-    assert not ok and why.startswith("CTL 5"), why
-    bad = [t.copy() for t in traces]
-    bad[A.CPU][24, 0] ^= np.uint64(1)                                         # row 0 claims opcode 0x59 at pc 0
-    (ok, why), _ = balance(bad)
-    assert not ok and why.startswith("CTL 6"), why
+
+    def first_failure(table, col, row, value=None):
+        bad = [t.copy() for t in traces]
+        bad[table][col, row] = bad[table][col, row] ^ np.uint64(4) if value is None else value
+        return balance(bad)[0]
+    assert first_failure(A.CPU, 41 + 5, 4, 4) == (False, "CTL 0 challenge 0")          # 2 + 1 = 4
+    assert first_failure(A.CPU, 41 + 5, 9)[1].startswith("CTL 2")                      # another digest on the stack
+    assert first_failure(A.LOGIC, 515, 0)[1].startswith("CTL 5")                       # another XOR result
+    assert first_failure(A.KECCAK, 2429, 23)[1].startswith("CTL 4")                    # another permutation output
+    assert first_failure(A.CPU, 24, 0)[1].startswith("CTL 6")                          # opcode 0x59 claimed at pc 0
