@@ -81,20 +81,29 @@ def build(rng, halt_pc, kernel_code=b"", kernel_hash=0, cpu_rows=32):
 
 
 # ---- a segment whose Cpu table really executes instructions ---------------------------------------------------------
-# PC PC PC ADD XOR PC PC ADD KECCAK_GENERAL POP, halt at pc = 10; bytes 10..15 are data (the hashed range is 11..13)
-CPU_PROGRAM = bytes([0x58, 0x58, 0x58, 0x01, 0x18, 0x58, 0x58, 0x01, 0x21, 0x50, 0xA1, 0xB2, 0xC3, 0xD4, 0xE5, 0xF6])
-CPU_EXECUTED = 10
-CPU_PROGRAM_CONSTS = (CPU_EXECUTED, 0, 777777, 888888)           # halt_final, init, syscall / exception jumptables
+# pc 0 PC, 1 PC, 2 PC, 3 ADD, 4 XOR, 5 PC, 6 PC, 7 ADD, 8 KECCAK_GENERAL, 9 PUSH32 <32 bytes at 10..41>,
+# 42 MSTORE_32BYTES_32, 43 POP, halt at pc = 44.  The PUSH32 argument is an address word (virt | segment << 32 |
+# context << 64) = (context 7, segment 11, virt 5); KECCAK_GENERAL hashes code bytes 11..13, which lie inside it.
+STORE_ADDR = (7, 11, 5)
+_ADDR_WORD = STORE_ADDR[2] | (STORE_ADDR[1] << 32) | (STORE_ADDR[0] << 64)
+CPU_PROGRAM = bytes([0x58, 0x58, 0x58, 0x01, 0x18, 0x58, 0x58, 0x01, 0x21, 0x7f]) + _ADDR_WORD.to_bytes(32, "big") + \
+    bytes([0xdf, 0x50, 0x00, 0x00, 0x00, 0x00])
+CPU_HALT_PC = 44
+CPU_EXECUTED = 12                                                # instructions = Cpu rows before the halting rows
+CPU_PROGRAM_CONSTS = (CPU_HALT_PC, 0, 777777, 888888)            # halt_final, init, syscall / exception jumptables
 
 
 def cpu_program_trace(keccak256, n=16):
     """The Cpu rows of the kernel-mode run of CPU_PROGRAM (cpu/columns/mod.rs:56-97 layout), with the memory-bus,
-    Arithmetic, Logic and KeccakSponge operations it performs.  Stack discipline as the reference's witness generator
-    keeps it: the top of the stack lives in mem_channels[0].value; a push writes the old top through the partial
-    channel (stack.rs:173-282); ADD / XOR / KECCAK_GENERAL read their second operand through GP channel 1;
-    KECCAK_GENERAL(addr, len) pushes keccak256(mem[addr .. addr + len]) (the word read big-endian); a POP that leaves
-    a non-empty stack makes the NEXT row read the new top through channel 0 (stack.rs:371-410); timestamps =
-    (clock - 1) * 5 + 1 + channel."""
+    Arithmetic, Logic, KeccakSponge and BytePacking operations it performs.  Stack discipline as the reference's
+    witness generator keeps it: the top of the stack lives in mem_channels[0].value; a push writes the old top through
+    the partial channel (stack.rs:173-282); ADD / XOR / KECCAK_GENERAL / MSTORE_32BYTES read their second operand
+    through GP channel 1; KECCAK_GENERAL(addr, len) pushes keccak256(mem[addr .. addr + len]) (the word read
+    big-endian); MSTORE_32BYTES_32(addr, value) writes the 32 big-endian bytes of value at addr through the
+    BytePacking table and pushes addr + 32 (byte_unpacking.rs); a kernel-mode PUSH is not tied to the code bytes
+    (its BytePacking looker is filtered by is_not_kernel, cpu_stark.rs:283-301); a POP that leaves a non-empty stack
+    makes the NEXT row read the new top through channel 0 (stack.rs:371-410); timestamps = (clock - 1) * 5 + 1 +
+    channel."""
     from oracle import airs
     ops = airs.C_OPS
     col = lambda name: 6 + ops.index(name)
@@ -102,34 +111,40 @@ def cpu_program_trace(keccak256, n=16):
     ch = lambda k: 41 + 13 * k
     limbs = lambda v: [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
     t = np.zeros((85, n), dtype=np.uint64)
-    stack, gas, mem_ops, arith, logic, sponge, top_read = [], 0, [], [], [], [], False
+    stack, gas, pc, top_read = [], 0, 0, False
+    mem_ops, arith, logic, sponge, packing = [], [], [], [], []
     for r in range(n):
-        t[clock, r], t[4, r], t[3, r], t[5, r] = r + 1, 1, len(stack), gas
+        t[clock, r], t[4, r], t[3, r], t[5, r], t[2, r] = r + 1, 1, len(stack), gas, pc
         base = r * 5 + 1
-        if r >= CPU_EXECUTED:
-            t[2, r] = CPU_EXECUTED                                    # halting rows
-            continue
-        op = CPU_PROGRAM[r]
-        t[2, r] = r
+        if pc == CPU_HALT_PC:
+            continue                                                  # halting rows
+        assert r < CPU_EXECUTED
+        op = CPU_PROGRAM[pc]
         for i in range(8):
             t[bits + i, r] = (op >> i) & 1
-        mem_ops.append(dict(filter=True, timestamp=base, ctx=0, seg=0, virt=r, is_read=True, value=op))   # code read
+        mem_ops.append(dict(filter=True, timestamp=base, ctx=0, seg=0, virt=pc, is_read=True, value=op))   # code read
         sl, top = len(stack), (stack[-1] if stack else 0)
         t[ch(0) + 5:ch(0) + 13, r] = limbs(top)
         if top_read:
             t[ch(0):ch(0) + 5, r] = [1, 1, 0, 1, sl - 1]
             mem_ops.append(dict(filter=True, timestamp=base + 1, ctx=0, seg=1, virt=sl - 1, is_read=True, value=top))
             top_read = False
-        if op == 0x58:                                                # PC: push the program counter
-            t[col("pc_push0"), r] = 1
+        next_pc = pc + 1
+        if op in (0x58, 0x7f):                                        # PC / PUSH32: push
+            t[col("pc_push0" if op == 0x58 else "push_prover_input"), r] = 1
             if sl:
                 t[gen + 4, r], t[gen + 5, r] = pow(sl, P_FIELD - 2, P_FIELD), 1      # stack_inv, stack_inv_aux
                 t[partial:partial + 5, r] = [1, 0, 0, 1, sl - 1]
                 mem_ops.append(dict(filter=True, timestamp=base + 4, ctx=0, seg=1, virt=sl - 1, is_read=False, value=top))
-            stack.append(r)
-            gas += 2
-        elif op in (0x01, 0x18, 0x21):            # ADD (Arithmetic CTL) / XOR (Logic CTL) / KECCAK_GENERAL (sponge CTL)
-            t[col({0x01: "binary_op", 0x18: "logic_op", 0x21: "jumpdest_keccak_general"}[op]), r] = 1
+            if op == 0x58:
+                stack.append(pc)
+                gas += 2
+            else:
+                stack.append(int.from_bytes(CPU_PROGRAM[pc + 1:pc + 33], "big"))
+                gas += 3
+                next_pc = pc + 33
+        elif op in (0x01, 0x18, 0x21, 0xdf):      # ADD / XOR / KECCAK_GENERAL / MSTORE_32BYTES_32: two operands
+            t[col({0x01: "binary_op", 0x18: "logic_op", 0x21: "jumpdest_keccak_general", 0xdf: "m_op_32bytes"}[op]), r] = 1
             a, b = stack[-1], stack[-2]
             t[ch(1):ch(1) + 5, r] = [1, 1, 0, 1, sl - 2]
             t[ch(1) + 5:ch(1) + 13, r] = limbs(b)
@@ -142,22 +157,32 @@ def cpu_program_trace(keccak256, n=16):
                 logic.append((2, a, b))                               # is_xor
                 stack[-2:] = [a ^ b]
                 gas += 3
-            else:                                                     # a = address word (virt | seg << 32 | ctx << 64)
+            else:                                                     # a = address word
                 virt, seg, ctx = a & 0xFFFFFFFF, (a >> 32) & 0xFFFFFFFF, (a >> 64) & 0xFFFFFFFF
-                assert (ctx, seg) == (0, 0) and virt + b <= len(CPU_PROGRAM), "this run hashes a slice of the kernel image"
-                data = CPU_PROGRAM[virt:virt + b]
-                sponge.append(((ctx, seg, virt), base, data))
-                mem_ops += [dict(filter=True, timestamp=base, ctx=ctx, seg=seg, virt=virt + i, is_read=True, value=x)
-                            for i, x in enumerate(data)]
-                stack[-2:] = [int.from_bytes(keccak256(data), "big")]
+                if op == 0x21:
+                    assert (ctx, seg) == (0, 0) and virt + b <= len(CPU_PROGRAM), "this run hashes a slice of the kernel image"
+                    data = CPU_PROGRAM[virt:virt + b]
+                    sponge.append(((ctx, seg, virt), base, data))
+                    mem_ops += [dict(filter=True, timestamp=base, ctx=ctx, seg=seg, virt=virt + i, is_read=True, value=x)
+                                for i, x in enumerate(data)]
+                    stack[-2:] = [int.from_bytes(keccak256(data), "big")]
+                else:
+                    data = b.to_bytes(32, "big")
+                    packing.append((False, (ctx, seg, virt), base, data))
+                    mem_ops += [dict(filter=True, timestamp=base, ctx=ctx, seg=seg, virt=virt + i, is_read=False, value=x)
+                                for i, x in enumerate(data)]
+                    stack[-2:] = [a + 32]
         else:                                                         # POP
+            assert op == 0x50
             t[col("not_pop"), r] = 1
             if sl - 1:
                 t[gen + 4, r], t[gen + 5, r], t[gen + 6, r] = pow(sl - 1, P_FIELD - 2, P_FIELD), 1, 1
                 top_read = True
             stack.pop()
             gas += 2
-    return t, mem_ops, arith, logic, sponge
+        pc = next_pc
+    assert pc == CPU_HALT_PC and not stack
+    return t, mem_ops, arith, logic, sponge, packing
 
 
 def logic_table(ops, n=32):
@@ -196,11 +221,12 @@ def sponge_side_effects(ks):
 def build_with_cpu_program(rng, oracle, kernel_hash=0):
     """Like `build`, but the kernel image IS CPU_PROGRAM and the Cpu table executes it: code reads, stack writes /
     reads and the hashed bytes join the Memory table, two ADD rows the Arithmetic table, the XOR and the sponge's
-    block XORs the Logic table, one KECCAK_GENERAL the KeccakSponge table and its permutation the Keccak table."""
+    block XORs the Logic table, one KECCAK_GENERAL the KeccakSponge table and its permutation the Keccak table, one
+    MSTORE_32BYTES the BytePacking table (whose 32 byte writes land in Memory and MemAfter): all nine tables live."""
     from tests.test_oracle_tracegen import _keccak_f
     pv = make_public_values(rng)
     code = CPU_PROGRAM
-    cpu, cpu_mem_ops, arith_ops, logic_ops, sponge_ops = cpu_program_trace(oracle.keccak256)
+    cpu, cpu_mem_ops, arith_ops, logic_ops, sponge_ops, packing_ops = cpu_program_trace(oracle.keccak256)
     sponge = otg.keccak_sponge_generate_trace(sponge_ops, 0, _keccak_f(oracle))
     perms, sponge_xors = sponge_side_effects(sponge)
     before = [((0, SEG_CODE, i), b) for i, b in enumerate(code)]
@@ -211,7 +237,7 @@ def build_with_cpu_program(rng, oracle, kernel_hash=0):
     before_rows = [[1, c, s, v] + [(val >> (32 * j)) & 0xFFFFFFFF for j in range(8)] for (c, s, v), val in before]
     traces = [None] * 9
     traces[0] = arith_trace.generate_trace(arith_ops)[0]
-    traces[1] = otg.byte_packing_generate_trace([], 0)
+    traces[1] = otg.byte_packing_generate_trace(packing_ops, 0)
     traces[2] = cpu
     traces[3] = np.ascontiguousarray(keccak_trace.generate_trace_rows(perms, 32).T)
     traces[4] = sponge

@@ -443,12 +443,13 @@ def test_cdk_erigon_segment_proof_matches_oracle(oracle, in_use):
 
 
 def test_segment_with_executing_cpu_accepted_by_verify_proof(oracle):
-    """`verify_proof` (verifier.rs:184-312) on a segment whose Cpu table executes a ten-instruction kernel
-    (tests/consistent_segment.py: PC PC PC ADD XOR PC PC ADD KECCAK_GENERAL POP, halt): the kernel image is the
-    MemBefore content (so `verify_initial_memory` uses it too); the Cpu rows look up their code bytes, stack writes /
-    reads, the ADDs, the XOR and the KECCAK_GENERAL in Memory, Arithmetic, Logic and KeccakSponge, the sponge in turn
-    its permutation in Keccak, its block XORs in Logic and its input bytes in Memory -- eight live tables, all ten
-    CTLs carrying traffic.  Proven by zk_prove_segment under standard_fast_config, accepted; rejected with one Cpu
+    """`verify_proof` (verifier.rs:184-312) on a segment whose Cpu table executes a twelve-instruction kernel
+    (tests/consistent_segment.py: PC PC PC ADD XOR PC PC ADD KECCAK_GENERAL PUSH32 MSTORE_32BYTES POP, halt): the
+    kernel image is the MemBefore content (so `verify_initial_memory` uses it too); the Cpu rows look up their code
+    bytes, stack writes / reads, the ADDs, the XOR, the KECCAK_GENERAL and the MSTORE_32BYTES in Memory, Arithmetic,
+    Logic, KeccakSponge and BytePacking, the sponge in turn its permutation in Keccak, its block XORs in Logic and its
+    input bytes in Memory, BytePacking its 32 byte writes in Memory -- all nine tables live, all ten CTLs carrying
+    traffic.  Proven by zk_prove_segment under standard_fast_config, accepted; rejected with one Cpu
     cell changed (the sum an ADD leaves on the stack: Arithmetic CTL; the digest: KeccakSponge CTL; one unit of gas:
     the Cpu AIR itself)."""
     import torch
@@ -463,7 +464,7 @@ def test_segment_with_executing_cpu_accepted_by_verify_proof(oracle):
     kh = int.from_bytes(rng.bytes(32), "big")
     traces, pvd, code = cs.build_with_cpu_program(rng, oracle, kh)
     consts = cs.CPU_PROGRAM_CONSTS
-    in_use = [True, False, True, True, True, True, True, True, True]
+    in_use = [True] * 9
     cfg = ol.make_cfg(hasher=0)
     init_cap = initial_memory_merkle_cap(code, 1, 4, hasher=0)
 

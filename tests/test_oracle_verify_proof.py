@@ -51,13 +51,15 @@ def test_consistent_segment_rows_and_ctls_balance():
 
 
 def test_segment_with_an_executing_cpu_table(oracle):
-    """A Cpu table that really runs instructions (PC PC PC ADD XOR PC PC ADD KECCAK_GENERAL POP in kernel mode, then
-    halts): its rows satisfy all 514 constraints of the restated Cpu AIR, and its bus traffic -- ten code reads of the
-    kernel image, stack writes through the partial channel, stack reads, two ADDs, one XOR, one KECCAK_GENERAL over
-    three bytes of the kernel image (a KeccakSponge row, its Keccak-f permutation, its five block XORs, its byte
-    reads) -- balances all ten CTLs of the real wiring across eight live tables.  A wrong gas charge or stack pointer
-    breaks the AIR; a wrong sum breaks exactly the Arithmetic CTL, a wrong XOR the Logic CTL, a wrong digest the
-    KeccakSponge CTL; executing a byte that is not in the kernel image breaks the Memory CTL."""
+    """A Cpu table that really runs instructions (PC PC PC ADD XOR PC PC ADD KECCAK_GENERAL PUSH32 MSTORE_32BYTES POP
+    in kernel mode, then halts): its rows satisfy all 514 constraints of the restated Cpu AIR, and its bus traffic --
+    twelve code reads of the kernel image, stack writes through the partial channel, stack reads, two ADDs, one XOR,
+    one KECCAK_GENERAL over three bytes of the kernel image (a KeccakSponge row, its Keccak-f permutation, its five
+    block XORs, its byte reads), one MSTORE_32BYTES of the digest (a BytePacking row and its 32 byte writes) --
+    balances all ten CTLs of the real wiring with ALL NINE tables live.  A wrong gas charge or stack pointer breaks the
+    AIR; a wrong sum breaks exactly the Arithmetic CTL, a wrong XOR the Logic CTL, a wrong digest the KeccakSponge CTL,
+    a wrong stored byte the BytePacking / Memory CTLs; executing a byte that is not in the kernel image breaks the
+    Memory CTL."""
     rng = np.random.default_rng(2)
     traces, pv, code = cs.build_with_cpu_program(rng, oracle, KH)
     air = oairs.make_eval_cpu(*cs.CPU_PROGRAM_CONSTS)
@@ -66,6 +68,8 @@ def test_segment_with_an_executing_cpu_table(oracle):
     _check_air(oairs.AIRS[2][0], traces[A.LOGIC])
     _check_air(oairs.eval_keccak_sponge, traces[A.KECCAK_SPONGE])
     _check_air(oairs.AIRS[6][0], traces[A.KECCAK])
+    _check_air(oairs.eval_byte_packing, traces[A.BYTE_PACKING])
+    assert int(traces[A.BYTE_PACKING][32].sum()) == 1                          # one 32-byte operation
     assert int(traces[A.ARITHMETIC][0].sum()) == 2 and int(traces[A.CPU][6:24].sum()) == cs.CPU_EXECUTED
     assert int(traces[A.LOGIC][2].sum()) == 1 + 5 and int(traces[A.KECCAK][0].sum()) == 1
     # the digest the Cpu pushed is keccak256 of the three hashed bytes, read big-endian
@@ -96,4 +100,9 @@ def test_segment_with_an_executing_cpu_table(oracle):
     assert first_failure(A.CPU, 41 + 5, 9)[1].startswith("CTL 2")                      # another digest on the stack
     assert first_failure(A.LOGIC, 515, 0)[1].startswith("CTL 5")                       # another XOR result
     assert first_failure(A.KECCAK, 2429, 23)[1].startswith("CTL 4")                    # another permutation output
+    assert first_failure(A.BYTE_PACKING, 37, 0)[1].startswith("CTL 1")                 # another stored byte
+    # the stored digest is in the final memory: 32 bytes at (7, 11, 5..36)
+    after = traces[A.MEM_AFTER]
+    stored = {int(after[3, r]): int(after[4, r]) for r in range(after.shape[1]) if after[0, r] and (after[1, r], after[2, r]) == (7, 11)}
+    assert bytes(stored.get(5 + i, 0) for i in range(32)) == oracle.keccak256(code[11:14])
     assert first_failure(A.CPU, 24, 0)[1].startswith("CTL 6")                          # opcode 0x59 claimed at pc 0
