@@ -218,11 +218,10 @@ def sponge_side_effects(ks):
     return perms, xors
 
 
-def build_with_cpu_program(rng, oracle, kernel_hash=0):
-    """Like `build`, but the kernel image IS CPU_PROGRAM and the Cpu table executes it: code reads, stack writes /
-    reads and the hashed bytes join the Memory table, two ADD rows the Arithmetic table, the XOR and the sponge's
-    block XORs the Logic table, one KECCAK_GENERAL the KeccakSponge table and its permutation the Keccak table, one
-    MSTORE_32BYTES the BytePacking table (whose 32 byte writes land in Memory and MemAfter): all nine tables live."""
+def program_logs(rng, oracle, kernel_hash=0):
+    """The operation logs of the run (what the reference's interpreter would hand to `generate_traces`): Cpu rows,
+    Memory operations (public-value writes + the Cpu's bus traffic), mem_before values, and the Arithmetic / Logic /
+    KeccakSponge / Keccak / BytePacking operation lists."""
     from tests.test_oracle_tracegen import _keccak_f
     pv = make_public_values(rng)
     code = CPU_PROGRAM
@@ -231,21 +230,31 @@ def build_with_cpu_program(rng, oracle, kernel_hash=0):
     perms, sponge_xors = sponge_side_effects(sponge)
     before = [((0, SEG_CODE, i), b) for i, b in enumerate(code)]
     before += [((0, SEG_SHIFT_TABLE, i), 1 << i) for i in range(256)]
-    ops = [dict(filter=True, timestamp=2, ctx=0, seg=seg, virt=idx, is_read=False, value=val)
-           for seg, idx, val in oseg.public_memory_writes(pv, kernel_hash, len(code))] + cpu_mem_ops
-    memory, mem_after = mem_trace.generate_trace(ops, before, [])
-    before_rows = [[1, c, s, v] + [(val >> (32 * j)) & 0xFFFFFFFF for j in range(8)] for (c, s, v), val in before]
+    mem_ops = [dict(filter=True, timestamp=2, ctx=0, seg=seg, virt=idx, is_read=False, value=val)
+               for seg, idx, val in oseg.public_memory_writes(pv, kernel_hash, len(code))] + cpu_mem_ops
+    return dict(pv=pv, code=code, cpu=cpu, memory=mem_ops, before=before, arithmetic=arith_ops,
+                logic=logic_ops + sponge_xors, sponge=sponge_ops, sponge_trace=sponge, keccak=perms, packing=packing_ops)
+
+
+def build_with_cpu_program(rng, oracle, kernel_hash=0):
+    """Like `build`, but the kernel image IS CPU_PROGRAM and the Cpu table executes it: code reads, stack writes /
+    reads and the hashed bytes join the Memory table, two ADD rows the Arithmetic table, the XOR and the sponge's
+    block XORs the Logic table, one KECCAK_GENERAL the KeccakSponge table and its permutation the Keccak table, one
+    MSTORE_32BYTES the BytePacking table (whose 32 byte writes land in Memory and MemAfter): all nine tables live."""
+    g = program_logs(rng, oracle, kernel_hash)
+    memory, mem_after = mem_trace.generate_trace(g["memory"], g["before"], [])
+    before_rows = [[1, c, s, v] + [(val >> (32 * j)) & 0xFFFFFFFF for j in range(8)] for (c, s, v), val in g["before"]]
     traces = [None] * 9
-    traces[0] = arith_trace.generate_trace(arith_ops)[0]
-    traces[1] = otg.byte_packing_generate_trace(packing_ops, 0)
-    traces[2] = cpu
-    traces[3] = np.ascontiguousarray(keccak_trace.generate_trace_rows(perms, 32).T)
-    traces[4] = sponge
-    traces[5] = logic_table(logic_ops + sponge_xors)
+    traces[0] = arith_trace.generate_trace(g["arithmetic"])[0]
+    traces[1] = otg.byte_packing_generate_trace(g["packing"], 0)
+    traces[2] = g["cpu"]
+    traces[3] = np.ascontiguousarray(keccak_trace.generate_trace_rows(g["keccak"], 32).T)
+    traces[4] = g["sponge_trace"]
+    traces[5] = logic_table(g["logic"])
     traces[6] = memory
     traces[7] = continuation_table(before_rows)
     traces[8] = continuation_table(mem_after)
-    return traces, pv, code
+    return traces, g["pv"], g["code"]
 
 
 P_FIELD = 0xFFFFFFFF00000001
