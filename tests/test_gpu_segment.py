@@ -492,9 +492,10 @@ def test_segment_with_executing_cpu_accepted_by_verify_proof(oracle):
 
 def test_executing_cpu_segment_with_device_generated_tables(oracle):
     """The same run, but the eight non-Cpu tables are built ON THE DEVICE from the operation logs (what
-    `generate_traces`, witness/traces.rs:164-234, does on the CPU): `arithmetic_generate_trace`,
-    `byte_packing_generate_trace`, `keccak_generate_trace`, `keccak_sponge_generate_trace`, `logic_generate_trace`,
-    `memory_generate_trace` (which also returns the MemAfter table) and `memory_continuation_generate_trace`.  Every
+    `Traces::into_tables`, witness/traces.rs:135-262, does on the CPU) through the product's `tracegen.Traces`
+    mirror: `arithmetic_generate_trace`, `byte_packing_generate_trace`, `keccak_generate_trace`,
+    `keccak_sponge_generate_trace`, `logic_generate_trace`, `memory_generate_trace` (which also returns the MemAfter
+    table) and `memory_continuation_generate_trace`.  Every
     device table equals the restated reference generator's, and the segment proof passes `verify_proof`."""
     import torch
     import zk_evm_amd as zk
@@ -507,20 +508,20 @@ def test_executing_cpu_segment_with_device_generated_tables(oracle):
     kh = 0x1234
     g = cs.program_logs(np.random.default_rng(80), oracle, kh)
     ref, pvd, code = cs.build_with_cpu_program(np.random.default_rng(80), oracle, kh)
-    mem_ops = [(o["filter"], o["timestamp"], (o["ctx"], o["seg"], o["virt"]), o["is_read"], o["value"]) for o in g["memory"]]
-    memory, mem_after, _, _ = tg.memory_generate_trace(mem_ops, g["before"], [])
-    dev = [None] * 9
-    dev[0], _ = tg.arithmetic_generate_trace([op[1:] for op in g["arithmetic"]])
-    dev[1] = tg.byte_packing_generate_trace(g["packing"], 0)
-    dev[2] = torch.from_numpy(g["cpu"].view(np.int64)).cuda()
-    dev[3] = tg.keccak_generate_trace(g["keccak"], 32)
-    dev[4] = tg.keccak_sponge_generate_trace(g["sponge"], 0)
-    dev[5] = tg.logic_generate_trace(g["logic"], 32)
-    dev[6], dev[7], dev[8] = memory, tg.memory_continuation_generate_trace(g["before"]), mem_after
+    tr = tg.Traces()                                                 # witness/traces.rs:36-48
+    tr.memory_ops = [(o["filter"], o["timestamp"], (o["ctx"], o["seg"], o["virt"]), o["is_read"], o["value"]) for o in g["memory"]]
+    tr.arithmetic_ops = [op[1:] for op in g["arithmetic"]]
+    tr.byte_packing_ops, tr.keccak_inputs, tr.keccak_sponge_ops, tr.logic_ops = g["packing"], g["keccak"], g["sponge"], g["logic"]
+    tr.cpu = np.ascontiguousarray(g["cpu"].T)                        # rows of CpuColumnsView
+    st = AllStark(cs.CPU_PROGRAM_CONSTS)
+    dev, final_values = tr.into_tables(st, g["before"], [], zk.StarkConfig())
+    assert len(final_values) == int(ref[8][0].sum()) and tr.unpadded_memory_length <= ref[6].shape[1]
+    ref[3] = np.ascontiguousarray(cs.keccak_trace.generate_trace_rows(g["keccak"], 16).T)   # min_rows = cap elements
+    ref[5] = cs.logic_table(g["logic"], 16)
     for t in range(9):
         assert np.array_equal(dev[t].cpu().numpy().view(np.uint64), ref[t]), t
     in_use = [True] * 9
-    got = sg.prove_with_traces(AllStark(cs.CPU_PROGRAM_CONSTS), zk.StarkConfig(), dev, in_use, to_public_values(pvd))
+    got = sg.prove_with_traces(st, zk.StarkConfig(), dev, in_use, to_public_values(pvd))
     before_cap = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
     ok, why = oseg.verify_proof(oracle, ol, ol.make_cfg(hasher=0), _proof_dicts(got), in_use, pvd, cs.CPU_PROGRAM_CONSTS, kh,
                                 len(code), is_initial=True, initial_mem_cap=tg.initial_memory_merkle_cap(code, 1, 4, hasher=0),

@@ -293,3 +293,47 @@ def keccak_sponge_generate_trace(ops, min_rows: int, device=0, ctx: Context = No
                                                       blob.ctypes.data if blob.size else None, blob.size, log_n,
                                                       C.c_void_p(out.data_ptr()), 1 << log_n))
     return out
+
+
+class Traces:
+    """`witness::traces::Traces` (witness/traces.rs:36-48): the operation logs the interpreter hands over, and
+    `into_tables` (:135-262), which turns them into the per-table `Vec<PolynomialValues>` -- here column-major CUDA
+    tensors built by the device generators, ready for `segment.prove_with_traces`.
+
+    arithmetic_ops / byte_packing_ops / logic_ops / memory_ops / keccak_inputs / keccak_sponge_ops / poseidon_ops are
+    lists in the formats of the corresponding `*_generate_trace` functions of this module; `cpu` is the (rows, 85 or
+    86) array of `CpuColumnsView` rows, already padded to a power of two by the caller (the interpreter appends the
+    halting rows)."""
+
+    def __init__(self):
+        self.arithmetic_ops, self.byte_packing_ops, self.cpu, self.logic_ops = [], [], None, []
+        self.memory_ops, self.keccak_inputs, self.keccak_sponge_ops, self.poseidon_ops = [], [], [], []
+
+    def into_tables(self, all_stark, mem_before_values, stale_contexts, config, device=0, ctx: Context = None):
+        """-> (tables in `Table` order, final_values): `Traces::into_tables(all_stark, mem_before_values,
+        stale_contexts, trace_lengths, config, timing)`.  min_rows of the optional tables = the number of cap elements,
+        as in the reference (:148)."""
+        import torch
+        cap_elements = 1 << config.fri_config.cap_height
+        cpu = self.cpu
+        if not torch.is_tensor(cpu):
+            cpu = torch.from_numpy(np.ascontiguousarray(np.asarray(cpu, dtype=np.uint64)).view(np.int64))
+        cpu = cpu.to(f"cuda:{device}")
+        n_cpu_cols = all_stark.table_columns[2]
+        if cpu.dim() != 2 or cpu.shape[1] != n_cpu_cols or cpu.shape[0] & (cpu.shape[0] - 1) or cpu.shape[0] == 0:
+            raise ZkStarkError(-1, "cpu: expected (2^k, %d) rows" % n_cpu_cols)
+        arithmetic, _ = arithmetic_generate_trace(self.arithmetic_ops, device=device, ctx=ctx)
+        byte_packing = byte_packing_generate_trace(self.byte_packing_ops, cap_elements, device=device, ctx=ctx)
+        cpu_trace = cpu.t().contiguous()                                   # trace_rows_to_poly_values
+        keccak = keccak_generate_trace(self.keccak_inputs, cap_elements, device=device, ctx=ctx)
+        keccak_sponge = keccak_sponge_generate_trace(self.keccak_sponge_ops, cap_elements, device=device, ctx=ctx)
+        logic = logic_generate_trace(self.logic_ops, cap_elements, device=device, ctx=ctx)
+        memory, mem_after, final_values, self.unpadded_memory_length = memory_generate_trace(
+            self.memory_ops, mem_before_values, stale_contexts, device=device, ctx=ctx)
+        mem_before = memory_continuation_generate_trace(mem_before_values, device=device, ctx=ctx)
+        tables = [arithmetic, byte_packing, cpu_trace, keccak, keccak_sponge, logic, memory, mem_before, mem_after]
+        if all_stark.cdk_erigon:
+            tables.append(poseidon_generate_trace(self.poseidon_ops, cap_elements, device=device, ctx=ctx))
+        elif self.poseidon_ops:
+            raise ZkStarkError(-1, "Poseidon operations in an eth_mainnet run")
+        return tables, final_values
