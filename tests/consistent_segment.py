@@ -93,7 +93,7 @@ CPU_EXECUTED = 12                                                # instructions 
 CPU_PROGRAM_CONSTS = (CPU_HALT_PC, 0, 777777, 888888)            # halt_final, init, syscall / exception jumptables
 
 
-def cpu_program_trace(keccak256, n=16):
+def cpu_program_trace(keccak256, n=16, program=None, halt_pc=None, cdk_erigon=False, poseidon_permute=None):
     """The Cpu rows of the kernel-mode run of CPU_PROGRAM (cpu/columns/mod.rs:56-97 layout), with the memory-bus,
     Arithmetic, Logic, KeccakSponge and BytePacking operations it performs.  Stack discipline as the reference's
     witness generator keeps it: the top of the stack lives in mem_channels[0].value; a push writes the old top through
@@ -105,21 +105,24 @@ def cpu_program_trace(keccak256, n=16):
     makes the NEXT row read the new top through channel 0 (stack.rs:371-410); timestamps = (clock - 1) * 5 + 1 +
     channel."""
     from oracle import airs
-    ops = airs.C_OPS
+    program = CPU_PROGRAM if program is None else program
+    halt_pc = CPU_HALT_PC if halt_pc is None else halt_pc
+    ops = airs.C_OPS_ERIGON if cdk_erigon else airs.C_OPS
+    x = 1 if cdk_erigon else 0                                        # `poseidon` flag column: later columns move by one
     col = lambda name: 6 + ops.index(name)
-    bits, gen, clock, partial = 24, 32, 40, 80
-    ch = lambda k: 41 + 13 * k
+    bits, gen, clock, partial = 24 + x, 32 + x, 40 + x, 80 + x
+    ch = lambda k: 41 + x + 13 * k
     limbs = lambda v: [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
-    t = np.zeros((85, n), dtype=np.uint64)
+    t = np.zeros((85 + x, n), dtype=np.uint64)
     stack, gas, pc, top_read = [], 0, 0, False
-    mem_ops, arith, logic, sponge, packing = [], [], [], [], []
+    mem_ops, arith, logic, sponge, packing, poseidon = [], [], [], [], [], []
+    CPU_PROGRAM_ = program
     for r in range(n):
         t[clock, r], t[4, r], t[3, r], t[5, r], t[2, r] = r + 1, 1, len(stack), gas, pc
         base = r * 5 + 1
-        if pc == CPU_HALT_PC:
+        if pc == halt_pc:
             continue                                                  # halting rows
-        assert r < CPU_EXECUTED
-        op = CPU_PROGRAM[pc]
+        op = CPU_PROGRAM_[pc]
         for i in range(8):
             t[bits + i, r] = (op >> i) & 1
         mem_ops.append(dict(filter=True, timestamp=base, ctx=0, seg=0, virt=pc, is_read=True, value=op))   # code read
@@ -140,7 +143,7 @@ def cpu_program_trace(keccak256, n=16):
                 stack.append(pc)
                 gas += 2
             else:
-                stack.append(int.from_bytes(CPU_PROGRAM[pc + 1:pc + 33], "big"))
+                stack.append(int.from_bytes(CPU_PROGRAM_[pc + 1:pc + 33], "big"))
                 gas += 3
                 next_pc = pc + 33
         elif op in (0x01, 0x18, 0x21, 0xdf):      # ADD / XOR / KECCAK_GENERAL / MSTORE_32BYTES_32: two operands
@@ -160,8 +163,8 @@ def cpu_program_trace(keccak256, n=16):
             else:                                                     # a = address word
                 virt, seg, ctx = a & 0xFFFFFFFF, (a >> 32) & 0xFFFFFFFF, (a >> 64) & 0xFFFFFFFF
                 if op == 0x21:
-                    assert (ctx, seg) == (0, 0) and virt + b <= len(CPU_PROGRAM), "this run hashes a slice of the kernel image"
-                    data = CPU_PROGRAM[virt:virt + b]
+                    assert (ctx, seg) == (0, 0) and virt + b <= len(CPU_PROGRAM_), "this run hashes a slice of the kernel image"
+                    data = CPU_PROGRAM_[virt:virt + b]
                     sponge.append(((ctx, seg, virt), base, data))
                     mem_ops += [dict(filter=True, timestamp=base, ctx=ctx, seg=seg, virt=virt + i, is_read=True, value=x)
                                 for i, x in enumerate(data)]
@@ -172,6 +175,17 @@ def cpu_program_trace(keccak256, n=16):
                     mem_ops += [dict(filter=True, timestamp=base, ctx=ctx, seg=seg, virt=virt + i, is_read=False, value=x)
                                 for i, x in enumerate(data)]
                     stack[-2:] = [a + 32]
+        elif op == 0x22:                                              # POSEIDON (cdk_erigon): hash three stack words
+            t[col("poseidon"), r] = 1
+            words = [stack[-1], stack[-2], stack[-3]]
+            for k in (1, 2):
+                t[ch(k):ch(k) + 5, r] = [1, 1, 0, 1, sl - 1 - k]
+                t[ch(k) + 5:ch(k) + 13, r] = limbs(words[k])
+                mem_ops.append(dict(filter=True, timestamp=base + 1 + k, ctx=0, seg=1, virt=sl - 1 - k, is_read=True, value=words[k]))
+            inp = [((w >> (64 * i)) & 0xFFFFFFFFFFFFFFFF) % P_FIELD for w in words for i in range(4)]
+            poseidon.append(("simple", inp))
+            out = [int(v) for v in poseidon_permute(inp)[:4]]
+            stack[-3:] = [sum(v << (64 * i) for i, v in enumerate(out))]
         else:                                                         # POP
             assert op == 0x50
             t[col("not_pop"), r] = 1
@@ -181,7 +195,9 @@ def cpu_program_trace(keccak256, n=16):
             stack.pop()
             gas += 2
         pc = next_pc
-    assert pc == CPU_HALT_PC and not stack
+    assert pc == halt_pc and not stack
+    if cdk_erigon:
+        return t, mem_ops, arith, logic, sponge, packing, poseidon
     return t, mem_ops, arith, logic, sponge, packing
 
 
@@ -255,6 +271,42 @@ def build_with_cpu_program(rng, oracle, kernel_hash=0):
     traces[7] = continuation_table(before_rows)
     traces[8] = continuation_table(mem_after)
     return traces, g["pv"], g["code"]
+
+
+# ---- the cdk_erigon feature set: PC PC PC POSEIDON POP, halt at pc = 5 ----------------------------------------------
+ERIGON_PROGRAM = bytes([0x58, 0x58, 0x58, 0x22, 0x50, 0x00, 0x00, 0x00])
+ERIGON_CONSTS = (5, 0, 777777, 888888)
+
+
+def build_cdk_erigon_with_cpu_program(rng, oracle, kernel_hash=0):
+    """Ten tables of a `cdk_erigon` run whose 86-column Cpu table executes POSEIDON on three stack words: the Poseidon
+    table gets the matching PoseidonSimpleOp row (CTL 10); public values carry a burn address and no eth_mainnet
+    fields.  -> (traces[10], pv, code)."""
+    from oracle import poseidon_table as pt
+    pv = make_public_values(rng)
+    pv.update(burn_addr=int.from_bytes(rng.bytes(20), "big"), blob_gas_used=0, excess_blob_gas=0, parent_beacon_root=bytes(32))
+    code = ERIGON_PROGRAM
+    cpu, cpu_mem_ops, arith_ops, logic_ops, sponge_ops, packing_ops, poseidon_ops = cpu_program_trace(
+        oracle.keccak256, program=code, halt_pc=ERIGON_CONSTS[0], cdk_erigon=True, poseidon_permute=oracle.poseidon_permute)
+    assert not (arith_ops or logic_ops or sponge_ops or packing_ops) and len(poseidon_ops) == 1
+    before = [((0, SEG_CODE, i), b) for i, b in enumerate(code)]
+    before += [((0, SEG_SHIFT_TABLE, i), 1 << i) for i in range(256)]
+    ops = [dict(filter=True, timestamp=2, ctx=0, seg=seg, virt=idx, is_read=False, value=val)
+           for seg, idx, val in oseg.public_memory_writes(pv, kernel_hash, len(code))] + cpu_mem_ops
+    memory, mem_after = mem_trace.generate_trace(ops, before, [])
+    before_rows = [[1, c, s, v] + [(val >> (32 * j)) & 0xFFFFFFFF for j in range(8)] for (c, s, v), val in before]
+    traces = [None] * 10
+    traces[0] = arith_trace.generate_trace([])[0]
+    traces[1] = otg.byte_packing_generate_trace([], 0)
+    traces[2] = cpu
+    traces[3] = np.ascontiguousarray(keccak_trace.generate_trace_rows([], 32).T)
+    traces[4] = otg.keccak_sponge_generate_trace([], 0, None)
+    traces[5] = np.zeros((523, 32), dtype=np.uint64)
+    traces[6] = memory
+    traces[7] = continuation_table(before_rows)
+    traces[8] = continuation_table(mem_after)
+    traces[9] = pt.generate_trace(poseidon_ops, 16)
+    return traces, pv, code
 
 
 P_FIELD = 0xFFFFFFFF00000001

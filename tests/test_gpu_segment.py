@@ -527,3 +527,46 @@ def test_executing_cpu_segment_with_device_generated_tables(oracle):
                                 len(code), is_initial=True, initial_mem_cap=tg.initial_memory_merkle_cap(code, 1, 4, hasher=0),
                                 mem_before_cap=before_cap)
     assert ok, why
+
+
+def test_cdk_erigon_executing_cpu_accepted_by_verify_proof(oracle):
+    """`verify_proof` for the cdk_erigon feature set (ten tables, 13 CTLs, burn address): the 86-column Cpu table runs
+    PC PC PC POSEIDON POP, the Poseidon table -- generated on the device -- holds the matching simple operation.
+    Accepted; with the Poseidon digest changed rejected at CTL 10."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    import zk_evm_amd.tracegen as tg
+    from oracle import all_stark as oas
+    from oracle import segment as oseg
+    from tests import consistent_segment as cs
+    from zk_evm_amd.all_stark import AllStark
+    ol.setup_fri_api(oracle)
+    kh = 0xABCDEF
+    traces, pvd, code = cs.build_cdk_erigon_with_cpu_program(np.random.default_rng(81), oracle, kh)
+    words = [2, 1, 0]
+    inp = [((w >> (64 * i)) & 0xFFFFFFFFFFFFFFFF) for w in words for i in range(4)]
+    dev_poseidon = tg.poseidon_generate_trace([("simple", inp)], 16)
+    assert np.array_equal(dev_poseidon.cpu().numpy().view(np.uint64), traces[9])
+    reg = oas.Registry(True)
+    in_use = [True, False, True, False, False, False, True, True, True, True]
+    st = AllStark(cs.ERIGON_CONSTS, cdk_erigon=True)
+    cfg = ol.make_cfg(hasher=0)
+    init_cap = tg.initial_memory_merkle_cap(code, 1, 4, hasher=0)
+
+    def run(trs):
+        dev = [torch.from_numpy(np.ascontiguousarray(t).view(np.int64)).cuda() for t in trs]
+        pv = to_public_values(pvd)
+        pv.burn_addr = pvd["burn_addr"]
+        got = sg.prove_with_traces(st, zk.StarkConfig(), dev, in_use, pv)
+        before_cap = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
+        return oseg.verify_proof(oracle, ol, cfg, _proof_dicts(got), in_use, pvd, cs.ERIGON_CONSTS, kh, len(code),
+                                 is_initial=True, initial_mem_cap=init_cap, mem_before_cap=before_cap, reg=reg)
+    ok, why = run(traces)
+    assert ok, why
+    from oracle import poseidon_table as pt
+    bad = [t.copy() for t in traces]
+    bad[9][pt.DIGEST_COL, 0] ^= np.uint64(1)
+    bad[9][pt.PINV:pt.PINV + 4, 0] = traces[9][pt.PINV:pt.PINV + 4, 0]
+    ok, why = run(bad)
+    assert not ok, why

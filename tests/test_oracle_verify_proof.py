@@ -106,3 +106,42 @@ def test_segment_with_an_executing_cpu_table(oracle):
     stored = {int(after[3, r]): int(after[4, r]) for r in range(after.shape[1]) if after[0, r] and (after[1, r], after[2, r]) == (7, 11)}
     assert bytes(stored.get(5 + i, 0) for i in range(32)) == oracle.keccak256(code[11:14])
     assert first_failure(A.CPU, 24, 0)[1].startswith("CTL 6")                          # opcode 0x59 claimed at pc 0
+
+
+def test_cdk_erigon_segment_with_an_executing_cpu_table(oracle):
+    """The `cdk_erigon` feature set with a live Cpu table: PC PC PC POSEIDON POP in the 86-column layout satisfies the
+    531-constraint variant of the Cpu AIR; the Poseidon table's PoseidonSimpleOp row matches it through CTL 10
+    (ctl_poseidon_simple: twelve 64-bit input elements from three stack words, eight digest limbs); the extra looking
+    sum of the Memory CTL is the cdk_erigon one (burn address written, no eth_mainnet metadata)."""
+    from oracle import poseidon_table as pt
+    traces, pv, code = cs.build_cdk_erigon_with_cpu_program(np.random.default_rng(3), oracle, KH)
+    reg = A.Registry(True)
+    assert [t.shape[0] for t in traces] == list(reg.TABLE_COLUMNS)
+    air = oairs.make_eval_cpu(*cs.ERIGON_CONSTS, cdk_erigon=True)
+    _check_air(air, traces[A.CPU])
+    _check_air(pt.eval_poseidon, traces[9])
+    _check_air(oairs.eval_memory, traces[A.MEMORY])
+    words = [0, 1, 2][::-1]                                             # stack top first: PC pushed 0, 1, 2
+    inp = [((w >> (64 * i)) & 0xFFFFFFFFFFFFFFFF) for w in words for i in range(4)]
+    digest = [int(v) for v in oracle.poseidon_permute(inp)[:4]]
+    pushed = sum(int(traces[A.CPU][42 + 5 + i, 4]) << (32 * i) for i in range(8))
+    assert pushed == sum(v << (64 * i) for i, v in enumerate(digest))
+    ch = [S.GrandProductChallenge(1234567, 7654321), S.GrandProductChallenge(99, 101)]
+
+    def balance(trs, pvx=pv):
+        zf = cs.ctl_first_values(trs, reg.ctls, ch)
+        extra = [[0, 0] for _ in reg.ctls]
+        extra[oseg.MEMORY_CTL_IDX] = [oseg.get_memory_extra_looking_sum(pvx, c, KH, len(code)) for c in ch]
+        return oseg.verify_cross_table_lookups(reg.ctls, zf, extra, 2), zf
+    (ok, why), zf = balance(traces)
+    assert ok, why
+    assert all(zf[9][2:4]) and not any(zf[9][:2])                        # simple-op CTL live, no Poseidon memory reads
+    bad = [t.copy() for t in traces]
+    bad[9][pt.DIGEST_COL, 0] ^= np.uint64(1)
+    assert balance(bad)[0] == (False, "CTL 10 challenge 0")
+    # the mainnet reading of the same public values (blob-gas / beacon-root writes, no burn address) does not balance
+    pv_mainnet = dict(pv, burn_addr=None)
+    assert balance(traces, pv_mainnet)[0][1].startswith("CTL 6")
+    # the same rows under the eth_mainnet Cpu AIR make no sense (columns shifted)
+    with pytest.raises(AssertionError):
+        _check_air(oairs.make_eval_cpu(*cs.ERIGON_CONSTS), traces[A.CPU][:85])
