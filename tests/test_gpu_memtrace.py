@@ -130,3 +130,13 @@ def test_packed_arrays_are_passed_through():
     t1, a1, f1, u1 = memory_generate_trace(pops, pbefore, stale)
     t2, a2, f2, u2 = memory_generate_trace(a, b, stale)
     assert torch.equal(t1, t2) and torch.equal(a1, a2) and f1 == f2 and u1 == u2
+
+
+def test_equal_keys_keep_input_order():
+    """`sort_by_key` is stable: operations with the same (context, segment, virt, timestamp) stay in log order
+    (memory_ops first, then the mem_before writes).  The device radix sort must do the same, cell for cell."""
+    v = 0xAABBCCDD00112233445566778899
+    ops = [_w(5, 1, 2, 3, v, read=True), _w(5, 1, 2, 3, v + 1), _w(5, 1, 2, 3, v + 2, read=True),
+           _w(0, 1, 2, 9, 7), _w(5, 0, 0, 0, 1), _w(5, 0, 0, 0, 2), _w(5, 0, 0, 0, 3)]
+    before = [((1, 2, 9), 8), ((1, 2, 9), 9)]                   # same key as the timestamp-0 operation above
+    _check(ops, before, [])
