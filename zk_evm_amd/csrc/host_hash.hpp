@@ -15,6 +15,13 @@
 
 namespace zkhost {
 
+// Host permutation for the transcript.  A wide table's opening set is ~10^4 elements (Keccak: 1200 permutations
+// per proof), so this is on the critical path between kernels: 128-bit products (one mulq each), the MDS rows over a
+// doubled state array (no modulo in the inner loop), constants added once per round.
+inline u64 mul_host(u64 a, u64 b) {
+    const unsigned __int128 p = (unsigned __int128)a * b;
+    return gl_reduce128((u64)(p >> 64), (u64)p);
+}
 inline void poseidon_permute(u64 (&s)[12]) {
     static const u64 RC[ZK_POSEIDON_ROUNDS * 12] = ZK_POSEIDON_RC_INIT;
     static const u32 CIRC[12] = ZK_POSEIDON_MDS_CIRC_INIT;
@@ -22,26 +29,30 @@ inline void poseidon_permute(u64 (&s)[12]) {
     for (int round = 0; round < ZK_POSEIDON_ROUNDS; ++round) {
         const bool full = round < ZK_POSEIDON_HALF_FULL_ROUNDS ||
                           round >= ZK_POSEIDON_HALF_FULL_ROUNDS + ZK_POSEIDON_PARTIAL_ROUNDS;
-        for (int i = 0; i < 12; ++i) s[i] = gl_add_ref(s[i], RC[round * 12 + i]);
-        for (int i = 0; i < (full ? 12 : 1); ++i) {
-            u64 x = s[i], x2 = gl_mul_ref(x, x), x4 = gl_mul_ref(x2, x2);
-            s[i] = gl_mul_ref(gl_mul_ref(x, x2), x4);
-        }
-        u64 out[12];
-        for (int r = 0; r < 12; ++r) {
-            // 12 terms of (< 2^64) * (<= 41): accumulate high and low 32-bit halves separately
-            u64 lo = 0, hi = 0;
-            for (int i = 0; i < 12; ++i) {
-                u64 v = s[(i + r) % 12];
-                lo += (v & 0xFFFFFFFFULL) * CIRC[i];
-                hi += (v >> 32) * CIRC[i];
+        const u64 *rc = RC + round * 12;
+        u64 lo[24], hi[24];
+        for (int i = 0; i < 12; ++i) {
+            u64 x = gl_add_ref(s[i], rc[i]);
+            if (full || i == 0) {
+                const u64 x2 = mul_host(x, x), x4 = mul_host(x2, x2);
+                x = mul_host(mul_host(x, x2), x4);
             }
-            if (r == 0) { lo += (s[0] & 0xFFFFFFFFULL) * 8; hi += (s[0] >> 32) * 8; }
-            u64 t = lo + (hi << 32);
-            u32 top = (u32)(hi >> 32) + (t < lo ? 1u : 0u);
-            out[r] = gl_reduce96(top, t);
+            lo[i] = lo[i + 12] = x & 0xFFFFFFFFULL;
+            hi[i] = hi[i + 12] = x >> 32;
         }
-        for (int r = 0; r < 12; ++r) s[r] = gl_canon(out[r]);
+        for (int r = 0; r < 12; ++r) {
+            // 12 terms of (< 2^32) * (<= 41) per half: no overflow
+            u64 al = 0, ah = 0;
+#pragma GCC unroll 12
+            for (int i = 0; i < 12; ++i) {
+                al += lo[r + i] * CIRC[i];
+                ah += hi[r + i] * CIRC[i];
+            }
+            if (r == 0) { al += lo[0] * 8; ah += hi[0] * 8; }
+            const u64 t = al + (ah << 32);
+            const u32 top = (u32)(ah >> 32) + (t < al ? 1u : 0u);
+            s[r] = gl_canon(gl_reduce96(top, t));
+        }
     }
 }
 

@@ -315,7 +315,12 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
     cfg = config.to_c()
     cfg.hasher = hasher
     pv = np.array(public_values_elements(public_values), dtype=np.uint64)      # may raise PublicValuesError
-    wiring = encode_ctl_wiring(all_stark.cross_table_lookups)
+    # the encoded CTL wiring / lookup programs depend only on the table definitions: built once per AllStark
+    cache = all_stark.__dict__.setdefault("_encoded", {})
+    if "wiring" not in cache:
+        cache["wiring"] = encode_ctl_wiring(all_stark.cross_table_lookups)
+        cache["lookups"] = [encode_lookup_set(all_stark.lookups[t]) for t in range(all_stark.num_tables)]
+    wiring = cache["wiring"]
     tables = (ZkTableIn * NUM_TABLES)()
     keep = []
     for t in range(NUM_TABLES):
@@ -323,7 +328,7 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
         n_cols, n, log_n, stride = _trace_args(tr)
         if n_cols != all_stark.table_columns[t]:
             raise ZkStarkError(-1, "table %s: expected %d columns, got %d" % (TABLE_NAMES[t], all_stark.table_columns[t], n_cols))
-        lp = encode_lookup_set(all_stark.lookups[t])
+        lp = cache["lookups"][t]
         ac = np.array(list(all_stark.air_consts[t]), dtype=np.uint64)
         keep += [lp, ac]
         ti = tables[t]
