@@ -9,6 +9,9 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "gl.cuh"
 #include "../../include/poseidon_constants.h"
@@ -22,9 +25,53 @@ inline u64 mul_host(u64 a, u64 b) {
     const unsigned __int128 p = (unsigned __int128)a * b;
     return gl_reduce128((u64)(p >> 64), (u64)p);
 }
+// MDS layer on the split state (lo / hi 32-bit halves, doubled to 24 entries): s[r] = sum_i C[i] * x[r + i] + 8 x[0] [r = 0]
+inline void mds_scalar(u64 (&s)[12], const u64 (&lo)[24], const u64 (&hi)[24]) {
+    static const u32 CIRC[12] = ZK_POSEIDON_MDS_CIRC_INIT;
+    for (int r = 0; r < 12; ++r) {
+        // 12 terms of (< 2^32) * (<= 41) per half: no overflow
+        u64 al = 0, ah = 0;
+#pragma GCC unroll 12
+        for (int i = 0; i < 12; ++i) {
+            al += lo[r + i] * CIRC[i];
+            ah += hi[r + i] * CIRC[i];
+        }
+        if (r == 0) { al += lo[0] * 8; ah += hi[0] * 8; }
+        const u64 t = al + (ah << 32);
+        const u32 top = (u32)(ah >> 32) + (t < al ? 1u : 0u);
+        s[r] = gl_canon(gl_reduce96(top, t));
+    }
+}
+#if defined(__x86_64__)
+// the same with vpmuludq: four rows per vector, 72 multiplies instead of 288
+__attribute__((target("avx2"))) inline void mds_avx2(u64 (&s)[12], const u64 (&lo)[24], const u64 (&hi)[24]) {
+    static const u32 CIRC[12] = ZK_POSEIDON_MDS_CIRC_INIT;
+    alignas(32) u64 al[12], ah[12];
+    for (int g = 0; g < 3; ++g) {
+        __m256i vl = _mm256_setzero_si256(), vh = _mm256_setzero_si256();
+#pragma GCC unroll 12
+        for (int i = 0; i < 12; ++i) {
+            const __m256i c = _mm256_set1_epi64x((long long)CIRC[i]);
+            vl = _mm256_add_epi64(vl, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i *)(lo + 4 * g + i)), c));
+            vh = _mm256_add_epi64(vh, _mm256_mul_epu32(_mm256_loadu_si256((const __m256i *)(hi + 4 * g + i)), c));
+        }
+        _mm256_store_si256((__m256i *)(al + 4 * g), vl);
+        _mm256_store_si256((__m256i *)(ah + 4 * g), vh);
+    }
+    al[0] += lo[0] * 8;
+    ah[0] += hi[0] * 8;
+    for (int r = 0; r < 12; ++r) {
+        const u64 t = al[r] + (ah[r] << 32);
+        const u32 top = (u32)(ah[r] >> 32) + (t < al[r] ? 1u : 0u);
+        s[r] = gl_canon(gl_reduce96(top, t));
+    }
+}
+#endif
 inline void poseidon_permute(u64 (&s)[12]) {
     static const u64 RC[ZK_POSEIDON_ROUNDS * 12] = ZK_POSEIDON_RC_INIT;
-    static const u32 CIRC[12] = ZK_POSEIDON_MDS_CIRC_INIT;
+#if defined(__x86_64__)
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+#endif
     for (int i = 0; i < 12; ++i) s[i] = gl_canon(s[i]);
     for (int round = 0; round < ZK_POSEIDON_ROUNDS; ++round) {
         const bool full = round < ZK_POSEIDON_HALF_FULL_ROUNDS ||
@@ -40,19 +87,10 @@ inline void poseidon_permute(u64 (&s)[12]) {
             lo[i] = lo[i + 12] = x & 0xFFFFFFFFULL;
             hi[i] = hi[i + 12] = x >> 32;
         }
-        for (int r = 0; r < 12; ++r) {
-            // 12 terms of (< 2^32) * (<= 41) per half: no overflow
-            u64 al = 0, ah = 0;
-#pragma GCC unroll 12
-            for (int i = 0; i < 12; ++i) {
-                al += lo[r + i] * CIRC[i];
-                ah += hi[r + i] * CIRC[i];
-            }
-            if (r == 0) { al += lo[0] * 8; ah += hi[0] * 8; }
-            const u64 t = al + (ah << 32);
-            const u32 top = (u32)(ah >> 32) + (t < al ? 1u : 0u);
-            s[r] = gl_canon(gl_reduce96(top, t));
-        }
+#if defined(__x86_64__)
+        if (have_avx2) { mds_avx2(s, lo, hi); continue; }
+#endif
+        mds_scalar(s, lo, hi);
     }
 }
 
