@@ -442,7 +442,8 @@ def test_cdk_erigon_segment_proof_matches_oracle(oracle, in_use):
         sg.prove_with_traces(st, scfg, dev, in_use, to_public_values(pvd))
 
 
-def test_segment_with_executing_cpu_accepted_by_verify_proof(oracle):
+@pytest.mark.parametrize("hasher", [0, 1])
+def test_segment_with_executing_cpu_accepted_by_verify_proof(oracle, hasher):
     """`verify_proof` (verifier.rs:184-312) on a segment whose Cpu table executes a twelve-instruction kernel
     (tests/consistent_segment.py: PC PC PC ADD XOR PC PC ADD KECCAK_GENERAL PUSH32 MSTORE_32BYTES POP, halt): the
     kernel image is the MemBefore content (so `verify_initial_memory` uses it too); the Cpu rows look up their code
@@ -451,7 +452,9 @@ def test_segment_with_executing_cpu_accepted_by_verify_proof(oracle):
     input bytes in Memory, BytePacking its 32 byte writes in Memory -- all nine tables live, all ten CTLs carrying
     traffic.  Proven by zk_prove_segment under standard_fast_config, accepted; rejected with one Cpu
     cell changed (the sum an ADD leaves on the stack: Arithmetic CTL; the digest: KeccakSponge CTL; one unit of gas:
-    the Cpu AIR itself)."""
+    the Cpu AIR itself).  hasher = 1 is the same under `KeccakGoldilocksConfig` (Keccak-256 Merkle trees truncated to
+    25 bytes and the Keccak-based challenger), the configuration of the reference's STARK-only integration tests
+    (evm_arithmetization/tests/simple_transfer.rs:30)."""
     import torch
     import zk_evm_amd as zk
     import zk_evm_amd.segment as sg
@@ -465,12 +468,12 @@ def test_segment_with_executing_cpu_accepted_by_verify_proof(oracle):
     traces, pvd, code = cs.build_with_cpu_program(rng, oracle, kh)
     consts = cs.CPU_PROGRAM_CONSTS
     in_use = [True] * 9
-    cfg = ol.make_cfg(hasher=0)
-    init_cap = initial_memory_merkle_cap(code, 1, 4, hasher=0)
+    cfg = ol.make_cfg(hasher=hasher)
+    init_cap = initial_memory_merkle_cap(code, 1, 4, hasher=hasher)
 
     def run(trs):
         dev = [torch.from_numpy(np.ascontiguousarray(t).view(np.int64)).cuda() for t in trs]
-        got = sg.prove_with_traces(AllStark(consts), zk.StarkConfig(), dev, in_use, to_public_values(pvd))
+        got = sg.prove_with_traces(AllStark(consts), zk.StarkConfig(hasher=hasher), dev, in_use, to_public_values(pvd))
         before_cap = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
         return oseg.verify_proof(oracle, ol, cfg, _proof_dicts(got), in_use, pvd, consts, kh, len(code), is_initial=True,
                                  initial_mem_cap=init_cap, mem_before_cap=before_cap)
