@@ -94,111 +94,17 @@ CPU_PROGRAM_CONSTS = (CPU_HALT_PC, 0, 777777, 888888)            # halt_final, i
 
 
 def cpu_program_trace(keccak256, n=16, program=None, halt_pc=None, cdk_erigon=False, poseidon_permute=None):
-    """The Cpu rows of the kernel-mode run of CPU_PROGRAM (cpu/columns/mod.rs:56-97 layout), with the memory-bus,
-    Arithmetic, Logic, KeccakSponge and BytePacking operations it performs.  Stack discipline as the reference's
-    witness generator keeps it: the top of the stack lives in mem_channels[0].value; a push writes the old top through
-    the partial channel (stack.rs:173-282); ADD / XOR / KECCAK_GENERAL / MSTORE_32BYTES read their second operand
-    through GP channel 1; KECCAK_GENERAL(addr, len) pushes keccak256(mem[addr .. addr + len]) (the word read
-    big-endian); MSTORE_32BYTES_32(addr, value) writes the 32 big-endian bytes of value at addr through the
-    BytePacking table and pushes addr + 32 (byte_unpacking.rs); a kernel-mode PUSH is not tied to the code bytes
-    (its BytePacking looker is filtered by is_not_kernel, cpu_stark.rs:283-301); a POP that leaves a non-empty stack
-    makes the NEXT row read the new top through channel 0 (stack.rs:371-410); timestamps = (clock - 1) * 5 + 1 +
-    channel."""
-    from oracle import airs
+    """The Cpu rows of the kernel-mode run of `program` (default CPU_PROGRAM) and the operation logs it produces, from
+    the miniature witness generator tests/kernel_run.py (a restatement of witness/operation.rs for a subset of
+    opcodes).  -> (cpu trace, memory ops, arithmetic ops, logic ops, sponge ops, byte-packing ops[, poseidon ops])."""
+    from tests.kernel_run import KernelRun
     program = CPU_PROGRAM if program is None else program
     halt_pc = CPU_HALT_PC if halt_pc is None else halt_pc
-    ops = airs.C_OPS_ERIGON if cdk_erigon else airs.C_OPS
-    x = 1 if cdk_erigon else 0                                        # `poseidon` flag column: later columns move by one
-    col = lambda name: 6 + ops.index(name)
-    bits, gen, clock, partial = 24 + x, 32 + x, 40 + x, 80 + x
-    ch = lambda k: 41 + x + 13 * k
-    limbs = lambda v: [(v >> (32 * i)) & 0xFFFFFFFF for i in range(8)]
-    t = np.zeros((85 + x, n), dtype=np.uint64)
-    stack, gas, pc, top_read = [], 0, 0, False
-    mem_ops, arith, logic, sponge, packing, poseidon = [], [], [], [], [], []
-    CPU_PROGRAM_ = program
-    for r in range(n):
-        t[clock, r], t[4, r], t[3, r], t[5, r], t[2, r] = r + 1, 1, len(stack), gas, pc
-        base = r * 5 + 1
-        if pc == halt_pc:
-            continue                                                  # halting rows
-        op = CPU_PROGRAM_[pc]
-        for i in range(8):
-            t[bits + i, r] = (op >> i) & 1
-        mem_ops.append(dict(filter=True, timestamp=base, ctx=0, seg=0, virt=pc, is_read=True, value=op))   # code read
-        sl, top = len(stack), (stack[-1] if stack else 0)
-        t[ch(0) + 5:ch(0) + 13, r] = limbs(top)
-        if top_read:
-            t[ch(0):ch(0) + 5, r] = [1, 1, 0, 1, sl - 1]
-            mem_ops.append(dict(filter=True, timestamp=base + 1, ctx=0, seg=1, virt=sl - 1, is_read=True, value=top))
-            top_read = False
-        next_pc = pc + 1
-        if op in (0x58, 0x7f):                                        # PC / PUSH32: push
-            t[col("pc_push0" if op == 0x58 else "push_prover_input"), r] = 1
-            if sl:
-                t[gen + 4, r], t[gen + 5, r] = pow(sl, P_FIELD - 2, P_FIELD), 1      # stack_inv, stack_inv_aux
-                t[partial:partial + 5, r] = [1, 0, 0, 1, sl - 1]
-                mem_ops.append(dict(filter=True, timestamp=base + 4, ctx=0, seg=1, virt=sl - 1, is_read=False, value=top))
-            if op == 0x58:
-                stack.append(pc)
-                gas += 2
-            else:
-                stack.append(int.from_bytes(CPU_PROGRAM_[pc + 1:pc + 33], "big"))
-                gas += 3
-                next_pc = pc + 33
-        elif op in (0x01, 0x18, 0x21, 0xdf):      # ADD / XOR / KECCAK_GENERAL / MSTORE_32BYTES_32: two operands
-            t[col({0x01: "binary_op", 0x18: "logic_op", 0x21: "jumpdest_keccak_general", 0xdf: "m_op_32bytes"}[op]), r] = 1
-            a, b = stack[-1], stack[-2]
-            t[ch(1):ch(1) + 5, r] = [1, 1, 0, 1, sl - 2]
-            t[ch(1) + 5:ch(1) + 13, r] = limbs(b)
-            mem_ops.append(dict(filter=True, timestamp=base + 2, ctx=0, seg=1, virt=sl - 2, is_read=True, value=b))
-            if op == 0x01:
-                arith.append(("bin", 0, a, b))                        # IS_ADD
-                stack[-2:] = [(a + b) % (1 << 256)]
-                gas += 3
-            elif op == 0x18:
-                logic.append((2, a, b))                               # is_xor
-                stack[-2:] = [a ^ b]
-                gas += 3
-            else:                                                     # a = address word
-                virt, seg, ctx = a & 0xFFFFFFFF, (a >> 32) & 0xFFFFFFFF, (a >> 64) & 0xFFFFFFFF
-                if op == 0x21:
-                    assert (ctx, seg) == (0, 0) and virt + b <= len(CPU_PROGRAM_), "this run hashes a slice of the kernel image"
-                    data = CPU_PROGRAM_[virt:virt + b]
-                    sponge.append(((ctx, seg, virt), base, data))
-                    mem_ops += [dict(filter=True, timestamp=base, ctx=ctx, seg=seg, virt=virt + i, is_read=True, value=x)
-                                for i, x in enumerate(data)]
-                    stack[-2:] = [int.from_bytes(keccak256(data), "big")]
-                else:
-                    data = b.to_bytes(32, "big")
-                    packing.append((False, (ctx, seg, virt), base, data))
-                    mem_ops += [dict(filter=True, timestamp=base, ctx=ctx, seg=seg, virt=virt + i, is_read=False, value=x)
-                                for i, x in enumerate(data)]
-                    stack[-2:] = [a + 32]
-        elif op == 0x22:                                              # POSEIDON (cdk_erigon): hash three stack words
-            t[col("poseidon"), r] = 1
-            words = [stack[-1], stack[-2], stack[-3]]
-            for k in (1, 2):
-                t[ch(k):ch(k) + 5, r] = [1, 1, 0, 1, sl - 1 - k]
-                t[ch(k) + 5:ch(k) + 13, r] = limbs(words[k])
-                mem_ops.append(dict(filter=True, timestamp=base + 1 + k, ctx=0, seg=1, virt=sl - 1 - k, is_read=True, value=words[k]))
-            inp = [((w >> (64 * i)) & 0xFFFFFFFFFFFFFFFF) % P_FIELD for w in words for i in range(4)]
-            poseidon.append(("simple", inp))
-            out = [int(v) for v in poseidon_permute(inp)[:4]]
-            stack[-3:] = [sum(v << (64 * i) for i, v in enumerate(out))]
-        else:                                                         # POP
-            assert op == 0x50
-            t[col("not_pop"), r] = 1
-            if sl - 1:
-                t[gen + 4, r], t[gen + 5, r], t[gen + 6, r] = pow(sl - 1, P_FIELD - 2, P_FIELD), 1, 1
-                top_read = True
-            stack.pop()
-            gas += 2
-        pc = next_pc
-    assert pc == halt_pc and not stack
-    if cdk_erigon:
-        return t, mem_ops, arith, logic, sponge, packing, poseidon
-    return t, mem_ops, arith, logic, sponge, packing
+    run = KernelRun(program, halt_pc, n, keccak256=keccak256, poseidon_permute=poseidon_permute, cdk_erigon=cdk_erigon,
+                    memory={(0, SEG_CODE, i): b for i, b in enumerate(program)}).run()
+    assert not run.stack
+    out = (run.t, run.mem_ops, run.arith, run.logic, run.sponge, run.packing)
+    return out + (run.poseidon,) if cdk_erigon else out
 
 
 def logic_table(ops, n=32):
@@ -234,14 +140,29 @@ def sponge_side_effects(ks):
     return perms, xors
 
 
-def program_logs(rng, oracle, kernel_hash=0):
+def _push32(v):
+    return bytes([0x7f]) + v.to_bytes(32, "big")
+
+
+# A second kernel: thirty instructions over the rest of the Cpu AIR's modules -- dup_swap, simple_logic (NOT, ISZERO),
+# shift (with its shift-table read), push0, memio (MSTORE_GENERAL / MLOAD_GENERAL), contextops (GET_CONTEXT), jumps
+# (JUMPI taken, JUMP), ternary and more binary Arithmetic operations, OR through Logic.
+_STORE_WORD = 7 | (11 << 32)                                       # (context 0, segment 11, virt 7)
+CPU_PROGRAM_2 = (bytes([0x58, 0x58, 0x58, 0x82, 0x15, 0x90, 0x1b, 0x19, 0x5f, 0x03, 0x02, 0x80, 0x58, 0x08, 0x11]) +
+                 _push32(_STORE_WORD) + bytes([0x90, 0xfc]) + _push32(_STORE_WORD) + bytes([0xfb, 0xf6, 0x17]) +
+                 _push32(123) + bytes([0x57, 0, 0, 0, 0x5b, 0x58]) + _push32(160) + bytes([0x56, 0, 0x5b, 0x50]))
+CPU_PROGRAM_2_CONSTS = (162, 0, 777777, 888888)
+
+
+def program_logs(rng, oracle, kernel_hash=0, program=None, halt_pc=None, n_rows=16):
     """The operation logs of the run (what the reference's interpreter would hand to `generate_traces`): Cpu rows,
     Memory operations (public-value writes + the Cpu's bus traffic), mem_before values, and the Arithmetic / Logic /
     KeccakSponge / Keccak / BytePacking operation lists."""
     from tests.test_oracle_tracegen import _keccak_f
     pv = make_public_values(rng)
-    code = CPU_PROGRAM
-    cpu, cpu_mem_ops, arith_ops, logic_ops, sponge_ops, packing_ops = cpu_program_trace(oracle.keccak256)
+    code = CPU_PROGRAM if program is None else program
+    cpu, cpu_mem_ops, arith_ops, logic_ops, sponge_ops, packing_ops = cpu_program_trace(oracle.keccak256, n=n_rows, program=code,
+                                                                                        halt_pc=halt_pc)
     sponge = otg.keccak_sponge_generate_trace(sponge_ops, 0, _keccak_f(oracle))
     perms, sponge_xors = sponge_side_effects(sponge)
     before = [((0, SEG_CODE, i), b) for i, b in enumerate(code)]
@@ -252,12 +173,12 @@ def program_logs(rng, oracle, kernel_hash=0):
                 logic=logic_ops + sponge_xors, sponge=sponge_ops, sponge_trace=sponge, keccak=perms, packing=packing_ops)
 
 
-def build_with_cpu_program(rng, oracle, kernel_hash=0):
+def build_with_cpu_program(rng, oracle, kernel_hash=0, program=None, halt_pc=None, n_rows=16):
     """Like `build`, but the kernel image IS CPU_PROGRAM and the Cpu table executes it: code reads, stack writes /
     reads and the hashed bytes join the Memory table, two ADD rows the Arithmetic table, the XOR and the sponge's
     block XORs the Logic table, one KECCAK_GENERAL the KeccakSponge table and its permutation the Keccak table, one
     MSTORE_32BYTES the BytePacking table (whose 32 byte writes land in Memory and MemAfter): all nine tables live."""
-    g = program_logs(rng, oracle, kernel_hash)
+    g = program_logs(rng, oracle, kernel_hash, program, halt_pc, n_rows)
     memory, mem_after = mem_trace.generate_trace(g["memory"], g["before"], [])
     before_rows = [[1, c, s, v] + [(val >> (32 * j)) & 0xFFFFFFFF for j in range(8)] for (c, s, v), val in g["before"]]
     traces = [None] * 9

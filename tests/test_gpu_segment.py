@@ -573,3 +573,34 @@ def test_cdk_erigon_executing_cpu_accepted_by_verify_proof(oracle):
     bad[9][pt.PINV:pt.PINV + 4, 0] = traces[9][pt.PINV:pt.PINV + 4, 0]
     ok, why = run(bad)
     assert not ok, why
+
+
+def test_second_kernel_segment_accepted_by_verify_proof(oracle):
+    """`verify_proof` on the run of CPU_PROGRAM_2 (tests/consistent_segment.py: thirty instructions over dup_swap,
+    simple_logic, shift, push0, memio, contextops and jumps; SHL / SUB / MUL / ADDMOD / GT in Arithmetic, OR in Logic,
+    a general store / load pair and the shift-table read in Memory).  The Arithmetic and Logic tables come from the
+    device generators; optional tables without operations are switched off."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    import zk_evm_amd.tracegen as tg
+    from oracle import segment as oseg
+    from tests import consistent_segment as cs
+    from zk_evm_amd.all_stark import AllStark
+    ol.setup_fri_api(oracle)
+    kh = 0x5EED
+    consts = cs.CPU_PROGRAM_2_CONSTS
+    traces, pvd, code = cs.build_with_cpu_program(np.random.default_rng(82), oracle, kh, cs.CPU_PROGRAM_2, consts[0], 32)
+    g = cs.program_logs(np.random.default_rng(82), oracle, kh, cs.CPU_PROGRAM_2, consts[0], 32)
+    dev = [torch.from_numpy(np.ascontiguousarray(t).view(np.int64)).cuda() for t in traces]
+    dev[0], _ = tg.arithmetic_generate_trace([op[1:] for op in g["arithmetic"]])
+    dev[5] = tg.logic_generate_trace(g["logic"], 32)
+    assert np.array_equal(dev[0].cpu().numpy().view(np.uint64), traces[0])
+    assert np.array_equal(dev[5].cpu().numpy().view(np.uint64), traces[5])
+    in_use = [True, False, True, False, False, True, True, True, True]
+    got = sg.prove_with_traces(AllStark(consts), zk.StarkConfig(), dev, in_use, to_public_values(pvd))
+    before_cap = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
+    ok, why = oseg.verify_proof(oracle, ol, ol.make_cfg(hasher=0), _proof_dicts(got), in_use, pvd, consts, kh, len(code),
+                                is_initial=True, initial_mem_cap=tg.initial_memory_merkle_cap(code, 1, 4, hasher=0),
+                                mem_before_cap=before_cap)
+    assert ok, why

@@ -145,3 +145,47 @@ def test_cdk_erigon_segment_with_an_executing_cpu_table(oracle):
     # the same rows under the eth_mainnet Cpu AIR make no sense (columns shifted)
     with pytest.raises(AssertionError):
         _check_air(oairs.make_eval_cpu(*cs.ERIGON_CONSTS), traces[A.CPU][:85])
+
+
+def test_second_kernel_covers_the_remaining_cpu_modules(oracle):
+    """CPU_PROGRAM_2: thirty kernel-mode instructions (PC DUP3 ISZERO SWAP1 SHL NOT PUSH0 SUB MUL DUP1 ADDMOD GT PUSH32
+    MSTORE_GENERAL MLOAD_GENERAL GET_CONTEXT OR JUMPI JUMPDEST JUMP POP ...) generated by tests/kernel_run.py from the
+    reference's witness conventions.  Every row satisfies the restated Cpu AIR -- this time exercising dup_swap,
+    simple_logic, shift, push0, memio, contextops and jumps non-vacuously -- and the run's traffic (five Arithmetic
+    operations incl. SHL with its shift-table read and a two-row ADDMOD, an OR, a general store / load pair, stack
+    spills through the partial channel and GP channels 1 and 2) balances the CTLs."""
+    traces, pv, code = cs.build_with_cpu_program(np.random.default_rng(5), oracle, KH, cs.CPU_PROGRAM_2,
+                                                 cs.CPU_PROGRAM_2_CONSTS[0], 32)
+    air = oairs.make_eval_cpu(*cs.CPU_PROGRAM_2_CONSTS)
+    _check_air(air, traces[A.CPU])
+    _check_air(oairs.eval_memory, traces[A.MEMORY])
+    cpu = traces[A.CPU]
+    flags = {name: int(cpu[6 + i].sum()) for i, name in enumerate(oairs.C_OPS)}
+    assert flags == dict(binary_op=3, ternary_op=1, fp254_op=0, eq_iszero=1, logic_op=1, not_pop=2, shift=1,
+                         jumpdest_keccak_general=2, jumps=2, push_prover_input=4, dup_swap=4, context_op=1, m_op_32bytes=0,
+                         exit_kernel=0, m_op_general=2, pc_push0=6, syscall=0, exception=0)
+    assert int(cpu[5, -1]) == 89 and int(cpu[2, -1]) == 162 and int(cpu[3, -1]) == 0        # gas, halt pc, empty stack
+    assert [int(traces[A.ARITHMETIC][i].sum()) for i in (1, 2, 5, 12, 14)] == [1, 1, 1, 1, 1]   # MUL SUB ADDMOD GT SHL
+    ctls = A.build_ctls()
+    ch = [S.GrandProductChallenge(1234567, 7654321), S.GrandProductChallenge(99, 101)]
+    zf = cs.ctl_first_values(traces, ctls, ch)
+    extra = [[0, 0] for _ in ctls]
+    extra[oseg.MEMORY_CTL_IDX] = [oseg.get_memory_extra_looking_sum(pv, c, KH, len(code)) for c in ch]
+    assert oseg.verify_cross_table_lookups(ctls, zf, extra, 2) == (True, "")
+    # each module notices its own kind of mistake
+    def violates(col, row, delta=1):
+        bad = cpu.copy()
+        bad[col, row] = (int(bad[col, row]) + delta) % oseg.P
+        try:
+            _check_air(air, bad)
+        except AssertionError:
+            return True
+        return False
+    rows = {int(cpu[2, r]): r for r in range(cpu.shape[1]) if int(cpu[6:24, r].sum())}       # pc -> row
+    assert violates(41 + 13 * 2 + 4, rows[3])           # DUP3 reads another stack slot
+    assert violates(41 + 5, rows[4] + 1)                # ISZERO's result
+    assert violates(41 + 13 * 2 + 4, rows[6])           # SHL's shift-table address
+    assert violates(41 + 5, rows[7] + 1)                # NOT's result
+    assert violates(80 + 4, rows[49])                   # MSTORE_GENERAL's target address
+    assert violates(2, rows[119] + 1)                   # JUMPI lands elsewhere
+    assert violates(41 + 5 + 2, rows[84] + 1)           # GET_CONTEXT pushes another context
