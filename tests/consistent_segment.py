@@ -93,15 +93,18 @@ CPU_EXECUTED = 12                                                # instructions 
 CPU_PROGRAM_CONSTS = (CPU_HALT_PC, 0, 777777, 888888)            # halt_final, init, syscall / exception jumptables
 
 
-def cpu_program_trace(keccak256, n=16, program=None, halt_pc=None, cdk_erigon=False, poseidon_permute=None):
+def cpu_program_trace(keccak256, n=16, program=None, halt_pc=None, cdk_erigon=False, poseidon_permute=None,
+                      extra_memory=None, **run_kw):
     """The Cpu rows of the kernel-mode run of `program` (default CPU_PROGRAM) and the operation logs it produces, from
     the miniature witness generator tests/kernel_run.py (a restatement of witness/operation.rs for a subset of
     opcodes).  -> (cpu trace, memory ops, arithmetic ops, logic ops, sponge ops, byte-packing ops[, poseidon ops])."""
     from tests.kernel_run import KernelRun
     program = CPU_PROGRAM if program is None else program
     halt_pc = CPU_HALT_PC if halt_pc is None else halt_pc
+    memory = {(0, SEG_CODE, i): b for i, b in enumerate(program)}
+    memory.update(extra_memory or {})
     run = KernelRun(program, halt_pc, n, keccak256=keccak256, poseidon_permute=poseidon_permute, cdk_erigon=cdk_erigon,
-                    memory={(0, SEG_CODE, i): b for i, b in enumerate(program)}).run()
+                    memory=memory, **run_kw).run()
     assert not run.stack
     out = (run.t, run.mem_ops, run.arith, run.logic, run.sponge, run.packing)
     return out + (run.poseidon,) if cdk_erigon else out
@@ -154,31 +157,50 @@ CPU_PROGRAM_2 = (bytes([0x58, 0x58, 0x58, 0x82, 0x15, 0x90, 0x1b, 0x19, 0x5f, 0x
 CPU_PROGRAM_2_CONSTS = (162, 0, 777777, 888888)
 
 
-def program_logs(rng, oracle, kernel_hash=0, program=None, halt_pc=None, n_rows=16):
+def _program_3():
+    code = bytearray(247)
+    code[0:33] = _push32(40)                                        # kexit_info: pc 40, user mode, gas 0
+    code[33] = 0xf9                                                 # EXIT_KERNEL
+    code[40:50] = bytes([0x60, 0x05, 0x60, 0x30, 0x56, 0, 0, 0, 0x5b, 0x30])   # PUSH1 5, PUSH1 48, JUMP, .., JUMPDEST, ADDRESS
+    code[60:62] = bytes([0x50, 0x50])                               # the "handler": POP POP, then halt at 62
+    code[100 + 3 * 0x30:100 + 3 * 0x30 + 3] = (60).to_bytes(3, "big")   # syscall_jumptable[0x30] = 60
+    return bytes(code)
+
+
+# A third kernel leaves kernel mode: EXIT_KERNEL to user code that PUSHes (BytePacking-checked arguments), JUMPs (reads
+# the JUMPDEST bit of its target) and executes ADDRESS, which is not native: a syscall through the jump table (read
+# through BytePacking, kexit_info range-checked through Arithmetic) back into the kernel, which pops and halts.
+CPU_PROGRAM_3 = _program_3()
+CPU_PROGRAM_3_CONSTS = (62, 0, 100, 888888)                        # halt_final, init, syscall_jumptable, exception_jumptable
+CPU_PROGRAM_3_MEMORY = {(0, 14, 48): 1}                            # JumpdestBits of context 0: pc 48 is a JUMPDEST
+
+
+def program_logs(rng, oracle, kernel_hash=0, program=None, halt_pc=None, n_rows=16, extra_memory=None, **run_kw):
     """The operation logs of the run (what the reference's interpreter would hand to `generate_traces`): Cpu rows,
     Memory operations (public-value writes + the Cpu's bus traffic), mem_before values, and the Arithmetic / Logic /
     KeccakSponge / Keccak / BytePacking operation lists."""
     from tests.test_oracle_tracegen import _keccak_f
     pv = make_public_values(rng)
     code = CPU_PROGRAM if program is None else program
-    cpu, cpu_mem_ops, arith_ops, logic_ops, sponge_ops, packing_ops = cpu_program_trace(oracle.keccak256, n=n_rows, program=code,
-                                                                                        halt_pc=halt_pc)
+    cpu, cpu_mem_ops, arith_ops, logic_ops, sponge_ops, packing_ops = cpu_program_trace(
+        oracle.keccak256, n=n_rows, program=code, halt_pc=halt_pc, extra_memory=extra_memory, **run_kw)
     sponge = otg.keccak_sponge_generate_trace(sponge_ops, 0, _keccak_f(oracle))
     perms, sponge_xors = sponge_side_effects(sponge)
     before = [((0, SEG_CODE, i), b) for i, b in enumerate(code)]
     before += [((0, SEG_SHIFT_TABLE, i), 1 << i) for i in range(256)]
+    before += sorted((extra_memory or {}).items())                  # not part of the kernel image: is_initial would fail
     mem_ops = [dict(filter=True, timestamp=2, ctx=0, seg=seg, virt=idx, is_read=False, value=val)
                for seg, idx, val in oseg.public_memory_writes(pv, kernel_hash, len(code))] + cpu_mem_ops
     return dict(pv=pv, code=code, cpu=cpu, memory=mem_ops, before=before, arithmetic=arith_ops,
                 logic=logic_ops + sponge_xors, sponge=sponge_ops, sponge_trace=sponge, keccak=perms, packing=packing_ops)
 
 
-def build_with_cpu_program(rng, oracle, kernel_hash=0, program=None, halt_pc=None, n_rows=16):
+def build_with_cpu_program(rng, oracle, kernel_hash=0, program=None, halt_pc=None, n_rows=16, extra_memory=None, **run_kw):
     """Like `build`, but the kernel image IS CPU_PROGRAM and the Cpu table executes it: code reads, stack writes /
     reads and the hashed bytes join the Memory table, two ADD rows the Arithmetic table, the XOR and the sponge's
     block XORs the Logic table, one KECCAK_GENERAL the KeccakSponge table and its permutation the Keccak table, one
     MSTORE_32BYTES the BytePacking table (whose 32 byte writes land in Memory and MemAfter): all nine tables live."""
-    g = program_logs(rng, oracle, kernel_hash, program, halt_pc, n_rows)
+    g = program_logs(rng, oracle, kernel_hash, program, halt_pc, n_rows, extra_memory, **run_kw)
     memory, mem_after = mem_trace.generate_trace(g["memory"], g["before"], [])
     before_rows = [[1, c, s, v] + [(val >> (32 * j)) & 0xFFFFFFFF for j in range(8)] for (c, s, v), val in g["before"]]
     traces = [None] * 9

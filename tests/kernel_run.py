@@ -16,8 +16,12 @@ against real instruction runs and the CTLs against the traffic those runs create
   the row with clock column 1).
 
 Supported: PUSH0 PC PUSH32 (kernel), DUPn SWAPn POP, ADD MUL SUB LT GT (binary), ADDMOD MULMOD SUBMOD, AND OR XOR, NOT ISZERO EQ,
-SHL, KECCAK_GENERAL, MLOAD_GENERAL MSTORE_GENERAL, MSTORE_32BYTES_n, JUMP JUMPI JUMPDEST, GET_CONTEXT, and, with
-cdk_erigon, POSEIDON."""
+SHL, KECCAK_GENERAL, MLOAD_GENERAL MSTORE_GENERAL, MSTORE_32BYTES_n, JUMP JUMPI JUMPDEST, GET_CONTEXT, EXIT_KERNEL and,
+with cdk_erigon, POSEIDON.  User mode (entered with EXIT_KERNEL): PUSHn reads its argument from the code through the
+BytePacking table, JUMP / JUMPI read the JUMPDEST bit of the target, a non-native opcode (`syscall_opcodes`) traps into
+the kernel through the syscall jump table (3-byte big-endian handler offsets at syscall_jumptable + 3 * opcode, read
+through BytePacking; a range-check row in Arithmetic covers the pushed kexit_info), pushing instructions keep
+stack_len_bounds_aux = 1 / (next stack_len - 1025)."""
 import numpy as np
 
 P = 0xFFFFFFFF00000001
@@ -38,7 +42,7 @@ def finv(x):
 
 class KernelRun:
     def __init__(self, code: bytes, halt_pc: int, n_rows: int, keccak256=None, poseidon_permute=None, cdk_erigon=False,
-                 memory=None):
+                 memory=None, syscall_jumptable=0, syscall_opcodes=()):
         from oracle import airs
         self.code, self.halt_pc, self.n = code, halt_pc, n_rows
         self.keccak256, self.poseidon_permute = keccak256, poseidon_permute
@@ -46,7 +50,8 @@ class KernelRun:
         self.x = x = 1 if cdk_erigon else 0
         self.bits, self.gen, self.clock, self.partial = 24 + x, 32 + x, 40 + x, 80 + x
         self.t = np.zeros((85 + x, n_rows), dtype=np.uint64)
-        self.stack, self.gas, self.pc, self.top_read, self.context = [], 0, 0, False, 0
+        self.stack, self.gas, self.pc, self.top_read, self.context, self.kernel = [], 0, 0, False, 0, 1
+        self.syscall_jumptable, self.syscall_opcodes = syscall_jumptable, set(syscall_opcodes)
         self.mem = dict(memory or {})                     # (ctx, seg, virt) -> value, for MLOAD / MSTORE consistency
         self.mem_ops, self.arith, self.logic, self.sponge, self.packing, self.poseidon = [], [], [], [], [], []
 
@@ -100,14 +105,19 @@ class KernelRun:
     # ---- the run ----
     def run(self):
         t = self.t
+        self.bounds_row = None
         for r in range(self.n):
-            t[self.clock, r], t[4, r], t[3, r], t[5, r], t[2, r], t[0, r] = r + 1, 1, len(self.stack), self.gas, self.pc, self.context
-            if self.pc == self.halt_pc:
+            t[self.clock, r], t[4, r], t[3, r], t[5, r], t[2, r], t[0, r] = r + 1, self.kernel, len(self.stack), self.gas, self.pc, self.context
+            t[1, r] = (1 - self.kernel) * self.context                # code_context (membus.rs)
+            if r and self.bounds_row is not None and not self.kernel:   # stack.rs MIGHT_OVERFLOW: the row before pushed
+                t[self.gen + 7, self.bounds_row] = finv(len(self.stack) - 1025)
+            self.bounds_row = None
+            if self.pc == self.halt_pc and self.kernel:
                 continue
             op = self.code[self.pc]
             for i in range(8):
                 t[self.bits + i, r] = (op >> i) & 1
-            self._log(r * 5 + 1, (0, SEG_CODE, self.pc), True, op)
+            self._log(r * 5 + 1, ((1 - self.kernel) * self.context, SEG_CODE, self.pc), True, op)
             sl, top = len(self.stack), (self.stack[-1] if self.stack else 0)
             t[self.ch(0) + 5:self.ch(0) + 13, r] = limbs(top)
             if self.top_read:
@@ -130,22 +140,53 @@ class KernelRun:
 
     def step(self, r, op, sl, top):
         t, S = self.t, self.stack
-        if op in (0x58, 0x5f, 0x7f):                                  # PC / PUSH0 / PUSH32
-            self.flag(r, "push_prover_input" if op == 0x7f else "pc_push0")
+        if op in self.syscall_opcodes and not self.kernel:            # generate_syscall
+            self.flag(r, "syscall")
+            table = self.syscall_jumptable + 3 * op
+            handler = int.from_bytes(self.code[table:table + 3], "big")
+            c = self.ch(1)                                            # describes the packed read; the channel itself is unused
+            t[c:c + 6, r] = [0, 1, 0, SEG_CODE, table, handler]
+            self.packing.append((True, (0, SEG_CODE, table), r * 5 + 1, self.code[table:table + 3]))
+            for i in range(3):
+                self._log(r * 5 + 1, (0, SEG_CODE, table + i), True, self.code[table + i])
+            info = (self.pc + 1) | (self.kernel << 32) | (self.gas << 192)
+            self.arith.append(("range_check", top, handler, 0, op, info))
             self.push_with_write(r)
+            S.append(info)
+            self.next_pc, self.kernel, self.gas = handler, 1, 0
+        elif op in (0x58, 0x5f) or 0x60 <= op <= 0x7f:                # PC / PUSH0 / PUSHn
+            self.flag(r, "pc_push0" if op in (0x58, 0x5f) else "push_prover_input")
+            self.push_with_write(r)
+            self.bounds_row = r
             if op == 0x58:
                 S.append(self.pc); self.gas += 2
             elif op == 0x5f:
                 S.append(0); self.gas += 2
             else:
-                S.append(int.from_bytes(self.code[self.pc + 1:self.pc + 33], "big")); self.gas += 3
-                self.next_pc = self.pc + 33
+                n = op - 0x5f
+                data = self.code[self.pc + 1:self.pc + 1 + n]
+                S.append(int.from_bytes(data, "big")); self.gas += 3
+                self.next_pc = self.pc + 1 + n
+                if not self.kernel:                                   # user-mode PUSH: argument checked through BytePacking
+                    t[self.gen, r] = 1                                # general.push().is_not_kernel
+                    addr = (self.context, SEG_CODE, self.pc + 1)
+                    self.packing.append((True, addr, r * 5 + 1, data))
+                    for i, v in enumerate(data):
+                        self._log(r * 5 + 1, (addr[0], addr[1], addr[2] + i), True, v)
+        elif op == 0xf9:                                              # EXIT_KERNEL(kexit_info)
+            self.flag(r, "exit_kernel")
+            if self.stack_inv(r, sl - 1):
+                self.top_read = True
+            S.pop()
+            self.bounds_row = r
+            self.next_pc, self.kernel, self.gas = top & 0xFFFFFFFF, (top >> 32) & 1, (top >> 192) & 0xFFFFFFFF
         elif 0x80 <= op <= 0x8f:                                      # DUPn (n = op & 15, zero-based)
             n = op & 0xF
             self.flag(r, "dup_swap")
             self.gp(r, 1, self.stack_addr(0), False, top)
             val = S[-1 - n]
             self.gp(r, 2, self.stack_addr(n), True, val)
+            self.bounds_row = r
             S.append(val); self.gas += 3
         elif 0x90 <= op <= 0x9f:                                      # SWAPn
             n = op & 0xF
@@ -222,8 +263,11 @@ class KernelRun:
             sj = 1 if cond else 0
             t[self.gen, r] = sj                                       # should_jump
             t[self.gen + 1, r] = finv(sum(limbs(cond)))               # cond_sum_pinv
-            c2 = self.ch(2)                                           # the (unused, kernel mode) JUMPDEST-bit channel
-            t[c2:c2 + 6, r] = [0, 1, self.context, SEG_JUMPDEST_BITS, top & 0xFFFFFFFF, 1]
+            c2 = self.ch(2)                                           # JUMPDEST-bit channel: a real read only in user mode
+            used = sj * (1 - self.kernel)
+            t[c2:c2 + 6, r] = [used, 1, self.context, SEG_JUMPDEST_BITS, top & 0xFFFFFFFF, 1]
+            if used:
+                self._log(r * 5 + 4, (self.context, SEG_JUMPDEST_BITS, top & 0xFFFFFFFF), True, 1)
             new_len = sl - (2 if jumpi else 1)
             if self.stack_inv(r, new_len):
                 self.top_read = True

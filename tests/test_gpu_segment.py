@@ -604,3 +604,31 @@ def test_second_kernel_segment_accepted_by_verify_proof(oracle):
                                 is_initial=True, initial_mem_cap=tg.initial_memory_merkle_cap(code, 1, 4, hasher=0),
                                 mem_before_cap=before_cap)
     assert ok, why
+
+
+def test_third_kernel_segment_accepted_by_verify_proof(oracle):
+    """`verify_proof` (a non-initial segment: MemBefore also holds a JumpdestBits entry) on the run of CPU_PROGRAM_3:
+    EXIT_KERNEL into user code that PUSHes, JUMPs and traps back into the kernel through a syscall.  BytePacking (three
+    reads) and Arithmetic (the syscall's range-check row) come from the device generators."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    import zk_evm_amd.tracegen as tg
+    from oracle import segment as oseg
+    from tests import consistent_segment as cs
+    from zk_evm_amd.all_stark import AllStark
+    ol.setup_fri_api(oracle)
+    kh = 0xC0FFEE
+    consts = cs.CPU_PROGRAM_3_CONSTS
+    kw = dict(extra_memory=cs.CPU_PROGRAM_3_MEMORY, syscall_jumptable=consts[2], syscall_opcodes=(0x30,))
+    traces, pvd, code = cs.build_with_cpu_program(np.random.default_rng(83), oracle, kh, cs.CPU_PROGRAM_3, consts[0], 16, **kw)
+    g = cs.program_logs(np.random.default_rng(83), oracle, kh, cs.CPU_PROGRAM_3, consts[0], 16, **kw)
+    dev = [torch.from_numpy(np.ascontiguousarray(t).view(np.int64)).cuda() for t in traces]
+    dev[0], _ = tg.arithmetic_generate_trace([(16,) + tuple(op[1:]) if op[0] == "range_check" else op[1:] for op in g["arithmetic"]])
+    dev[1] = tg.byte_packing_generate_trace(g["packing"], 0)
+    assert np.array_equal(dev[0].cpu().numpy().view(np.uint64), traces[0])
+    assert np.array_equal(dev[1].cpu().numpy().view(np.uint64), traces[1])
+    in_use = [True, True, True, False, False, False, True, True, True]
+    got = sg.prove_with_traces(AllStark(consts), zk.StarkConfig(), dev, in_use, to_public_values(pvd))
+    ok, why = oseg.verify_proof(oracle, ol, ol.make_cfg(hasher=0), _proof_dicts(got), in_use, pvd, consts, kh, len(code))
+    assert ok, why

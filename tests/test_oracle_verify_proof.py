@@ -189,3 +189,44 @@ def test_second_kernel_covers_the_remaining_cpu_modules(oracle):
     assert violates(80 + 4, rows[49])                   # MSTORE_GENERAL's target address
     assert violates(2, rows[119] + 1)                   # JUMPI lands elsewhere
     assert violates(41 + 5 + 2, rows[84] + 1)           # GET_CONTEXT pushes another context
+
+
+def test_third_kernel_leaves_kernel_mode(oracle):
+    """CPU_PROGRAM_3: EXIT_KERNEL into user code -- PUSH1 PUSH1 JUMP JUMPDEST ADDRESS -- and back through a syscall.
+    Exercises, non-vacuously, the user-mode halves of the Cpu AIR (decode availability, `is_not_kernel`, the stack
+    bound `stack_len_bounds_aux`, the JUMPDEST-bit read of jumps.rs, syscalls_exceptions.rs, the exit_kernel part of
+    jumps.rs) and the CTLs only user code drives: BytePacking `push` (arguments read from the code) and `jumptable`
+    (the 3-byte handler offset), the Arithmetic range check of the pushed kexit_info, the JumpdestBits read in Memory."""
+    kw = dict(extra_memory=cs.CPU_PROGRAM_3_MEMORY, syscall_jumptable=cs.CPU_PROGRAM_3_CONSTS[2], syscall_opcodes=(0x30,))
+    traces, pv, code = cs.build_with_cpu_program(np.random.default_rng(6), oracle, KH, cs.CPU_PROGRAM_3,
+                                                 cs.CPU_PROGRAM_3_CONSTS[0], 16, **kw)
+    air = oairs.make_eval_cpu(*cs.CPU_PROGRAM_3_CONSTS)
+    cpu = traces[A.CPU]
+    _check_air(air, cpu)
+    _check_air(oairs.eval_memory, traces[A.MEMORY])
+    _check_air(oairs.eval_byte_packing, traces[A.BYTE_PACKING])
+    assert [int(v) for v in cpu[4, :10]] == [1, 1, 0, 0, 0, 0, 0, 1, 1, 1]          # kernel, 5 user rows, kernel again
+    assert int(cpu[6 + oairs.C_OPS.index("syscall")].sum()) == 1 and int(cpu[6 + oairs.C_OPS.index("exit_kernel")].sum()) == 1
+    assert int(traces[A.ARITHMETIC][16].sum()) == 1                                  # one range-check row
+    assert int(traces[A.BYTE_PACKING][1:33].sum()) == 3                              # two PUSH1 arguments + the jump-table entry
+    ctls = A.build_ctls()
+    ch = [S.GrandProductChallenge(1234567, 7654321), S.GrandProductChallenge(99, 101)]
+
+    def balance(trs):
+        zf = cs.ctl_first_values(trs, ctls, ch)
+        extra = [[0, 0] for _ in ctls]
+        extra[oseg.MEMORY_CTL_IDX] = [oseg.get_memory_extra_looking_sum(pv, c, KH, len(code)) for c in ch]
+        return oseg.verify_cross_table_lookups(ctls, zf, extra, 2)
+    assert balance(traces) == (True, "")
+    bad = [t.copy() for t in traces]
+    bad[A.CPU][41 + 5, 3] = 6                          # the value PUSH1 5 left on the stack: BytePacking `push` CTL
+    assert balance(bad)[1].startswith("CTL 1")
+    bad = [t.copy() for t in traces]
+    bad[A.CPU][41 + 13 + 5, 6] = 61                    # the handler offset claimed by the syscall row: `jumptable` CTL
+    bad[A.CPU][2, 7] = 61
+    assert balance(bad)[1].startswith("CTL")
+    for col, row in ((4, 3), (39, 2), (41 + 13 * 2, 4)):   # user row claims kernel mode; stack bound aux; JUMPDEST-bit channel unused
+        b2 = cpu.copy()
+        b2[col, row] = (int(b2[col, row]) + 1) % oseg.P
+        with pytest.raises(AssertionError):
+            _check_air(air, b2)
