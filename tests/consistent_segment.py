@@ -94,7 +94,7 @@ CPU_PROGRAM_CONSTS = (CPU_HALT_PC, 0, 777777, 888888)            # halt_final, i
 
 
 def cpu_program_trace(keccak256, n=16, program=None, halt_pc=None, cdk_erigon=False, poseidon_permute=None,
-                      extra_memory=None, **run_kw):
+                      extra_memory=None, return_run=False, **run_kw):
     """The Cpu rows of the kernel-mode run of `program` (default CPU_PROGRAM) and the operation logs it produces, from
     the miniature witness generator tests/kernel_run.py (a restatement of witness/operation.rs for a subset of
     opcodes).  -> (cpu trace, memory ops, arithmetic ops, logic ops, sponge ops, byte-packing ops[, poseidon ops])."""
@@ -106,6 +106,8 @@ def cpu_program_trace(keccak256, n=16, program=None, halt_pc=None, cdk_erigon=Fa
     run = KernelRun(program, halt_pc, n, keccak256=keccak256, poseidon_permute=poseidon_permute, cdk_erigon=cdk_erigon,
                     memory=memory, **run_kw).run()
     assert not run.stack
+    if return_run:
+        return run
     out = (run.t, run.mem_ops, run.arith, run.logic, run.sponge, run.packing)
     return out + (run.poseidon,) if cdk_erigon else out
 
@@ -175,6 +177,13 @@ CPU_PROGRAM_3_CONSTS = (62, 0, 100, 888888)                        # halt_final,
 CPU_PROGRAM_3_MEMORY = {(0, 14, 48): 1}                            # JumpdestBits of context 0: pc 48 is a JUMPDEST
 
 
+# A fourth kernel switches contexts: SET_CONTEXT to context 1, some stack traffic there, SET_CONTEXT back with the prune
+# flag -- context 1 becomes stale: its Memory rows are flagged, kept out of MemAfter, and the context-pruning CTL (the
+# only one the other runs leave idle) carries it.
+CPU_PROGRAM_4 = bytes([0x58]) + _push32(1 << 64) + bytes([0xf7, 0x58, 0x58, 0x50]) + _push32(1) + bytes([0xf7, 0x50])
+CPU_PROGRAM_4_CONSTS = (73, 0, 777777, 888888)
+
+
 def program_logs(rng, oracle, kernel_hash=0, program=None, halt_pc=None, n_rows=16, extra_memory=None, **run_kw):
     """The operation logs of the run (what the reference's interpreter would hand to `generate_traces`): Cpu rows,
     Memory operations (public-value writes + the Cpu's bus traffic), mem_before values, and the Arithmetic / Logic /
@@ -182,8 +191,9 @@ def program_logs(rng, oracle, kernel_hash=0, program=None, halt_pc=None, n_rows=
     from tests.test_oracle_tracegen import _keccak_f
     pv = make_public_values(rng)
     code = CPU_PROGRAM if program is None else program
-    cpu, cpu_mem_ops, arith_ops, logic_ops, sponge_ops, packing_ops = cpu_program_trace(
-        oracle.keccak256, n=n_rows, program=code, halt_pc=halt_pc, extra_memory=extra_memory, **run_kw)
+    run = cpu_program_trace(oracle.keccak256, n=n_rows, program=code, halt_pc=halt_pc, extra_memory=extra_memory,
+                            return_run=True, **run_kw)
+    cpu, cpu_mem_ops, arith_ops, logic_ops, sponge_ops, packing_ops = run.t, run.mem_ops, run.arith, run.logic, run.sponge, run.packing
     sponge = otg.keccak_sponge_generate_trace(sponge_ops, 0, _keccak_f(oracle))
     perms, sponge_xors = sponge_side_effects(sponge)
     before = [((0, SEG_CODE, i), b) for i, b in enumerate(code)]
@@ -191,7 +201,7 @@ def program_logs(rng, oracle, kernel_hash=0, program=None, halt_pc=None, n_rows=
     before += sorted((extra_memory or {}).items())                  # not part of the kernel image: is_initial would fail
     mem_ops = [dict(filter=True, timestamp=2, ctx=0, seg=seg, virt=idx, is_read=False, value=val)
                for seg, idx, val in oseg.public_memory_writes(pv, kernel_hash, len(code))] + cpu_mem_ops
-    return dict(pv=pv, code=code, cpu=cpu, memory=mem_ops, before=before, arithmetic=arith_ops,
+    return dict(pv=pv, code=code, cpu=cpu, memory=mem_ops, before=before, arithmetic=arith_ops, stale=list(run.stale_contexts),
                 logic=logic_ops + sponge_xors, sponge=sponge_ops, sponge_trace=sponge, keccak=perms, packing=packing_ops)
 
 
@@ -201,7 +211,7 @@ def build_with_cpu_program(rng, oracle, kernel_hash=0, program=None, halt_pc=Non
     block XORs the Logic table, one KECCAK_GENERAL the KeccakSponge table and its permutation the Keccak table, one
     MSTORE_32BYTES the BytePacking table (whose 32 byte writes land in Memory and MemAfter): all nine tables live."""
     g = program_logs(rng, oracle, kernel_hash, program, halt_pc, n_rows, extra_memory, **run_kw)
-    memory, mem_after = mem_trace.generate_trace(g["memory"], g["before"], [])
+    memory, mem_after = mem_trace.generate_trace(g["memory"], g["before"], g["stale"])
     before_rows = [[1, c, s, v] + [(val >> (32 * j)) & 0xFFFFFFFF for j in range(8)] for (c, s, v), val in g["before"]]
     traces = [None] * 9
     traces[0] = arith_trace.generate_trace(g["arithmetic"])[0]

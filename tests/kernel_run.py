@@ -54,6 +54,7 @@ class KernelRun:
         self.syscall_jumptable, self.syscall_opcodes = syscall_jumptable, set(syscall_opcodes)
         self.mem = dict(memory or {})                     # (ctx, seg, virt) -> value, for MLOAD / MSTORE consistency
         self.mem_ops, self.arith, self.logic, self.sponge, self.packing, self.poseidon = [], [], [], [], [], []
+        self.stacks, self.stale_contexts = {}, []         # other contexts' stacks (their tops are in memory)
 
     def col(self, name): return 6 + self.ops.index(name)
     def ch(self, k): return 41 + self.x + 13 * k
@@ -301,6 +302,27 @@ class KernelRun:
                 self._log(r * 5 + 1, (addr[0], addr[1], addr[2] + i), False, v)
                 self.mem[(addr[0], addr[1], addr[2] + i)] = v
             S[-2:] = [top + n]
+        elif op == 0xf7:                                              # SET_CONTEXT(new_ctx << 64 | prune_flag)
+            self.flag(r, "context_op")
+            new_ctx, prune = (top >> 64) & 0xFFFFFFFF, top & 1
+            assert new_ctx != self.context, "same-context switch not modelled"
+            S.pop()
+            # the two stack-pointer operations have no channel of their own: their tuples are built by the CTL from
+            # registers (cpu_stark.rs:228-281), with the timestamps of GP channels 1 and 2
+            self._log(r * 5 + 3, (self.context, 6, 11), False, len(S))              # ContextMetadata::StackSize
+            self.mem[(self.context, 6, 11)] = len(S)
+            new_sp = self.mem.get((new_ctx, 6, 11), 0)
+            self._log(r * 5 + 4, (new_ctx, 6, 11), True, new_sp)
+            self.stacks[self.context] = list(S)
+            S[:] = self.stacks.pop(new_ctx, [])
+            assert len(S) == new_sp
+            if prune:
+                t[self.gen, r] = 1                                                  # context_pruning().pruning_flag
+                self.stale_contexts.append(self.context)
+            old_ctx, self.context = self.context, new_ctx
+            if new_sp:
+                t[self.gen + 4, r], t[self.gen + 5, r], t[self.gen + 6, r] = finv(new_sp), 1, 1
+                self.gp(r, 2, (new_ctx, SEG_STACK, new_sp - 1), True, S[-1])
         elif op == 0xf6:                                              # GET_CONTEXT
             self.flag(r, "context_op")
             if sl:

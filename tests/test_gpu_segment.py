@@ -449,8 +449,8 @@ def test_segment_with_executing_cpu_accepted_by_verify_proof(oracle, hasher):
     kernel image is the MemBefore content (so `verify_initial_memory` uses it too); the Cpu rows look up their code
     bytes, stack writes / reads, the ADDs, the XOR, the KECCAK_GENERAL and the MSTORE_32BYTES in Memory, Arithmetic,
     Logic, KeccakSponge and BytePacking, the sponge in turn its permutation in Keccak, its block XORs in Logic and its
-    input bytes in Memory, BytePacking its 32 byte writes in Memory -- all nine tables live, all ten CTLs carrying
-    traffic.  Proven by zk_prove_segment under standard_fast_config, accepted; rejected with one Cpu
+    input bytes in Memory, BytePacking its 32 byte writes in Memory -- all nine tables live, nine of the ten CTLs
+    carrying traffic (the tenth, context pruning, in the fourth kernel's test).  Proven by zk_prove_segment under standard_fast_config, accepted; rejected with one Cpu
     cell changed (the sum an ADD leaves on the stack: Arithmetic CTL; the digest: KeccakSponge CTL; one unit of gas:
     the Cpu AIR itself).  hasher = 1 is the same under `KeccakGoldilocksConfig` (Keccak-256 Merkle trees truncated to
     25 bytes and the Keccak-based challenger), the configuration of the reference's STARK-only integration tests
@@ -631,4 +631,35 @@ def test_third_kernel_segment_accepted_by_verify_proof(oracle):
     in_use = [True, True, True, False, False, False, True, True, True]
     got = sg.prove_with_traces(AllStark(consts), zk.StarkConfig(), dev, in_use, to_public_values(pvd))
     ok, why = oseg.verify_proof(oracle, ol, ol.make_cfg(hasher=0), _proof_dicts(got), in_use, pvd, consts, kh, len(code))
+    assert ok, why
+
+
+def test_fourth_kernel_segment_accepted_by_verify_proof(oracle):
+    """`verify_proof` on the run of CPU_PROGRAM_4 (context switch to context 1 and back with pruning).  The Memory
+    table -- stale-context columns included -- and MemAfter come from the device generator; the context-pruning CTL
+    carries traffic."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    import zk_evm_amd.tracegen as tg
+    from oracle import segment as oseg
+    from tests import consistent_segment as cs
+    from zk_evm_amd.all_stark import AllStark
+    ol.setup_fri_api(oracle)
+    kh = 0xFACE
+    consts = cs.CPU_PROGRAM_4_CONSTS
+    traces, pvd, code = cs.build_with_cpu_program(np.random.default_rng(84), oracle, kh, cs.CPU_PROGRAM_4, consts[0], 16)
+    g = cs.program_logs(np.random.default_rng(84), oracle, kh, cs.CPU_PROGRAM_4, consts[0], 16)
+    assert g["stale"] == [1]
+    dev = [torch.from_numpy(np.ascontiguousarray(t).view(np.int64)).cuda() for t in traces]
+    mem_ops = [(o["filter"], o["timestamp"], (o["ctx"], o["seg"], o["virt"]), o["is_read"], o["value"]) for o in g["memory"]]
+    dev[6], dev[8], _, _ = tg.memory_generate_trace(mem_ops, g["before"], g["stale"])
+    assert np.array_equal(dev[6].cpu().numpy().view(np.uint64), traces[6])
+    assert np.array_equal(dev[8].cpu().numpy().view(np.uint64), traces[8])
+    in_use = [True, False, True, False, False, False, True, True, True]
+    got = sg.prove_with_traces(AllStark(consts), zk.StarkConfig(), dev, in_use, to_public_values(pvd))
+    before_cap = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
+    ok, why = oseg.verify_proof(oracle, ol, ol.make_cfg(hasher=0), _proof_dicts(got), in_use, pvd, consts, kh, len(code),
+                                is_initial=True, initial_mem_cap=tg.initial_memory_merkle_cap(code, 1, 4, hasher=0),
+                                mem_before_cap=before_cap)
     assert ok, why

@@ -56,7 +56,8 @@ def test_segment_with_an_executing_cpu_table(oracle):
     twelve code reads of the kernel image, stack writes through the partial channel, stack reads, two ADDs, one XOR,
     one KECCAK_GENERAL over three bytes of the kernel image (a KeccakSponge row, its Keccak-f permutation, its five
     block XORs, its byte reads), one MSTORE_32BYTES of the digest (a BytePacking row and its 32 byte writes) --
-    balances all ten CTLs of the real wiring with ALL NINE tables live.  A wrong gas charge or stack pointer breaks the
+    balances all ten CTLs of the real wiring with ALL NINE tables live (nine CTLs with traffic; context pruning in
+    the fourth kernel).  A wrong gas charge or stack pointer breaks the
     AIR; a wrong sum breaks exactly the Arithmetic CTL, a wrong XOR the Logic CTL, a wrong digest the KeccakSponge CTL,
     a wrong stored byte the BytePacking / Memory CTLs; executing a byte that is not in the kernel image breaks the
     Memory CTL."""
@@ -230,3 +231,32 @@ def test_third_kernel_leaves_kernel_mode(oracle):
         b2[col, row] = (int(b2[col, row]) + 1) % oseg.P
         with pytest.raises(AssertionError):
             _check_air(air, b2)
+
+
+def test_fourth_kernel_switches_and_prunes_a_context(oracle):
+    """CPU_PROGRAM_4: SET_CONTEXT to context 1, stack traffic there, SET_CONTEXT back to context 0 with the prune flag.
+    contextops.rs is exercised for real (stack-pointer save / restore through ContextMetadata::StackSize, the new top
+    fetched through GP channel 2), the Memory generator marks context 1 stale, MemAfter forgets it, and the
+    context-pruning CTL -- idle in the other runs -- carries the pruned context from Memory to the Cpu table."""
+    from oracle import mem_trace as mt
+    traces, pv, code = cs.build_with_cpu_program(np.random.default_rng(7), oracle, KH, cs.CPU_PROGRAM_4,
+                                                 cs.CPU_PROGRAM_4_CONSTS[0], 16)
+    air = oairs.make_eval_cpu(*cs.CPU_PROGRAM_4_CONSTS)
+    cpu, mem = traces[A.CPU], traces[A.MEMORY]
+    _check_air(air, cpu)
+    _check_air(oairs.eval_memory, mem)
+    assert [int(v) for v in cpu[0, :9]] == [0, 0, 0, 1, 1, 1, 1, 1, 0]               # the context register
+    assert int(mem[mt.IS_PRUNED].sum()) == 1 and int(mem[mt.STALE_CONTEXTS].max()) == 2
+    after = traces[A.MEM_AFTER]
+    assert not any(int(after[1, r]) == 1 for r in range(after.shape[1]) if after[0, r])   # nothing of context 1 survives
+    ctls = A.build_ctls()
+    ch = [S.GrandProductChallenge(1234567, 7654321), S.GrandProductChallenge(99, 101)]
+    zf = cs.ctl_first_values(traces, ctls, ch)
+    extra = [[0, 0] for _ in ctls]
+    extra[oseg.MEMORY_CTL_IDX] = [oseg.get_memory_extra_looking_sum(pv, c, KH, len(code)) for c in ch]
+    assert oseg.verify_cross_table_lookups(ctls, zf, extra, 2) == (True, "")
+    assert all(zf[A.CPU][-2:]) and zf[A.CPU][-2:] == zf[A.MEMORY][-2:]               # CTL 9 carries the pruned context
+    bad = [t.copy() for t in traces]
+    bad[A.CPU][32, 7] = 0                                                             # the Cpu row forgets the prune flag
+    zf = cs.ctl_first_values(bad, ctls, ch)
+    assert oseg.verify_cross_table_lookups(ctls, zf, extra, 2)[1].startswith("CTL 9")
