@@ -184,6 +184,11 @@ CPU_PROGRAM_4 = bytes([0x58]) + _push32(1 << 64) + bytes([0xf7, 0x58, 0x58, 0x50
 CPU_PROGRAM_4_CONSTS = (73, 0, 777777, 888888)
 
 
+# A fifth, tiny one for the last looker shape: MLOAD_32BYTES packs 32 bytes of the kernel image (BytePacking `pack`).
+CPU_PROGRAM_5 = _push32(32) + _push32(5) + bytes([0xf8, 0x50])
+CPU_PROGRAM_5_CONSTS = (68, 0, 777777, 888888)
+
+
 def program_logs(rng, oracle, kernel_hash=0, program=None, halt_pc=None, n_rows=16, extra_memory=None, **run_kw):
     """The operation logs of the run (what the reference's interpreter would hand to `generate_traces`): Cpu rows,
     Memory operations (public-value writes + the Cpu's bus traffic), mem_before values, and the Arithmetic / Logic /

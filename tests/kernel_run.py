@@ -16,7 +16,8 @@ against real instruction runs and the CTLs against the traffic those runs create
   the row with clock column 1).
 
 Supported: PUSH0 PC PUSH32 (kernel), DUPn SWAPn POP, ADD MUL SUB LT GT (binary), ADDMOD MULMOD SUBMOD, AND OR XOR, NOT ISZERO EQ,
-SHL, KECCAK_GENERAL, MLOAD_GENERAL MSTORE_GENERAL, MSTORE_32BYTES_n, JUMP JUMPI JUMPDEST, GET_CONTEXT, EXIT_KERNEL and,
+SHL, KECCAK_GENERAL, MLOAD_GENERAL MSTORE_GENERAL, MSTORE_32BYTES_n MLOAD_32BYTES, JUMP JUMPI JUMPDEST, GET_CONTEXT
+SET_CONTEXT, EXIT_KERNEL and,
 with cdk_erigon, POSEIDON.  User mode (entered with EXIT_KERNEL): PUSHn reads its argument from the code through the
 BytePacking table, JUMP / JUMPI read the JUMPDEST bit of the target, a non-native opcode (`syscall_opcodes`) traps into
 the kernel through the syscall jump table (3-byte big-endian handler offsets at syscall_jumptable + 3 * opcode, read
@@ -291,6 +292,15 @@ class KernelRun:
                 if self.stack_inv(r, sl - 2, aux2=1):
                     self.top_read = True
                 del S[-2:]
+        elif op == 0xf8:                                              # MLOAD_32BYTES(addr, len)
+            self.flag(r, "m_op_32bytes")
+            ln = self.operand(r, 1)
+            addr = (top >> 64 & 0xFFFFFFFF, top >> 32 & 0xFFFFFFFF, top & 0xFFFFFFFF)
+            data = bytes(self.mem.get((addr[0], addr[1], addr[2] + i), 0) for i in range(ln))
+            self.packing.append((True, addr, r * 5 + 1, data))
+            for i, v in enumerate(data):
+                self._log(r * 5 + 1, (addr[0], addr[1], addr[2] + i), True, v)
+            S[-2:] = [int.from_bytes(data, "big")]
         elif 0xc0 <= op <= 0xdf:                                      # MSTORE_32BYTES_n(addr, value)
             n = (op & 0x1F) + 1
             self.flag(r, "m_op_32bytes")

@@ -260,3 +260,25 @@ def test_fourth_kernel_switches_and_prunes_a_context(oracle):
     bad[A.CPU][32, 7] = 0                                                             # the Cpu row forgets the prune flag
     zf = cs.ctl_first_values(bad, ctls, ch)
     assert oseg.verify_cross_table_lookups(ctls, zf, extra, 2)[1].startswith("CTL 9")
+
+
+def test_fifth_kernel_mload_32bytes(oracle):
+    """MLOAD_32BYTES: 32 bytes of the kernel image packed big-endian through the BytePacking `pack` looker
+    (cpu_stark.rs:150-176) -- the one CTL entry shape the other runs do not touch."""
+    traces, pv, code = cs.build_with_cpu_program(np.random.default_rng(8), oracle, KH, cs.CPU_PROGRAM_5,
+                                                 cs.CPU_PROGRAM_5_CONSTS[0], 8)
+    _check_air(oairs.make_eval_cpu(*cs.CPU_PROGRAM_5_CONSTS), traces[A.CPU])
+    _check_air(oairs.eval_byte_packing, traces[A.BYTE_PACKING])
+    assert int(traces[A.BYTE_PACKING][0, 0]) == 1                                     # a read operation
+    loaded = sum(int(traces[A.CPU][41 + 5 + i, 3]) << (32 * i) for i in range(8))
+    assert loaded == int.from_bytes(code[5:37], "big")
+    ctls = A.build_ctls()
+    ch = [S.GrandProductChallenge(1234567, 7654321), S.GrandProductChallenge(99, 101)]
+    zf = cs.ctl_first_values(traces, ctls, ch)
+    extra = [[0, 0] for _ in ctls]
+    extra[oseg.MEMORY_CTL_IDX] = [oseg.get_memory_extra_looking_sum(pv, c, KH, len(code)) for c in ch]
+    assert oseg.verify_cross_table_lookups(ctls, zf, extra, 2) == (True, "")
+    bad = [t.copy() for t in traces]
+    bad[A.CPU][41 + 5, 3] ^= np.uint64(1)
+    zf = cs.ctl_first_values(bad, ctls, ch)
+    assert oseg.verify_cross_table_lookups(ctls, zf, extra, 2)[1].startswith("CTL 1")
