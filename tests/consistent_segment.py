@@ -184,6 +184,21 @@ CPU_PROGRAM_4 = bytes([0x58]) + _push32(1 << 64) + bytes([0xf7, 0x58, 0x58, 0x50
 CPU_PROGRAM_4_CONSTS = (73, 0, 777777, 888888)
 
 
+def _program_6():
+    code = bytearray(330)
+    code[0:33] = _push32(40)
+    code[33] = 0xf9
+    code[40:43] = bytes([0x60, 0x09, 0xfe])                        # user code: PUSH1 9, INVALID
+    code[60:62] = bytes([0x50, 0x50])
+    code[300 + 3 * 3:300 + 3 * 3 + 3] = (60).to_bytes(3, "big")   # exception_jumptable[exc_invalid_opcode = 3] = 60
+    return bytes(code)
+
+
+# A sixth: user code hits an invalid opcode -- an exception (code 3) through the exception jump table.
+CPU_PROGRAM_6 = _program_6()
+CPU_PROGRAM_6_CONSTS = (62, 0, 100, 300)
+
+
 # A fifth, tiny one for the last looker shape: MLOAD_32BYTES packs 32 bytes of the kernel image (BytePacking `pack`).
 CPU_PROGRAM_5 = _push32(32) + _push32(5) + bytes([0xf8, 0x50])
 CPU_PROGRAM_5_CONSTS = (68, 0, 777777, 888888)

@@ -43,7 +43,7 @@ def finv(x):
 
 class KernelRun:
     def __init__(self, code: bytes, halt_pc: int, n_rows: int, keccak256=None, poseidon_permute=None, cdk_erigon=False,
-                 memory=None, syscall_jumptable=0, syscall_opcodes=()):
+                 memory=None, syscall_jumptable=0, syscall_opcodes=(), exception_jumptable=0, exception_opcodes=None):
         from oracle import airs
         self.code, self.halt_pc, self.n = code, halt_pc, n_rows
         self.keccak256, self.poseidon_permute = keccak256, poseidon_permute
@@ -53,6 +53,7 @@ class KernelRun:
         self.t = np.zeros((85 + x, n_rows), dtype=np.uint64)
         self.stack, self.gas, self.pc, self.top_read, self.context, self.kernel = [], 0, 0, False, 0, 1
         self.syscall_jumptable, self.syscall_opcodes = syscall_jumptable, set(syscall_opcodes)
+        self.exception_jumptable, self.exception_opcodes = exception_jumptable, dict(exception_opcodes or {})
         self.mem = dict(memory or {})                     # (ctx, seg, virt) -> value, for MLOAD / MSTORE consistency
         self.mem_ops, self.arith, self.logic, self.sponge, self.packing, self.poseidon = [], [], [], [], [], []
         self.stacks, self.stale_contexts = {}, []         # other contexts' stacks (their tops are in memory)
@@ -142,16 +143,22 @@ class KernelRun:
 
     def step(self, r, op, sl, top):
         t, S = self.t, self.stack
-        if op in self.syscall_opcodes and not self.kernel:            # generate_syscall
-            self.flag(r, "syscall")
-            table = self.syscall_jumptable + 3 * op
+        trap = op in self.syscall_opcodes or op in self.exception_opcodes
+        if trap and not self.kernel:                                  # generate_syscall / generate_exception
+            exc = op in self.exception_opcodes
+            self.flag(r, "exception" if exc else "syscall")
+            if exc:
+                code_ = self.exception_opcodes[op]
+                for i in range(3):
+                    t[self.gen + i, r] = (code_ >> i) & 1             # general.exception().exc_code_bits
+            table = self.exception_jumptable + 3 * self.exception_opcodes[op] if exc else self.syscall_jumptable + 3 * op
             handler = int.from_bytes(self.code[table:table + 3], "big")
             c = self.ch(1)                                            # describes the packed read; the channel itself is unused
             t[c:c + 6, r] = [0, 1, 0, SEG_CODE, table, handler]
             self.packing.append((True, (0, SEG_CODE, table), r * 5 + 1, self.code[table:table + 3]))
             for i in range(3):
                 self._log(r * 5 + 1, (0, SEG_CODE, table + i), True, self.code[table + i])
-            info = (self.pc + 1) | (self.kernel << 32) | (self.gas << 192)
+            info = (self.pc + (0 if exc else 1)) | (self.kernel << 32) | (self.gas << 192)
             self.arith.append(("range_check", top, handler, 0, op, info))
             self.push_with_write(r)
             S.append(info)

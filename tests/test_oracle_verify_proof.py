@@ -282,3 +282,29 @@ def test_fifth_kernel_mload_32bytes(oracle):
     bad[A.CPU][41 + 5, 3] ^= np.uint64(1)
     zf = cs.ctl_first_values(bad, ctls, ch)
     assert oseg.verify_cross_table_lookups(ctls, zf, extra, 2)[1].startswith("CTL 1")
+
+
+def test_sixth_kernel_exception(oracle):
+    """User code executes an invalid opcode: the exception half of syscalls_exceptions.rs (exc_code bits, handler from
+    exception_jumptable + 3 * code, the pushed info holds pc -- not pc + 1 --, user gas dropped) plus the same two
+    CTL shapes a syscall uses (BytePacking `jumptable`, Arithmetic range check)."""
+    kw = dict(syscall_jumptable=100, exception_jumptable=300, exception_opcodes={0xfe: 3})
+    traces, pv, code = cs.build_with_cpu_program(np.random.default_rng(9), oracle, KH, cs.CPU_PROGRAM_6,
+                                                 cs.CPU_PROGRAM_6_CONSTS[0], 8, **kw)
+    air = oairs.make_eval_cpu(*cs.CPU_PROGRAM_6_CONSTS)
+    cpu = traces[A.CPU]
+    _check_air(air, cpu)
+    r = next(i for i in range(8) if cpu[6 + oairs.C_OPS.index("exception"), i])
+    assert [int(cpu[32 + i, r]) for i in range(3)] == [1, 1, 0] and int(cpu[2, r + 1]) == 60 and int(cpu[4, r + 1]) == 1
+    info = sum(int(cpu[41 + 5 + i, r + 1]) << (32 * i) for i in range(8))
+    assert info & 0xFFFFFFFF == int(cpu[2, r]) and (info >> 32) & 1 == 0 and info >> 192 == int(cpu[5, r])
+    ctls = A.build_ctls()
+    ch = [S.GrandProductChallenge(1234567, 7654321), S.GrandProductChallenge(99, 101)]
+    zf = cs.ctl_first_values(traces, ctls, ch)
+    extra = [[0, 0] for _ in ctls]
+    extra[oseg.MEMORY_CTL_IDX] = [oseg.get_memory_extra_looking_sum(pv, c, KH, len(code)) for c in ch]
+    assert oseg.verify_cross_table_lookups(ctls, zf, extra, 2) == (True, "")
+    bad = cpu.copy()
+    bad[32, r] = 0                                                  # exception code 2 instead of 3: another handler slot
+    with pytest.raises(AssertionError):
+        _check_air(air, bad)
