@@ -199,6 +199,11 @@ CPU_PROGRAM_6 = _program_6()
 CPU_PROGRAM_6_CONSTS = (62, 0, 100, 300)
 
 
+# A seventh: the BN254 field operations (modfp254.rs: mem_channels[2] must show the modulus).
+CPU_PROGRAM_7 = bytes([0x58, 0x58, 0x58, 0x0c, 0x58, 0x90, 0x0e, 0x0d, 0x50])   # PC PC PC ADDFP254 PC SWAP1 SUBFP254 MULFP254 POP
+CPU_PROGRAM_7_CONSTS = (9, 0, 777777, 888888)
+
+
 # A fifth, tiny one for the last looker shape: MLOAD_32BYTES packs 32 bytes of the kernel image (BytePacking `pack`).
 CPU_PROGRAM_5 = _push32(32) + _push32(5) + bytes([0xf8, 0x50])
 CPU_PROGRAM_5_CONSTS = (68, 0, 777777, 888888)

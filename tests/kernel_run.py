@@ -30,6 +30,7 @@ M256 = (1 << 256) - 1
 SEG_CODE, SEG_STACK, SEG_SHIFT_TABLE, SEG_JUMPDEST_BITS = 0, 1, 13, 14
 ARITH_CODE = {0x01: 0, 0x02: 1, 0x03: 2, 0x10: 11, 0x11: 12, 0x08: 5, 0x09: 6, 0x1b: 14}   # opcode -> IS_* column
 LOGIC_KIND = {0x16: 0, 0x17: 1, 0x18: 2}
+BN254 = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
 
 
 def limbs(v):
@@ -251,6 +252,13 @@ class KernelRun:
                        0x10: int(top < b), 0x11: int(top > b)}[op]
                 self.arith.append(("bin", ARITH_CODE[op], top, b))
                 S[-2:] = [res]; self.gas += 5 if op == 0x02 else 3
+        elif op in (0x0c, 0x0d, 0x0e):                                # ADDFP254 / MULFP254 / SUBFP254 (kernel only)
+            self.flag(r, "fp254_op")
+            b = self.operand(r, 1)
+            t[self.ch(2) + 5:self.ch(2) + 13, r] = limbs(BN254)       # modfp254.rs: channel 2 shows the modulus (no memory op)
+            res = ((top + b) % BN254, (top * b) % BN254, (top - b) % BN254)[op - 0x0c]
+            self.arith.append(("bin", 7 + op - 0x0c, top, b))
+            S[-2:] = [res]
         elif op == 0x21:                                              # KECCAK_GENERAL(addr, len)
             self.flag(r, "jumpdest_keccak_general")
             ln = self.operand(r, 1)

@@ -308,3 +308,26 @@ def test_sixth_kernel_exception(oracle):
     bad[32, r] = 0                                                  # exception code 2 instead of 3: another handler slot
     with pytest.raises(AssertionError):
         _check_air(air, bad)
+
+
+def test_seventh_kernel_fp254(oracle):
+    """ADDFP254 MULFP254 SUBFP254: modfp254.rs live (channel 2 shows the BN254 modulus), three two-row modular operations
+    in the Arithmetic table through the real CTL (SUBFP254 with a negative difference: 3 - 4 = p - 1)."""
+    traces, pv, code = cs.build_with_cpu_program(np.random.default_rng(10), oracle, KH, cs.CPU_PROGRAM_7,
+                                                 cs.CPU_PROGRAM_7_CONSTS[0], 16)
+    air = oairs.make_eval_cpu(*cs.CPU_PROGRAM_7_CONSTS)
+    _check_air(air, traces[A.CPU])
+    assert [int(traces[A.ARITHMETIC][i].sum()) for i in (7, 8, 9)] == [1, 1, 1]
+    from tests.kernel_run import BN254
+    top = sum(int(traces[A.CPU][41 + 5 + i, 7]) << (32 * i) for i in range(8))        # what SUBFP254 left for MULFP254
+    assert top == BN254 - 1
+    ctls = A.build_ctls()
+    ch = [S.GrandProductChallenge(1234567, 7654321), S.GrandProductChallenge(99, 101)]
+    zf = cs.ctl_first_values(traces, ctls, ch)
+    extra = [[0, 0] for _ in ctls]
+    extra[oseg.MEMORY_CTL_IDX] = [oseg.get_memory_extra_looking_sum(pv, c, KH, len(code)) for c in ch]
+    assert oseg.verify_cross_table_lookups(ctls, zf, extra, 2) == (True, "")
+    bad = traces[A.CPU].copy()
+    bad[41 + 13 * 2 + 5, 3] ^= np.uint64(1)                          # channel 2 shows another modulus
+    with pytest.raises(AssertionError):
+        _check_air(air, bad)
