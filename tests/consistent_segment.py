@@ -254,18 +254,22 @@ def build_with_cpu_program(rng, oracle, kernel_hash=0, program=None, halt_pc=Non
 # ---- the cdk_erigon feature set: PC PC PC POSEIDON POP, halt at pc = 5 ----------------------------------------------
 ERIGON_PROGRAM = bytes([0x58, 0x58, 0x58, 0x22, 0x50, 0x00, 0x00, 0x00])
 ERIGON_CONSTS = (5, 0, 777777, 888888)
+# POSEIDON_GENERAL over the first 56 bytes of the kernel image: PUSH32 56, PUSH32 (0, Code, 0), POSEIDON_GENERAL, POP
+ERIGON_PROGRAM_2 = bytes([0x7f]) + (56).to_bytes(32, "big") + bytes([0x7f]) + (0).to_bytes(32, "big") + bytes([0x23, 0x50])
+ERIGON_CONSTS_2 = (68, 0, 777777, 888888)
 
 
-def build_cdk_erigon_with_cpu_program(rng, oracle, kernel_hash=0):
+def build_cdk_erigon_with_cpu_program(rng, oracle, kernel_hash=0, program=None, consts=None, n_rows=16):
     """Ten tables of a `cdk_erigon` run whose 86-column Cpu table executes POSEIDON on three stack words: the Poseidon
     table gets the matching PoseidonSimpleOp row (CTL 10); public values carry a burn address and no eth_mainnet
     fields.  -> (traces[10], pv, code)."""
     from oracle import poseidon_table as pt
     pv = make_public_values(rng)
     pv.update(burn_addr=int.from_bytes(rng.bytes(20), "big"), blob_gas_used=0, excess_blob_gas=0, parent_beacon_root=bytes(32))
-    code = ERIGON_PROGRAM
+    code = ERIGON_PROGRAM if program is None else program
+    consts = ERIGON_CONSTS if consts is None else consts
     cpu, cpu_mem_ops, arith_ops, logic_ops, sponge_ops, packing_ops, poseidon_ops = cpu_program_trace(
-        oracle.keccak256, program=code, halt_pc=ERIGON_CONSTS[0], cdk_erigon=True, poseidon_permute=oracle.poseidon_permute)
+        oracle.keccak256, n=n_rows, program=code, halt_pc=consts[0], cdk_erigon=True, poseidon_permute=oracle.poseidon_permute)
     assert not (arith_ops or logic_ops or sponge_ops or packing_ops) and len(poseidon_ops) == 1
     before = [((0, SEG_CODE, i), b) for i, b in enumerate(code)]
     before += [((0, SEG_SHIFT_TABLE, i), 1 << i) for i in range(256)]

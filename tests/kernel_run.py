@@ -354,6 +354,21 @@ class KernelRun:
                 self.stack_inv(r, sl)
                 self.gp(r, 2, self.stack_addr(0), False, top)
             S.append(self.context << 64)
+        elif op == 0x23 and self.x:                                   # POSEIDON_GENERAL(addr, len) (cdk_erigon)
+            self.flag(r, "poseidon")
+            ln = self.operand(r, 1)
+            assert ln and ln % 56 == 0, "the table's generator handles whole 56-byte blocks (see its TODO)"
+            addr = (top >> 64 & 0xFFFFFFFF, top >> 32 & 0xFFFFFFFF, top & 0xFFFFFFFF)
+            data = bytes(self.mem.get((addr[0], addr[1], addr[2] + i), 0) for i in range(ln))
+            ts = (r + 1) * 5                                          # cpu_stark.rs:503: clock * NUM_CHANNELS
+            self.poseidon.append(("general", addr, ts, data, ln))
+            for i, v in enumerate(data):
+                self._log(ts, (addr[0], addr[1], addr[2] + i), True, v)
+            cap = [0, 0, 0, 0]
+            for off in range(0, ln, 56):                              # poseidon_hash_padded_byte_vec, smt_trie/src/code.rs:16-35
+                st = [int.from_bytes(data[off + 7 * i:off + 7 * i + 7], "little") for i in range(8)] + cap
+                cap = [int(v) for v in self.poseidon_permute(st)[:4]]
+            S[-2:] = [sum(v << (64 * i) for i, v in enumerate(cap))]
         elif op == 0x22 and self.x:                                   # POSEIDON (cdk_erigon)
             self.flag(r, "poseidon")
             words = [top, self.operand(r, 1), self.operand(r, 2)]

@@ -532,10 +532,12 @@ def test_executing_cpu_segment_with_device_generated_tables(oracle):
     assert ok, why
 
 
-def test_cdk_erigon_executing_cpu_accepted_by_verify_proof(oracle):
+@pytest.mark.parametrize("general", [False, True])
+def test_cdk_erigon_executing_cpu_accepted_by_verify_proof(oracle, general):
     """`verify_proof` for the cdk_erigon feature set (ten tables, 13 CTLs, burn address): the 86-column Cpu table runs
     PC PC PC POSEIDON POP, the Poseidon table -- generated on the device -- holds the matching simple operation.
-    Accepted; with the Poseidon digest changed rejected at CTL 10."""
+    Accepted; with the Poseidon digest changed rejected at CTL 10.  general = True: PUSH32 PUSH32 POSEIDON_GENERAL POP
+    over 56 bytes of the kernel image instead -- the table's general operation with its 56 Memory reads (CTLs 6, 11, 12)."""
     import torch
     import zk_evm_amd as zk
     import zk_evm_amd.segment as sg
@@ -546,14 +548,19 @@ def test_cdk_erigon_executing_cpu_accepted_by_verify_proof(oracle):
     from zk_evm_amd.all_stark import AllStark
     ol.setup_fri_api(oracle)
     kh = 0xABCDEF
-    traces, pvd, code = cs.build_cdk_erigon_with_cpu_program(np.random.default_rng(81), oracle, kh)
-    words = [2, 1, 0]
-    inp = [((w >> (64 * i)) & 0xFFFFFFFFFFFFFFFF) for w in words for i in range(4)]
-    dev_poseidon = tg.poseidon_generate_trace([("simple", inp)], 16)
+    consts = cs.ERIGON_CONSTS_2 if general else cs.ERIGON_CONSTS
+    traces, pvd, code = cs.build_cdk_erigon_with_cpu_program(np.random.default_rng(81), oracle, kh,
+                                                             cs.ERIGON_PROGRAM_2 if general else None, consts, 16)
+    if general:
+        dev_poseidon = tg.poseidon_generate_trace([("general", (0, 0, 0), 3 * 5, code[:56], 56)], 16)
+    else:
+        words = [2, 1, 0]
+        inp = [((w >> (64 * i)) & 0xFFFFFFFFFFFFFFFF) for w in words for i in range(4)]
+        dev_poseidon = tg.poseidon_generate_trace([("simple", inp)], 16)
     assert np.array_equal(dev_poseidon.cpu().numpy().view(np.uint64), traces[9])
     reg = oas.Registry(True)
     in_use = [True, False, True, False, False, False, True, True, True, True]
-    st = AllStark(cs.ERIGON_CONSTS, cdk_erigon=True)
+    st = AllStark(consts, cdk_erigon=True)
     cfg = ol.make_cfg(hasher=0)
     init_cap = tg.initial_memory_merkle_cap(code, 1, 4, hasher=0)
 
@@ -563,7 +570,7 @@ def test_cdk_erigon_executing_cpu_accepted_by_verify_proof(oracle):
         pv.burn_addr = pvd["burn_addr"]
         got = sg.prove_with_traces(st, zk.StarkConfig(), dev, in_use, pv)
         before_cap = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
-        return oseg.verify_proof(oracle, ol, cfg, _proof_dicts(got), in_use, pvd, cs.ERIGON_CONSTS, kh, len(code),
+        return oseg.verify_proof(oracle, ol, cfg, _proof_dicts(got), in_use, pvd, consts, kh, len(code),
                                  is_initial=True, initial_mem_cap=init_cap, mem_before_cap=before_cap, reg=reg)
     ok, why = run(traces)
     assert ok, why

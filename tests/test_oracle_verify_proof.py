@@ -331,3 +331,31 @@ def test_seventh_kernel_fp254(oracle):
     bad[41 + 13 * 2 + 5, 3] ^= np.uint64(1)                          # channel 2 shows another modulus
     with pytest.raises(AssertionError):
         _check_air(air, bad)
+
+
+def test_cdk_erigon_poseidon_general(oracle):
+    """POSEIDON_GENERAL on the 86-column Cpu table: the Poseidon table's general operation reads its 56 input bytes from
+    Memory (the 56 extra Memory lookers of the cdk_erigon wiring), is matched to the Cpu row's (address, len, timestamp)
+    by CTL 11 and hands back the digest by CTL 12; the digest equals the reference's `poseidon_hash_padded_byte_vec`."""
+    from oracle import poseidon_table as pt
+    traces, pv, code = cs.build_cdk_erigon_with_cpu_program(np.random.default_rng(11), oracle, KH, cs.ERIGON_PROGRAM_2,
+                                                            cs.ERIGON_CONSTS_2, 8)
+    reg = A.Registry(True)
+    _check_air(oairs.make_eval_cpu(*cs.ERIGON_CONSTS_2, cdk_erigon=True), traces[A.CPU])
+    _check_air(pt.eval_poseidon, traces[9])
+    _check_air(oairs.eval_memory, traces[A.MEMORY])
+    cap = [0, 0, 0, 0]
+    st = [int.from_bytes(code[7 * i:7 * i + 7], "little") for i in range(8)] + cap
+    digest = [int(v) for v in oracle.poseidon_permute(st)[:4]]
+    pushed = sum(int(traces[A.CPU][42 + 5 + i, 3]) << (32 * i) for i in range(8))
+    assert pushed == sum(v << (64 * i) for i, v in enumerate(digest))
+    ch = [S.GrandProductChallenge(1234567, 7654321), S.GrandProductChallenge(99, 101)]
+    zf = cs.ctl_first_values(traces, reg.ctls, ch)
+    extra = [[0, 0] for _ in reg.ctls]
+    extra[oseg.MEMORY_CTL_IDX] = [oseg.get_memory_extra_looking_sum(pv, c, KH, len(code)) for c in ch]
+    assert oseg.verify_cross_table_lookups(reg.ctls, zf, extra, 2) == (True, "")
+    assert all(zf[9][0:2]) and not any(zf[9][2:4]) and all(zf[9][4:8])   # memory reads, no simple op, general in / out
+    bad = [t.copy() for t in traces]
+    bad[9][pt.INPUT_BYTES + 3, 0] ^= np.uint64(1)                        # one input byte differs from memory
+    zf = cs.ctl_first_values(bad, reg.ctls, ch)
+    assert oseg.verify_cross_table_lookups(reg.ctls, zf, extra, 2)[1].startswith("CTL 6")
