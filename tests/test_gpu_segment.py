@@ -670,3 +670,28 @@ def test_fourth_kernel_segment_accepted_by_verify_proof(oracle):
                                 is_initial=True, initial_mem_cap=tg.initial_memory_merkle_cap(code, 1, 4, hasher=0),
                                 mem_before_cap=before_cap)
     assert ok, why
+
+
+def test_traces_into_tables_cdk_erigon(oracle):
+    """`tracegen.Traces.into_tables` for the ten-table feature set: operation logs of the POSEIDON run in, ten device
+    tables out, each equal to the restated reference generator's."""
+    import zk_evm_amd as zk
+    import zk_evm_amd.tracegen as tg
+    from tests import consistent_segment as cs
+    from zk_evm_amd.all_stark import AllStark
+    ref, pvd, code = cs.build_cdk_erigon_with_cpu_program(np.random.default_rng(85), oracle, 1)
+    run = cs.cpu_program_trace(oracle.keccak256, program=code, halt_pc=cs.ERIGON_CONSTS[0], cdk_erigon=True,
+                               poseidon_permute=oracle.poseidon_permute, return_run=True)
+    from oracle import segment as oseg
+    before = [((0, cs.SEG_CODE, i), b) for i, b in enumerate(code)] + [((0, cs.SEG_SHIFT_TABLE, i), 1 << i) for i in range(256)]
+    tr = tg.Traces()
+    tr.cpu = np.ascontiguousarray(run.t.T)
+    tr.poseidon_ops = run.poseidon
+    tr.memory_ops = [(True, 2, (0, seg, idx), False, val) for seg, idx, val in oseg.public_memory_writes(pvd, 1, len(code))] + \
+                    [(o["filter"], o["timestamp"], (o["ctx"], o["seg"], o["virt"]), o["is_read"], o["value"]) for o in run.mem_ops]
+    tables, final_values = tr.into_tables(AllStark(cs.ERIGON_CONSTS, cdk_erigon=True), before, [], zk.StarkConfig())
+    assert len(tables) == 10 and len(final_values) == int(ref[8][0].sum())
+    for t in (0, 2, 6, 7, 8, 9):
+        assert np.array_equal(tables[t].cpu().numpy().view(np.uint64), ref[t]), t
+    with pytest.raises(zk.ZkStarkError):
+        tr.into_tables(AllStark(cs.ERIGON_CONSTS), before, [], zk.StarkConfig())    # 86-column rows, eth_mainnet registry
