@@ -67,9 +67,25 @@ REALISTIC_LOG_NS = [17, 14, 19, 17, 13, 16, 21, 19, 19]
 def cpu_baseline(cols, log_n, sample_log_n, hasher):
     """Time the oracle's from_values on a bounded sample (cols x 2^sample_log_n) and extrapolate
     linearly in rows to the full workload (slightly optimistic for the CPU: NTT is n log n)."""
+    import ctypes
+    import math
     import numpy as np
     from tests.oracle_lib import load_oracle, splitmix64
     o = load_oracle()
+    # threads actually available to this process: affinity mask and cgroup CPU quota, not just the core count OpenMP
+    # sees (running 128 threads inside a smaller quota makes the baseline look worse than the hardware is)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else int(o.lib.orc_num_threads())
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cores = min(cores, int(o.lib.orc_num_threads()))
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
     n = 1 << sample_log_n
     vals = np.stack([splitmix64(0x6FEB51B7EC230F25 + c, n) for c in range(cols)])
     o.commit_values(vals[:, : 1 << 10].copy(), want_leaves=False, hasher=hasher)  # warm
@@ -86,7 +102,7 @@ def cpu_baseline(cols, log_n, sample_log_n, hasher):
     return {
         "value": 1.0 / (per_sample * scale),
         "unit": "commits/s",
-        "cores": int(o.lib.orc_num_threads()),
+        "cores": cores,
         "kind": "port",
         "sample": f"oracle from_values on {cols} x 2^{sample_log_n} rows ({reps} reps, "
                   f"{per_sample:.3f} s each), scaled x{int(scale)} rows to 2^{log_n}",

@@ -123,6 +123,16 @@ void orc_commit_values(const uint64_t *values, size_t n_cols, unsigned log_n, un
     if (!coeffs_out) free(coeffs);
 }
 
+/* the fast 128-bit reduction against its defining statement x % p; returns the number of mismatches */
+size_t orc_gl_reduce128_check(const uint64_t *lo, const uint64_t *hi, size_t n) {
+    size_t bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        u128 x = ((u128)hi[i] << 64) | lo[i];
+        bad += gl_reduce128(x) != gl_reduce128_slow(x);
+    }
+    return bad;
+}
+
 /* thin exports of the inline field ops for python tests */
 uint64_t orc_gl_add(uint64_t a, uint64_t b) { return gl_add(a, b); }
 uint64_t orc_gl_sub(uint64_t a, uint64_t b) { return gl_sub(a, b); }
