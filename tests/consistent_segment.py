@@ -204,6 +204,15 @@ CPU_PROGRAM_7 = bytes([0x58, 0x58, 0x58, 0x0c, 0x58, 0x90, 0x0e, 0x0d, 0x50])   
 CPU_PROGRAM_7_CONSTS = (9, 0, 777777, 888888)
 
 
+def loop_program(n_iterations):
+    """A countdown loop: PUSH32 n; L: JUMPDEST PUSH32 1 SWAP1 SUB DUP1 PUSH32 L JUMPI; POP -- seven rows per iteration,
+    so that valid tables of a few thousand rows can be produced (one SUB per iteration in Arithmetic, ~13 Memory
+    operations per iteration)."""
+    loop = 33
+    code = _push32(n_iterations) + bytes([0x5b]) + _push32(1) + bytes([0x90, 0x03, 0x80]) + _push32(loop) + bytes([0x57, 0x50])
+    return code, len(code)                                          # halt right after the final POP
+
+
 # A fifth, tiny one for the last looker shape: MLOAD_32BYTES packs 32 bytes of the kernel image (BytePacking `pack`).
 CPU_PROGRAM_5 = _push32(32) + _push32(5) + bytes([0xf8, 0x50])
 CPU_PROGRAM_5_CONSTS = (68, 0, 777777, 888888)

@@ -695,3 +695,40 @@ def test_traces_into_tables_cdk_erigon(oracle):
         assert np.array_equal(tables[t].cpu().numpy().view(np.uint64), ref[t]), t
     with pytest.raises(zk.ZkStarkError):
         tr.into_tables(AllStark(cs.ERIGON_CONSTS), before, [], zk.StarkConfig())    # 86-column rows, eth_mainnet registry
+
+
+def test_thousand_iteration_loop_accepted_by_verify_proof(oracle):
+    """A larger valid witness: a 1000-iteration countdown loop (tests/consistent_segment.py `loop_program`: 7002
+    instructions -- PUSH32 SWAP1 SUB DUP1 JUMPI JUMPDEST ...; Cpu table 2^13 rows, 1000 SUB rows in Arithmetic, a
+    Memory table of ~2^15 rows with its gap-filling and range-check frequencies) whose Memory / MemAfter / Arithmetic
+    tables are built by the device generators (and equal the restated reference generators' at this size too).
+    Proven under standard_fast_config, accepted by the restated `verify_proof`."""
+    import time
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    import zk_evm_amd.tracegen as tg
+    from oracle import segment as oseg
+    from tests import consistent_segment as cs
+    from zk_evm_amd.all_stark import AllStark
+    ol.setup_fri_api(oracle)
+    kh = 0x100F
+    code, halt = cs.loop_program(1000)
+    consts = (halt, 0, 777777, 888888)
+    traces, pvd, _ = cs.build_with_cpu_program(np.random.default_rng(86), oracle, kh, code, halt, 8192)
+    g = cs.program_logs(np.random.default_rng(86), oracle, kh, code, halt, 8192)
+    assert int(traces[2][6:24].sum()) == 7002 and traces[2].shape == (85, 8192) and traces[6].shape[1] >= 1 << 14
+    dev = [torch.from_numpy(np.ascontiguousarray(t).view(np.int64)).cuda() for t in traces]
+    mem_ops = [(o["filter"], o["timestamp"], (o["ctx"], o["seg"], o["virt"]), o["is_read"], o["value"]) for o in g["memory"]]
+    dev[6], dev[8], _, _ = tg.memory_generate_trace(mem_ops, g["before"], [])
+    dev[0], used = tg.arithmetic_generate_trace([op[1:] for op in g["arithmetic"]])
+    assert used == 1000
+    for t in (0, 6, 8):
+        assert np.array_equal(dev[t].cpu().numpy().view(np.uint64), traces[t]), t
+    in_use = [True, False, True, False, False, False, True, True, True]
+    got = sg.prove_with_traces(AllStark(consts), zk.StarkConfig(), dev, in_use, to_public_values(pvd))
+    before_cap = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
+    ok, why = oseg.verify_proof(oracle, ol, ol.make_cfg(hasher=0), _proof_dicts(got), in_use, pvd, consts, kh, len(code),
+                                is_initial=True, initial_mem_cap=tg.initial_memory_merkle_cap(code, 1, 4, hasher=0),
+                                mem_before_cap=before_cap)
+    assert ok, why
