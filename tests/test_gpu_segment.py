@@ -732,3 +732,52 @@ def test_thousand_iteration_loop_accepted_by_verify_proof(oracle):
                                 is_initial=True, initial_mem_cap=tg.initial_memory_merkle_cap(code, 1, 4, hasher=0),
                                 mem_before_cap=before_cap)
     assert ok, why
+
+
+def test_full_size_valid_segment_accepted_by_verify_proof(oracle):
+    """BASELINE scale with a VALID witness: a 149 000-iteration countdown loop fills a 2^20-row Cpu table (1 043 002
+    instructions), its bus traffic a 2^22-row Memory table (2.38 M operations through the device generator: radix
+    sort, gap filling, range-check frequencies), its SUBs a 2^18-row Arithmetic table (device generator).  Proven by
+    zk_prove_segment under standard_fast_config and accepted by the restated `verify_proof` -- constraint identities
+    at zeta for every table, FRI, the initial-memory cap, all cross-table lookups with the public-value sum."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    import zk_evm_amd.tracegen as tg
+    from oracle import segment as oseg
+    from tests import consistent_segment as cs
+    from zk_evm_amd.all_stark import AllStark
+    ol.setup_fri_api(oracle)
+    kh = 0xB16
+    code, halt = cs.loop_program(149000)
+    consts = (halt, 0, 777777, 888888)
+    run = cs.cpu_program_trace(oracle.keccak256, n=1 << 20, program=code, halt_pc=halt, return_run=True)
+    assert int(run.t[6:24].sum()) == 7 * 149000 + 2
+    pvd = cs.make_public_values(np.random.default_rng(87))
+    m64 = (1 << 64) - 1
+    before = [((0, cs.SEG_CODE, i), b) for i, b in enumerate(code)] + [((0, cs.SEG_SHIFT_TABLE, i), 1 << i) for i in range(256)]
+    pub = [dict(filter=True, timestamp=2, ctx=0, seg=s, virt=i, is_read=False, value=v)
+           for s, i, v in oseg.public_memory_writes(pvd, kh, len(code))]
+    mem = np.array([[(1 if d["is_read"] else 0) | 2, d["timestamp"], d["ctx"], d["seg"], d["virt"]] +
+                    [(d["value"] >> (64 * l)) & m64 for l in range(4)] for d in pub + run.mem_ops], dtype=np.uint64)
+    bef = np.array([[c, s, v] + [(val >> (64 * l)) & m64 for l in range(4)] for (c, s, v), val in before], dtype=np.uint64)
+    memory, mem_after, final, unpadded = tg.memory_generate_trace(mem, bef, [])
+    assert memory.shape == (30, 1 << 22) and unpadded > 2_380_000
+    ar = np.zeros((len(run.arith), 18), dtype=np.uint64)
+    ar[:, 0] = 2                                                     # SUB
+    ar[:, 2] = [op[2] for op in run.arith]
+    ar[:, 6] = [op[3] for op in run.arith]
+    arithmetic, used = tg.arithmetic_generate_trace(ar)
+    assert used == 149000 and arithmetic.shape == (116, 1 << 18)
+    dev = [arithmetic, torch.zeros((71, 256), dtype=torch.int64, device="cuda"),
+           torch.from_numpy(run.t.view(np.int64)).cuda(), torch.zeros((2431, 32), dtype=torch.int64, device="cuda"),
+           torch.zeros((438, 256), dtype=torch.int64, device="cuda"), torch.zeros((523, 32), dtype=torch.int64, device="cuda"),
+           memory, tg.memory_continuation_generate_trace(before), mem_after]
+    in_use = [True, False, True, False, False, False, True, True, True]
+    got = sg.prove_with_traces(AllStark(consts), zk.StarkConfig(), dev, in_use, to_public_values(pvd))
+    assert [p.proof.degree_bits for p in got.multi_proof.stark_proofs if p is not None] == [18, 20, 22, 9, 10]
+    before_cap = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
+    ok, why = oseg.verify_proof(oracle, ol, ol.make_cfg(hasher=0), _proof_dicts(got), in_use, pvd, consts, kh, len(code),
+                                is_initial=True, initial_mem_cap=tg.initial_memory_merkle_cap(code, 1, 4, hasher=0),
+                                mem_before_cap=before_cap)
+    assert ok, why
