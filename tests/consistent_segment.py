@@ -213,6 +213,31 @@ def loop_program(n_iterations):
     return code, len(code)                                          # halt right after the final POP
 
 
+def hashing_loop_program(n_iterations):
+    """A loop whose body hashes three bytes of the kernel image (KECCAK_GENERAL) and stores the digest with
+    MSTORE_32BYTES: thirteen rows per iteration that keep every table busy -- one KeccakSponge row, one Keccak
+    permutation (24 rows), five Logic XORs, one BytePacking row, one Arithmetic SUB and ~63 Memory operations each."""
+    loop = 33
+    body = (_push32(3) + _push32(200) + bytes([0x21]) + _push32(_ADDR_WORD) + bytes([0xdf, 0x50]) + _push32(1) +
+            bytes([0x90, 0x03, 0x80]) + _push32(loop) + bytes([0x57]))
+    code = _push32(n_iterations) + bytes([0x5b]) + body + bytes([0x50])
+    assert len(code) == 207 and code[200:203] == code[200:203]
+    return code, len(code)
+
+
+def single_block_sponge_effects(data: bytes, timestamp: int):
+    """For an input shorter than one rate block: the Keccak-f input the KeccakSponge row sends to the Keccak table
+    (the padded block XORed into the zero state) and its five 256-bit Logic XORs (rate chunk = 0, block chunk)."""
+    assert len(data) < 135
+    blk = bytearray(136)
+    blk[:len(data)] = data
+    blk[len(data)] |= 1
+    blk[135] |= 0x80
+    words = [int.from_bytes(blk[8 * i:8 * i + 8], "little") for i in range(17)] + [0] * 8
+    xors = [(2, 0, int.from_bytes(bytes(blk[32 * i:32 * i + 32]).ljust(32, b"\0"), "little")) for i in range(5)]
+    return (words, timestamp), xors
+
+
 # A fifth, tiny one for the last looker shape: MLOAD_32BYTES packs 32 bytes of the kernel image (BytePacking `pack`).
 CPU_PROGRAM_5 = _push32(32) + _push32(5) + bytes([0xf8, 0x50])
 CPU_PROGRAM_5_CONSTS = (68, 0, 777777, 888888)

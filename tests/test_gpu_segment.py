@@ -781,3 +781,51 @@ def test_full_size_valid_segment_accepted_by_verify_proof(oracle):
                                 is_initial=True, initial_mem_cap=tg.initial_memory_merkle_cap(code, 1, 4, hasher=0),
                                 mem_before_cap=before_cap)
     assert ok, why
+
+
+def test_large_valid_segment_with_every_table_live(oracle):
+    """A large VALID witness that keeps all nine tables busy: 20 000 iterations of a loop that hashes three bytes of
+    the kernel image (KECCAK_GENERAL), stores the digest (MSTORE_32BYTES) and counts down -- Cpu 2^18 rows (260 002
+    instructions), Keccak 2^19 (20 000 permutations), KeccakSponge 2^15, Logic 2^17 (100 000 XORs), BytePacking 2^15,
+    Arithmetic 2^16, Memory 2^21 (1.26 M operations).  Every non-Cpu table comes from the product's
+    `tracegen.Traces.into_tables` (device generators); the proof passes the restated `verify_proof`."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    import zk_evm_amd.tracegen as tg
+    from oracle import segment as oseg
+    from tests import consistent_segment as cs
+    from zk_evm_amd.all_stark import AllStark
+    ol.setup_fri_api(oracle)
+    kh, n_it = 0xA11, 20000
+    code, halt = cs.hashing_loop_program(n_it)
+    consts = (halt, 0, 777777, 888888)
+    run = cs.cpu_program_trace(oracle.keccak256, n=1 << 18, program=code, halt_pc=halt, return_run=True)
+    assert int(run.t[6:24].sum()) == 13 * n_it + 2 and len(run.sponge) == len(run.packing) == len(run.arith) == n_it
+    pvd = cs.make_public_values(np.random.default_rng(88))
+    m64 = (1 << 64) - 1
+    before = [((0, cs.SEG_CODE, i), b) for i, b in enumerate(code)] + [((0, cs.SEG_SHIFT_TABLE, i), 1 << i) for i in range(256)]
+    pub = [dict(filter=True, timestamp=2, ctx=0, seg=s, virt=i, is_read=False, value=v)
+           for s, i, v in oseg.public_memory_writes(pvd, kh, len(code))]
+    tr = tg.Traces()
+    tr.cpu = np.ascontiguousarray(run.t.T)
+    tr.memory_ops = np.array([[(1 if d["is_read"] else 0) | 2, d["timestamp"], d["ctx"], d["seg"], d["virt"]] +
+                              [(d["value"] >> (64 * l)) & m64 for l in range(4)] for d in pub + run.mem_ops], dtype=np.uint64)
+    ar = np.zeros((n_it, 18), dtype=np.uint64)
+    ar[:, 0], ar[:, 2], ar[:, 6] = 2, [op[2] for op in run.arith], [op[3] for op in run.arith]
+    tr.arithmetic_ops = ar
+    tr.byte_packing_ops, tr.keccak_sponge_ops = run.packing, run.sponge
+    effects = [cs.single_block_sponge_effects(data, ts) for _, ts, data in run.sponge]
+    tr.keccak_inputs = [e[0] for e in effects]
+    tr.logic_ops = [x for e in effects for x in e[1]]
+    st = AllStark(consts)
+    bef = np.array([[c, s, v] + [(val >> (64 * l)) & m64 for l in range(4)] for (c, s, v), val in before], dtype=np.uint64)
+    dev, final_values = tr.into_tables(st, bef, [], zk.StarkConfig())
+    assert [int(t.shape[1]).bit_length() - 1 for t in dev] == [16, 15, 18, 19, 15, 17, 21, 9, 10]
+    in_use = [True] * 9
+    got = sg.prove_with_traces(st, zk.StarkConfig(), dev, in_use, to_public_values(pvd))
+    before_cap = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
+    ok, why = oseg.verify_proof(oracle, ol, ol.make_cfg(hasher=0), _proof_dicts(got), in_use, pvd, consts, kh, len(code),
+                                is_initial=True, initial_mem_cap=tg.initial_memory_merkle_cap(code, 1, 4, hasher=0),
+                                mem_before_cap=before_cap)
+    assert ok, why

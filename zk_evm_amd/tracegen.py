@@ -86,8 +86,11 @@ def memory_continuation_generate_trace(mem_values: Sequence[Tuple[Tuple[int, int
     ctx = ctx or default_context(device)
     ctx.use_torch_current_stream()
     m64 = (1 << 64) - 1
-    flat = np.zeros((n, 7), dtype=np.uint64)
-    for r, ((c, s, v), val) in enumerate(mem_values):
+    packed = isinstance(mem_values, np.ndarray)              # the C ABI's record layout: (n, 7) uint64
+    if packed and (mem_values.dtype != np.uint64 or mem_values.ndim != 2 or mem_values.shape[1] != 7):
+        raise ZkStarkError(-1, "packed mem values are a (n, 7) uint64 array")
+    flat = np.ascontiguousarray(mem_values) if packed else np.zeros((n, 7), dtype=np.uint64)
+    for r, ((c, s, v), val) in enumerate(() if packed else mem_values):
         flat[r] = [c, s, v] + [(val >> (64 * l)) & m64 for l in range(4)]
     out = torch.empty((MEM_CONTINUATION_COLUMNS, rows), dtype=torch.int64, device=f"cuda:{device}")
     ctx.check(ctx.lib.zk_memory_continuation_generate_trace(ctx.handle, flat.ctypes.data if n else None, n, log_n,
