@@ -386,3 +386,22 @@ def test_memory_table_valid_trace_verifies(oracle):
     bad[mt.VIRT, i + 1], bad[mt.VIRT, i] = t[mt.VIRT, i], t[mt.VIRT, i + 1]      # two rows out of address order
     ok, why = _prove_and_verify(oracle, 3, bad, 0, zlist, lookup_spec=lookups)
     assert not ok, why
+
+
+def test_packed_logs_give_the_same_tables():
+    """logic / keccak / byte_packing generators: numpy arrays in the C ABI's record layouts == the tuple forms."""
+    import torch
+    import zk_evm_amd.tracegen as tg
+    rng = np.random.default_rng(91)
+    m64 = (1 << 64) - 1
+    ops = [(int(rng.integers(0, 3)), int.from_bytes(rng.bytes(32), "little"), int.from_bytes(rng.bytes(32), "little")) for _ in range(40)]
+    packed = np.array([[k] + [(a >> (64 * l)) & m64 for l in range(4)] + [(b >> (64 * l)) & m64 for l in range(4)] for k, a, b in ops], dtype=np.uint64)
+    assert torch.equal(tg.logic_generate_trace(ops, 16), tg.logic_generate_trace(packed, 16))
+    perms = [([int(x) for x in rng.integers(0, 1 << 63, 25)], int(rng.integers(0, 1000))) for _ in range(7)]
+    arrs = (np.array([p[0] for p in perms], dtype=np.uint64), np.array([p[1] for p in perms], dtype=np.uint64))
+    assert torch.equal(tg.keccak_generate_trace(perms, 16), tg.keccak_generate_trace(arrs, 16))
+    bp = [(bool(rng.integers(0, 2)), (int(rng.integers(0, 5)), int(rng.integers(0, 30)), int(rng.integers(0, 1000))), int(rng.integers(1, 500)),
+           rng.bytes(int(rng.integers(1, 33)))) for _ in range(30)]
+    bpa = np.array([[1 if rd else 0, c, s, v, ts, len(d)] + [int.from_bytes(d[8 * k:8 * k + 8].ljust(8, b"\0"), "little") for k in range(4)]
+                    for rd, (c, s, v), ts, d in bp], dtype=np.uint64)
+    assert torch.equal(tg.byte_packing_generate_trace(bp, 0), tg.byte_packing_generate_trace(bpa, 0))

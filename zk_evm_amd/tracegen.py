@@ -23,8 +23,14 @@ def keccak_generate_trace(inputs_and_timestamps: Sequence[Tuple[Sequence[int], i
     log_n = (n - 1).bit_length()
     ctx = ctx or default_context(device)
     ctx.use_torch_current_stream()
-    inp = np.array([[int(w) for w in i] for i, _ in inputs_and_timestamps], dtype=np.uint64).reshape(n_perms, NUM_INPUTS)
-    ts = np.array([int(t) for _, t in inputs_and_timestamps], dtype=np.uint64)
+    if isinstance(inputs_and_timestamps, tuple) and len(inputs_and_timestamps) == 2 and isinstance(inputs_and_timestamps[0], np.ndarray):
+        inp, ts = (np.ascontiguousarray(a, dtype=np.uint64) for a in inputs_and_timestamps)   # packed: ((n, 25), (n,))
+        n_perms = inp.shape[0]
+        n = max(n_perms * NUM_ROUNDS, min_rows, 1)
+        log_n = (n - 1).bit_length()
+    else:
+        inp = np.array([[int(w) for w in i] for i, _ in inputs_and_timestamps], dtype=np.uint64).reshape(n_perms, NUM_INPUTS)
+        ts = np.array([int(t) for _, t in inputs_and_timestamps], dtype=np.uint64)
     if inp.shape != (n_perms, NUM_INPUTS):
         raise ZkStarkError(-1, "every Keccak input is 25 words")
     out = torch.empty((KECCAK_COLUMNS, 1 << log_n), dtype=torch.int64, device=f"cuda:{device}")
@@ -61,8 +67,11 @@ def logic_generate_trace(operations: Sequence[Tuple[int, int, int]], min_rows: i
     ctx = ctx or default_context(device)
     ctx.use_torch_current_stream()
     m64 = (1 << 64) - 1
-    flat = np.zeros((n_ops, 9), dtype=np.uint64)
-    for r, (op, a, b) in enumerate(operations):
+    packed = isinstance(operations, np.ndarray)              # the C ABI's record layout: (n, 9) uint64
+    if packed and (operations.dtype != np.uint64 or operations.ndim != 2 or operations.shape[1] != 9):
+        raise ZkStarkError(-1, "packed logic operations are a (n, 9) uint64 array")
+    flat = np.ascontiguousarray(operations) if packed else np.zeros((n_ops, 9), dtype=np.uint64)
+    for r, (op, a, b) in enumerate(() if packed else operations):
         if not (0 <= a < (1 << 256) and 0 <= b < (1 << 256)):
             raise ZkStarkError(-1, "logic inputs are U256")
         flat[r] = [op] + [(a >> (64 * l)) & m64 for l in range(4)] + [(b >> (64 * l)) & m64 for l in range(4)]
@@ -265,9 +274,12 @@ def byte_packing_generate_trace(ops, min_rows: int, device=0, ctx: Context = Non
     timestamp, bytes); -> CUDA int64 tensor (71, max(len(ops), 256, min_rows).next_power_of_two())."""
     import torch
     log_n = _pow2_log(max(len(ops), BYTE_RANGE_MAX, min_rows))
-    live = [op for op in ops if len(op[3])]
-    flat = np.zeros((len(live), 10), dtype=np.uint64)
-    for r, (is_read, (c, s, v), ts, data) in enumerate(live):
+    packed = isinstance(ops, np.ndarray)                     # the C ABI's record layout: (n, 10) uint64, no empty operations
+    if packed and (ops.dtype != np.uint64 or ops.ndim != 2 or ops.shape[1] != 10):
+        raise ZkStarkError(-1, "packed byte-packing operations are a (n, 10) uint64 array")
+    live = ops if packed else [op for op in ops if len(op[3])]
+    flat = np.ascontiguousarray(ops) if packed else np.zeros((len(live), 10), dtype=np.uint64)
+    for r, (is_read, (c, s, v), ts, data) in enumerate(() if packed else live):
         data = bytes(data)
         if len(data) > 32:
             raise ZkStarkError(-1, "byte sequences are at most 32 bytes")
