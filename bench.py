@@ -381,7 +381,7 @@ def main():
                     out["cpu_baseline"] = {"error": repr(e)}
     else:
         import zk_evm_amd.segment as sg
-        from zk_evm_amd.all_stark import TABLE_COLUMNS, TABLE_NAMES, AllStark
+        from zk_evm_amd.all_stark import AllStark
         n_tab = 10 if a.cdk_erigon else 9
         log_ns = [a.log_n] * n_tab
         if a.log_ns:

@@ -703,7 +703,6 @@ def test_thousand_iteration_loop_accepted_by_verify_proof(oracle):
     Memory table of ~2^15 rows with its gap-filling and range-check frequencies) whose Memory / MemAfter / Arithmetic
     tables are built by the device generators (and equal the restated reference generators' at this size too).
     Proven under standard_fast_config, accepted by the restated `verify_proof`."""
-    import time
     import torch
     import zk_evm_amd as zk
     import zk_evm_amd.segment as sg

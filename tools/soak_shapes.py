@@ -1,7 +1,6 @@
 """Soak with CHANGING shapes: a long-running worker proves segments of different table heights back to back.  The arena
 must not creep (fragmentation) and every shape must reproduce its own proof bit for bit.
 Usage: python tools/soak_shapes.py [rounds]"""
-import hashlib
 import json
 import os
 import sys
