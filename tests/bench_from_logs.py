@@ -1,7 +1,7 @@
 """From operation logs to a segment proof: time `tracegen.Traces.into_tables` (device witness generation, log upload
 included) and `prove_with_traces` on the VALID 20 000-iteration hash-and-store workload of the test suite (all nine
 tables live: Cpu 2^18, Keccak 2^19, KeccakSponge 2^15, Logic 2^17, BytePacking 2^15, Arithmetic 2^16, Memory 2^21).
-The interpreter run that produces the logs is test infrastructure and not timed.  Usage: python tools/bench_from_logs.py"""
+The interpreter run that produces the logs is test infrastructure and not timed.  Usage: python -m tests.bench_from_logs"""
 import json
 import os
 import sys

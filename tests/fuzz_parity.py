@@ -1,0 +1,55 @@
+"""Randomised differential parity: replay every per-table case of tests/test_gpu_stark_prove.py (all eleven AIRs with
+their lookups / CTL shapes) at randomly drawn heights, hashers, FRI shapes and seeds, device prover against the oracle
+prover word for word.  The pinned tests fix one (height, seed) per table; this walks the neighbourhood.
+Usage: python -m tests.fuzz_parity [seconds] [seed]   (GPU box; prints one JSON line)"""
+import inspect
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
+    import tests.test_gpu_stark_prove as t
+    from tests.oracle_lib import load_oracle
+    oracle = load_oracle()
+    drawn = []
+
+    def draw(n_cols, log_n, hasher, seed, kw):
+        # keep the oracle's pure-Python prover to about a second per case: cells = n_cols << log_n
+        hi = max(4, min(10, int(np.log2(max(1, 150_000 // n_cols)))))
+        c = (int(rng.integers(4, hi + 1)), int(rng.integers(0, 2)), int(rng.integers(1, 1 << 30)),
+             dict(pow_bits=int(rng.integers(0, 9)), queries=int(rng.integers(1, 7))))
+        drawn.append(c)
+        return c
+
+    t.FUZZ = draw
+    cases = [(n, f) for n, f in inspect.getmembers(t, inspect.isfunction) if n.startswith("test_")]
+    t0, runs, per_case = time.perf_counter(), 0, {}
+    while time.perf_counter() - t0 < budget:
+        for name, fn in cases:
+            kwargs = {"oracle": oracle}
+            if "hasher" in inspect.signature(fn).parameters:
+                kwargs["hasher"] = 0
+            mark = len(drawn)
+            try:
+                fn(**kwargs)
+            except AssertionError:
+                print(json.dumps({"FAILED": name, "draws": drawn[mark:]}))
+                raise
+            runs += len(drawn) - mark
+            per_case[name] = per_case.get(name, 0) + len(drawn) - mark
+            if time.perf_counter() - t0 >= budget:
+                break
+    print(json.dumps({"cases": runs, "seconds": round(time.perf_counter() - t0, 1), "per_table_case": per_case,
+                      "log_n_range": [min(d[0] for d in drawn), max(d[0] for d in drawn)], "mismatches": 0}))
+
+
+if __name__ == "__main__":
+    main()
