@@ -1,7 +1,7 @@
 """Randomised differential parity: replay every per-table case of tests/test_gpu_stark_prove.py (all eleven AIRs with
 their lookups / CTL shapes) at randomly drawn heights, hashers, FRI shapes and seeds, device prover against the oracle
 prover word for word.  The pinned tests fix one (height, seed) per table; this walks the neighbourhood.
-Usage: python -m tests.fuzz_parity [seconds] [seed]   (GPU box; prints one JSON line)"""
+Usage: python -m tests.fuzz_parity [seconds] [seed] [segment]   (GPU box; prints one JSON line)"""
 import inspect
 import json
 import os
@@ -30,6 +30,8 @@ def main():
         return c
 
     t.FUZZ = draw
+    if len(sys.argv) > 3 and sys.argv[3] == "segment":
+        return fuzz_segments(oracle, rng, budget)
     cases = [(n, f) for n, f in inspect.getmembers(t, inspect.isfunction) if n.startswith("test_")]
     t0, runs, per_case = time.perf_counter(), 0, {}
     while time.perf_counter() - t0 < budget:
@@ -49,6 +51,36 @@ def main():
                 break
     print(json.dumps({"cases": runs, "seconds": round(time.perf_counter() - t0, 1), "per_table_case": per_case,
                       "log_n_range": [min(d[0] for d in drawn), max(d[0] for d in drawn)], "mismatches": 0}))
+
+
+def fuzz_segments(oracle, rng, budget):
+    """Whole-segment proofs (all tables, 10 CTLs, lookups, public values) at random heights / live-table sets /
+    hashers / FRI shapes against the oracle's prove_with_traces, word for word."""
+    import tests.test_gpu_segment as ts
+    caps = [7, 7, 7, 5, 6, 7, 7, 7, 7]                  # per-table height cap: keeps the Python prover to seconds
+    optional = [1, 3, 4, 5, 8]
+    drawn = []
+
+    def draw(log_n):
+        log_n[:] = [int(rng.integers(4, c + 1)) for c in caps]
+        in_use = [True] * 9
+        for t in optional:
+            in_use[t] = bool(rng.integers(0, 4))          # each optional table absent a quarter of the time
+        c = (int(rng.integers(0, 2)), in_use, int(rng.integers(1, 1 << 30)),
+             dict(pow_bits=int(rng.integers(0, 9)), queries=int(rng.integers(1, 5))))
+        drawn.append((list(log_n),) + c)
+        return c
+
+    ts.FUZZ = draw
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < budget:
+        try:
+            ts.test_segment_proof_matches_oracle(oracle, 0, [True] * 9)
+        except AssertionError:
+            print(json.dumps({"FAILED": "segment", "draw": drawn[-1]}))
+            raise
+    print(json.dumps({"segment_cases": len(drawn), "seconds": round(time.perf_counter() - t0, 1),
+                      "absent_table_sets": len({tuple(d[2]) for d in drawn}), "mismatches": 0}))
 
 
 if __name__ == "__main__":

@@ -15,6 +15,9 @@ P = 0xFFFFFFFF00000001
 LOG_N = [5, 4, 5, 4, 4, 4, 5, 4, 4]
 
 
+FUZZ = None
+
+
 def _one_hot(trace, cols, rng, p_none=0.25):
     n = trace.shape[1]
     pick = rng.integers(0, len(cols), size=n)
@@ -85,13 +88,15 @@ def test_segment_proof_matches_oracle(oracle, hasher, in_use):
     from oracle import segment as oseg
     from zk_evm_amd.all_stark import AllStark
     ol.setup_fri_api(oracle)
-    rng = np.random.default_rng(2024 + hasher)
+    seed, kw = 2024 + hasher, dict(pow_bits=3, queries=2)
+    if FUZZ is not None:                               # tests/fuzz_parity.py: other heights (rewrites LOG_N) / shapes
+        hasher, in_use, seed, kw = FUZZ(LOG_N)
+    rng = np.random.default_rng(seed)
     traces = make_traces(rng)
     for t, used in enumerate(in_use):
         if not used:                                   # unused optional tables: minimal all-zero trace
             traces[t] = np.zeros((traces[t].shape[0], 16), dtype=np.uint64)
     pvd = make_pv(rng)
-    kw = dict(pow_bits=3, queries=2)
     cfg = ol.make_cfg(hasher=hasher, **kw)
     exp = oseg.prove_with_traces(oracle, ol, cfg, traces, in_use, pvd, oairs.CPU_TEST_CONSTS)
     scfg = zk.StarkConfig(hasher=hasher, num_challenges=cfg.num_challenges,
