@@ -1,7 +1,7 @@
 """Randomised differential parity: replay every per-table case of tests/test_gpu_stark_prove.py (all eleven AIRs with
 their lookups / CTL shapes) at randomly drawn heights, hashers, FRI shapes and seeds, device prover against the oracle
 prover word for word.  The pinned tests fix one (height, seed) per table; this walks the neighbourhood.
-Usage: python -m tests.fuzz_parity [seconds] [seed] [segment]   (GPU box; prints one JSON line)"""
+Usage: python -m tests.fuzz_parity [seconds] [seed] [segment|tracegen]   (GPU box; prints one JSON line)"""
 import inspect
 import json
 import os
@@ -32,6 +32,8 @@ def main():
     t.FUZZ = draw
     if len(sys.argv) > 3 and sys.argv[3] == "segment":
         return fuzz_segments(oracle, rng, budget)
+    if len(sys.argv) > 3 and sys.argv[3] == "tracegen":
+        return fuzz_tracegen(rng, budget)
     cases = [(n, f) for n, f in inspect.getmembers(t, inspect.isfunction) if n.startswith("test_")]
     t0, runs, per_case = time.perf_counter(), 0, {}
     while time.perf_counter() - t0 < budget:
@@ -51,6 +53,30 @@ def main():
                 break
     print(json.dumps({"cases": runs, "seconds": round(time.perf_counter() - t0, 1), "per_table_case": per_case,
                       "log_n_range": [min(d[0] for d in drawn), max(d[0] for d in drawn)], "mismatches": 0}))
+
+
+def fuzz_tracegen(rng, budget):
+    """The two generators with real control flow -- Memory (sort, fill_gaps, padding, final memory) and Arithmetic
+    (modular / division / shift operations on 256-bit integers) -- on random logs of random sizes against the oracle's
+    literal restatements, cell for cell."""
+    import tests.test_gpu_arithtrace as ta
+    import tests.test_gpu_memtrace as tm
+    from tests.test_oracle_tracegen import sample_memory_ops
+    t0, n_mem, n_arith, cells = time.perf_counter(), 0, 0, 0
+    while time.perf_counter() - t0 < budget:
+        r = np.random.default_rng(int(rng.integers(1, 1 << 30)))
+        if rng.random() < 0.5:                           # small logs with wide gaps in every address component
+            ops, before, stale = sample_memory_ops(r, int(rng.integers(1, 300)))
+        else:                                            # dense logs: reads of earlier writes, few timestamp gaps
+            ops, before = tm.random_log(r, int(rng.integers(1, 3000)), int(rng.integers(0, 200)),
+                                        int(rng.choice([4, 64, 3000, 1 << 20])))
+            stale = sorted({int(c) for c in rng.integers(0, 6, size=int(rng.integers(0, 3)))})
+        cells += 30 * tm._check(ops, before, stale).shape[1]
+        n_mem += 1
+        cells += 116 * ta._check(ta.random_operations(r, int(rng.integers(0, 400)))).shape[1]
+        n_arith += 1
+    print(json.dumps({"memory_logs": n_mem, "arithmetic_logs": n_arith, "cells_compared": cells,
+                      "seconds": round(time.perf_counter() - t0, 1), "mismatches": 0}))
 
 
 def fuzz_segments(oracle, rng, budget):

@@ -57,12 +57,11 @@ def test_every_operation_kind_and_edge_case():
     _check([])
 
 
-def test_many_random_operations():
-    rng = np.random.default_rng(8)
+def random_operations(rng, count):
     def r(bits): return int.from_bytes(rng.bytes(32), "little") >> (256 - bits) if bits else 0
     sizes = (0, 1, 16, 17, 64, 65, 128, 200, 255, 256)
     ops = []
-    for _ in range(1500):
+    for _ in range(count):
         f = int(rng.integers(0, 16))
         a, b, c = (r(int(rng.choice(sizes))) for _ in range(3))
         if f in (at.IS_ADDMOD, at.IS_MULMOD, at.IS_SUBMOD):
@@ -75,7 +74,11 @@ def test_many_random_operations():
             ops.append(("bin", f, int(rng.integers(0, 40)), b))
         else:
             ops.append(("bin", f, a, b))
-    _check(ops)
+    return ops
+
+
+def test_many_random_operations():
+    _check(random_operations(np.random.default_rng(8), 1500))
 
 
 def test_generated_arithmetic_table_is_proven_and_accepted(oracle):

@@ -67,12 +67,11 @@ def test_fill_gaps_all_three_cases_and_front_dummy():
     _check([_w(4, 0, 0, 0, 5), _w(1, 0, 0, 0, 6), _w(2, 1, 1, 0, 7)], [((3, 35, 0), 0)], [3])   # unsorted input
 
 
-def test_large_log_matches():
-    rng = np.random.default_rng(9)
+def random_log(rng, n_ops=6000, n_before=500, virt_range=3000):
     ops, ts = [], 1
     state = {}
-    for _ in range(6000):
-        addr = (int(rng.integers(0, 6)), int(rng.integers(0, 36)), int(rng.integers(0, 3000)))
+    for _ in range(n_ops):
+        addr = (int(rng.integers(0, 6)), int(rng.integers(0, 36)), int(rng.integers(0, virt_range)))
         ts += int(rng.integers(1, 3))
         if rng.random() < 0.5 or addr not in state:
             state[addr] = int.from_bytes(rng.bytes(32), "little") if rng.random() < 0.9 else 0
@@ -80,11 +79,16 @@ def test_large_log_matches():
         else:
             ops.append(_w(ts, *addr, state[addr], read=True))
     before = []
-    for _ in range(500):
-        addr = (int(rng.integers(0, 6)), int(rng.integers(0, 36)), int(rng.integers(3000, 9000)))
+    for _ in range(n_before):
+        addr = (int(rng.integers(0, 6)), int(rng.integers(0, 36)), int(rng.integers(virt_range, 3 * virt_range)))
         if addr not in state:
             state[addr] = 1
             before.append((addr, int.from_bytes(rng.bytes(32), "little")))
+    return ops, before
+
+
+def test_large_log_matches():
+    ops, before = random_log(np.random.default_rng(9))
     _check(ops, before, [1, 4])
 
 
