@@ -54,7 +54,7 @@ def parse():
                     help="nine comma-separated table heights (log2) instead of --log-n for all; 'realistic' = the upper "
                          "ends of the per-table ranges of the reference's scripts/prove_stdio.rs:89-101")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-log-n", type=int, default=16)
+    ap.add_argument("--cpu-sample-log-n", type=int, default=18)
     ap.add_argument("--proof-steps", type=int, default=0,
                     help="also time N full ArithmeticStark table proofs (0 disables)")
     return ap.parse_args()
