@@ -127,12 +127,14 @@ def test_segment_proof_matches_oracle(oracle, hasher, in_use):
         assert all(x == 0 for h in got.public_values.mem_after.mem_cap for x in h)
 
 
-def test_full_size_segment_openings_and_fri_verify(oracle):
+@pytest.mark.parametrize("log_ns", [[20] * 9, [18, 16, 22, 16, 16, 16, 24, 22, 22]], ids=["all_2p20", "memory_2p24"])
+def test_full_size_segment_openings_and_fri_verify(oracle, log_ns):
     """BASELINE configs[2] at FULL size (nine tables x 2^20 rows, standard_fast_config: 84 queries, 16 PoW bits)
     through size-independent properties: the oracle replays the transcript (caps, public values, CTL challenges,
     every table's init_challenger_state, alphas, zeta) and its FRI verifier accepts every table's opening proof --
     Merkle paths of the trace / auxiliary / quotient oracles at all 84 query positions, the claimed openings, the
-    fold consistency, the final polynomial and the proof of work."""
+    fold consistency, the final polynomial and the proof of work.  Second shape: beyond the BASELINE heights -- a 2^24-row
+    Memory table (2^25 leaves per tree; 32-bit index arithmetic in the NTT / leaf / FRI kernels near its limits)."""
     import torch
     import zk_evm_amd as zk
     import zk_evm_amd.segment as sg
@@ -144,9 +146,8 @@ def test_full_size_segment_openings_and_fri_verify(oracle):
     from zk_evm_amd.all_stark import AllStark, TABLE_COLUMNS
     ol.setup_fri_api(oracle)
     L = oracle.lib
-    log_n = 20
     dev = torch.device("cuda:0")
-    traces = synthetic_segment_traces([log_n] * 9, dev, seed=11)
+    traces = synthetic_segment_traces(log_ns, dev, seed=11)
     scfg = zk.StarkConfig()                      # standard_fast_config
     in_use = [True] * 9
     pvd = make_pv(np.random.default_rng(5))
@@ -175,10 +176,10 @@ def test_full_size_segment_openings_and_fri_verify(oracle):
             k = len(z.columns_filters)
             z.n_helpers = -(-k // 2) if k > 1 else 0
         p = sp.proof
-        assert p.degree_bits == log_n
+        assert p.degree_bits == log_ns[t]
         proof = dict(trace_cap=p.trace_cap, aux_cap=p.auxiliary_polys_cap, quotient_cap=p.quotient_polys_cap,
                      openings=p.openings, fri=p.opening_proof)
-        ok, why = overify.verify_stark_proof(oracle, ol, cfg, None, TABLE_COLUMNS[t], log_n, lookups[t], per_table[t],
+        ok, why = overify.verify_stark_proof(oracle, ol, cfg, None, TABLE_COLUMNS[t], log_ns[t], lookups[t], per_table[t],
                                              pairs, proof, och, check_identity=False)
         assert ok, (t, why)
 
