@@ -85,6 +85,8 @@ class Oracle:
         n_cols, n = values.shape
         log_n = n.bit_length() - 1
         assert 1 << log_n == n
+        if cap_height > log_n + rate_bits:               # plonky2's MerkleTree::new asserts the same; the C code does not
+            raise ValueError(f"cap_height {cap_height} exceeds tree height {log_n + rate_bits}")
         N = n << rate_bits
         nd = self.lib.orc_merkle_num_digests(log_n + rate_bits, cap_height)
         coeffs = np.zeros((n_cols, n), dtype=np.uint64)

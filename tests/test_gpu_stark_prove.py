@@ -112,6 +112,17 @@ def test_generic_machinery_no_air(oracle, hasher):
     _run_case(oracle, 0, 12, 6, hasher, [LOOKUP_A], [CTL_MULTI, CTL_SINGLE], seed=5, binary_cols=(10, 11))
 
 
+def test_minimum_height(oracle):
+    # 2^3 rows: the LDE has 2^4 leaves, so the cap (height 4) IS the leaf digests and every Merkle path is empty;
+    # one row fewer and plonky2 (and zk_commit_columns) refuse the cap height
+    import zk_evm_amd as zk
+    _run_case(oracle, 0, 12, 3, 0, [LOOKUP_A], [CTL_MULTI, CTL_SINGLE], seed=21, binary_cols=(10, 11))
+    _run_case(oracle, 3, 30, 3, 1, [], [], seed=22)
+    import torch
+    with pytest.raises(zk.ZkStarkError, match="cap_height 4 exceeds tree height 3"):
+        zk.PolynomialBatch.from_values(torch.zeros((5, 4), dtype=torch.int64, device="cuda"), 1, False, 4)
+
+
 def test_no_aux_at_all(oracle):
     _run_case(oracle, 0, 5, 5, 0, [], [], seed=6)
 
