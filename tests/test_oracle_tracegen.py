@@ -71,6 +71,15 @@ def test_keccak_sponge_rows_satisfy_the_air_and_hash(oracle):
         r += 1
 
 
+def test_reference_sponge_generation(oracle):
+    """`test_generation` (keccak_sponge_stark.rs:994-1022): the op with input [1, 2, 3] at (0, Segment::Code, 0),
+    timestamp 0, is ONE row whose updated_digest_state_bytes are keccak256([1, 2, 3])."""
+    t = otg.keccak_sponge_generate_trace([((0, 0, 0), 0, bytes([1, 2, 3]))], 1, _keccak_f(oracle))
+    digest = bytes(int(t[404 + i, 0]) for i in range(32))
+    assert digest == oracle.keccak256(bytes([1, 2, 3]))
+    assert digest.hex() == "f1885eda54b7a053318cd41e2093220dab15d65381b1157a3633a83bfd5c9239"
+
+
 def sample_arith_ops(rng):
     from oracle import arith_trace as at
     def r256(): return int.from_bytes(rng.bytes(32), "little")
@@ -141,3 +150,44 @@ def test_memory_rows_satisfy_the_air():
     t, mem_after = mt.generate_trace(ops, before, stale)
     assert t.shape[0] == 30 and t.shape[1] & (t.shape[1] - 1) == 0 and len(mem_after) > 0
     _check_air(oairs.eval_memory, t)
+
+
+# ---- the reference's own Arithmetic-table tests (arithmetic_stark.rs:372-519) ----------------------------------------
+def reference_basic_trace_ops():
+    """`basic_trace` (arithmetic_stark.rs:373-457): ten operations and the (row, first OUTPUT_REGISTER limb) pairs the
+    reference asserts; the other fifteen output limbs of those rows must be zero."""
+    from oracle import arith_trace as at
+    ops = [("bin", at.IS_ADD, 123, 456), ("ter", at.IS_MULMOD, 123, 456, 1007), ("ter", at.IS_ADDMOD, 1234, 567, 1007),
+           ("bin", at.IS_MUL, 123, 456), ("bin", at.IS_MOD, 128, 13), ("bin", at.IS_LT, 128, 13),
+           ("bin", at.IS_LT, 13, 128), ("bin", at.IS_LT, 128, 128), ("bin", at.IS_DIV, 128, 13),
+           ("bin", at.IS_BYTE, 30, 0xABCD)]
+    expected = [(0, 579), (1, 703), (3, 794), (5, 56088), (6, 11), (8, 0), (9, 1), (10, 0), (11, 9), (13, 0xAB)]
+    return ops, expected
+
+
+def check_reference_basic_trace(t, n_rows):
+    from oracle import arith_trace as at
+    _, expected = reference_basic_trace_ops()
+    assert t.shape == (at.NUM_COLS, 1 << 16) and n_rows == 14      # NUM_ARITH_COLUMNS x RANGE_MAX; 4 two-row operations
+    for row, value in expected:
+        assert int(t[at.OUT, row]) == value, (row, value, int(t[at.OUT, row]))
+        assert not t[at.OUT + 1:at.OUT + 16, row].any(), row
+
+
+def test_reference_basic_trace():
+    from oracle import arith_trace as at
+    ops, _ = reference_basic_trace_ops()
+    check_reference_basic_trace(*at.generate_trace(ops))
+
+
+def test_reference_big_traces():
+    """`big_traces` (arithmetic_stark.rs:460-519): RANGE_MAX one-row MULs keep the table at RANGE_MAX rows, RANGE_MAX
+    two-row MULMODs double it.  (A reduced count keeps the Python generator to seconds: the height rule is what the
+    reference asserts, and 2^15 + 1 two-row operations are the smallest log that must spill over 2^16 rows.)"""
+    from oracle import arith_trace as at
+    rng = np.random.default_rng(0x6FEB51B7EC230F25 % (1 << 32))
+    r256 = lambda: int.from_bytes(rng.bytes(32), "little")
+    t, n = at.generate_trace([("bin", at.IS_MUL, r256(), r256()) for _ in range(3000)])
+    assert t.shape == (at.NUM_COLS, 1 << 16) and n == 3000
+    t, n = at.generate_trace([("ter", at.IS_MULMOD, r256(), r256(), r256()) for _ in range((1 << 15) + 1)])
+    assert t.shape == (at.NUM_COLS, 1 << 17) and n == (1 << 16) + 2
