@@ -126,3 +126,18 @@ def test_public_values_range_errors():
     with pytest.raises(sg.PublicValuesError):
         sg.public_values_elements(pv)
     assert len(sg.public_values_elements(sg.PublicValues())) == 48 + 5 + 3 + 8 + 2 + 2 + 1 + 4 + 8 + 64 + 257 * 8 + 8 + 4 + 4
+
+
+def test_generated_registry_header_is_current():
+    """include/zk_all_stark.h (the registry in zk_prove_segment's flat encodings, for C / C++ / Rust callers) is what
+    tools/gen_all_stark_header.py renders from the definitions tested above; `check_num_ctls` (all_stark.rs:451-454)
+    holds for the header's counts."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import gen_all_stark_header as g
+    text = open(os.path.join(root, "include", "zk_all_stark.h")).read()
+    assert text == g.render(), "stale: run python tools/gen_all_stark_header.py"
+    assert "#define ZK_ALLSTARK_NUM_CTLS 10\n" in text and "#define ZK_ALLSTARK_ERIGON_NUM_CTLS 13\n" in text
+    assert "#define ZK_ALLSTARK_NUM_TABLES 9\n" in text and "#define ZK_ALLSTARK_ERIGON_NUM_TABLES 10\n" in text

@@ -6,6 +6,7 @@ import os
 import shutil
 import subprocess
 
+import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -34,3 +35,71 @@ def test_c_harness_matches_golden_caps(tmp_path):
         assert cap == [x for row in c["cap"] for x in row], c["name"]
         assert out[2] == "memory log_n 3 unpadded 4"          # three operations + one timestamp-gap dummy, padded to 8 rows
         assert out[3].startswith('error "') and "cfg" in out[3]
+
+
+def _fnv(h, words):
+    for b in np.ascontiguousarray(words, dtype=np.uint64).reshape(-1).view(np.uint8).tolist():
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.parametrize("cdk_erigon", [False, True])
+def test_c_segment_proof_matches_python_mirror(tmp_path, cdk_erigon):
+    """tests/cabi/segment.c: a complete segment proof from plain C -- the generated registry header
+    include/zk_all_stark.h, hipMalloc'd traces, zk_prove_segment -- equals, word for word (FNV-1a per table), the proof
+    the Python mirror obtains for the same traces; both feature sets, one optional table absent."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    from tests.test_gpu_segment import make_pv, make_traces, make_traces_cdk_erigon, to_public_values
+    from zk_evm_amd.all_stark import AllStark
+    exe = str(tmp_path / "cabi_segment")
+    libdir = os.path.join(ROOT, "zk_evm_amd")
+    subprocess.run([shutil.which("gcc") or "gcc", "-std=c11", "-O1", "-Wall", "-Werror",
+                    os.path.join(ROOT, "tests", "cabi", "segment.c"), "-I", os.path.join(ROOT, "include"),
+                    "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L", libdir, "-lzkstark_hip",
+                    "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+                    "-o", exe], check=True)
+    rng = np.random.default_rng(77 + cdk_erigon)
+    traces = (make_traces_cdk_erigon if cdk_erigon else make_traces)(rng)
+    in_use = [True] * len(traces)
+    in_use[5] = False                                   # Logic absent: minimal all-zero trace, zero cap observed
+    traces[5] = np.zeros((traces[5].shape[0], 16), dtype=np.uint64)
+    labels = (11, 22, 33, 44)
+    pvd = make_pv(rng)
+    if cdk_erigon:                                      # features_check: no eth_mainnet block-metadata fields
+        pvd.update(blob_gas_used=0, excess_blob_gas=0, parent_beacon_root=bytes(32))
+    pv = to_public_values(pvd)
+    if cdk_erigon:
+        pv.burn_addr = 0x1234
+    scfg = zk.StarkConfig(fri_config=zk.FriConfig(proof_of_work_bits=3, num_query_rounds=2))
+    c = scfg.to_c()
+    words = [int(cdk_erigon)] + [int(getattr(c, name)) for name, _ in c._fields_] + list(labels)
+    elems = sg.public_values_elements(pv)
+    words += [len(elems)] + [int(e) for e in elems]
+    with open(tmp_path / "segment.bin", "wb") as f:
+        f.write(np.array(words, dtype=np.uint64).tobytes())
+        for t, used in zip(traces, in_use):
+            f.write(np.array([int(used), t.shape[1].bit_length() - 1], dtype=np.uint64).tobytes())
+            f.write(np.ascontiguousarray(t).tobytes())
+    out = subprocess.run([exe, str(tmp_path / "segment.bin")], check=True, capture_output=True, text=True,
+                         timeout=300).stdout.splitlines()
+    st = AllStark(labels, cdk_erigon=cdk_erigon)
+    got = sg.prove_with_traces(st, scfg, [torch.from_numpy(t.view(np.int64)).cuda() for t in traces], in_use, pv)
+    assert out[0].split()[1:] == [str(x) for bg in got.multi_proof.ctl_challenges for x in bg]
+    for t, line in enumerate(out[1:1 + st.num_tables]):
+        sp = got.multi_proof.stark_proofs[t]
+        if sp is None:
+            assert line == f"table {st.table_names[t]} absent" and not in_use[t]
+            continue
+        p = sp.proof
+        h = _fnv(0xCBF29CE484222325, sp.init_challenger_state)
+        h = _fnv(h, p.trace_cap)
+        if p.auxiliary_polys_cap is not None:
+            h = _fnv(h, p.auxiliary_polys_cap)
+        h = _fnv(_fnv(_fnv(h, p.quotient_polys_cap), p.openings), p.opening_proof)
+        assert line.split()[1] == st.table_names[t] and line.split()[3] == str(p.degree_bits)
+        assert line.split()[-1] == f"{h:016x}", (st.table_names[t], line)
+    mb = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
+    ma = np.array(got.public_values.mem_after.mem_cap, dtype=np.uint64)
+    assert out[-1] == f"mem_caps fnv {_fnv(0xCBF29CE484222325, mb):016x} {_fnv(0xCBF29CE484222325, ma):016x}"
