@@ -12,7 +12,8 @@ OUT = os.path.join(_HERE, "libzkstark_hip.so")
 def _deps():
     d = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))]
     inc = os.path.join(os.path.dirname(_HERE), "include")
-    d += [os.path.join(inc, f) for f in os.listdir(inc)]
+    # zk_all_stark.h is generated data for callers; the library does not include it
+    d += [os.path.join(inc, f) for f in os.listdir(inc) if f != "zk_all_stark.h"]
     return d
 
 
