@@ -834,3 +834,44 @@ def test_large_valid_segment_with_every_table_live(oracle):
                                 is_initial=True, initial_mem_cap=tg.initial_memory_merkle_cap(code, 1, 4, hasher=0),
                                 mem_before_cap=before_cap)
     assert ok, why
+
+
+def test_two_contexts_prove_concurrently():
+    """a zk_ctx has no global state, so one worker thread + ctx + stream per in-flight segment is
+    safe.  Two threads, each with its own Context and torch stream on the same GPU, prove different segments at the
+    same time (ctypes drops the GIL during the call), several rounds; every proof equals the one computed serially."""
+    import threading
+
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    from tools.soak_segment import digest
+    from zk_evm_amd.all_stark import AllStark
+    scfg = zk.StarkConfig(fri_config=zk.FriConfig(proof_of_work_bits=4, num_query_rounds=3))
+    jobs = []
+    for seed in (31, 32):
+        traces = make_traces(np.random.default_rng(seed))
+        jobs.append([torch.from_numpy(t.view(np.int64)).cuda() for t in traces])
+    st = AllStark((1, 2, 3, 4))
+    serial = [digest(sg.prove_with_traces(st, scfg, dev, [True] * 9, sg.PublicValues())) for dev in jobs]
+    assert serial[0] != serial[1]
+    torch.cuda.synchronize()
+    results, errors = [[], []], []
+
+    def worker(k):
+        try:
+            ctx = zk.Context(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(6):
+                    results[k].append(digest(sg.prove_with_traces(AllStark((1, 2, 3, 4)), scfg, jobs[k], [True] * 9,
+                                                                  sg.PublicValues(), ctx=ctx)))
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:                      # surfaced in the main thread
+            errors.append(repr(e))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=240)
+    assert not errors, errors
+    assert results[0] == [serial[0]] * 6 and results[1] == [serial[1]] * 6
