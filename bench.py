@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--log-ns", type=str, default="",
                     help="nine comma-separated table heights (log2) instead of --log-n for all; 'realistic' = the upper "
                          "ends of the per-table ranges of the reference's scripts/prove_stdio.rs:89-101")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="also report W segments in flight per GPU as a secondary object (1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=18)
     ap.add_argument("--proof-steps", type=int, default=0,
@@ -301,6 +303,48 @@ def commit_report(a, stage, ms_per_step):
     return roof, extra
 
 
+def segments_in_flight(ctx, workers, per_worker, arena_peak, all_stark, cfg, traces, in_use, cdk_erigon):
+    """W worker threads, each with its own Context and stream, prove the resident traces `per_worker` times."""
+    import threading
+
+    import torch
+    import zk_evm_amd
+    import zk_evm_amd.segment as sg
+    free, total = torch.cuda.mem_get_info()
+    ctx.mem_trim()                                    # the main ctx hands its idle slabs back; every worker grows its own
+    free, total = torch.cuda.mem_get_info()
+    need = workers * arena_peak
+    if need > 0.9 * free:
+        return {"skipped": f"{workers} arenas of {arena_peak / 1e9:.0f} GB do not fit in the {free / 1e9:.0f} GB free"}
+    ctxs = [zk_evm_amd.Context(ctx.device) for _ in range(workers)]
+    streams = [torch.cuda.Stream() for _ in range(workers)]
+    errors = []
+
+    def run(w, n):
+        try:
+            with torch.cuda.stream(streams[w]):
+                for _ in range(n):
+                    sg.prove_with_traces(all_stark, cfg, traces, in_use, sg.PublicValues(burn_addr=1 if cdk_erigon else None),
+                                         ctx=ctxs[w])
+                streams[w].synchronize()
+        except Exception as e:
+            errors.append(repr(e))
+    el = 0.0
+    for n in (2, per_worker):                          # warm-up (arena growth), then the timed round
+        th = [threading.Thread(target=run, args=(w, n)) for w in range(workers)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t0
+    if errors:
+        return {"error": errors[0]}
+    return {"workers_per_gpu": workers, "proofs": workers * per_worker, "value": workers * per_worker / el,
+            "unit": "segment proofs/s", "note": "one Context + stream + worker thread per in-flight segment, shared inputs"}
+
+
 def main():
     a = parse()
     import numpy as np
@@ -465,6 +509,15 @@ def main():
                 "segment_timing_s": timing,
                 "arena": {k: v / 1e9 for k, v in mem.items()},
             }
+        if world == 1 and a.in_flight > 1:
+            # Secondary object, never `value`: W segments in flight on this GPU (one worker thread + Context + stream
+            # each, the same resident read-only inputs): what a deployment with W workers per GPU gets.  Skipped unless
+            # W arenas fit beside the inputs; any failure only drops the object.
+            try:
+                out["in_flight"] = segments_in_flight(ctx, a.in_flight, max(2, a.steps), mem["peak_in_use"], all_stark, cfg,
+                                                      traces, in_use, a.cdk_erigon)
+            except Exception as e:
+                out["in_flight"] = {"error": repr(e)}
         del traces
         torch.cuda.empty_cache()
         if a.commit_steps > 0 and a.hasher == 0:
@@ -479,8 +532,9 @@ def main():
                 out["commit_config1"].update(extra_c)
         if rank == 0 and not a.no_cpu_baseline and world == 1:
             try:
-                cb = cpu_baseline(116, 16, 16, a.hasher)
-                sample_cells = 116 << 16
+                sl = a.cpu_sample_log_n
+                cb = cpu_baseline(116, sl, sl, a.hasher)
+                sample_cells = 116 << sl
                 sec = (1.0 / cb["value"]) * cells / sample_cells
                 out["cpu_baseline"] = {
                     "value": 1.0 / sec, "unit": "segment proofs/s", "cores": cb["cores"], "kind": "port",
