@@ -1,7 +1,7 @@
 """Segments in flight per GPU: W worker threads, each with its own Context + stream, prove the same shape back to back;
 aggregate proofs/s for W = 1, 2, 3 (the input traces are shared and read-only; a W whose arenas would not fit is skipped).  At 2^20 a single segment already keeps the GPU 98.5 % busy; at the realistic table
 heights the small tables leave SIMDs idle that a second in-flight segment can use.
-Usage: python tools/bench_concurrent.py [realistic|<log_n>] [proofs per worker]"""
+Usage: python tools/bench_concurrent.py [realistic|<log_n>] [proofs per worker] [stagger seconds]"""
 import json
 import os
 import sys
@@ -19,10 +19,11 @@ def main():
     from zk_evm_amd.all_stark import AllStark
     shape = sys.argv[1] if len(sys.argv) > 1 else "realistic"
     per = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    stagger = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0    # seconds between worker starts
     log_ns = REALISTIC_LOG_NS if shape == "realistic" else [int(shape)] * 9
     dev = torch.device("cuda:0")
     cfg = zk.StarkConfig()
-    out = {"log_ns": log_ns, "proofs_per_worker": per, "proofs_per_s": {}}
+    out = {"log_ns": log_ns, "proofs_per_worker": per, "stagger_s": stagger, "proofs_per_s": {}}
     shared = synthetic_segment_traces(log_ns, dev, seed=3)     # read-only inputs, resident once, proven by every worker
     total_hbm = torch.cuda.get_device_properties(0).total_memory
     peak = None
@@ -38,6 +39,7 @@ def main():
 
         def run(w, n):
             try:
+                time.sleep(w * stagger)                          # offset the workers' phases
                 with torch.cuda.stream(streams[w]):
                     st = AllStark((1, 2, 3, 4))
                     for _ in range(n):
