@@ -67,3 +67,15 @@ def test_host_argument_validation():
         PolynomialBatch.from_values([np.zeros(8, np.uint64), np.zeros(4, np.uint64)], 1, False, 2)
     with pytest.raises(zk_evm_amd.ZkStarkError):
         PolynomialBatch.from_values(np.zeros((2, 8), np.uint64), 1, True, 2)
+
+
+def test_c_callers_compile_against_the_headers(tmp_path):
+    """The plain-C callers (tests/cabi/*.c) compile with gcc -Wall -Werror against include/zkstark.h and the generated
+    include/zk_all_stark.h -- ABI drift shows up here without a GPU (they run in tests/test_gpu_cabi_harness.py)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    for src, extra in (("harness.c", []), ("segment.c", ["-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__"])):
+        subprocess.run([gcc, "-std=c11", "-O1", "-Wall", "-Werror", "-c", os.path.join(ROOT, "tests", "cabi", src),
+                        "-I", os.path.join(ROOT, "include")] + extra + ["-o", str(tmp_path / (src + ".o"))], check=True)
