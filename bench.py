@@ -40,7 +40,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks = GPUs of this node; with N > 1 and no WORLD_SIZE in the environment bench.py launches "
+                         "the N ranks itself (one process per GPU, RCCL); under torchrun it joins the given world")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default=os.environ.get("ZK_BENCH_BACKEND", "nccl"),
+                    help="nccl = RCCL (one rank per GPU); gloo lets several ranks share one GPU (launcher test)")
+    ap.add_argument("--devices", type=str, default=os.environ.get("ZK_BENCH_DEVICES", ""),
+                    help="comma-separated device index per local rank (default: rank r -> device r)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["segment", "commit"], default="segment")
@@ -304,49 +310,72 @@ def commit_report(a, stage, ms_per_step):
 
 
 def segments_in_flight(ctx, workers, per_worker, arena_peak, all_stark, cfg, traces, in_use, cdk_erigon):
-    """W worker threads, each with its own Context and stream, prove the resident traces `per_worker` times."""
-    import threading
-
+    """W segments in flight on this GPU through the product scheduler (zk_evm_amd/scheduler.py: one worker thread +
+    Context + HIP stream per slot, one shared job queue); every job proves the resident traces."""
     import torch
-    import zk_evm_amd
     import zk_evm_amd.segment as sg
-    free, total = torch.cuda.mem_get_info()
+    from zk_evm_amd.scheduler import SegmentJob, SegmentScheduler
     ctx.mem_trim()                                    # the main ctx hands its idle slabs back; every worker grows its own
     free, total = torch.cuda.mem_get_info()
     need = workers * arena_peak
     if need > 0.9 * free:
         return {"skipped": f"{workers} arenas of {arena_peak / 1e9:.0f} GB do not fit in the {free / 1e9:.0f} GB free"}
-    ctxs = [zk_evm_amd.Context(ctx.device) for _ in range(workers)]
-    streams = [torch.cuda.Stream() for _ in range(workers)]
-    errors = []
 
-    def run(w, n):
-        try:
-            with torch.cuda.stream(streams[w]):
-                for _ in range(n):
-                    sg.prove_with_traces(all_stark, cfg, traces, in_use, sg.PublicValues(burn_addr=1 if cdk_erigon else None),
-                                         ctx=ctxs[w])
-                streams[w].synchronize()
-        except Exception as e:
-            errors.append(repr(e))
+    def job():
+        return SegmentJob(lambda dev: traces, in_use, sg.PublicValues(burn_addr=1 if cdk_erigon else None))
     el = 0.0
-    for n in (2, per_worker):                          # warm-up (arena growth), then the timed round
-        th = [threading.Thread(target=run, args=(w, n)) for w in range(workers)]
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        el = time.perf_counter() - t0
+    with SegmentScheduler(all_stark, cfg, [ctx.device], workers) as sch:
+        for n in (2, per_worker):                      # warm-up (arena growth), then the timed round
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sch.map([job() for _ in range(workers * n)])
+            el = time.perf_counter() - t0
+        errors = [e for st in sch.stats for e in st.errors]
     if errors:
         return {"error": errors[0]}
     return {"workers_per_gpu": workers, "proofs": workers * per_worker, "value": workers * per_worker / el,
-            "unit": "segment proofs/s", "note": "one Context + stream + worker thread per in-flight segment, shared inputs"}
+            "unit": "segment proofs/s", "note": "SegmentScheduler: one Context + stream + worker thread per in-flight "
+                                                "segment, one job queue, shared resident inputs"}
+
+
+def self_launch(a) -> int:
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks here -- one process per GPU, rank r on
+    device r (or --devices), rendezvous on 127.0.0.1 -- and pass rank 0's JSON line through.  The children are this
+    same script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, i.e. exactly what `python -m
+    torch.distributed.run --nproc-per-node N bench.py --gpus N` gives them."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while procs and rc == 0:
+            for p in list(procs):
+                try:
+                    p.wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                procs.remove(p)
+                rc = rc or p.returncode
+    finally:
+        for p in procs:                                   # a rank failed (or we were interrupted): stop the others
+            p.kill()
+            p.wait()
+    return rc
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -354,12 +383,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    if a.devices:
+        local_dev = [int(x) for x in a.devices.split(",")][local]
+    else:
+        local_dev = local
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_dev}"))
+        else:
+            dist.init_process_group("gloo")
+    torch.cuda.set_device(local_dev)
+    dev = torch.device(f"cuda:{local_dev}")
+    local = local_dev
 
     import zk_evm_amd
     ctx = zk_evm_amd.Context(local)
@@ -373,7 +410,7 @@ def main():
 
     def max_over_ranks(x):
         if world > 1:
-            tt = torch.tensor([x], dtype=torch.float64, device=dev)
+            tt = torch.tensor([x], dtype=torch.float64, device=dev if a.dist_backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item())
         return x

@@ -79,3 +79,57 @@ def test_gather_caps_gloo_world2():
     for t, (c, ln) in enumerate(shapes):
         vals = np.stack([splitmix64(100 * t + k, 1 << ln) for k in range(c)])
         assert o.commit_values(vals, want_leaves=False)["cap"].tolist() == res[0][t]
+
+
+# ---- segment scheduler (zk_evm_amd/scheduler.py) -- no GPU: the prove step is injected -----------------------
+def _fake_prove(st, job):
+    import time
+    time.sleep(0.01 * (job.tag % 3))
+    if job.tag == 13:
+        raise RuntimeError("segment 13 is cursed")
+    return ("proof", job.tag, job.load(None))
+
+
+def test_scheduler_orders_results_and_isolates_failures():
+    from zk_evm_amd.scheduler import SegmentJob, SegmentScheduler
+    jobs = [SegmentJob(lambda dev, i=i: i * i, [True] * 9, None, tag=i) for i in range(12)]
+    with SegmentScheduler(None, None, devices=[0, 1], in_flight=2, prove_fn=_fake_prove) as sch:
+        out = sch.map(jobs)
+        assert out == [("proof", i, i * i) for i in range(12)]
+        assert sum(st.segments for st in sch.stats) == 12 and len(sch.stats) == 4
+        bad = sch.submit(SegmentJob(lambda dev: 0, [True] * 9, None, tag=13))
+        with pytest.raises(RuntimeError):
+            bad.result(timeout=30)
+        # the worker that hit the failure keeps serving
+        assert sch.map([SegmentJob(lambda dev: 5, [True] * 9, None, tag=1)]) == [("proof", 1, 5)]
+    with pytest.raises(RuntimeError):
+        sch.submit(jobs[0])
+
+
+def _sched_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zk_evm_amd.scheduler import SegmentJob, run_distributed
+    jobs = [SegmentJob(lambda dev, i=i: 100 + i, [True] * 9, None, tag=i) for i in range(7)]
+    out = run_distributed(None, None, jobs, device=0, in_flight=2,
+                          prove_fn=lambda st, job: (dist.get_rank(), job.tag, job.load(None)))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_distributed_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sched_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] is None
+    # rank 0 holds every proof in segment order; segment i was proven by rank i % 2
+    assert res[0] == [(i % 2, i, 100 + i) for i in range(7)]

@@ -1,0 +1,87 @@
+"""-m gpu: the N > 1 run path executed on ONE GPU.
+
+gpurun boxes have a single MI355X, so the launcher (`python bench.py --gpus 2` with no WORLD_SIZE in the
+environment), the rendezvous, the barrier + MAX-over-ranks timing and the per-rank work are exercised with two ranks
+mapped onto device 0 under gloo (RCCL refuses two ranks on one device); on the 8-GPU node the same code runs with the
+default nccl backend and rank r on device r.  Also: the product scheduler (zk_evm_amd/scheduler.py) proving real
+segments, two in flight on one GPU, must reproduce the direct call word for word."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, env_extra=None, timeout=900):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                       timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+SMALL = ["--log-n", "12", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--in-flight", "1",
+         "--commit-steps", "0"]
+
+
+def test_bench_self_launches_two_ranks_on_one_gpu():
+    one = _bench("--gpus", "1", *SMALL)
+    two = _bench("--gpus", "2", "--devices", "0,0", "--dist-backend", "gloo", *SMALL)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["scaling"] == "weak" and two["steps"] == 2
+    for k in ("metric", "unit", "roofline", "ms_per_step", "value"):
+        assert k in two
+    # value = segments of all ranks / max-over-ranks time; both ranks share one GPU here, so it is no faster than
+    # 2x the single-rank rate and (sharing aside) of the same order
+    assert 0.2 * one["value"] < two["value"] < 2.5 * one["value"]
+    assert abs(two["value"] - 2 * two["steps"] / (two["ms_per_step"] * two["steps"] / 1e3)) < 1e-6 * two["value"]
+
+
+def test_bench_joins_an_external_launcher():
+    """the driver's form: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ZK_BENCH_BACKEND="gloo", ZK_BENCH_DEVICES="0,0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29671", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", *SMALL], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_scheduler_two_in_flight_reproduces_direct_proofs(oracle):
+    import torch
+    import zk_evm_amd
+    import zk_evm_amd.segment as sg
+    from tests.gpu_util import to_dev
+    from tests.test_gpu_segment import make_pv, make_traces, to_public_values
+    from zk_evm_amd.all_stark import AllStark
+    from zk_evm_amd.scheduler import SegmentJob, SegmentScheduler
+    st = AllStark((1, 2, 3, 4))
+    cfg = zk_evm_amd.StarkConfig(fri_config=zk_evm_amd.FriConfig(num_query_rounds=5, proof_of_work_bits=4))
+    host = [(make_traces(np.random.default_rng(100 + i)), make_pv(np.random.default_rng(200 + i))) for i in range(6)]
+
+    def words(p):
+        out = []
+        for tp in p.multi_proof.stark_proofs:
+            pr = tp.proof
+            out += [np.asarray(tp.init_challenger_state).ravel(), np.asarray(pr.opening_proof).ravel(),
+                    np.asarray(pr.openings).ravel(), np.asarray(pr.quotient_polys_cap).ravel()]
+        return np.concatenate([np.asarray(x, dtype=np.uint64) for x in out])
+    direct = [words(sg.prove_with_traces(st, cfg, [to_dev(t) for t in tr], [True] * 9, to_public_values(pv)))
+              for tr, pv in host]
+    jobs = [SegmentJob(lambda dev, tr=tr: [to_dev(t).to(dev) for t in tr], [True] * 9, to_public_values(pv), tag=i)
+            for i, (tr, pv) in enumerate(host)]
+    with SegmentScheduler(st, cfg, devices=[torch.cuda.current_device()], in_flight=2) as sch:
+        got = sch.map(jobs)
+        assert sum(s.segments for s in sch.stats) == 6 and all(s.segments > 0 for s in sch.stats)
+    for d, g in zip(direct, got):
+        assert np.array_equal(d, words(g))
