@@ -51,7 +51,9 @@ typedef struct {
     uint32_t final_poly_bits;    /* ... final_poly_bits = 5 */
 } zk_cfg;
 
-typedef struct zk_ctx zk_ctx;     /* one per GPU / stream; re-entrant per ctx */
+typedef struct zk_ctx zk_ctx;     /* one per GPU / stream.  The library is re-entrant ACROSS contexts (no global state);
+                                   * one zk_ctx must not be used by two threads at once: it owns the HBM arena free
+                                   * list, the stream, the cached tables and the error string */
 typedef struct zk_batch zk_batch; /* device-resident PolynomialBatch */
 
 /* ---- context ---------------------------------------------------------------------------- */
@@ -180,7 +182,8 @@ typedef struct {
     const uint32_t *poly_idx;
 } zk_fri_batch;
 
-/* [EXT] FriReductionStrategy::ConstantArityBits -> reduction_arity_bits; returns the count */
+/* [EXT] FriReductionStrategy::ConstantArityBits -> reduction_arity_bits; returns the count, or (size_t)-1 for a
+ * configuration plonky2 itself panics on (`assert!(degree_bits >= arity_bits)` inside the reduction loop) */
 size_t zk_fri_reduction_arity_bits(const zk_cfg *cfg, unsigned degree_bits, uint32_t *out, size_t max);
 /* Evaluate every polynomial of every batch at the batch point (the evaluation work of starky
  * `StarkOpeningSet::new`): out = 2 u64 per (batch, poly), batch-major, host memory. */
@@ -333,7 +336,9 @@ size_t zk_segment_proof_num_tables(const zk_segment_proof *proof);
 const zk_table_proof *zk_segment_proof_table(const zk_segment_proof *proof, size_t table);
 /* (beta, gamma) x num_challenges; returns the number of words available */
 size_t zk_segment_proof_ctl_challenges(const zk_segment_proof *proof, uint64_t *out, size_t max_words);
-/* the two memory caps (cap_digests x 4 words each); returns the words per cap */
+/* the two memory caps as `MemCap::from_merkle_cap` builds them (proof.rs:606-621): cap_digests x 4 field elements
+ * each, a hash h contributing `h.to_vec()` -- its four words for Poseidon, the 7,7,7,4-byte little-endian chunks of
+ * the 25-byte digest for Keccak-25; returns the words per cap */
 size_t zk_segment_proof_mem_caps(const zk_segment_proof *proof, uint64_t *mem_before, uint64_t *mem_after,
                                  size_t max_words);
 /* host wall-clock per stage in ms, the reference's TimingTree scopes: [0] "compute all trace commitments",

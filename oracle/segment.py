@@ -70,6 +70,20 @@ def cross_table_lookup_data(traces, ctls, challenges, constraint_degree):
     return per_table
 
 
+def mem_cap_from_merkle_cap(cap, hasher):
+    """`MemCap::from_merkle_cap` (proof.rs:606-621): `h.to_vec()` of every cap hash.  PoseidonHash out = its four
+    elements; KeccakHash<25> out (`BytesHash<25>`) = four elements from 7,7,7,4-byte little-endian chunks ([EXT]
+    plonky2 1.0.0 hash/hash_types.rs `impl GenericHashOut for BytesHash<N>`: `chunks(7)` + `from_noncanonical_u64`)."""
+    slots = np.ascontiguousarray(np.asarray(cap, dtype=np.uint64).reshape(-1, 4))
+    if hasher == 0:
+        return slots.copy()
+    out = np.zeros_like(slots)
+    for i, h in enumerate(slots):
+        b = h.tobytes()[:25]
+        out[i] = [int.from_bytes(b[7 * k: 7 * k + 7], "little") for k in range(4)]
+    return out
+
+
 def prove_with_traces(o, fri_api, cfg, traces, table_in_use, pv, cpu_air_consts, ctls=None, lookups=None, reg=None):
     """traces: list of 9 (C_t, n_t) uint64 arrays (10 with reg = A.Registry(cdk_erigon=True)).  Returns
     dict(ctl_challenges, proofs (None if unused), init_states, mem_before, mem_after, trace_caps)."""
@@ -110,8 +124,9 @@ def prove_with_traces(o, fri_api, cfg, traces, table_in_use, pv, cpu_air_consts,
     mem_after = commits[A.MEM_AFTER]["cap"].copy()
     if not table_in_use[A.MEM_AFTER]:
         mem_after[:] = 0
-    return dict(ctl_challenges=ctl_pairs, proofs=proofs, init_states=inits, mem_before=commits[A.MEM_BEFORE]["cap"],
-                mem_after=mem_after, trace_caps=[c["cap"] for c in commits], final_challenge=L.orc_challenger_get(C.byref(och)))
+    return dict(ctl_challenges=ctl_pairs, proofs=proofs, init_states=inits,
+                mem_before=mem_cap_from_merkle_cap(commits[A.MEM_BEFORE]["cap"], cfg.hasher),
+                mem_after=mem_cap_from_merkle_cap(mem_after, cfg.hasher), trace_caps=[c["cap"] for c in commits], final_challenge=L.orc_challenger_get(C.byref(och)))
 
 
 def verify_cross_table_lookups(ctls, ctl_zs_first, extra_looking_sums, num_challenges):

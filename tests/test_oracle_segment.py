@@ -65,3 +65,23 @@ def test_cross_table_lookups_balance_and_detect_tampering():
     traces[oas.MEMORY][7, 2] ^= 1                                      # one value limb of one looked-up row
     ok, why = oseg.verify_cross_table_lookups(ctls, _ctl_zs_first(traces, ctls, challenges), None, 2)
     assert not ok and why.startswith("CTL")
+
+
+def test_mem_cap_from_merkle_cap_keccak_matches_to_vec(oracle):
+    """`MemCap::from_merkle_cap` (proof.rs:606-621) takes `h.to_vec()`: for KeccakHash<25> that is four elements from the
+    7,7,7,4-byte little-endian chunks of the 25-byte digest, not the four 8-byte words of the padded 32-byte slot."""
+    from tests.oracle_lib import splitmix64
+    from zk_evm_amd.segment import MemCap
+    vals = np.stack([splitmix64(900 + k, 64) for k in range(12)])
+    for hasher in (0, 1):
+        cap = oracle.commit_values(vals, rate_bits=1, cap_height=4, hasher=hasher, want_leaves=False)["cap"]
+        exp = oseg.mem_cap_from_merkle_cap(cap, hasher)
+        got = MemCap.from_merkle_cap(cap, hasher).mem_cap
+        assert got == [[int(x) for x in h] for h in exp]
+        assert MemCap.from_elements(exp).mem_cap == got
+    digest = bytes(range(1, 26)) + bytes(7)                      # a hand-checkable 25-byte digest in its 32-byte slot
+    slot = np.frombuffer(digest, dtype=np.uint64).reshape(1, 4)
+    got = MemCap.from_merkle_cap(slot, 1).mem_cap[0]
+    assert got == [int.from_bytes(bytes(range(1, 8)), "little"), int.from_bytes(bytes(range(8, 15)), "little"),
+                   int.from_bytes(bytes(range(15, 22)), "little"), int.from_bytes(bytes(range(22, 26)), "little")]
+    assert got != [int(x) for x in slot[0]]

@@ -27,6 +27,10 @@ class Table:
 
 NUM_TABLES = 9
 TABLE_NAMES = ["Arithmetic", "BytePacking", "Cpu", "Keccak", "KeccakSponge", "Logic", "Memory", "MemBefore", "MemAfter"]
+# the `AllStark` field names: `stringify!($stark)` in prove_table! (prover.rs:227-249) keys the TimingTree scopes
+# "prove arithmetic_stark STARK", ...
+STARK_FIELD_NAMES = ["arithmetic_stark", "byte_packing_stark", "cpu_stark", "keccak_stark", "keccak_sponge_stark",
+                     "logic_stark", "memory_stark", "mem_before_stark", "mem_after_stark"]
 # all_stark.rs:124-131
 OPTIONAL_TABLE_INDICES = [Table.BytePacking, Table.Keccak, Table.KeccakSponge, Table.Logic, Table.MemAfter]
 NUM_CTLS = 10          # all_stark.rs:148
@@ -736,6 +740,7 @@ class AllStark:
         self.table_air = list(TABLE_AIR)
         self.table_columns = list(TABLE_COLUMNS)
         self.table_names = list(TABLE_NAMES)
+        self.stark_field_names = list(STARK_FIELD_NAMES)
         self.optional_table_indices = list(OPTIONAL_TABLE_INDICES)
         if cdk_erigon:
             self.table_air[Table.Cpu] = 10
@@ -743,6 +748,7 @@ class AllStark:
             self.table_air.append(9)
             self.table_columns.append(_P.NUM_COLUMNS)
             self.table_names.append("Poseidon")
+            self.stark_field_names.append("poseidon_stark")
             self.optional_table_indices.append(POSEIDON_TABLE)
         self.num_tables = len(self.table_air)
         self.lookups = [table_lookups(t) for t in range(self.num_tables)]

@@ -90,12 +90,17 @@ class Context:
             pass
 
 
-_default = {}
-_lock = threading.Lock()
+_tls = threading.local()
 
 
 def default_context(device: int = 0) -> Context:
-    with _lock:
-        if device not in _default:
-            _default[device] = Context(device)
-        return _default[device]
+    """The calling THREAD's context for `device`.  A zk_ctx is not thread-safe (arena free list, stream, error string:
+    include/zkstark.h), and ctypes releases the GIL during calls, so a process-wide default would let two threads that
+    omit `ctx=` race inside one arena.  Workers that want explicit control create their own `Context`
+    (zk_evm_amd/scheduler.py does)."""
+    d = getattr(_tls, "ctx", None)
+    if d is None:
+        d = _tls.ctx = {}
+    if device not in d:
+        d[device] = Context(device)
+    return d[device]

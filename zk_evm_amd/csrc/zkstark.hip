@@ -288,15 +288,22 @@ static int get_coset_table(zk_ctx *ctx, int log_n, u64 shift, bool inverse, cons
 // NTT pass planning
 struct PassPlan { int log_d, r; };
 #include <cstdlib>
-static int env_int(const char *name, int dflt) {
+// Tunables.  Environment overrides exist for on-GPU tuning experiments only: each is read ONCE at load time and clamped
+// to the range the kernels were written for, so a stray variable can change speed but never break a launch.
+static int env_int(const char *name, int dflt, int lo, int hi) {
     const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
+    if (!v || !*v) return dflt;
+    char *end = nullptr;
+    long x = strtol(v, &end, 10);
+    if (end == v || *end) return dflt;
+    return x < lo ? lo : x > hi ? hi : (int)x;
 }
-// tunables (environment overrides exist for on-GPU tuning experiments only)
-static const int kMaxContigBits = env_int("ZK_NTT_CONTIG_BITS", 11);   // 2^11 * 8 B = 16 KiB tile
-static const int kMaxStridedBits = env_int("ZK_NTT_STRIDED_BITS", 10);
-static const int kTileElemBits = env_int("ZK_NTT_TILE_BITS", 13);      // strided tile elements (2^13 = 64 KiB)
-static const int kThreadsShift = env_int("ZK_NTT_THREADS_SHIFT", 3);   // threads = elems >> shift
+static const int kMaxContigBits = env_int("ZK_NTT_CONTIG_BITS", 11, 6, 13);    // 2^11 * 8 B = 16 KiB tile
+static const int kMaxStridedBits = env_int("ZK_NTT_STRIDED_BITS", 10, 3, 13);
+static const int kTileElemBits = env_int("ZK_NTT_TILE_BITS", 13, 10, 14);      // strided tile elements (2^13 = 64 KiB)
+static const int kThreadsShift = env_int("ZK_NTT_THREADS_SHIFT", 3, 1, 5);     // threads = elems >> shift
+static const int kArithHeavy = env_int("ZK_ARITH_HEAVY", 1, 0, 1);             // Arithmetic quotient: launch_bounds(256,4) variant
+static const int kMerkleCoopLog = env_int("ZK_MERKLE_COOP_LOG", 13, 0, 20);    // levels <= 2^this nodes: 16 lanes / node
 
 // Passes in decimation-in-frequency order (largest distance first); DIT runs them reversed.
 // The last entry is always the contiguous (log_d = 0) pass.
@@ -557,7 +564,7 @@ static int merkle_levels(zk_ctx *ctx, uint32_t hasher, u64 *digests, unsigned lo
         size_t cnt = (size_t)1 << l;
         u64 *parent = child + 4 * (cnt * 2);
         unsigned blocks = (unsigned)((cnt + 255) / 256);
-        if (hasher == ZK_HASH_POSEIDON && cnt <= ((size_t)1 << env_int("ZK_MERKLE_COOP_LOG", 13)))
+        if (hasher == ZK_HASH_POSEIDON && cnt <= ((size_t)1 << kMerkleCoopLog))
             poseidon_merkle_level_coop_kernel<<<(unsigned)((cnt * 16 + 255) / 256), 256, 0, ctx->stream>>>(child, parent, (u32)cnt);
         else if (hasher == ZK_HASH_POSEIDON)
             poseidon_merkle_level_kernel<<<blocks, 256, 0, ctx->stream>>>(child, parent, cnt);
@@ -763,6 +770,7 @@ extern "C" int zk_batch_leaf(const zk_batch *b, size_t leaf_index, uint64_t *out
 extern "C" int zk_batch_lde_values(const zk_batch *b, size_t index, size_t step, uint64_t *out) {
     if (!b || !out) return ZK_ERR_BAD_ARG;
     unsigned log_N = b->log_n + b->rate_bits;
+    if (step != 0 && index > SIZE_MAX / step) return set_err(b->ctx, ZK_ERR_BAD_ARG, "lde index out of range");
     size_t nat = index * step;
     if (nat >> log_N) return set_err(b->ctx, ZK_ERR_BAD_ARG, "lde index out of range");
     return gather_row(b, nat, out);  // leaves[bitrev(index*step)] == natural row index*step

@@ -77,8 +77,25 @@ class MemCap:
     mem_cap: List[List[int]] = field(default_factory=list)
 
     @staticmethod
-    def from_merkle_cap(cap: np.ndarray) -> "MemCap":
-        return MemCap([[int(x) % P for x in h] for h in np.asarray(cap).reshape(-1, 4)])
+    def from_merkle_cap(cap: np.ndarray, hasher: int = 0) -> "MemCap":
+        """proof.rs:606-621: `h.to_vec()` per cap hash.  `cap`: 32-byte digest slots as (n, 4) u64.  A Poseidon hash is
+        its four elements; a Keccak-25 hash (`BytesHash<25>`) is four elements read from 7,7,7,4-byte little-endian
+        chunks of the digest ([EXT] plonky2 hash_types.rs `BytesHash::to_vec`)."""
+        slots = np.ascontiguousarray(np.asarray(cap, dtype=np.uint64).reshape(-1, 4))
+        if hasher == 0:
+            if (slots >= np.uint64(P)).any():
+                raise ZkStarkError(-1, "non-canonical Poseidon digest in a Merkle cap")
+            return MemCap([[int(x) for x in h] for h in slots])
+        out = []
+        for h in slots:
+            b = h.tobytes()
+            out.append([int.from_bytes(b[7 * k: 7 * k + (7 if k < 3 else 4)], "little") for k in range(4)])
+        return MemCap(out)
+
+    @staticmethod
+    def from_elements(elems: np.ndarray) -> "MemCap":
+        """from the output of zk_segment_proof_mem_caps (already `to_vec` elements)."""
+        return MemCap([[int(x) for x in h] for h in np.asarray(elems, dtype=np.uint64).reshape(-1, 4)])
 
 
 @dataclass
@@ -366,8 +383,8 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
         nd = 1 << config.fri_config.cap_height
         mb, ma = np.zeros(4 * nd, dtype=np.uint64), np.zeros(4 * nd, dtype=np.uint64)
         lib.zk_segment_proof_mem_caps(h, mb.ctypes.data, ma.ctypes.data, 4 * nd)
-        public_values.mem_before = MemCap.from_merkle_cap(mb)
-        public_values.mem_after = MemCap.from_merkle_cap(ma)
+        public_values.mem_before = MemCap.from_elements(mb)
+        public_values.mem_after = MemCap.from_elements(ma)
         if timing is not None:
             ms = (C.c_double * (2 + NUM_TABLES))()
             lib.zk_segment_proof_stage_ms(h, ms, 2 + NUM_TABLES)
@@ -375,7 +392,7 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
             timing["compute CTL data"] = timing.get("compute CTL data", 0.0) + ms[1] / 1e3
             for t in range(NUM_TABLES):
                 if table_in_use[t]:
-                    k = "prove %s STARK" % TABLE_NAMES[t]
+                    k = "prove %s STARK" % all_stark.stark_field_names[t]     # prover.rs:232
                     timing[k] = timing.get(k, 0.0) + ms[2 + t] / 1e3
     finally:
         lib.zk_segment_proof_free(h)
