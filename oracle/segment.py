@@ -84,9 +84,11 @@ def mem_cap_from_merkle_cap(cap, hasher):
     return out
 
 
-def prove_with_traces(o, fri_api, cfg, traces, table_in_use, pv, cpu_air_consts, ctls=None, lookups=None, reg=None):
+def prove_with_traces(o, fri_api, cfg, traces, table_in_use, pv, cpu_air_consts, ctls=None, lookups=None, reg=None,
+                      fast=False):
     """traces: list of 9 (C_t, n_t) uint64 arrays (10 with reg = A.Registry(cdk_erigon=True)).  Returns
-    dict(ctl_challenges, proofs (None if unused), init_states, mem_before, mem_after, trace_caps)."""
+    dict(ctl_challenges, proofs (None if unused), init_states, mem_before, mem_after, trace_caps).
+    fast: run the per-row loops in C (oracle/fast_stark.py: the same restatements traced to tapes) -- any size."""
     from . import airs
     L = o.lib
     reg = reg or A.Registry(False)
@@ -119,8 +121,12 @@ def prove_with_traces(o, fri_api, cfg, traces, table_in_use, pv, cpu_air_consts,
         L.orc_challenger_compact(C.byref(och), st)
         inits.append(st)
         air = airs.AIRS[reg.TABLE_AIR[t]][0] if t != A.CPU else airs.make_eval_cpu(*cpu_air_consts, cdk_erigon=reg.cdk_erigon)
-        proofs.append(SP.prove_with_commitment(o, fri_api, cfg, air, traces[t], commits[t], lookups[t], per_table[t],
-                                               ctl_pairs, och))
+        if fast:
+            from . import fast_stark as FS
+            prove = FS.prove_with_commitment
+        else:
+            prove = SP.prove_with_commitment
+        proofs.append(prove(o, fri_api, cfg, air, traces[t], commits[t], lookups[t], per_table[t], ctl_pairs, och))
     mem_after = commits[A.MEM_AFTER]["cap"].copy()
     if not table_in_use[A.MEM_AFTER]:
         mem_after[:] = 0
@@ -259,8 +265,10 @@ def verify_proof(o, fri_api, cfg, stark_proofs, table_in_use, pv, cpu_air_consts
             return False, "table %d: ctl_zs_first outside the base field" % t
         zs_first.append([int(a) for a, _ in first])      # ctl_zs_first: base-field openings at 1
     if is_initial:
+        # verify_initial_memory (verifier.rs:149-170): `hash1.to_vec()` of initial_memory_merkle_cap limb by limb
+        # against public_values.mem_before.mem_cap (itself `to_vec` elements, proof.rs:606-621)
         if initial_mem_cap is None or mem_before_cap is None or not np.array_equal(
-                np.asarray(initial_mem_cap, dtype=np.uint64), np.asarray(mem_before_cap, dtype=np.uint64)):
+                mem_cap_from_merkle_cap(initial_mem_cap, cfg.hasher), np.asarray(mem_before_cap, dtype=np.uint64)):
             return False, "Invalid initial MemBefore Merkle cap."
     extra = [[0] * cfg.num_challenges for _ in ctls]
     extra[MEMORY_CTL_IDX] = [get_memory_extra_looking_sum(pv, c, kernel_hash, kernel_len) for c in chal]

@@ -26,9 +26,9 @@ def _one_hot(trace, cols, rng, p_none=0.25):
         trace[c] = ((pick == k) & ~none).astype(np.uint64)
 
 
-def make_traces(rng):
+def make_traces(rng, log_ns=None):
     from zk_evm_amd.all_stark import TABLE_COLUMNS
-    tr = [rng.integers(0, 1 << 64, size=(c, 1 << l), dtype=np.uint64) for c, l in zip(TABLE_COLUMNS, LOG_N)]
+    tr = [rng.integers(0, 1 << 64, size=(c, 1 << l), dtype=np.uint64) for c, l in zip(TABLE_COLUMNS, log_ns or LOG_N)]
     binary = lambda t, cols: [t.__setitem__(c, rng.integers(0, 2, size=t.shape[1], dtype=np.uint64)) for c in cols]
     _one_hot(tr[0], list(range(17)), rng)                       # Arithmetic op flags + IS_RANGE_CHECK
     _one_hot(tr[1], list(range(1, 33)), rng)                    # BytePacking index_len
@@ -46,7 +46,13 @@ def make_traces(rng):
     binary(m, [0, 22, 24, 26])
     _one_hot(m, [15, 16], rng, 0.5)
     ts = rng.integers(1, 1 << 30, size=m.shape[1], dtype=np.uint64)
-    inv = np.array([pow(int(t), P - 2, P) for t in ts], dtype=np.uint64)
+    if m.shape[1] <= 1 << 10:
+        inv = np.array([pow(int(t), P - 2, P) for t in ts], dtype=np.uint64)
+    else:                                                       # large heights: a few distinct timestamps, inverted once
+        pool = rng.integers(1, 1 << 30, size=64, dtype=np.uint64)
+        pinv = np.array([pow(int(t), P - 2, P) for t in pool], dtype=np.uint64)
+        pick = rng.integers(0, 64, size=m.shape[1])
+        ts, inv = pool[pick], pinv[pick]
     m[1] = ts
     m[2] = np.where(rng.random(m.shape[1]) < 0.5, inv, 0)       # filter_mem_before = 1 - t * t_inv in {0, 1}
     binary(tr[7], [0])
@@ -125,6 +131,44 @@ def test_segment_proof_matches_oracle(oracle, hasher, in_use):
     assert got.public_values.mem_after.mem_cap == [[int(x) for x in h] for h in exp["mem_after"]]
     if not in_use[8]:
         assert all(x == 0 for h in got.public_values.mem_after.mem_cap for x in h)
+
+
+@pytest.mark.parametrize("hasher,log_ns", [(0, [16, 13, 15, 12, 13, 14, 17, 12, 13]), (1, [12, 12, 13, 12, 12, 12, 14, 12, 12])],
+                         ids=["poseidon_2p12_to_2p17", "keccak_2p12_to_2p14"])
+def test_segment_proof_matches_oracle_at_scale(oracle, hasher, log_ns):
+    """The same word-for-word comparison as test_segment_proof_matches_oracle at 2^12 .. 2^17 rows per table (multi-pass
+    NTT, grid-stride quotient, multi-block scans, FRI with real reduction rounds), standard_fast_config except for the
+    query count: the oracle runs its per-row loops in C (oracle/fast_stark.py -- the Python restatements traced to
+    tapes, pinned to the pure-Python path by tests/test_oracle_fast_stark.py)."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    from oracle import airs as oairs
+    from oracle import segment as oseg
+    from zk_evm_amd.all_stark import AllStark
+    ol.setup_fri_api(oracle)
+    rng = np.random.default_rng(4000 + hasher)
+    traces = make_traces(rng, log_ns)
+    pvd = make_pv(rng)
+    kw = dict(pow_bits=8, queries=10)
+    cfg = ol.make_cfg(hasher=hasher, **kw)
+    in_use = [True] * 9
+    exp = oseg.prove_with_traces(oracle, ol, cfg, traces, in_use, pvd, oairs.CPU_TEST_CONSTS, fast=True)
+    scfg = zk.StarkConfig(hasher=hasher, fri_config=zk.FriConfig(proof_of_work_bits=kw["pow_bits"], num_query_rounds=kw["queries"]))
+    dev = [torch.from_numpy(t.view(np.int64)).cuda() for t in traces]
+    got = sg.prove_with_traces(AllStark(oairs.CPU_TEST_CONSTS), scfg, dev, in_use, to_public_values(pvd))
+    assert got.multi_proof.ctl_challenges == exp["ctl_challenges"]
+    for t in range(9):
+        sp, ep = got.multi_proof.stark_proofs[t], exp["proofs"][t]
+        assert np.array_equal(sp.init_challenger_state, exp["init_states"][t]), t
+        assert np.array_equal(sp.proof.trace_cap, exp["trace_caps"][t]), t
+        assert np.array_equal(sp.proof.auxiliary_polys_cap, ep["aux_cap"]), t
+        assert np.array_equal(sp.proof.quotient_polys_cap, ep["quotient_cap"]), t
+        assert np.array_equal(sp.proof.openings.reshape(-1), ep["openings"]), t
+        assert np.array_equal(sp.proof.opening_proof, ep["fri"]), t
+        assert sp.proof.degree_bits == log_ns[t]
+    assert got.public_values.mem_before.mem_cap == [[int(x) for x in h] for h in exp["mem_before"]]
+    assert got.public_values.mem_after.mem_cap == [[int(x) for x in h] for h in exp["mem_after"]]
 
 
 @pytest.mark.parametrize("log_ns", [[20] * 9, [18, 16, 22, 16, 16, 16, 24, 22, 22]], ids=["all_2p20", "memory_2p24"])
