@@ -63,8 +63,9 @@ def parse():
                     help="also report W segments in flight per GPU as a secondary object (1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=18)
-    ap.add_argument("--proof-steps", type=int, default=0,
-                    help="also time N full ArithmeticStark table proofs (0 disables)")
+    ap.add_argument("--cpu-table-log-n", type=int, default=20,
+                    help="height of the ArithmeticStark table proven on the CPU for cpu_baseline (0 = skip, fall back to "
+                         "the commit-sample extrapolation)")
     return ap.parse_args()
 
 
@@ -72,7 +73,7 @@ def parse():
 REALISTIC_LOG_NS = [17, 14, 19, 17, 13, 16, 21, 19, 19]
 
 
-def cpu_baseline(cols, log_n, sample_log_n, hasher):
+def cpu_baseline(cols, log_n, sample_log_n, hasher, max_reps=5):
     """Time the oracle's from_values on a bounded sample (cols x 2^sample_log_n) and extrapolate
     linearly in rows to the full workload (slightly optimistic for the CPU: NTT is n log n)."""
     import ctypes
@@ -103,7 +104,7 @@ def cpu_baseline(cols, log_n, sample_log_n, hasher):
         o.commit_values(vals, rate_bits=1, cap_height=4, hasher=hasher, want_leaves=False)
         reps += 1
         el = time.perf_counter() - t0
-        if el > 10.0 or reps >= 5:
+        if el > 10.0 or reps >= max_reps:
             break
     per_sample = el / reps
     scale = float(1 << (log_n - sample_log_n))
@@ -118,17 +119,11 @@ def cpu_baseline(cols, log_n, sample_log_n, hasher):
     }
 
 
-def table_proof_bench(ctx, dev, log_n, steps):
-    """Secondary measurement (not `value`): one full ArithmeticStark TABLE proof = starky
-    prove_with_commitment (logUp helper columns, CTL partial sums, auxiliary commit, quotient with
-    the complete Arithmetic AIR, quotient commit, openings, FRI with the production parameters)
-    on top of the trace commit.  Synthetic trace: one-hot op flags, 16-bit limbs, real range-counter
-    and frequency columns, so the lookup argument is the real one."""
-    import numpy as np
+def arithmetic_table_trace(dev, log_n):
+    """ArithmeticStark-shaped table for the table-proof comparison: one-hot operation flags, 16-bit limbs, the real
+    range-counter and frequency columns (arithmetic_stark.rs:130-156), so the table's own logUp argument and its CTL
+    (looked side of CTL 0, all_stark.rs:176-181) are exactly the reference's."""
     import torch
-    import zk_evm_amd as zk
-    import zk_evm_amd.prover as zp
-    from zk_evm_amd.stark import Column, Filter, Lookup, ctl_partial_sums
     n = 1 << log_n
     g = torch.Generator(device=dev)
     g.manual_seed(7)
@@ -136,41 +131,127 @@ def table_proof_bench(ctx, dev, log_n, steps):
     which = torch.randint(0, 18, (n,), device=dev, generator=g)
     for i in range(17):
         trace[i] = (which == i).to(torch.int64)
+    trace[17] = torch.randint(0, 256, (n,), dtype=torch.int64, device=dev, generator=g)        # opcode
     trace[18:114] = torch.randint(0, 1 << 16, (96, n), dtype=torch.int64, device=dev, generator=g)
     trace[114] = torch.clamp(torch.arange(n, device=dev), max=65535)
     trace[115, : 1 << 16] = torch.bincount(trace[18:114].reshape(-1), minlength=1 << 16)
-    lookup = Lookup(Column.singles(range(18, 114)), Column.single(114), Column.single(115), [Filter() for _ in range(96)])
-    cols = [Column.single(17)]
-    for reg in (18, 34, 50, 66):
-        cols += [Column.linear_combination([(reg + 2 * k, 1), (reg + 2 * k + 1, 1 << 16)]) for k in range(8)]
-    ctl_entry = [(cols, Filter.new_simple(Column.sum(range(17))))]
-    cfg = zk.StarkConfig.standard_fast_config()
-    times = []
-    stages = {}
-    for it in range(steps + 1):
+    return trace
+
+
+def gpu_table_proof(ctx, trace, all_stark, cfg, reps):
+    """One ArithmeticStark table proof on the GPU: from_values + transcript + CTL data + prove_single_table
+    (= the reference's keccak_benchmark shape, keccak_stark.rs:692-760: `from_values` and `prove_single_table` timed
+    together).  -> (seconds per proof, stage seconds, last proof)."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.prover as zp
+    from zk_evm_amd.all_stark import Table
+    from zk_evm_amd.stark import ctl_partial_sums
+    looked = all_stark.cross_table_lookups[0].looked_table
+    assert looked.table == Table.Arithmetic
+    entry = [(looked.columns, looked.filter)]
+    times, stages, pr = [], {}, None
+    for it in range(reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         tb = zk.PolynomialBatch.from_values(trace, 1, False, 4, ctx=ctx)
         ch = zk.Challenger(0)
         ch.observe_cap(tb.merkle_tree.cap)
         chal = [(ch.get_challenge(), ch.get_challenge()) for _ in range(cfg.num_challenges)]
+        torch.cuda.synchronize()
         t1 = time.perf_counter()
-        zd = []
-        for b, gm in chal:
-            zd.append(zp.CtlZData(b, gm, ctl_entry, ctl_partial_sums(trace, ctl_entry, b, gm, 3, ctx=ctx)))
+        zd = [zp.CtlZData(b, gm, entry, ctl_partial_sums(trace, entry, b, gm, 3, ctx=ctx)) for b, gm in chal]
+        torch.cuda.synchronize()
         t2 = time.perf_counter()
-        pr = zp.prove_single_table(zp.AIR_ARITHMETIC, cfg, trace, tb, [lookup], zd, chal, ch)
+        pr = zp.prove_single_table(zp.AIR_ARITHMETIC, cfg, trace, tb, all_stark.lookups[Table.Arithmetic], zd, chal, ch)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         tb.free()
         if it:  # first iteration is warm-up
             times.append(t3 - t0)
-            for k, v in (("trace_commit", t1 - t0), ("ctl_data", t2 - t1), ("prove_with_commitment", t3 - t2)):
-                stages[k] = stages.get(k, 0.0) + v * 1e3 / steps
-    sec = sum(times) / len(times)
-    return {"what": f"ArithmeticStark table proof, 2^{log_n} rows, standard_fast_config (2 challenges, 84 queries, 16 PoW bits)",
-            "proofs_per_s": 1.0 / sec, "ms_per_proof": sec * 1e3, "steps": steps, "stages_ms": stages,
-            "proof_words": int(pr.opening_proof.size)}
+            for k, v in (("trace commitment", t1 - t0), ("ctl columns", t2 - t1), ("prove_with_commitment", t3 - t2)):
+                stages[k] = stages.get(k, 0.0) + v / reps
+    return sum(times) / len(times), stages, pr
+
+
+def cpu_table_proof_baseline(ctx, dev, log_n, gpu_reps=3):
+    """`cpu_baseline`: ONE whole ArithmeticStark table proof MEASURED on the host -- trace commitment, logUp helper
+    columns, CTL columns, auxiliary commitment, quotient (the complete Arithmetic AIR, 707 constraints, + lookup + CTL
+    checks), quotient commitment, openings, FRI with standard_fast_config -- by the CPU oracle (C + OpenMP over columns /
+    leaves / rows, the axes rayon uses in the reference), next to the same proof of the same trace on the GPU, and the
+    two proofs compared word for word."""
+    import ctypes as C
+    import math
+    import platform
+    import numpy as np
+    import zk_evm_amd as zk
+    import tests.oracle_lib as ol
+    from oracle import airs as oairs
+    from oracle import all_stark as oas
+    from oracle import fast_stark as FS
+    from oracle import stark as OS
+    from zk_evm_amd.all_stark import AllStark
+    o = ol.load_oracle()
+    ol.setup_fri_api(o)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else int(o.lib.orc_num_threads())
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cores = min(cores, int(o.lib.orc_num_threads()))
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
+    model = platform.processor() or "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    trace = arithmetic_table_trace(dev, log_n)
+    cfg = zk.StarkConfig.standard_fast_config()
+    gpu_s, gpu_stages, gp = gpu_table_proof(ctx, trace, AllStark((1, 2, 3, 4)), cfg, gpu_reps)
+    host = trace.cpu().numpy().view(np.uint64)
+    del trace
+    # ---- the CPU proof, measured once ----
+    reg = oas.Registry(False)
+    ocfg = ol.make_cfg()
+    stages = {}
+    t0 = time.perf_counter()
+    commit = o.commit_values(host, rate_bits=1, cap_height=4, hasher=0)
+    och = ol.new_challenger(o, 0)
+    o.lib.orc_challenger_observe_cap(C.byref(och), commit["cap"], 16)
+    chal = [OS.GrandProductChallenge(o.lib.orc_challenger_get(C.byref(och)), o.lib.orc_challenger_get(C.byref(och)))
+            for _ in range(ocfg.num_challenges)]
+    stages["trace commitment"] = time.perf_counter() - t0
+    looked = reg.ctls[0].looked_table
+    zds = [OS.CtlZData(ch, [(looked.columns, looked.filter)], 0) for ch in chal]
+    init = np.zeros(12, dtype=np.uint64)
+    o.lib.orc_challenger_compact(C.byref(och), init)
+    cp = FS.prove_with_commitment(o, ol, ocfg, oairs.AIRS[5][0], host, commit, reg.lookups[0], zds,
+                                  [(c.beta, c.gamma) for c in chal], och, timing=stages)
+    cpu_s = time.perf_counter() - t0
+    same = (np.array_equal(gp.trace_cap, commit["cap"]) and np.array_equal(gp.auxiliary_polys_cap, cp["aux_cap"])
+            and np.array_equal(gp.quotient_polys_cap, cp["quotient_cap"])
+            and np.array_equal(gp.openings.reshape(-1), cp["openings"]) and np.array_equal(gp.opening_proof, cp["fri"]))
+    return {
+        "value": 1.0 / cpu_s, "unit": "ArithmeticStark table proofs/s (116 columns x 2^%d rows)" % log_n, "cores": cores,
+        "kind": "port", "cpu_model": model, "omp_num_threads": cores,
+        "sample": "ONE whole ArithmeticStark table proof, 116 x 2^%d rows, standard_fast_config (2 challenges, 84 queries, "
+                  "16 PoW bits), measured end to end, not scaled: from_values + logUp (96 columns) + CTL + auxiliary "
+                  "commitment + quotient (707 AIR constraints + lookup / CTL checks) + quotient commitment + openings + "
+                  "FRI; oracle = C/OpenMP restatement (NTT, Poseidon, Merkle, FRI) with the constraint program traced from "
+                  "the Python restatement and interpreted per row" % log_n,
+        "seconds": cpu_s, "stages_s": {k: round(v, 3) for k, v in stages.items()},
+        "gpu_same_proof": {"seconds": gpu_s, "proofs_per_s": 1.0 / gpu_s, "stages_s": {k: round(v, 4) for k, v in gpu_stages.items()},
+                           "speedup_vs_cpu": cpu_s / gpu_s},
+        "proofs_identical": bool(same),
+    }
 
 
 def synthetic_segment_traces(log_ns, dev, seed=1, cdk_erigon=False):
@@ -450,11 +531,6 @@ def main():
                            "parallelism": f"{world} independent traces (one per GPU), no collective"},
                 "roofline": roof}
             out.update(extra)
-            if a.proof_steps > 0 and a.cols == 116 and a.hasher == 0:
-                try:
-                    out["table_proof"] = table_proof_bench(ctx, dev, a.log_n, a.proof_steps)
-                except Exception as e:
-                    out["table_proof"] = {"error": repr(e)}
             if not a.no_cpu_baseline and world == 1:
                 try:
                     out["cpu_baseline"] = cpu_baseline(a.cols, a.log_n, min(a.cpu_sample_log_n, a.log_n), a.hasher)
@@ -568,19 +644,30 @@ def main():
                                          "ms_per_commit": 1e3 * elapsed_c / a.commit_steps, "roofline": roof_c}
                 out["commit_config1"].update(extra_c)
         if rank == 0 and not a.no_cpu_baseline and world == 1:
+            extrap = None
             try:
                 sl = a.cpu_sample_log_n
-                cb = cpu_baseline(116, sl, sl, a.hasher)
+                cb = cpu_baseline(116, sl, sl, a.hasher, max_reps=2)
                 sample_cells = 116 << sl
                 sec = (1.0 / cb["value"]) * cells / sample_cells
-                out["cpu_baseline"] = {
+                extrap = {
                     "value": 1.0 / sec, "unit": "segment proofs/s", "cores": cb["cores"], "kind": "port",
                     "sample": cb["sample"].split(", scaled")[0] + f"; scaled by committed cells ({cells} / {sample_cells}) to "
-                              "the segment's 27 commitments -- COMMIT PHASE ONLY (the CPU quotient / FRI are not timed, the "
-                              "Python constraint oracle is not a performance port), so this is an upper bound on the CPU rate",
+                              "the segment's 27 commitments -- COMMIT PHASE ONLY, an extrapolation and an upper bound on the "
+                              "CPU rate",
                     "seconds_per_segment_est": sec}
             except Exception as e:  # the oracle is only a reported baseline; never fatal
-                out["cpu_baseline"] = {"error": repr(e)}
+                extrap = {"error": repr(e)}
+            if a.cpu_table_log_n > 0 and a.hasher == 0:
+                try:
+                    ctx.mem_trim()
+                    out["cpu_baseline"] = cpu_table_proof_baseline(ctx, dev, a.cpu_table_log_n)
+                    out["cpu_baseline"]["segment_commit_phase_extrapolation"] = extrap
+                except Exception as e:
+                    out["cpu_baseline"] = extrap or {}
+                    out["cpu_baseline"]["table_proof_error"] = repr(e)
+            else:
+                out["cpu_baseline"] = extrap
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -108,15 +108,36 @@ class Oracle:
 _cached = None
 
 
+def usable_cores() -> int:
+    """Threads this process can actually run: affinity mask and cgroup CPU quota (the GPU box shows 256 CPUs inside a
+    16-core quota; 256 OpenMP threads there spend their time being throttled at barriers)."""
+    import math
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def load_oracle() -> Oracle:
     global _cached
     if _cached is None:
+        if "OMP_NUM_THREADS" not in os.environ:
+            os.environ["OMP_NUM_THREADS"] = str(usable_cores())     # read by libgomp when the library is loaded
         so = os.path.join(ORACLE_DIR, "liboracle.so")
         if not os.path.exists(so) or os.path.exists(os.path.join(ORACLE_DIR, "Makefile")) and \
                 any(os.path.getmtime(os.path.join(ORACLE_DIR, f)) > os.path.getmtime(so)
                     for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))):
             build_oracle()
         _cached = Oracle(C.CDLL(so))
+        if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+            try:                                            # libgomp may have been initialised before the variable was set
+                C.CDLL("libgomp.so.1").omp_set_num_threads(int(os.environ["OMP_NUM_THREADS"]))
+            except OSError:
+                pass
     return _cached
 
 

@@ -77,7 +77,11 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
         u32 t0 = (blk << (log_q + K)) + j;
         u64 v[1 << K];
 #pragma unroll
+#ifdef NTT_EXPERIMENT_NOCONFLICT   /* timing experiment only (wrong results): register-major, conflict-free LDS accesses */
+        for (int m = 0; m < (1 << K); ++m) v[m] = tile[sp + m * nsub];
+#else
         for (int m = 0; m < (1 << K); ++m) v[m] = tile[((t0 + m * q) << log_t) + u];
+#endif
         // g = x0 mod D0 (x0 = global index of v[0]); x_m mod D = g + (m mod hm) * D0
         const u32 g = ((base + (t0 << p.log_d) + u) & ((1u << log_D0) - 1));
 #pragma unroll
@@ -93,7 +97,11 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
             }
         }
 #pragma unroll
+#ifdef NTT_EXPERIMENT_NOCONFLICT
+        for (int m = 0; m < (1 << K); ++m) tile[sp + m * nsub] = v[m];
+#else
         for (int m = 0; m < (1 << K); ++m) tile[((t0 + m * q) << log_t) + u] = v[m];
+#endif
     }
 }
 

@@ -33,96 +33,7 @@
 #include "arithtrace.cuh"
 #include "host_hash.hpp"
 
-// ------------------------------------------------------------------------------------------
-struct zk_ctx {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    std::string err;
-    volatile const int *abort_flag = nullptr;
-    std::map<int, u64 *> tw_fwd, tw_inv;                    // log size -> table
-    std::map<std::pair<int, u64>, u64 *> coset_tabs;        // (log_n, shift) -> s^bitrev(i)
-    std::map<std::pair<int, u64>, u64 *> coset_inv_tabs;    // (log_n, shift) -> n^-1 s^-bitrev(i)
-    hipEvent_t ev[5] = {};
-    float timings[4] = {0, 0, 0, 0};
-    // running totals over all commits since the last reset (zk_ctx_commit_totals)
-    double total_ms[4] = {0, 0, 0, 0};
-    double total_leaf_bytes = 0, total_leaf_perms = 0, total_ntt_bytes = 0;
-    uint64_t total_commits = 0;
-    int cu_count = 0;
-    std::set<zk_batch *> live_batches;  // freed by zk_ctx_destroy if the caller leaked them
-    DevArena arena;                     // all batch + scratch HBM (arena.hpp)
-    std::map<std::vector<u64>, u32> constraint_counts;   // quotient: constraints yielded per (AIR, lookup/CTL shape)
-};
-
-struct zk_batch {
-    zk_ctx *ctx = nullptr;
-    size_t n_cols = 0;
-    unsigned log_n = 0, rate_bits = 0, cap_height = 0;
-    uint32_t hasher = 0;
-    u64 *d_coeffs = nullptr;   // [n_cols][n], bit-reversed coefficient order
-    u64 *d_lde = nullptr;      // [n_cols][N], natural order
-    u64 *d_digests = nullptr;  // level-concatenated 32-byte slots
-    size_t n_digests = 0;
-    std::vector<u64> cap;      // host copy
-};
-
-static int set_err(zk_ctx *ctx, int code, const char *fmt, ...) {
-    if (ctx) {
-        char buf[512];
-        va_list ap;
-        va_start(ap, fmt);
-        vsnprintf(buf, sizeof buf, fmt, ap);
-        va_end(ap);
-        ctx->err = buf;
-    }
-    return code;
-}
-
-#define HIP_TRY(ctx, expr)                                                                   \
-    do {                                                                                     \
-        hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess)                                                                \
-            return set_err(ctx, e_ == hipErrorOutOfMemory ? ZK_ERR_OOM : ZK_ERR_HIP,         \
-                           "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,  \
-                           __LINE__);                                                        \
-    } while (0)
-
-#define ZK_TRY(expr)               \
-    do {                           \
-        int rc_ = (expr);          \
-        if (rc_ != ZK_OK) return rc_; \
-    } while (0)
-
-// Scoped device scratch from the ctx arena: every block is returned on scope exit, on error paths too.
-struct DevBuf {
-    zk_ctx *ctx;
-    std::vector<void *> ptrs;
-    explicit DevBuf(zk_ctx *c) : ctx(c) {}
-    ~DevBuf() { for (void *p : ptrs) ctx->arena.free(p); }
-    DevBuf(const DevBuf &) = delete;
-    DevBuf &operator=(const DevBuf &) = delete;
-    template <class T> int alloc(T **out, size_t count) {
-        void *p = nullptr;
-        hipError_t e = ctx->arena.alloc(&p, count * sizeof(T) ? count * sizeof(T) : 8);
-        if (e != hipSuccess) return set_err(ctx, e == hipErrorOutOfMemory ? ZK_ERR_OOM : ZK_ERR_HIP, "device arena: %s", hipGetErrorString(e));
-        ptrs.push_back(p);
-        *out = (T *)p;
-        return ZK_OK;
-    }
-};
-
-static int check_abort(zk_ctx *ctx) {
-    if (ctx->abort_flag && *ctx->abort_flag) return set_err(ctx, ZK_ERR_ABORTED, "aborted");
-    return ZK_OK;
-}
-
-static int check_launch(zk_ctx *ctx, const char *what) {
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess)
-        return set_err(ctx, ZK_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
-    return ZK_OK;
-}
+#include "ctx.hpp"
 
 // ------------------------------------------------------------------------------------------
 extern "C" const char *zk_version(void) { return "zkstark-hip 0.1 (gfx950)"; }
@@ -243,185 +154,8 @@ extern "C" int zk_ctx_last_timings(const zk_ctx *ctx, float out_ms[4]) {
     return ZK_OK;
 }
 
-// ------------------------------------------------------------------------------------------
-// tables
-static int get_twiddles(zk_ctx *ctx, int log_size, bool inverse, const u64 **out) {
-    auto &m = inverse ? ctx->tw_inv : ctx->tw_fwd;
-    auto it = m.find(log_size);
-    if (it != m.end()) { *out = it->second; return ZK_OK; }
-    size_t count = log_size > 0 ? (size_t)1 << (log_size - 1) : 1;
-    u64 *d = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d, count * sizeof(u64)));
-    u64 w = gl_root_of_unity(log_size);
-    if (inverse) w = gl_canon(gl_inv(w));
-    unsigned blocks = (unsigned)((count + 255) / 256);
-    twiddle_table_kernel<<<blocks, 256, 0, ctx->stream>>>(d, count, w);
-    ZK_TRY(check_launch(ctx, "twiddle_table_kernel"));
-    m[log_size] = d;
-    *out = d;
-    return ZK_OK;
-}
-
-// s^bitrev(i) (inverse=false) or n^-1 * s^-bitrev(i) (inverse=true), i < 2^log_n
-static int get_coset_table(zk_ctx *ctx, int log_n, u64 shift, bool inverse, const u64 **out) {
-    auto &m = inverse ? ctx->coset_inv_tabs : ctx->coset_tabs;
-    auto key = std::make_pair(log_n, shift);
-    auto it = m.find(key);
-    if (it != m.end()) { *out = it->second; return ZK_OK; }
-    size_t count = (size_t)1 << log_n;
-    u64 *d = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d, count * sizeof(u64)));
-    u64 s = gl_canon(shift), c = 1;
-    if (inverse) {
-        s = gl_canon(gl_inv(s));
-        c = gl_canon(gl_inv((u64)count));
-    }
-    unsigned blocks = (unsigned)((count + 255) / 256);
-    coset_table_kernel<<<blocks, 256, 0, ctx->stream>>>(d, log_n, s, c);
-    ZK_TRY(check_launch(ctx, "coset_table_kernel"));
-    m[key] = d;
-    *out = d;
-    return ZK_OK;
-}
-
-// ------------------------------------------------------------------------------------------
-// NTT pass planning
-struct PassPlan { int log_d, r; };
-#include <cstdlib>
-// Tunables.  Environment overrides exist for on-GPU tuning experiments only: each is read ONCE at load time and clamped
-// to the range the kernels were written for, so a stray variable can change speed but never break a launch.
-static int env_int(const char *name, int dflt, int lo, int hi) {
-    const char *v = getenv(name);
-    if (!v || !*v) return dflt;
-    char *end = nullptr;
-    long x = strtol(v, &end, 10);
-    if (end == v || *end) return dflt;
-    return x < lo ? lo : x > hi ? hi : (int)x;
-}
-static const int kMaxContigBits = env_int("ZK_NTT_CONTIG_BITS", 11, 6, 13);    // 2^11 * 8 B = 16 KiB tile
-static const int kMaxStridedBits = env_int("ZK_NTT_STRIDED_BITS", 10, 3, 13);
-static const int kTileElemBits = env_int("ZK_NTT_TILE_BITS", 13, 10, 14);      // strided tile elements (2^13 = 64 KiB)
-static const int kThreadsShift = env_int("ZK_NTT_THREADS_SHIFT", 3, 1, 5);     // threads = elems >> shift
-static const int kArithHeavy = env_int("ZK_ARITH_HEAVY", 1, 0, 1);             // Arithmetic quotient: launch_bounds(256,4) variant
-static const int kMerkleCoopLog = env_int("ZK_MERKLE_COOP_LOG", 13, 0, 20);    // levels <= 2^this nodes: 16 lanes / node
-
-// Passes in decimation-in-frequency order (largest distance first); DIT runs them reversed.
-// The last entry is always the contiguous (log_d = 0) pass.
-static std::vector<PassPlan> plan_passes(int L) {
-    std::vector<PassPlan> v;
-    if (L <= kMaxContigBits) { v.push_back({0, L}); return v; }
-    int ns = 1;
-    while (L > ns * kMaxStridedBits + kMaxContigBits) ++ns;
-    const int base = L / (ns + 1);
-    int extra = L % (ns + 1);
-    int contig = base;
-    std::vector<int> strided(ns, base);
-    while (extra > 0 && contig < kMaxContigBits) { ++contig; --extra; }
-    for (int i = 0; i < ns && extra > 0; ++i)
-        while (extra > 0 && strided[i] < kMaxStridedBits) { ++strided[i]; --extra; }
-    int acc = L;
-    for (int i = 0; i < ns; ++i) { acc -= strided[i]; v.push_back({acc, strided[i]}); }
-    v.push_back({0, acc});
-    return v;
-}
-
-template <bool DIT>
-static int launch_pass(zk_ctx *ctx, NttPass p, size_t n_cols) {
-    if (p.log_d == 0) p.log_t = 0;
-    else {
-        int lt = kTileElemBits - p.r;
-        if (lt < 0) lt = 0;
-        if (lt > p.log_d) lt = p.log_d;
-        p.log_t = lt;
-    }
-    size_t elems = (size_t)1 << (p.r + p.log_t);
-    size_t n = (size_t)1 << p.log_n;
-    size_t tiles = n / elems;
-    if (tiles == 0) tiles = 1;
-    unsigned nthr = (unsigned)(elems >> kThreadsShift);
-    if (nthr < 64) nthr = 64;
-    if (nthr > 1024) nthr = 1024;
-    size_t lds = elems * sizeof(u64);
-    size_t done = 0;
-    while (done < n_cols) {  // grid.y limit
-        size_t chunk = n_cols - done < 65535 ? n_cols - done : 65535;
-        NttPass q = p;
-        q.src = p.src + done * p.src_stride;
-        q.dst = p.dst + done * p.dst_stride;
-        dim3 grid((unsigned)tiles, (unsigned)chunk);
-        ntt_pass_kernel<DIT><<<grid, nthr, lds, ctx->stream>>>(q);
-        ZK_TRY(check_launch(ctx, DIT ? "ntt_pass_kernel<DIT>" : "ntt_pass_kernel<DIF>"));
-        done += chunk;
-    }
-    return ZK_OK;
-}
-
-// values (natural) -> coefficients (bit-reversed), size 2^log_n.
-// out_scale: optional table applied on the final store (coset_ifft); otherwise multiply by n^-1.
-static int ntt_values_to_coeffs(zk_ctx *ctx, const u64 *src, size_t src_stride, u64 *dst,
-                                size_t dst_stride, size_t n_cols, int log_n, const u64 *out_scale) {
-    const u64 *tw = nullptr;
-    ZK_TRY(get_twiddles(ctx, log_n, true, &tw));
-    auto plan = plan_passes(log_n);
-    for (size_t i = 0; i < plan.size(); ++i) {
-        NttPass p = {};
-        p.src = i == 0 ? src : dst;
-        p.src_stride = i == 0 ? src_stride : dst_stride;
-        p.dst = dst; p.dst_stride = dst_stride;
-        p.tw = tw; p.log_tw = log_n;
-        p.log_n = log_n; p.log_d = plan[i].log_d; p.r = plan[i].r;
-        if (i + 1 == plan.size()) {
-            if (out_scale) p.out_scale = out_scale;
-            else { p.apply_out_const = 1; p.out_const = gl_canon(gl_inv((u64)1 << log_n)); }
-        }
-        ZK_TRY(launch_pass<false>(ctx, p, n_cols));
-    }
-    return ZK_OK;
-}
-
-// coefficients (bit-reversed, size 2^log_n) -> values (natural) on size 2^(log_n + rate_bits),
-// optional per-coefficient factor in_scale (coset powers, bit-reversed order).
-static int ntt_coeffs_to_values(zk_ctx *ctx, const u64 *src, size_t src_stride, u64 *dst,
-                                size_t dst_stride, size_t n_cols, int log_n, int rate_bits,
-                                const u64 *in_scale) {
-    int L = log_n + rate_bits;
-    const u64 *tw = nullptr;
-    ZK_TRY(get_twiddles(ctx, L, false, &tw));
-    auto plan = plan_passes(L);
-    // the contiguous pass must be able to absorb the replication stages
-    if (plan.back().r < rate_bits)
-        return set_err(ctx, ZK_ERR_UNSUPPORTED, "rate_bits %d too large for log_n %d", rate_bits, log_n);
-    for (size_t k = 0; k < plan.size(); ++k) {
-        size_t i = plan.size() - 1 - k;  // reversed order for DIT
-        NttPass p = {};
-        p.dst = dst; p.dst_stride = dst_stride;
-        p.tw = tw; p.log_tw = L;
-        p.log_n = L; p.log_d = plan[i].log_d; p.r = plan[i].r;
-        if (k == 0) {
-            p.src = src; p.src_stride = src_stride;
-            p.in_scale = in_scale;
-            p.log_rep = rate_bits; p.first_stage = rate_bits;
-        } else {
-            p.src = dst; p.src_stride = dst_stride;
-        }
-        ZK_TRY(launch_pass<true>(ctx, p, n_cols));
-    }
-    return ZK_OK;
-}
-
-static int bitrev_columns(zk_ctx *ctx, u64 *d, size_t stride, size_t n_cols, int log_n) {
-    if (log_n <= 1) return ZK_OK;
-    size_t n = (size_t)1 << log_n;
-    size_t done = 0;
-    while (done < n_cols) {
-        size_t chunk = n_cols - done < 65535 ? n_cols - done : 65535;
-        dim3 grid((unsigned)((n + 255) / 256), (unsigned)chunk);
-        bitrev_permute_kernel<<<grid, 256, 0, ctx->stream>>>(d + done * stride, stride, log_n);
-        ZK_TRY(check_launch(ctx, "bitrev_permute_kernel"));
-        done += chunk;
-    }
-    return ZK_OK;
-}
+#include "ntt_host.inc"
+#include "merkle_host.inc"
 
 static int check_ntt_args(zk_ctx *ctx, const void *d, size_t stride, size_t n_cols, unsigned log_n) {
     if (!ctx) return ZK_ERR_BAD_ARG;
@@ -516,31 +250,6 @@ extern "C" int zk_keccak_f1600(zk_ctx *ctx, uint64_t *d_states, size_t n_states)
     return check_launch(ctx, "keccak_f1600_states_kernel");
 }
 
-// col_off == nullptr: column c at cols + c*stride; else column c at cols + col_off[c] (device array)
-static int hash_rows(zk_ctx *ctx, uint32_t hasher, const u64 *cols, size_t stride, size_t n_cols,
-                     size_t n_rows, int log_rows, int do_bitrev, u64 *digests,
-                     const u64 *col_off = nullptr) {
-    unsigned blocks = (unsigned)((n_rows + 255) / 256);
-    if (hasher == ZK_HASH_POSEIDON) {
-        if (col_off)
-            poseidon_hash_rows_kernel<true><<<blocks, 256, 0, ctx->stream>>>(
-                cols, stride, col_off, (u32)n_cols, n_rows, log_rows, do_bitrev, digests);
-        else
-            poseidon_hash_rows_kernel<false><<<blocks, 256, 0, ctx->stream>>>(
-                cols, stride, nullptr, (u32)n_cols, n_rows, log_rows, do_bitrev, digests);
-        return check_launch(ctx, "poseidon_hash_rows_kernel");
-    } else if (hasher == ZK_HASH_KECCAK25) {
-        if (col_off)
-            keccak_hash_rows_kernel<true><<<blocks, 256, 0, ctx->stream>>>(
-                cols, stride, col_off, (u32)n_cols, n_rows, log_rows, do_bitrev, digests);
-        else
-            keccak_hash_rows_kernel<false><<<blocks, 256, 0, ctx->stream>>>(
-                cols, stride, nullptr, (u32)n_cols, n_rows, log_rows, do_bitrev, digests);
-        return check_launch(ctx, "keccak_hash_rows_kernel");
-    }
-    return set_err(ctx, ZK_ERR_BAD_ARG, "unknown hasher %u", hasher);
-}
-
 extern "C" int zk_hash_rows(zk_ctx *ctx, uint32_t hasher, const uint64_t *d_cols, size_t col_stride,
                             size_t n_cols, size_t n_rows, uint64_t *d_digests) {
     if (!ctx) return ZK_ERR_BAD_ARG;
@@ -555,27 +264,6 @@ extern "C" size_t zk_merkle_num_digests(unsigned log_leaves, unsigned cap_height
     if (cap_height > log_leaves) return 0;
     for (unsigned l = log_leaves + 1; l-- > cap_height;) tot += (size_t)1 << l;
     return tot;
-}
-
-static int merkle_levels(zk_ctx *ctx, uint32_t hasher, u64 *digests, unsigned log_leaves,
-                         unsigned cap_height) {
-    u64 *child = digests;
-    for (unsigned l = log_leaves; l-- > cap_height;) {
-        size_t cnt = (size_t)1 << l;
-        u64 *parent = child + 4 * (cnt * 2);
-        unsigned blocks = (unsigned)((cnt + 255) / 256);
-        if (hasher == ZK_HASH_POSEIDON && cnt <= ((size_t)1 << kMerkleCoopLog))
-            poseidon_merkle_level_coop_kernel<<<(unsigned)((cnt * 16 + 255) / 256), 256, 0, ctx->stream>>>(child, parent, (u32)cnt);
-        else if (hasher == ZK_HASH_POSEIDON)
-            poseidon_merkle_level_kernel<<<blocks, 256, 0, ctx->stream>>>(child, parent, cnt);
-        else if (hasher == ZK_HASH_KECCAK25)
-            keccak_merkle_level_kernel<<<blocks, 256, 0, ctx->stream>>>(child, parent, cnt);
-        else
-            return set_err(ctx, ZK_ERR_BAD_ARG, "unknown hasher %u", hasher);
-        ZK_TRY(check_launch(ctx, "merkle_level_kernel"));
-        child = parent;
-    }
-    return ZK_OK;
 }
 
 extern "C" int zk_merkle_build(zk_ctx *ctx, uint32_t hasher, uint64_t *d_digests, unsigned log_leaves,
