@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=2,
                     help="also report W segments in flight per GPU as a secondary object (1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the h2d / realistic secondary objects")
     ap.add_argument("--cpu-sample-log-n", type=int, default=18)
     ap.add_argument("--cpu-table-log-n", type=int, default=20,
                     help="height of the ArithmeticStark table proven on the CPU for cpu_baseline (0 = skip, fall back to "
@@ -374,7 +375,8 @@ def commit_report(a, stage, ms_per_step):
                 valu = {"wave_insts_per_launch": insts, "achieved_wave_insts_per_s": ach,
                         "peak_wave_insts_per_s": peak, "frac": ach / peak,
                         "assumes": "1024 SIMDs x 2.4 GHz / 4 cycles per integer VALU wave-instruction",
-                        "source": pmc.get("source")}
+                        "source": pmc.get("source"), "source_commit": pmc.get("git_commit"),
+                        "measured_in_this_run": False}
         except Exception:
             traffic = None
     roof = {"bound": "hbm", "kernel": "poseidon_hash_rows_kernel" if a.hasher == 0 else "keccak_hash_rows_kernel",
@@ -417,6 +419,81 @@ def segments_in_flight(ctx, workers, per_worker, arena_peak, all_stark, cfg, tra
     return {"workers_per_gpu": workers, "proofs": workers * per_worker, "value": workers * per_worker / el,
             "unit": "segment proofs/s", "note": "SegmentScheduler: one Context + stream + worker thread per in-flight "
                                                 "segment, one job queue, shared resident inputs"}
+
+
+def realistic_profile(ctx, dev, a, all_stark, cfg, steps=4, in_flight=3):
+    """Secondary object: the `north_star` shape -- per-table heights at the upper ends of the reference's own ranges
+    (scripts/prove_stdio.rs:89-101: Arithmetic 2^17, BytePacking 2^14, Cpu 2^19, Keccak 2^17, KeccakSponge 2^13, Logic
+    2^16, Memory 2^21, MemBefore / MemAfter 2^19) -- one segment at a time, and `in_flight` segments per GPU through the
+    product scheduler."""
+    import torch
+    import zk_evm_amd.segment as sg
+    from zk_evm_amd.scheduler import SegmentJob, SegmentScheduler
+    n_tab = all_stark.num_tables
+    log_ns = REALISTIC_LOG_NS + [14] * (n_tab - 9)
+    traces = synthetic_segment_traces(log_ns, dev, seed=11, cdk_erigon=a.cdk_erigon)
+    in_use = [True] * n_tab
+
+    def pv():
+        return sg.PublicValues(burn_addr=1 if a.cdk_erigon else None)
+    sg.prove_with_traces(all_stark, cfg, traces, in_use, pv(), ctx=ctx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sg.prove_with_traces(all_stark, cfg, traces, in_use, pv(), ctx=ctx)
+    torch.cuda.synchronize()
+    single = (time.perf_counter() - t0) / steps
+    peak = ctx.mem_stats()["peak_in_use"]
+    out = {"log_ns": log_ns, "steps": steps, "single": {"value": 1.0 / single, "unit": "segment proofs/s", "ms_per_proof": 1e3 * single},
+           "trace_GB": 8.0 * sum(c << l for c, l in zip(all_stark.table_columns, log_ns)) / 1e9}
+    try:
+        with SegmentScheduler(all_stark, cfg, [ctx.device], in_flight) as sch:
+            mk = lambda: SegmentJob(lambda d: traces, in_use, pv())
+            sch.map([mk() for _ in range(2 * in_flight)])                # warm-up: every worker grows its arena
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sch.map([mk() for _ in range(steps * in_flight)])
+            el = time.perf_counter() - t0
+        out["in_flight"] = {"workers_per_gpu": in_flight, "value": steps * in_flight / el, "unit": "segment proofs/s"}
+    except Exception as e:
+        out["in_flight"] = {"error": repr(e)}
+    del traces
+    torch.cuda.empty_cache()
+    return out
+
+
+def h2d_profile(dev, trace_bytes, step_s):
+    """Secondary object: host->device bandwidth measured here (1 GiB, pageable and pinned) and what uploading the step's
+    traces costs -- `value` itself starts with the traces resident in HBM (bench contract)."""
+    import torch
+    n = 1 << 27                                             # 1 GiB of int64
+    dst = torch.empty(n, dtype=torch.int64, device=dev)
+    res = {}
+    for kind in ("pageable", "pinned"):
+        try:
+            src = torch.ones(n, dtype=torch.int64)
+            if kind == "pinned":
+                src = src.pin_memory()
+            dst.copy_(src)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            res[kind + "_GBs"] = 3 * 8.0 * n / (time.perf_counter() - t0) / 1e9
+            del src
+        except Exception as e:
+            res[kind + "_error"] = repr(e)
+    bw = max([v for k, v in res.items() if k.endswith("_GBs")] or [0.0])
+    if bw > 0:
+        up = trace_bytes / 1e9 / bw
+        res.update(trace_GB=trace_bytes / 1e9, upload_s=up,
+                   serial_upload_then_prove={"value": 1.0 / (step_s + up), "unit": "segment proofs/s"},
+                   overlapped_upload={"value": 1.0 / max(step_s, up), "unit": "segment proofs/s",
+                                      "note": "upload of segment k+1 under the proof of segment k (two streams)"},
+                   note="the eight non-Cpu tables can be generated on the device from operation logs (zk_*_generate_trace), "
+                        "which leaves only the Cpu rows and the logs on PCIe")
+    return res
 
 
 def self_launch(a) -> int:
@@ -588,7 +665,8 @@ def main():
                                 "achieved_wave_insts_per_s": ach, "peak_wave_insts_per_s": 1024 * 2.4e9 / 4.0,
                                 "frac": ach / (1024 * 2.4e9 / 4.0),
                                 "assumes": "1024 SIMDs x 2.4 GHz / 4 cycles per integer VALU wave-instruction",
-                                "source": pm["source"]}
+                                "source": pm["source"], "source_commit": pm.get("git_commit"),
+                                "measured_in_this_run": False}
             except Exception:
                 pass
             cells = segment_committed_cells(log_ns, a.cdk_erigon)
@@ -603,9 +681,13 @@ def main():
                                        f"10 CTLs + lookups, standard_fast_config, hasher {hname}",
                            "parallelism": f"{world} independent segments (one per GPU), no collective",
                            "committed_cells": cells, "proof_words": proof_words},
-                "roofline": {"bound": "hbm", "kernel": "poseidon_hash_rows_kernel" if a.hasher == 0 else "keccak_hash_rows_kernel",
+                "roofline": {"bound": "hbm", "limiting_resource": "integer VALU issue (the `valu` object), not HBM: `frac` is the "
+                                                                    "contract's HBM fraction, `valu.frac` says how good the kernel is",
+                             "kernel": "poseidon_hash_rows_kernel" if a.hasher == 0 else "keccak_hash_rows_kernel",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                              "traffic": seg_traffic,
+                             "traffic_source": "rocprofv3 --pmc passes committed under profiles/ (pmc_latest.json), not collected "
+                                               "in this run" if seg_traffic else None,
                              "launches": tot["commits"], "ms_per_launch": leaf_ms / max(tot["commits"], 1),
                              "ms_per_step": leaf_ms / a.steps, "share_of_step": leaf_ms / a.steps / ms_per_step,
                              "algorithmic_bytes": tot["leaf_hash_bytes"] / max(tot["commits"], 1),
@@ -643,6 +725,17 @@ def main():
                                          "commits_per_s": world * a.commit_steps / elapsed_c,
                                          "ms_per_commit": 1e3 * elapsed_c / a.commit_steps, "roofline": roof_c}
                 out["commit_config1"].update(extra_c)
+        if rank == 0 and world == 1 and not a.no_secondary:
+            try:
+                out["h2d"] = h2d_profile(dev, trace_bytes, ms_per_step / 1e3)
+            except Exception as e:
+                out["h2d"] = {"error": repr(e)}
+            if log_ns == [20] * n_tab and a.hasher == 0:
+                try:
+                    ctx.mem_trim()
+                    out["realistic"] = realistic_profile(ctx, dev, a, all_stark, cfg)
+                except Exception as e:
+                    out["realistic"] = {"error": repr(e)}
         if rank == 0 and not a.no_cpu_baseline and world == 1:
             extrap = None
             try:

@@ -86,41 +86,26 @@ GL_HD u64 gl_mul_ref(u64 a, u64 b) {
     "v_add_co_u32 %[lo], vcc, %[lo], %[e]\n\t"                                                    \
     "v_addc_co_u32 %[hi], vcc, 0, %[hi], vcc"
 
+// Chained partial products: each v_mad_u64_u32 takes the previous product's high word as its 64-bit addend
+// ({x, 0} pairs cost one v_mov each, and v_mov / v_add_u32 / logic ops issue at ~2.4 cycles where every carry op costs
+// ~4.3), so the 128-bit product needs 4 mad + 2 carry adds instead of 4 mad + 6 carry adds.  Measured
+// (tools/ubench_mul.hip): 72.7 cycles per wave-multiply per SIMD against 91.2 for the four-independent-products form
+// and 81.4 for the three-product squaring -- so a square is just gl_mul(a, a).
 __device__ __forceinline__ u64 gl_mul(u64 a, u64 b) {
-    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    u64 P = (u64)a0 * b0, Q = (u64)a0 * b1, R = (u64)a1 * b0, S = (u64)a1 * b1;  // 4 v_mad_u64_u32
-    u32 lo, hi, t1, t2, t3, e, x0, x1;
-    asm("v_add_co_u32 %[x0], vcc, %[q0], %[r0]\n\t"          // X = Q + R (65 bit)
-        "v_addc_co_u32 %[x1], vcc, %[q1], %[r1], vcc\n\t"
-        "v_addc_co_u32 %[t3], vcc, 0, %[s1], vcc\n\t"        // t3 = S1 + carry(X)   (cannot overflow)
-        "v_add_co_u32 %[t1], vcc, %[p1], %[x0]\n\t"          // T1 = P1 + X0
-        "v_addc_co_u32 %[t2], vcc, %[s0], %[x1], vcc\n\t"    // T2 = S0 + X1 + c
-        "v_addc_co_u32 %[t3], vcc, 0, %[t3], vcc\n\t"        // T3 += c
-        GL_ASM_REDUCE
-        : [lo] "=&v"(lo), [hi] "=&v"(hi), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
-          [e] "=&v"(e), [x0] "=&v"(x0), [x1] "=&v"(x1)
-        : [p0] "v"((u32)P), [p1] "v"((u32)(P >> 32)), [q0] "v"((u32)Q), [q1] "v"((u32)(Q >> 32)),
-          [r0] "v"((u32)R), [r1] "v"((u32)(R >> 32)), [s0] "v"((u32)S), [s1] "v"((u32)(S >> 32))
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 P = (u64)a0 * b0;
+    const u64 M = (u64)a0 * b1 + (P >> 32);            // <= (2^32-1)^2 + 2^32 - 1: no overflow
+    const u64 M2 = (u64)a1 * b0 + (u32)M;              // likewise
+    const u64 H = (u64)a1 * b1 + (M >> 32) + (M2 >> 32);
+    u32 lo, hi, t1 = (u32)M2, t2 = (u32)H, t3 = (u32)(H >> 32), e;
+    asm(GL_ASM_REDUCE
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [t1] "+&v"(t1), [t2] "+&v"(t2), [t3] "+&v"(t3), [e] "=&v"(e)
+        : [p0] "v"((u32)P)
         : "vcc");
     return ((u64)hi << 32) | lo;
 }
 
-__device__ __forceinline__ u64 gl_sqr(u64 a) {
-    u32 a0 = (u32)a, a1 = (u32)(a >> 32);
-    u64 P = (u64)a0 * a0, Q = (u64)a0 * a1, S = (u64)a1 * a1;  // 3 v_mad_u64_u32
-    u64 X = Q << 1;                                            // v_lshlrev_b64
-    u32 c = (u32)(Q >> 63);
-    u32 lo, hi, t1, t2, t3, e;
-    asm("v_add_co_u32 %[t1], vcc, %[p1], %[x0]\n\t"
-        "v_addc_co_u32 %[t2], vcc, %[s0], %[x1], vcc\n\t"
-        "v_addc_co_u32 %[t3], vcc, %[s1], %[c], vcc\n\t"
-        GL_ASM_REDUCE
-        : [lo] "=&v"(lo), [hi] "=&v"(hi), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [e] "=&v"(e)
-        : [p0] "v"((u32)P), [p1] "v"((u32)(P >> 32)), [x0] "v"((u32)X), [x1] "v"((u32)(X >> 32)),
-          [c] "v"(c), [s0] "v"((u32)S), [s1] "v"((u32)(S >> 32))
-        : "vcc");
-    return ((u64)hi << 32) | lo;
-}
+__device__ __forceinline__ u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 
 // a, b arbitrary u64 representatives; result arbitrary representative of a+b.
 __device__ __forceinline__ u64 gl_add(u64 a, u64 b) {
