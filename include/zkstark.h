@@ -72,6 +72,14 @@ int zk_ctx_synchronize(zk_ctx *ctx);
 int zk_ctx_mem_reserve(zk_ctx *ctx, size_t bytes);
 int zk_ctx_mem_trim(zk_ctx *ctx, size_t *released);
 int zk_ctx_mem_stats(const zk_ctx *ctx, size_t *reserved, size_t *in_use, size_t *peak_in_use);
+/* Device buffers from the ctx arena for callers without a device-memory library of their own (the Rust shim; the Python
+ * mirror uses torch tensors, tests/cabi/segment.c the HIP runtime directly).  zk_dev_upload_columns copies host columns
+ * (`Vec<PolynomialValues<F>>`: cols[c] -> n elements) into a column-major device matrix d_out[c * col_stride + i] on the
+ * ctx stream and returns once the host memory may be reused. */
+int zk_dev_alloc(zk_ctx *ctx, size_t bytes, void **d_out);
+int zk_dev_free(zk_ctx *ctx, void *d_ptr);
+int zk_dev_upload_columns(zk_ctx *ctx, const uint64_t *const *cols, size_t n_cols, size_t n, uint64_t *d_out,
+                          size_t col_stride);
 const char *zk_last_error(const zk_ctx *ctx);
 /* Cooperative cancellation, polled between kernels: mirrors `abort_signal` /
  * `check_abort_signal` (evm_arithmetization/src/prover.rs:56,346-354). NULL disables. */

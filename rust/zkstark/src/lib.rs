@@ -1,0 +1,212 @@
+//! Safe layer over `zkstark-sys` (include/zkstark.h).  Mirrors the Python host mirror of this repository
+//! (`zk_evm_amd/context.py`, `polynomial_batch.py`, `segment.py`): RAII handles, `anyhow` errors carrying
+//! `zk_last_error`, owned copies of proofs.  No arithmetic happens here and there is no CPU fallback.
+use std::ffi::CStr;
+use std::ptr::{null, null_mut};
+use std::sync::atomic::AtomicI32;
+use std::sync::Arc;
+
+use anyhow::{anyhow, Result};
+pub use zkstark_sys as sys;
+use zkstark_sys::*;
+
+/// `StarkConfig` / `FriConfig` fields the path consumes (`StarkConfig::standard_fast_config()` by default).
+#[derive(Clone, Copy)]
+pub struct Config(pub zk_cfg);
+
+impl Config {
+    pub fn standard_fast(hasher: zk_hasher) -> Self {
+        Config(zk_cfg { rate_bits: 1, cap_height: 4, hasher: hasher as u32, num_challenges: 2, proof_of_work_bits: 16,
+                        num_query_rounds: 84, arity_bits: 4, final_poly_bits: 5 })
+    }
+}
+
+/// One `zk_ctx`: a GPU, a stream, an HBM arena.  Not `Sync`: a context must not be used by two threads at once
+/// (include/zkstark.h); create one per worker thread, several per GPU if segments should overlap.
+pub struct Context {
+    raw: *mut zk_ctx,
+    abort: Option<Arc<AtomicI32>>,
+}
+unsafe impl Send for Context {}
+
+impl Context {
+    pub fn new(device: i32) -> Result<Self> {
+        let mut raw = null_mut();
+        let rc = unsafe { zk_ctx_create(device, &mut raw) };
+        if rc != ZK_OK || raw.is_null() {
+            return Err(anyhow!("zk_ctx_create(device {device}) failed ({rc}): no usable HIP device (no CPU fallback)"));
+        }
+        Ok(Context { raw, abort: None })
+    }
+    pub fn raw(&self) -> *mut zk_ctx { self.raw }
+    pub fn check(&self, rc: i32) -> Result<()> {
+        if rc == ZK_OK { return Ok(()); }
+        if rc == ZK_ERR_ABORTED { return Err(anyhow!("Stopping job from abort signal.")); }   // prover.rs:346-354
+        let msg = unsafe { CStr::from_ptr(zk_last_error(self.raw)) }.to_string_lossy().into_owned();
+        Err(anyhow!("zkstark error {rc}: {msg}"))
+    }
+    /// `abort_signal` of `prove` (prover.rs:56): the flag is polled between kernels.  The reference uses an
+    /// `AtomicBool`; the shim keeps an `AtomicI32` twin that the abort handler sets alongside it.
+    pub fn set_abort_flag(&mut self, flag: Option<Arc<AtomicI32>>) -> Result<()> {
+        let p = flag.as_ref().map(|f| f.as_ptr() as *const i32).unwrap_or(null());
+        let rc = unsafe { zk_ctx_set_abort_flag(self.raw, p) };
+        self.abort = flag;
+        self.check(rc)
+    }
+    pub fn mem_reserve(&self, bytes: usize) -> Result<()> { self.check(unsafe { zk_ctx_mem_reserve(self.raw, bytes) }) }
+    pub fn synchronize(&self) -> Result<()> { self.check(unsafe { zk_ctx_synchronize(self.raw) }) }
+    /// [ifft, lde, leaf hash, tree] ms of the last commit: children of the reference's "compute trace commitment" scope.
+    pub fn last_timings(&self) -> Result<[f32; 4]> {
+        let mut t = [0f32; 4];
+        self.check(unsafe { zk_ctx_last_timings(self.raw, t.as_mut_ptr()) })?;
+        Ok(t)
+    }
+}
+impl Drop for Context {
+    fn drop(&mut self) { unsafe { zk_ctx_destroy(self.raw) } }
+}
+
+/// `PolynomialBatch::from_values` result, resident in HBM.
+pub struct Batch<'c> { ctx: &'c Context, raw: *mut zk_batch, cap_digests: usize }
+
+impl<'c> Batch<'c> {
+    /// `cols[c]` = the `values` of `PolynomialValues<GoldilocksField>` number c (`#[repr(transparent)]` over u64;
+    /// non-canonical representatives are fine).  Replaces prover.rs:100-107 without the `trace.clone()`.
+    pub fn from_values(ctx: &'c Context, cfg: &Config, cols: &[&[u64]]) -> Result<Self> {
+        let n = cols.first().map(|c| c.len()).unwrap_or(0);
+        if n == 0 || !n.is_power_of_two() || cols.iter().any(|c| c.len() != n) {
+            return Err(anyhow!("columns must have one power-of-two length"));
+        }
+        let ptrs: Vec<*const u64> = cols.iter().map(|c| c.as_ptr()).collect();
+        let mut raw = null_mut();
+        ctx.check(unsafe { zk_commit_columns(ctx.raw, &cfg.0, ptrs.as_ptr(), ptrs.len(), n.trailing_zeros(), &mut raw) })?;
+        Ok(Batch { ctx, raw, cap_digests: 1usize << cfg.0.cap_height })
+    }
+    /// `merkle_tree.cap` as 32-byte slots (Poseidon: 4 x u64; Keccak-25: 25 bytes + padding).
+    pub fn cap(&self) -> Result<Vec<[u64; 4]>> {
+        let mut out = vec![[0u64; 4]; self.cap_digests];
+        self.ctx.check(unsafe { zk_batch_cap(self.raw, out.as_mut_ptr() as *mut u64) })?;
+        Ok(out)
+    }
+    pub fn raw(&self) -> *const zk_batch { self.raw }
+}
+impl Drop for Batch<'_> {
+    fn drop(&mut self) { unsafe { zk_batch_free(self.raw) } }
+}
+
+/// A column-major `[cols][rows]` device matrix from the context's arena (`zk_dev_alloc` / `zk_dev_upload_columns`).
+pub struct DeviceMatrix<'c> { ctx: &'c Context, ptr: *mut u64, cols: usize, rows: usize }
+
+impl<'c> DeviceMatrix<'c> {
+    pub fn upload(ctx: &'c Context, cols: &[&[u64]]) -> Result<Self> {
+        let rows = cols.first().map(|c| c.len()).unwrap_or(0);
+        let mut p: *mut core::ffi::c_void = null_mut();
+        ctx.check(unsafe { zk_dev_alloc(ctx.raw, 8 * rows * cols.len(), &mut p) })?;
+        let m = DeviceMatrix { ctx, ptr: p as *mut u64, cols: cols.len(), rows };
+        let ptrs: Vec<*const u64> = cols.iter().map(|c| c.as_ptr()).collect();
+        ctx.check(unsafe { zk_dev_upload_columns(ctx.raw, ptrs.as_ptr(), ptrs.len(), rows, m.ptr, rows) })?;
+        Ok(m)
+    }
+    pub fn ptr(&self) -> *const u64 { self.ptr }
+    pub fn cols(&self) -> usize { self.cols }
+    pub fn rows(&self) -> usize { self.rows }
+}
+impl Drop for DeviceMatrix<'_> {
+    fn drop(&mut self) { unsafe { zk_dev_free(self.ctx.raw, self.ptr as *mut core::ffi::c_void); } }
+}
+
+/// One table handed to `prove_segment` (`zk_table_in`): device trace + the table's static description.
+pub struct TableIn<'a> {
+    pub d_trace: *const u64,
+    pub col_stride: usize,
+    pub n_cols: usize,
+    pub log_n: u32,
+    pub air_id: zk_air,
+    pub air_consts: &'a [u64],
+    pub lookup_program: &'a [u64],
+    pub in_use: bool,
+    pub optional: bool,
+}
+
+/// `StarkProofWithMetadata` in the flat layout of `zk_table_proof_view` (owned copy).
+#[derive(Clone, Debug)]
+pub struct TableProof {
+    pub degree_bits: u32,
+    pub n_trace_cols: usize,
+    pub n_aux_cols: usize,
+    pub n_quotient_cols: usize,
+    pub n_ctl_zs: usize,
+    pub trace_cap: Vec<[u64; 4]>,
+    pub aux_cap: Option<Vec<[u64; 4]>>,
+    pub quotient_cap: Vec<[u64; 4]>,
+    /// (c0, c1) per opened value: at zeta (trace, aux, quotient), at g*zeta (trace, aux), at 1 (ctl_zs_first)
+    pub openings: Vec<[u64; 2]>,
+    /// flat `FriProof`, layout documented at `zk_fri_prove_openings`
+    pub opening_proof: Vec<u64>,
+    pub init_challenger_state: [u64; 12],
+}
+
+/// `AllProof` minus the `PublicValues` the caller already owns.
+#[derive(Clone, Debug)]
+pub struct SegmentProof {
+    pub tables: Vec<Option<TableProof>>,
+    pub ctl_challenges: Vec<(u64, u64)>,
+    /// `MemCap::from_merkle_cap` of the MemBefore / MemAfter trace caps (prover.rs:261-271), as `to_vec` elements
+    pub mem_before: Vec<[u64; 4]>,
+    pub mem_after: Vec<[u64; 4]>,
+    /// ms: [0] "compute all trace commitments", [1] "compute CTL data", [2 + t] "prove <stark field> STARK"
+    pub stage_ms: Vec<f64>,
+}
+
+unsafe fn caps(p: *const u64, n: usize) -> Vec<[u64; 4]> {
+    (0..n).map(|i| { let s = std::slice::from_raw_parts(p.add(4 * i), 4); [s[0], s[1], s[2], s[3]] }).collect()
+}
+
+/// `prove_with_traces` (prover.rs:72-194) as one call.  `ctl_wiring` / the lookup programs are the encodings of
+/// `all_stark.cross_table_lookups` and each table's `lookups()` (shipped ready-made in include/zk_all_stark.h).
+pub fn prove_segment(ctx: &Context, cfg: &Config, tables: &[TableIn], ctl_wiring: &[u64], public_value_elements: &[u64],
+                     constraint_degree: u32, mem_before_table: i32, mem_after_table: i32) -> Result<SegmentProof> {
+    let tin: Vec<zk_table_in> = tables.iter().map(|t| zk_table_in {
+        d_trace: t.d_trace, col_stride: t.col_stride, n_cols: t.n_cols, log_n: t.log_n, air_id: t.air_id as u32,
+        air_consts: if t.air_consts.is_empty() { null() } else { t.air_consts.as_ptr() }, n_air_consts: t.air_consts.len(),
+        lookup_program: if t.lookup_program.is_empty() { null() } else { t.lookup_program.as_ptr() },
+        lookup_words: t.lookup_program.len(), in_use: t.in_use as i32, optional: t.optional as i32,
+    }).collect();
+    let mut h: *mut zk_segment_proof = null_mut();
+    ctx.check(unsafe {
+        zk_prove_segment(ctx.raw, &cfg.0, tin.as_ptr(), tin.len(), ctl_wiring.as_ptr(), ctl_wiring.len(),
+                         public_value_elements.as_ptr(), public_value_elements.len(), constraint_degree,
+                         mem_before_table, mem_after_table, &mut h)
+    })?;
+    struct Guard(*mut zk_segment_proof);
+    impl Drop for Guard { fn drop(&mut self) { unsafe { zk_segment_proof_free(self.0) } } }
+    let _g = Guard(h);
+    let nd = 1usize << cfg.0.cap_height;
+    let mut out = SegmentProof { tables: Vec::new(), ctl_challenges: Vec::new(), mem_before: vec![[0; 4]; nd],
+                                 mem_after: vec![[0; 4]; nd], stage_ms: vec![0.0; 2 + tables.len()] };
+    unsafe {
+        let mut cc = vec![0u64; 2 * cfg.0.num_challenges as usize];
+        zk_segment_proof_ctl_challenges(h, cc.as_mut_ptr(), cc.len());
+        out.ctl_challenges = cc.chunks(2).map(|c| (c[0], c[1])).collect();
+        zk_segment_proof_mem_caps(h, out.mem_before.as_mut_ptr() as *mut u64, out.mem_after.as_mut_ptr() as *mut u64, 4 * nd);
+        zk_segment_proof_stage_ms(h, out.stage_ms.as_mut_ptr(), out.stage_ms.len());
+        for t in 0..tables.len() {
+            let tp = zk_segment_proof_table(h, t);
+            if tp.is_null() { out.tables.push(None); continue; }
+            let mut v: zk_table_proof_view = std::mem::zeroed();
+            ctx.check(zk_table_proof_get(tp, &mut v))?;
+            let op = std::slice::from_raw_parts(v.openings, 2 * v.n_openings);
+            out.tables.push(Some(TableProof {
+                degree_bits: v.degree_bits, n_trace_cols: v.n_trace_cols, n_aux_cols: v.n_aux_cols,
+                n_quotient_cols: v.n_quotient_cols, n_ctl_zs: v.n_ctl_zs,
+                trace_cap: caps(v.trace_cap, v.cap_digests),
+                aux_cap: if v.aux_cap.is_null() { None } else { Some(caps(v.aux_cap, v.cap_digests)) },
+                quotient_cap: caps(v.quotient_cap, v.cap_digests),
+                openings: op.chunks(2).map(|c| [c[0], c[1]]).collect(),
+                opening_proof: std::slice::from_raw_parts(v.opening_proof, v.proof_words).to_vec(),
+                init_challenger_state: v.init_challenger_state,
+            }));
+        }
+    }
+    Ok(out)
+}

@@ -34,6 +34,9 @@ SIGNATURES = {
     "zk_ctx_mem_reserve": (C.c_int, [vp, sz]),
     "zk_ctx_mem_trim": (C.c_int, [vp, C.POINTER(sz)]),
     "zk_ctx_mem_stats": (C.c_int, [vp, C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]),
+    "zk_dev_alloc": (C.c_int, [vp, sz, C.POINTER(vp)]),
+    "zk_dev_free": (C.c_int, [vp, vp]),
+    "zk_dev_upload_columns": (C.c_int, [vp, C.POINTER(vp), sz, sz, u64p, sz]),
     "zk_last_error": (C.c_char_p, [vp]),
     "zk_ctx_set_abort_flag": (C.c_int, [vp, vp]),
     "zk_ctx_last_timings": (C.c_int, [vp, C.POINTER(C.c_float)]),

@@ -122,6 +122,31 @@ extern "C" int zk_ctx_mem_stats(const zk_ctx *ctx, size_t *reserved, size_t *in_
     if (peak_in_use) *peak_in_use = ctx->arena.peak_in_use;
     return ZK_OK;
 }
+extern "C" int zk_dev_alloc(zk_ctx *ctx, size_t bytes, void **d_out) {
+    if (!ctx || !d_out) return ZK_ERR_BAD_ARG;
+    *d_out = nullptr;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = ctx->arena.alloc(d_out, bytes ? bytes : 8);
+    if (e != hipSuccess) return set_err(ctx, e == hipErrorOutOfMemory ? ZK_ERR_OOM : ZK_ERR_HIP, "device arena: %s", hipGetErrorString(e));
+    return ZK_OK;
+}
+extern "C" int zk_dev_free(zk_ctx *ctx, void *d_ptr) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    if (d_ptr) ctx->arena.free(d_ptr);
+    return ZK_OK;
+}
+extern "C" int zk_dev_upload_columns(zk_ctx *ctx, const uint64_t *const *cols, size_t n_cols, size_t n, uint64_t *d_out,
+                                     size_t col_stride) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    if (!cols || !d_out || col_stride < n) return set_err(ctx, ZK_ERR_BAD_ARG, "bad upload arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (size_t c = 0; c < n_cols; ++c) {
+        if (!cols[c]) return set_err(ctx, ZK_ERR_BAD_ARG, "null column %zu", c);
+        HIP_TRY(ctx, hipMemcpyAsync(d_out + c * col_stride, cols[c], n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return ZK_OK;
+}
 extern "C" int zk_ctx_synchronize(zk_ctx *ctx) {
     if (!ctx) return ZK_ERR_BAD_ARG;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
