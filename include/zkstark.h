@@ -354,6 +354,67 @@ size_t zk_segment_proof_mem_caps(const zk_segment_proof *proof, uint64_t *mem_be
 size_t zk_segment_proof_stage_ms(const zk_segment_proof *proof, double *out, size_t max);
 void zk_segment_proof_free(zk_segment_proof *proof);
 
+/* ---- PLONK prover for the recursion layer -----------------------------------------
+ * plonky2 1.0.0 `prove` ([EXT] plonky2/src/plonk/prover.rs `prove_with_partition_witness`) as the reference runs it after
+ * every segment STARK: `StarkWrapperCircuit::prove` / `shrink` and `root.circuit.prove`
+ * (evm_arithmetization/src/fixed_recursive_verifier.rs:2146, 3167-3179; `CircuitConfig::standard_recursion_config()`:
+ * 135 wires, 80 routed, 2 challenges, quotient degree factor 8, FRI rate_bits 3, cap 4, 28 queries, 16 PoW bits).
+ * This slice covers the whole protocol skeleton -- wires commitment, transcript, permutation argument (partial products
+ * and Zs), selector-filtered gate constraints, quotient, openings, FRI over the four oracles -- for circuits built from the
+ * gate kinds below; the remaining gate types of the recursion circuits are listed in DESIGN.md (PLONK plan).  Witness
+ * generation (running the generators) stays with the caller. */
+typedef enum {
+    ZK_PLONK_GATE_NOOP = 0,          /* gates/noop.rs */
+    ZK_PLONK_GATE_CONSTANT = 1,      /* gates/constant.rs `ConstantGate { num_consts = param }` */
+    ZK_PLONK_GATE_PUBLIC_INPUT = 2,  /* gates/public_input.rs */
+    ZK_PLONK_GATE_ARITHMETIC = 3,    /* gates/arithmetic_base.rs `ArithmeticGate { num_ops = param }` */
+} zk_plonk_gate_kind;
+/* one entry of `common_data.gates` (sorted by (degree, id) as the builder sorts them) with its selector:
+ * `selectors_info.selector_indices[gate]` and `selectors_info.groups[selector_index]` = [group_start, group_end) */
+typedef struct {
+    uint32_t kind, param, selector_index, group_start, group_end;
+} zk_plonk_gate;
+typedef struct {
+    uint32_t degree_bits;
+    uint32_t num_wires, num_routed_wires;
+    uint32_t num_constants;          /* columns of the constants part: selectors first, then the gates' constants */
+    uint32_t num_selectors;
+    uint32_t quotient_degree_factor; /* 8; the partial-product chunk size */
+    uint32_t num_gate_constraints;   /* max over the gates */
+    zk_cfg fri;                      /* rate_bits 3, cap_height 4, num_challenges 2, ... (hasher: Poseidon) */
+} zk_plonk_common;
+typedef struct zk_plonk_circuit zk_plonk_circuit;
+typedef struct zk_plonk_proof zk_plonk_proof;
+/* d_constants_sigmas: device, column-major, (num_constants + num_routed_wires) columns of 2^degree_bits VALUES:
+ * the selector / constant polynomials, then the sigma polynomials (`sigma_j(w^i)` = k_{j'} w^{i'} of the cell the
+ * permutation maps (i, j) to).  Commits them once (`constants_sigmas_commitment`).  k_is: `get_unique_coset_shifts`. */
+int zk_plonk_circuit_create(zk_ctx *ctx, const zk_plonk_common *common, const zk_plonk_gate *gates, size_t n_gates,
+                            const uint64_t *d_constants_sigmas, size_t col_stride, const uint64_t *k_is,
+                            const uint64_t circuit_digest[4], zk_plonk_circuit **out);
+void zk_plonk_circuit_free(zk_plonk_circuit *circuit);
+/* `constants_sigmas_cap` (verifier data): 2^cap_height 32-byte slots */
+int zk_plonk_circuit_cap(const zk_plonk_circuit *circuit, uint64_t *out);
+/* d_wires: device, column-major witness `wire_values[wire][row]` (num_wires columns).  The proof is host memory owned by
+ * the library until zk_plonk_proof_free. */
+int zk_plonk_prove(zk_plonk_circuit *circuit, const uint64_t *d_wires, size_t col_stride, const uint64_t *public_inputs,
+                   size_t n_public_inputs, zk_plonk_proof **out);
+typedef struct {
+    size_t cap_digests;
+    const uint64_t *wires_cap;                       /* Proof.wires_cap */
+    const uint64_t *plonk_zs_partial_products_cap;   /* Proof.plonk_zs_partial_products_cap */
+    const uint64_t *quotient_polys_cap;              /* Proof.quotient_polys_cap */
+    const uint64_t *openings;                        /* OpeningSet, 2 u64 per value, in `to_fri_openings` order: constants,
+                                                        plonk_sigmas, wires, plonk_zs, partial_products, quotient_polys (at
+                                                        zeta), then plonk_zs_next (at g * zeta) */
+    size_t n_openings;
+    const uint64_t *opening_proof;                   /* flat FriProof (layout under zk_fri_prove_openings), 4 oracles */
+    size_t proof_words;
+    uint64_t public_inputs_hash[4];
+    double stage_ms[6];   /* [0] wires commitment [1] partial products + commitment [2] quotient + commitment [3] openings [4] FRI */
+} zk_plonk_proof_view;
+int zk_plonk_proof_get(const zk_plonk_proof *proof, zk_plonk_proof_view *view);
+void zk_plonk_proof_free(zk_plonk_proof *proof);
+
 /* ---- trace finalisation on the device -------------------------------------
  * Keccak table: replaces `KeccakStark::generate_trace_rows` (evm_arithmetization/src/keccak/keccak_stark.rs:65-234):
  * 24 rows x 2431 columns per permutation from its 25-word input (reference order input[y*5 + x]) and the timestamp

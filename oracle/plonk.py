@@ -1,0 +1,549 @@
+"""oracle/plonk.py -- TEST INFRASTRUCTURE ONLY (CPU oracle; never imported by the product).
+
+Restatement of the plonky2 1.0.0 PLONK prover and verifier for the recursion layer: what the
+reference runs after every segment STARK -- `StarkWrapperCircuit::prove` / `shrink` and `root.circuit.prove`
+(evm_arithmetization/src/fixed_recursive_verifier.rs:2146, 3167-3179; circuit configs :69, 3081-3165 =
+`CircuitConfig::standard_recursion_config()`: 135 wires, 80 routed, 2 constants, 2 challenges, quotient degree factor
+8, FRI rate_bits 3 / cap 4 / 28 queries / 16 PoW bits / arity 4).  The arithmetic lives in the un-vendored crate
+plonky2 1.0.0 (Cargo.lock:3702-3705): [EXT] plonk/prover.rs `prove_with_partition_witness`, plonk/vanishing_poly.rs
+`eval_vanishing_poly(_base_batch)`, plonk/plonk_common.rs (`ZeroPolyOnCoset`, `reduce_with_powers_multi`),
+plonk/permutation_argument.rs + plonk/prover.rs `wires_permutation_partial_products_and_zs`,
+gates/selectors.rs, gates/gate.rs `eval_filtered` / `compute_filter`, gates/{arithmetic_base, constant,
+public_input, noop}.rs, plonk/proof.rs `OpeningSet`, plonk/circuit_data.rs `get_fri_instance`,
+plonk/verifier.rs `verify_with_challenges`.  PARITY UNPINNED: the reference tree holds no golden PLONK proof and
+cannot be built here; this file is self-consistent (prover <-> verifier) and the HIP library must equal it word for
+word.
+
+Scope of this slice: the permutation argument, the public-input binding, selectors and the four gate types a circuit
+of constants and base-field arithmetic needs.  The recursion circuits add Poseidon / PoseidonMds / BaseSum /
+RandomAccess / Reducing(+Extension) / ArithmeticExtension / MulExtension / Exponentiation / CosetInterpolation gates:
+DESIGN.md (PLONK plan) lists them with their constraint counts; the vanishing-polynomial driver below is already
+written against a gate list, not against these four.
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+
+from . import stark as S
+from . import tape as T
+
+P = S.P
+G = S.G                      # F::coset_shift() == MULTIPLICATIVE_GROUP_GENERATOR
+UNUSED_SELECTOR = (1 << 32) - 1
+
+
+# ---- quadratic extension (verifier side only) ---------------------------------------------------------------------
+class Ext:
+    """F_p[X]/(X^2 - 7) with the operators the vanishing-polynomial code uses (+ - * with Ext / int)."""
+    __slots__ = ("a", "b")
+
+    def __init__(self, a, b=0):
+        self.a, self.b = a % P, b % P
+
+    @staticmethod
+    def of(x):
+        return x if isinstance(x, Ext) else Ext(int(x))
+
+    def __add__(self, o):
+        o = Ext.of(o)
+        return Ext(self.a + o.a, self.b + o.b)
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        o = Ext.of(o)
+        return Ext(self.a - o.a, self.b - o.b)
+
+    def __rsub__(self, o):
+        return Ext.of(o) - self
+
+    def __mul__(self, o):
+        o = Ext.of(o)
+        return Ext(self.a * o.a + 7 * self.b * o.b, self.a * o.b + self.b * o.a)
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return Ext(-self.a, -self.b)
+
+    def __eq__(self, o):
+        o = Ext.of(o)
+        return self.a == o.a and self.b == o.b
+
+    def inverse(self):
+        nrm = pow((self.a * self.a - 7 * self.b * self.b) % P, P - 2, P)
+        return Ext(self.a * nrm, -self.b * nrm)
+
+    def pow(self, e):
+        r, b = Ext(1), self
+        while e:
+            if e & 1:
+                r = r * b
+            b = b * b
+            e >>= 1
+        return r
+
+
+# ---- gates ([EXT] plonky2 gates/*.rs).  eval_unfiltered(local_constants (selectors removed), local_wires, pi_hash) ---
+class NoopGate:
+    id, degree, num_constants, num_constraints = "NoopGate", 0, 0, 0
+    KIND, PARAM = 0, 0
+
+    def eval_unfiltered(self, consts, wires, pi_hash):
+        return []
+
+
+class ConstantGate:
+    """gates/constant.rs: wire i carries constant i."""
+    degree = 1
+    KIND = 1
+
+    def __init__(self, num_consts=2):
+        self.num_consts = self.num_constants = self.num_constraints = self.PARAM = num_consts
+        self.id = "ConstantGate { num_consts: %d }" % num_consts
+
+    def eval_unfiltered(self, consts, wires, pi_hash):
+        return [consts[i] - wires[i] for i in range(self.num_consts)]
+
+
+class PublicInputGate:
+    """gates/public_input.rs: wires 0..3 equal the hash of the public inputs."""
+    id, degree, num_constants, num_constraints = "PublicInputGate", 1, 0, 4
+    KIND, PARAM = 2, 0
+
+    def eval_unfiltered(self, consts, wires, pi_hash):
+        return [wires[i] - pi_hash[i] for i in range(4)]
+
+
+class ArithmeticGate:
+    """gates/arithmetic_base.rs: num_ops x (output = c0 * multiplicand_0 * multiplicand_1 + c1 * addend);
+    wires of op i: 4i (multiplicand_0), 4i+1 (multiplicand_1), 4i+2 (addend), 4i+3 (output)."""
+    degree, num_constants = 3, 2
+    KIND = 3
+
+    def __init__(self, num_ops=20):                      # new_from_config: num_routed_wires / 4
+        self.num_ops = self.num_constraints = self.PARAM = num_ops
+        self.id = "ArithmeticGate { num_ops: %d }" % num_ops
+
+    def eval_unfiltered(self, consts, wires, pi_hash):
+        c0, c1 = consts[0], consts[1]
+        return [wires[4 * i + 3] - (wires[4 * i] * wires[4 * i + 1] * c0 + wires[4 * i + 2] * c1)
+                for i in range(self.num_ops)]
+
+
+@dataclass
+class CircuitConfig:
+    """CircuitConfig::standard_recursion_config()"""
+    num_wires: int = 135
+    num_routed_wires: int = 80
+    num_constants: int = 2
+    num_challenges: int = 2
+    max_quotient_degree_factor: int = 8
+    rate_bits: int = 3
+    cap_height: int = 4
+    proof_of_work_bits: int = 16
+    num_query_rounds: int = 28
+    arity_bits: int = 4
+    final_poly_bits: int = 5
+    hasher: int = 0
+
+
+def selector_polynomials(gates, instance_gate_index, max_degree):
+    """[EXT] gates/selectors.rs `selector_polynomials`.  gates: sorted by (degree, id); instance_gate_index[row] = index
+    into gates.  -> (selector columns [n_sel][n] of ints, selector_indices[gate], groups[(start, end)])"""
+    n, num_gates = len(instance_gate_index), len(gates)
+    max_gate_degree = gates[-1].degree
+    if max_gate_degree + num_gates - 1 <= max_degree:
+        return [list(instance_gate_index)], [0] * num_gates, [(0, num_gates)]
+    assert max_gate_degree < max_degree, "No gate can be added: all degrees are too high"
+    groups, start = [], 0
+    while start < num_gates:
+        size = 0
+        while start + size < num_gates and size + gates[start + size].degree < max_degree:
+            size += 1
+        groups.append((start, start + size))
+        start += size
+    group_of = lambda i: next(k for k, (a, b) in enumerate(groups) if a <= i < b)
+    sel = [[UNUSED_SELECTOR] * n for _ in groups]
+    for row, gi in enumerate(instance_gate_index):
+        sel[group_of(gi)][row] = gi
+    return sel, [group_of(i) for i in range(num_gates)], groups
+
+
+def get_unique_coset_shifts(num_shifts):
+    """[EXT] plonk_common / field `get_unique_coset_shifts`: g^0 .. g^(num_shifts - 1)."""
+    out, x = [], 1
+    for _ in range(num_shifts):
+        out.append(x)
+        x = x * G % P
+    return out
+
+
+@dataclass
+class Circuit:
+    """What `ProverOnlyCircuitData` + `CommonCircuitData` hold for this prover."""
+    config: CircuitConfig
+    degree_bits: int
+    gates: list
+    selector_indices: List[int]
+    groups: List[tuple]
+    num_selectors: int
+    constants: np.ndarray            # [num_constants_total][n]: selectors first, then gate constants
+    sigmas: np.ndarray               # [num_routed][n]  (values k_{j'} * w^{i'} of the permuted cell)
+    k_is: List[int]
+    circuit_digest: List[int]
+    quotient_degree_factor: int = 8
+    constants_sigmas_commit: dict = field(default=None, repr=False)
+
+    @property
+    def n(self): return 1 << self.degree_bits
+    @property
+    def num_constants_total(self): return self.constants.shape[0]
+    @property
+    def num_partial_products(self):
+        return -(-self.config.num_routed_wires // self.quotient_degree_factor) - 1
+    @property
+    def num_gate_constraints(self): return max(g.num_constraints for g in self.gates)
+
+    def gate_descriptors(self):
+        """(kind, param, selector_index, group_start, group_end) per gate: the zk_plonk_gate records of the C ABI"""
+        return [(g.KIND, g.PARAM, self.selector_indices[i], *self.groups[self.selector_indices[i]])
+                for i, g in enumerate(self.gates)]
+
+
+def compute_filter(row, group, s, many_selector):
+    """[EXT] gates/gate.rs `compute_filter`"""
+    f = 1
+    for i in list(range(group[0], group[1])) + ([UNUSED_SELECTOR] if many_selector else []):
+        if i != row:
+            f = f * (i - s)
+    return f
+
+
+def eval_vanishing_terms(c: Circuit, x, l0_x, local_constants, s_sigmas, local_wires, local_zs, next_zs, partial_products,
+                         pi_hash, betas, gammas):
+    """[EXT] vanishing_poly.rs: all terms of the vanishing polynomial at one point, in the order they are alpha-combined:
+    L_0(x) (Z(x) - 1) per challenge, the partial-product checks per challenge, then the gate constraints.  Generic over
+    the element type (tape symbols on the prover side, Ext at zeta on the verifier side)."""
+    cfg = c.config
+    nr, chunk, num_prods = cfg.num_routed_wires, c.quotient_degree_factor, c.num_partial_products
+    z1_terms, pp_terms = [], []
+    for i in range(cfg.num_challenges):
+        z_x, z_gx = local_zs[i], next_zs[i]
+        z1_terms.append(l0_x * (z_x - 1))
+        nums = [local_wires[j] + betas[i] * (c.k_is[j] * x) + gammas[i] for j in range(nr)]
+        dens = [local_wires[j] + betas[i] * s_sigmas[j] + gammas[i] for j in range(nr)]
+        accs = [z_x] + list(partial_products[i * num_prods:(i + 1) * num_prods]) + [z_gx]
+        for k in range(0, nr, chunk):                    # check_partial_products
+            num_p, den_p = 1, 1
+            for v in nums[k:k + chunk]:
+                num_p = num_p * v
+            for v in dens[k:k + chunk]:
+                den_p = den_p * v
+            pp_terms.append(accs[k // chunk] * num_p - accs[k // chunk + 1] * den_p)
+    # evaluate_gate_constraints: constraints of different gates share slots (at most one filter is non-zero per row)
+    gate_terms = [0] * c.num_gate_constraints
+    many = c.num_selectors > 1
+    for gi, g in enumerate(c.gates):
+        si = c.selector_indices[gi]
+        filt = compute_filter(gi, c.groups[si], local_constants[si], many)
+        for j, v in enumerate(g.eval_unfiltered(local_constants[c.num_selectors:], local_wires, pi_hash)):
+            gate_terms[j] = gate_terms[j] + filt * v
+    return z1_terms + pp_terms + gate_terms
+
+
+# ---- a small circuit family for the tests -----------------------------------------------------------------------------
+def build_arithmetic_circuit(degree_bits, seed, cfg: CircuitConfig = None, n_public_inputs=3):
+    """A valid circuit + witness over {Noop, Constant, PublicInput, Arithmetic} gates: one PublicInputGate row, a few
+    ConstantGate rows, rows of 20 multiply-adds whose operands are wired to earlier outputs / constants (so the
+    permutation argument carries real copy constraints), Noop padding.  -> (Circuit, wires [135][n] uint64,
+    public_inputs).  The builder side of plonky2 (generators, in-circuit hashing of the public inputs) is not restated:
+    the prover takes the finished circuit data and witness, which is what is produced here."""
+    cfg = cfg or CircuitConfig()
+    rng = np.random.default_rng(seed)
+    n = 1 << degree_bits
+    gates = sorted([NoopGate(), ConstantGate(cfg.num_constants), PublicInputGate(), ArithmeticGate(cfg.num_routed_wires // 4)],
+                   key=lambda g: (g.degree, g.id))
+    gidx = {type(g): i for i, g in enumerate(gates)}
+    rnd = lambda: int(rng.integers(0, P, dtype=np.uint64))
+    wires = [[0] * n for _ in range(cfg.num_wires)]
+    gate_of_row = [gidx[NoopGate]] * n
+    gate_consts = [[0] * n for _ in range(cfg.num_constants)]
+    parent = {}
+
+    def find(a):
+        while parent.setdefault(a, a) != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    def connect(a, b):
+        parent[find(a)] = find(b)
+    public_inputs = [rnd() for _ in range(n_public_inputs)]
+    gate_of_row[0] = gidx[PublicInputGate]               # wires 0..3 of row 0 are set to the hash by the prover's caller
+    n_const_rows = max(1, n // 64)
+    pool = []                                            # (cell, value) usable as operands
+    for r in range(1, 1 + n_const_rows):
+        gate_of_row[r] = gidx[ConstantGate]
+        for i in range(cfg.num_constants):
+            v = rnd()
+            gate_consts[i][r] = v
+            wires[i][r] = v
+            pool.append(((r, i), v))
+    first_arith = 1 + n_const_rows
+    n_arith = max(1, (n - first_arith) * 3 // 4)
+    for r in range(first_arith, first_arith + n_arith):
+        gate_of_row[r] = gidx[ArithmeticGate]
+        c0, c1 = rnd(), rnd()
+        gate_consts[0][r], gate_consts[1][r] = c0, c1
+        for op in range(cfg.num_routed_wires // 4):
+            vals = []
+            for k in range(3):
+                cell = (r, 4 * op + k)
+                if rng.random() < 0.7:
+                    src, v = pool[int(rng.integers(0, len(pool)))]
+                    connect(cell, src)
+                else:
+                    v = rnd()
+                wires[4 * op + k][r] = v
+                vals.append(v)
+            out = (vals[0] * vals[1] % P * c0 + vals[2] * c1) % P
+            wires[4 * op + 3][r] = out
+            pool.append(((r, 4 * op + 3), out))
+        if len(pool) > 4096:
+            pool = pool[-4096:]
+    for w in range(cfg.num_routed_wires, cfg.num_wires):  # unrouted wires: free advice
+        for r in range(n):
+            wires[w][r] = rnd()
+    sel, selector_indices, groups = selector_polynomials(gates, gate_of_row, cfg.max_quotient_degree_factor + 1)
+    constants = np.array(sel + gate_consts, dtype=np.uint64)
+    # sigma: every copy-constraint class becomes one cycle ([EXT] permutation_argument.rs `get_sigma_polys`)
+    k_is = get_unique_coset_shifts(cfg.num_routed_wires)
+    w = S.root_of_unity(degree_bits)
+    subgroup = [1] * n
+    for i in range(1, n):
+        subgroup[i] = subgroup[i - 1] * w % P
+    classes = {}
+    for r in range(n):
+        for j in range(cfg.num_routed_wires):
+            classes.setdefault(find((r, j)), []).append((r, j))
+    sigmas = np.zeros((cfg.num_routed_wires, n), dtype=np.uint64)
+    for cells in classes.values():
+        for a, b in zip(cells, cells[1:] + cells[:1]):
+            sigmas[a[1], a[0]] = k_is[b[1]] * subgroup[b[0]] % P
+    circ = Circuit(cfg, degree_bits, gates, selector_indices, groups, len(sel), constants, sigmas, k_is,
+                   [rnd() for _ in range(4)])
+    return circ, np.array(wires, dtype=np.uint64), public_inputs
+
+
+def set_public_input_wires(o, circ, wires, public_inputs):
+    """the PublicInputGate row carries hash_no_pad(public_inputs) in wires 0..3 -> (wires, pi_hash)"""
+    h = [int(x) for x in o.poseidon_hash_no_pad(np.array(public_inputs, dtype=np.uint64))]
+    row = next(r for r in range(circ.n) if int(circ.constants[0][r]) == next(i for i, g in enumerate(circ.gates)
+                                                                            if isinstance(g, PublicInputGate)))
+    for i in range(4):
+        wires[i, row] = h[i]
+    return wires, h
+
+
+def _fri_cfg(fri_api, cfg: CircuitConfig):
+    return fri_api.make_cfg(rate_bits=cfg.rate_bits, cap_height=cfg.cap_height, hasher=cfg.hasher,
+                            num_challenges=cfg.num_challenges, pow_bits=cfg.proof_of_work_bits,
+                            queries=cfg.num_query_rounds, arity_bits=cfg.arity_bits, final_poly_bits=cfg.final_poly_bits)
+
+
+def _setup(L):
+    if getattr(L, "_plonk_ready", False):
+        return
+    vp = C.c_void_p
+    L.orc_plonk_partial_products.restype = C.c_int
+    L.orc_plonk_partial_products.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_uint, C.c_uint64, C.c_uint64, vp]
+    L.orc_plonk_quotient_values.restype = C.c_int
+    L.orc_plonk_quotient_values.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t,
+                                            vp, C.c_size_t, C.c_uint, C.c_uint, C.c_uint, vp, C.c_size_t, vp]
+    L._plonk_ready = True
+
+
+def commit_circuit(o, circ: Circuit):
+    """`constants_sigmas_commitment` (circuit_builder.rs `build`: from_values of constants ++ sigmas, no blinding)"""
+    if circ.constants_sigmas_commit is None:
+        cs = np.ascontiguousarray(np.concatenate([circ.constants, circ.sigmas]), dtype=np.uint64)
+        circ.constants_sigmas_commit = o.commit_values(cs, rate_bits=circ.config.rate_bits,
+                                                       cap_height=circ.config.cap_height, hasher=circ.config.hasher)
+    return circ.constants_sigmas_commit
+
+
+def fri_instance(fri_api, circ: Circuit, zeta, g_zeta):
+    """[EXT] circuit_data.rs `get_fri_instance`: every polynomial of the four oracles at zeta, the Zs at g * zeta."""
+    cfg = circ.config
+    n0 = circ.num_constants_total + cfg.num_routed_wires
+    n2 = cfg.num_challenges * (1 + circ.num_partial_products)
+    n3 = cfg.num_challenges * circ.quotient_degree_factor
+    all_polys = [(0, i) for i in range(n0)] + [(1, i) for i in range(cfg.num_wires)] + [(2, i) for i in range(n2)] + \
+                [(3, i) for i in range(n3)]
+    return fri_api.FriInstance([(zeta, all_polys), (g_zeta, [(2, i) for i in range(cfg.num_challenges)])])
+
+
+def prove(o, fri_api, circ: Circuit, wires, public_inputs, timing=None):
+    """[EXT] plonk/prover.rs `prove_with_partition_witness` from the full witness on.  wires: [num_wires][n] uint64.
+    -> dict(wires_cap, zs_pp_cap, quotient_cap, openings (flat ext pairs: to_fri_openings order, then plonk_zs_next),
+            fri, public_inputs)"""
+    import time
+    L = o.lib
+    _setup(L)
+    cfg = circ.config
+    n, db = circ.n, circ.degree_bits
+    fcfg = _fri_cfg(fri_api, cfg)
+    t0 = time.perf_counter()
+
+    def lap(k):
+        nonlocal t0
+        if timing is not None:
+            t1 = time.perf_counter()
+            timing[k] = timing.get(k, 0.0) + t1 - t0
+            t0 = t1
+    cs_commit = commit_circuit(o, circ)
+    lap("constants_sigmas commitment (once per circuit)")
+    pi_hash = [int(x) for x in o.poseidon_hash_no_pad(np.array(public_inputs, dtype=np.uint64))]
+    wires = np.ascontiguousarray(wires, dtype=np.uint64)
+    w_commit = o.commit_values(wires, rate_bits=cfg.rate_bits, cap_height=cfg.cap_height, hasher=cfg.hasher)
+    lap("wires commitment")
+    ch = fri_api.new_challenger(o, cfg.hasher)
+    obs = lambda e: L.orc_challenger_observe(C.byref(ch), np.array(e, dtype=np.uint64), len(e))
+    obs(circ.circuit_digest)                              # challenger.observe_hash(circuit_digest)
+    obs(pi_hash)                                          # challenger.observe_hash(public_inputs_hash)
+    L.orc_challenger_observe_cap(C.byref(ch), w_commit["cap"], w_commit["cap"].shape[0])
+    betas = [L.orc_challenger_get(C.byref(ch)) for _ in range(cfg.num_challenges)]
+    gammas = [L.orc_challenger_get(C.byref(ch)) for _ in range(cfg.num_challenges)]
+    # partial products and Zs: Zs first, then the partial products of challenge 0, 1, ..
+    nch = circ.num_partial_products + 1
+    k_is = np.array(circ.k_is, dtype=np.uint64)
+    zs, pps = [], []
+    sig = np.ascontiguousarray(circ.sigmas)
+    for b, g in zip(betas, gammas):
+        out = np.zeros((nch, n), dtype=np.uint64)
+        rc = L.orc_plonk_partial_products(wires.ctypes.data, sig.ctypes.data, k_is.ctypes.data, cfg.num_routed_wires,
+                                          circ.quotient_degree_factor, db, b, g, out.ctypes.data)
+        assert rc == 0
+        zs.append(out[nch - 1])
+        pps += [out[k] for k in range(nch - 1)]
+    zs_pp = np.ascontiguousarray(np.stack(zs + pps))
+    lap("partial products and Zs")
+    z_commit = o.commit_values(zs_pp, rate_bits=cfg.rate_bits, cap_height=cfg.cap_height, hasher=cfg.hasher)
+    L.orc_challenger_observe_cap(C.byref(ch), z_commit["cap"], z_commit["cap"].shape[0])
+    lap("Zs / partial products commitment")
+    alphas = [L.orc_challenger_get(C.byref(ch)) for _ in range(cfg.num_challenges)]
+    # quotient: trace eval_vanishing_terms once, run it on the coset of size n * 2^quotient_degree_bits
+    qdf = circ.quotient_degree_factor
+    qdb = (qdf - 1).bit_length()
+    assert qdb <= cfg.rate_bits
+    C0, C1, C2 = circ.num_constants_total + cfg.num_routed_wires, cfg.num_wires, zs_pp.shape[0]
+    tb = T.TapeBuilder(C0 + C1 + 2 * C2 + 2)
+    v = tb.inputs
+    consts_in, sig_in = v[:circ.num_constants_total], v[circ.num_constants_total:C0]
+    wires_in = v[C0:C0 + C1]
+    loc, nxt = v[C0 + C1:C0 + C1 + C2], v[C0 + C1 + C2:C0 + C1 + 2 * C2]
+    x_in, l0_in = v[-2], v[-1]
+    terms = eval_vanishing_terms(circ, x_in, l0_in, consts_in, sig_in, wires_in, loc[:cfg.num_challenges],
+                                 nxt[:cfg.num_challenges], loc[cfg.num_challenges:], pi_hash, betas, gammas)
+    tp = tb.finish(terms)
+    qvals = np.zeros((cfg.num_challenges, n << qdb), dtype=np.uint64)
+    al = np.array(alphas, dtype=np.uint64)
+    ptrs = (C.c_void_p * cfg.num_challenges)(*[qvals[k].ctypes.data for k in range(cfg.num_challenges)])
+    ops = tp.ops if tp.ops.size else np.zeros((1, 3), dtype=np.uint32)
+    rc = L.orc_plonk_quotient_values(ops.ctypes.data, len(tp.ops), tp.consts.ctypes.data, len(tp.consts),
+                                     tp.outputs.ctypes.data, len(tp.outputs), cs_commit["leaves"].ctypes.data, C0,
+                                     w_commit["leaves"].ctypes.data, C1, z_commit["leaves"].ctypes.data, C2, db,
+                                     cfg.rate_bits, qdb, al.ctypes.data, len(al), ptrs)
+    assert rc == 0
+    lap("quotient values")
+    chunks = []
+    for a in qvals:
+        a = np.ascontiguousarray(a)
+        L.orc_coset_ifft(a, db + qdb, G)
+        # trim_to_len(quotient_degree) (the upper coefficients vanish for a satisfied circuit), then chunks(degree)
+        chunks += [a[j * n:(j + 1) * n].copy() for j in range(qdf)]
+    qco = np.ascontiguousarray(np.stack(chunks))
+    N = n << cfg.rate_bits
+    leaves = np.zeros((N, qco.shape[0]), dtype=np.uint64)
+    nd = L.orc_merkle_num_digests(db + cfg.rate_bits, cfg.cap_height)
+    digests = np.zeros((nd, 4), dtype=np.uint64)
+    cap = np.zeros((1 << cfg.cap_height, 4), dtype=np.uint64)
+    L.orc_commit_coeffs(qco, qco.shape[0], db, cfg.rate_bits, cfg.cap_height, cfg.hasher, leaves.ctypes.data,
+                        digests.ctypes.data, cap.ctypes.data)
+    q_commit = dict(coeffs=qco, leaves=leaves, digests=digests, cap=cap)
+    L.orc_challenger_observe_cap(C.byref(ch), cap, cap.shape[0])
+    lap("quotient commitment")
+    zeta = np.zeros(2, dtype=np.uint64)
+    L.orc_challenger_get_ext(C.byref(ch), zeta)
+    zeta = (int(zeta[0]), int(zeta[1]))
+    assert Ext(*zeta).pow(n) != Ext(1), "Opening point is in the subgroup."
+    g = S.root_of_unity(db)
+    gz = (zeta[0] * g % P, zeta[1] * g % P)
+    inst = fri_instance(fri_api, circ, zeta, gz)
+    commits = [cs_commit, w_commit, z_commit, q_commit]
+    opn, proof = fri_api.oracle_fri_prove(o, fcfg, db, commits, inst, ch)
+    lap("openings + FRI")
+    return dict(wires_cap=w_commit["cap"], zs_pp_cap=z_commit["cap"], quotient_cap=cap, openings=opn, fri=proof,
+                public_inputs=list(public_inputs), zs_pp=zs_pp, quotient_coeffs=qco, betas=betas, gammas=gammas,
+                alphas=alphas, zeta=zeta, final_challenge=L.orc_challenger_get(C.byref(ch)))
+
+
+def verify(o, fri_api, circ: Circuit, proof):
+    """[EXT] plonk/verifier.rs `verify_with_challenges` + get_challenges: re-derive the challenges from the transcript,
+    check the vanishing-polynomial identity at zeta against the quotient openings, verify the FRI proof."""
+    L = o.lib
+    cfg = circ.config
+    n, db = circ.n, circ.degree_bits
+    fcfg = _fri_cfg(fri_api, cfg)
+    cs_commit = commit_circuit(o, circ)
+    pi_hash = [int(x) for x in o.poseidon_hash_no_pad(np.array(proof["public_inputs"], dtype=np.uint64))]
+    ch = fri_api.new_challenger(o, cfg.hasher)
+    obs = lambda e: L.orc_challenger_observe(C.byref(ch), np.array(e, dtype=np.uint64), len(e))
+    obs(circ.circuit_digest)
+    obs(pi_hash)
+    cap_of = lambda k: np.ascontiguousarray(proof[k], dtype=np.uint64)
+    L.orc_challenger_observe_cap(C.byref(ch), cap_of("wires_cap"), 1 << cfg.cap_height)
+    betas = [L.orc_challenger_get(C.byref(ch)) for _ in range(cfg.num_challenges)]
+    gammas = [L.orc_challenger_get(C.byref(ch)) for _ in range(cfg.num_challenges)]
+    L.orc_challenger_observe_cap(C.byref(ch), cap_of("zs_pp_cap"), 1 << cfg.cap_height)
+    alphas = [L.orc_challenger_get(C.byref(ch)) for _ in range(cfg.num_challenges)]
+    L.orc_challenger_observe_cap(C.byref(ch), cap_of("quotient_cap"), 1 << cfg.cap_height)
+    z = np.zeros(2, dtype=np.uint64)
+    L.orc_challenger_get_ext(C.byref(ch), z)
+    zeta = Ext(int(z[0]), int(z[1]))
+    opn = np.ascontiguousarray(proof["openings"], dtype=np.uint64).reshape(-1, 2)
+    E = [Ext(int(a), int(b)) for a, b in opn]
+    nc, nr, nw = circ.num_constants_total, cfg.num_routed_wires, cfg.num_wires
+    nz, npp, nq = cfg.num_challenges, cfg.num_challenges * circ.num_partial_products, cfg.num_challenges * circ.quotient_degree_factor
+    if len(E) != nc + nr + nw + nz + npp + nq + nz:
+        return False, "opening set has the wrong size"
+    pos = 0
+
+    def take(k):
+        nonlocal pos
+        r = E[pos:pos + k]
+        pos += k
+        return r
+    consts, sigmas, wires, zs, pps, quot, zs_next = take(nc), take(nr), take(nw), take(nz), take(npp), take(nq), take(nz)
+    zeta_n = zeta.pow(n)
+    z_h = zeta_n - 1
+    l0 = z_h * (Ext(n) * (zeta - 1)).inverse()            # eval_l_0(n, zeta)
+    terms = eval_vanishing_terms(circ, zeta, l0, consts, sigmas, wires, zs, zs_next, pps, pi_hash, betas, gammas)
+    for i, alpha in enumerate(alphas):
+        acc = Ext(0)
+        for t in reversed(terms):                         # reduce_with_powers
+            acc = acc * alpha + t
+        # quotient(zeta) = sum_j zeta^(n j) chunk_j(zeta)  (reduce_with_powers of the chunk openings with zeta^n)
+        q = Ext(0)
+        for cj in reversed(quot[i * circ.quotient_degree_factor:(i + 1) * circ.quotient_degree_factor]):
+            q = q * zeta_n + cj
+        if not acc == z_h * q:
+            return False, "vanishing polynomial identity fails for challenge %d" % i
+    g = S.root_of_unity(db)
+    inst = fri_instance(fri_api, circ, (zeta.a, zeta.b), (zeta.a * g % P, zeta.b * g % P))
+    caps = [cs_commit["cap"], cap_of("wires_cap"), cap_of("zs_pp_cap"), cap_of("quotient_cap")]
+    cols = [nc + nr, nw, nz + npp, nq]
+    ok, why = fri_api.oracle_fri_verify(o, fcfg, db, caps, cols, inst, np.ascontiguousarray(opn.reshape(-1)),
+                                        np.ascontiguousarray(proof["fri"], dtype=np.uint64), ch)
+    return (True, "") if ok else (False, "FRI verification failed (%d)" % why)

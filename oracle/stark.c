@@ -183,3 +183,99 @@ int orc_quotient_values(const uint32_t *ops, size_t n_ops, const uint64_t *const
     }
     return fail ? -1 : 0;
 }
+
+/* ---- plonky2 PLONK prover row loops ([EXT] plonky2 1.0.0 plonk/prover.rs; reference call sites
+ * evm_arithmetization/src/fixed_recursive_verifier.rs:2146 `root.circuit.prove`, :3167-3179 `shrink`) ------------- */
+
+/* `wires_permutation_partial_products_and_zs` for one (beta, gamma): per row i the quotients
+ * (w_j + beta k_j x_i + gamma) / (w_j + beta sigma_j(x_i) + gamma), j < routed, multiplied in chunks of `chunk`;
+ * running products across the row starting from Z(x_i); the row's last running product is Z(g x_i) and is swapped with
+ * Z(x_i).  wires / sigmas: column-major [cols][n].  out: (num_chunks) columns [num_chunks][n] laid out as plonky2 returns
+ * them: partial products 0 .. num_chunks-2, then Z. */
+int orc_plonk_partial_products(const uint64_t *wires, const uint64_t *sigmas, const uint64_t *k_is, size_t routed,
+                               size_t chunk, unsigned degree_bits, uint64_t beta, uint64_t gamma, uint64_t *out) {
+    const size_t n = (size_t)1 << degree_bits, nch = (routed + chunk - 1) / chunk;
+    const uint64_t w = gl_root_of_unity(degree_bits);
+    uint64_t *q = (uint64_t *)malloc(sizeof(uint64_t) * n * nch);   /* chunk products, row-major */
+    if (!q) return -1;
+#pragma omp parallel for schedule(static)
+    for (size_t i = 0; i < n; ++i) {
+        const uint64_t x = gl_pow(w, i);
+        for (size_t c = 0; c < nch; ++c) {
+            uint64_t num = 1, den = 1;
+            for (size_t j = c * chunk; j < routed && j < (c + 1) * chunk; ++j) {
+                const uint64_t wv = gl_canon(wires[j * n + i]);
+                num = gl_mul(num, gl_add(gl_add(wv, gl_mul(beta, gl_mul(k_is[j], x))), gamma));
+                den = gl_mul(den, gl_add(gl_add(wv, gl_mul(beta, gl_canon(sigmas[j * n + i]))), gamma));
+            }
+            q[i * nch + c] = gl_mul(num, gl_inv(den));      /* product of quotients == quotient of products */
+        }
+    }
+    uint64_t z = 1;
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t acc = z;
+        for (size_t c = 0; c < nch; ++c) {
+            acc = gl_mul(acc, q[i * nch + c]);
+            if (c + 1 < nch) out[c * n + i] = acc;
+        }
+        out[(nch - 1) * n + i] = z;   /* swap(z_x, last): the column holds Z(x_i) */
+        z = acc;
+    }
+    free(q);
+    return 0;
+}
+
+/* [EXT] plonk/prover.rs `compute_quotient_polys` up to (excluding) the coset_ifft.  One tape evaluates every
+ * vanishing-polynomial term of `eval_vanishing_poly_base_batch` at one point; its inputs are
+ *   constants_sigmas row (C0) | wires row (C1) | zs/partial-products row (C2) | the same oracle's row at i_next (C2) |
+ *   x (the shifted point) | L_0(x)
+ * leaves: [N][cols] row-major, rows bit-reversed (orc_commit_values).  out[c][i] = (sum_k alpha_c^k term_k) / Z_H(x_i)
+ * (`reduce_with_powers_multi`: the FIRST term carries alpha^0). */
+int orc_plonk_quotient_values(const uint32_t *ops, size_t n_ops, const uint64_t *consts, size_t n_consts,
+                              const uint32_t *out_nodes, size_t n_terms, const uint64_t *l0, size_t C0,
+                              const uint64_t *l1, size_t C1, const uint64_t *l2, size_t C2, unsigned degree_bits,
+                              unsigned rate_bits, unsigned qdb, const uint64_t *alphas, size_t n_alphas,
+                              uint64_t *const *out) {
+    const size_t n = (size_t)1 << degree_bits, size = n << qdb;
+    const unsigned log_lde = degree_bits + rate_bits;
+    const size_t step = (size_t)1 << (rate_bits - qdb), next_step = (size_t)1 << qdb;
+    const size_t n_in = C0 + C1 + 2 * C2 + 2, n_nodes = n_in + n_consts + n_ops;
+    const uint64_t w = gl_root_of_unity(degree_bits + qdb);
+    const uint64_t n_f = gl_canon((uint64_t)n);
+    int fail = 0;
+#pragma omp parallel
+    {
+        uint64_t *v = (uint64_t *)malloc(sizeof(uint64_t) * n_nodes);
+        uint64_t acc[16];
+        if (!v || n_alphas > 16) {
+#pragma omp atomic write
+            fail = 1;
+        } else {
+            memcpy(v + n_in, consts, sizeof(uint64_t) * n_consts);
+#pragma omp for schedule(static)
+            for (size_t i = 0; i < size; ++i) {
+                const uint64_t x = gl_mul(GL_GENERATOR, gl_pow(w, i));            /* shifted_x */
+                const uint64_t zh = gl_sub(gl_pow(x, n), 1);                      /* ZeroPolyOnCoset::eval(i) */
+                const uint64_t l0x = gl_mul(zh, gl_inv(gl_mul(n_f, gl_sub(x, 1)))); /* eval_l_0(i, x) */
+                const size_t i_next = (i + next_step) % size;
+                const size_t r = bitrev(i * step, log_lde), rn = bitrev(i_next * step, log_lde);
+                uint64_t *p = v;
+                memcpy(p, l0 + r * C0, 8 * C0); p += C0;
+                memcpy(p, l1 + r * C1, 8 * C1); p += C1;
+                memcpy(p, l2 + r * C2, 8 * C2); p += C2;
+                memcpy(p, l2 + rn * C2, 8 * C2); p += C2;
+                p[0] = x; p[1] = l0x;
+                tape_run(v, ops, n_ops, n_in + n_consts);
+                for (size_t c = 0; c < n_alphas; ++c) acc[c] = 0;
+                for (size_t k = n_terms; k-- > 0;) {
+                    const uint64_t t = v[out_nodes[k]];
+                    for (size_t c = 0; c < n_alphas; ++c) acc[c] = gl_add(gl_mul(acc[c], alphas[c]), t);
+                }
+                const uint64_t zinv = gl_inv(zh);
+                for (size_t c = 0; c < n_alphas; ++c) out[c][i] = gl_mul(acc[c], zinv);
+            }
+        }
+        free(v);
+    }
+    return fail ? -1 : 0;
+}

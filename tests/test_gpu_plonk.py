@@ -1,0 +1,75 @@
+"""-m gpu: the PLONK prover slice (zk_plonk_prove) against the oracle's restatement of plonky2's
+`prove` (oracle/plonk.py), word for word -- wires / Zs+partial-products / quotient caps, the whole opening set, the FRI
+proof over the four oracles, the transcript state afterwards -- on circuits of 2^6 .. 2^14 rows under
+`standard_recursion_config` (135 wires, 80 routed, rate_bits 3, quotient degree factor 8), and the oracle's verifier
+accepts the device proof."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import tests.oracle_lib as ol
+from oracle import plonk as PK
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_circuit(circ):
+    import zk_evm_amd.plonk as zp
+    from tests.gpu_util import to_dev
+    cfg = circ.config
+    pcfg = zp.CircuitConfig(num_wires=cfg.num_wires, num_routed_wires=cfg.num_routed_wires, num_challenges=cfg.num_challenges,
+                            rate_bits=cfg.rate_bits, cap_height=cfg.cap_height, proof_of_work_bits=cfg.proof_of_work_bits,
+                            num_query_rounds=cfg.num_query_rounds, arity_bits=cfg.arity_bits, final_poly_bits=cfg.final_poly_bits)
+    cs = to_dev(np.concatenate([circ.constants, circ.sigmas]))
+    return zp.CircuitData(pcfg, circ.degree_bits, circ.gate_descriptors(), circ.num_selectors, cs, circ.k_is,
+                          circ.circuit_digest, circ.num_gate_constraints, circ.quotient_degree_factor)
+
+
+@pytest.mark.parametrize("degree_bits,seed,kw", [(6, 1, dict(proof_of_work_bits=3, num_query_rounds=4)),
+                                                 (9, 2, dict(proof_of_work_bits=5, num_query_rounds=7)),
+                                                 (12, 3, dict()),           # standard_recursion_config: 28 queries, 16 PoW bits
+                                                 (14, 4, dict(num_query_rounds=12))])
+def test_plonk_proof_matches_oracle(oracle, degree_bits, seed, kw):
+    from tests.gpu_util import to_dev
+    ol.setup_fri_api(oracle)
+    circ, wires, pis = PK.build_arithmetic_circuit(degree_bits, seed=seed, cfg=PK.CircuitConfig(**kw))
+    wires, pi_hash = PK.set_public_input_wires(oracle, circ, wires, pis)
+    exp = PK.prove(oracle, ol, circ, wires, pis)
+    cd = _device_circuit(circ)
+    assert np.array_equal(cd.constants_sigmas_cap(), PK.commit_circuit(oracle, circ)["cap"])
+    got = cd.prove(to_dev(wires), pis)
+    assert got.public_inputs_hash == pi_hash
+    assert np.array_equal(got.wires_cap, exp["wires_cap"])
+    assert np.array_equal(got.plonk_zs_partial_products_cap, exp["zs_pp_cap"])
+    assert np.array_equal(got.quotient_polys_cap, exp["quotient_cap"])
+    assert np.array_equal(got.openings.reshape(-1), exp["openings"])
+    assert np.array_equal(got.opening_proof, exp["fri"])
+    ok, why = PK.verify(oracle, ol, circ, dict(wires_cap=got.wires_cap, zs_pp_cap=got.plonk_zs_partial_products_cap,
+                                               quotient_cap=got.quotient_polys_cap, openings=got.openings,
+                                               fri=got.opening_proof, public_inputs=pis))
+    assert ok, why
+    # the same circuit proves a second witness (other public inputs) without re-committing constants / sigmas
+    pis2 = [p ^ 5 for p in pis]
+    w2, _ = PK.set_public_input_wires(oracle, circ, wires.copy(), pis2)
+    got2 = cd.prove(to_dev(w2), pis2)
+    exp2 = PK.prove(oracle, ol, circ, w2, pis2)
+    assert np.array_equal(got2.opening_proof, exp2["fri"]) and not np.array_equal(got2.wires_cap, got.wires_cap)
+    cd.free()
+
+
+def test_plonk_rejects_bad_circuit_descriptions():
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.plonk as zp
+    cs = torch.zeros((83, 64), dtype=torch.int64, device="cuda")
+    good = [(0, 0, 0, 0, 4), (1, 2, 0, 0, 4), (2, 0, 0, 0, 4), (3, 20, 0, 0, 4)]
+    with pytest.raises(zk.ZkStarkError, match="gate kind 9"):
+        zp.CircuitData(zp.CircuitConfig(), 6, good[:3] + [(9, 0, 0, 0, 4)], 1, cs, [1] * 80, [0] * 4, 4)
+    with pytest.raises(zk.ZkStarkError, match="num_gate_constraints"):
+        zp.CircuitData(zp.CircuitConfig(), 6, good, 1, cs, [1] * 80, [0] * 4, 7)
+    with pytest.raises(zk.ZkStarkError, match="selector group"):
+        zp.CircuitData(zp.CircuitConfig(), 6, [(0, 0, 0, 1, 4)] + good[1:], 1, cs, [1] * 80, [0] * 4, 20)
+    cd = zp.CircuitData(zp.CircuitConfig(), 6, good, 1, cs, [1] * 80, [0] * 4, 20)
+    with pytest.raises(zk.ZkStarkError, match="witness must be"):
+        cd.prove(torch.zeros((135, 32), dtype=torch.int64, device="cuda"), [])

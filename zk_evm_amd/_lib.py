@@ -97,6 +97,12 @@ SIGNATURES = {
     "zk_segment_proof_mem_caps": (sz, [vp, u64p, u64p, sz]),
     "zk_segment_proof_stage_ms": (sz, [vp, C.POINTER(C.c_double), sz]),
     "zk_segment_proof_free": (None, [vp]),
+    "zk_plonk_circuit_create": (C.c_int, [vp, vp, vp, sz, u64p, sz, u64p, u64p, C.POINTER(vp)]),
+    "zk_plonk_circuit_free": (None, [vp]),
+    "zk_plonk_circuit_cap": (C.c_int, [vp, u64p]),
+    "zk_plonk_prove": (C.c_int, [vp, u64p, sz, u64p, sz, C.POINTER(vp)]),
+    "zk_plonk_proof_get": (C.c_int, [vp, vp]),
+    "zk_plonk_proof_free": (None, [vp]),
     "zk_keccak_generate_trace": (C.c_int, [vp, u64p, u64p, sz, ui, u64p, sz]),
     "zk_range_check_columns": (C.c_int, [vp, u64p, sz, sz, ui, sz, sz, sz, sz, C.c_uint64]),
     "zk_logic_generate_trace": (C.c_int, [vp, u64p, sz, ui, u64p, sz]),

@@ -1,0 +1,281 @@
+// PLONK prover kernels for the recursion layer: plonky2 1.0.0 `prove` as the reference drives it
+// after every segment STARK -- `StarkWrapperCircuit::prove` / `shrink` and `root.circuit.prove`
+// (evm_arithmetization/src/fixed_recursive_verifier.rs:2146, 3167-3179), circuits of 2^12..2^14 rows under
+// `CircuitConfig::standard_recursion_config()` (135 wires, 80 routed, quotient degree factor 8, FRI rate_bits 3).
+// [EXT] plonky2/src/plonk/{prover.rs, vanishing_poly.rs, plonk_common.rs}, gates/{gate, selectors, arithmetic_base,
+// constant, public_input, noop}.rs.  The commitments, openings and FRI are the STARK path's own kernels (ntt.cuh,
+// merkle.cuh, fri.cuh) at rate_bits 3; what is new here is the permutation argument and the gate-filtered quotient.
+//
+// MI355X mapping: both kernels are one lane per row / coset point over column-major matrices (64 lanes read 64
+// consecutive u64 of one column), the wires are loaded once and shared by all challenges, the running product across
+// rows is an exclusive prefix product (three-kernel block scan) instead of plonky2's sequential loop, and all
+// divisions of a row share one inversion.
+#pragma once
+#include "gl.cuh"
+
+#define ZK_PLONK_MAX_CHALLENGES 2
+#define ZK_PLONK_MAX_CHUNKS 16          // ceil(num_routed_wires / quotient_degree_factor): 10 for the standard config
+#define ZK_PLONK_MAX_GATES 32
+#define ZK_PLONK_UNUSED_SELECTOR 0xFFFFFFFFULL
+
+struct PlonkGateDesc {
+    u32 kind, param, selector_index, group_start, group_end;
+};
+
+struct PlonkPermArgs {
+    const u64 *wires; size_t wires_stride;       // [num_wires][n] witness values (natural order)
+    const u64 *sigmas; size_t sigmas_stride;     // [routed][n] sigma VALUES on the subgroup
+    const u64 *k_is;                             // [routed]
+    const u64 *tw;                               // w_n^k, k < n/2
+    u32 log_n, routed, chunk, n_chunks, n_challenges;
+    u64 betas[ZK_PLONK_MAX_CHALLENGES], gammas[ZK_PLONK_MAX_CHALLENGES];
+    u64 *q;                                      // [n_challenges][n_chunks][n] chunk quotients
+    u64 *totals;                                 // [n_challenges][n] product of the row's chunk quotients
+};
+
+// per row: quotient_chunk_products of `wires_permutation_partial_products_and_zs`
+__global__ void __launch_bounds__(256) plonk_chunk_quotients_kernel(PlonkPermArgs A) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 n = 1u << A.log_n;
+    if (i >= n) return;
+    u64 x = 1;
+    if (A.log_n) {
+        const u32 half = n >> 1;
+        x = A.tw[i & (half - 1)];
+        if (i & half) x = gl_neg(x);
+    }
+    u64 num[ZK_PLONK_MAX_CHALLENGES][ZK_PLONK_MAX_CHUNKS], den[ZK_PLONK_MAX_CHALLENGES][ZK_PLONK_MAX_CHUNKS];
+    u64 bx[ZK_PLONK_MAX_CHALLENGES];
+    for (u32 c = 0; c < A.n_challenges; ++c) bx[c] = gl_mul(A.betas[c], x);
+    for (u32 k = 0; k < A.n_chunks; ++k) {
+        u64 pn[ZK_PLONK_MAX_CHALLENGES], pd[ZK_PLONK_MAX_CHALLENGES];
+        for (u32 c = 0; c < A.n_challenges; ++c) pn[c] = pd[c] = 1;
+        const u32 j1 = (k + 1) * A.chunk < A.routed ? (k + 1) * A.chunk : A.routed;
+        for (u32 j = k * A.chunk; j < j1; ++j) {
+            const u64 wv = A.wires[(size_t)j * A.wires_stride + i];
+            const u64 sg = A.sigmas[(size_t)j * A.sigmas_stride + i];
+            const u64 kj = A.k_is[j];
+            for (u32 c = 0; c < A.n_challenges; ++c) {
+                pn[c] = gl_mul(pn[c], gl_add(gl_add(wv, gl_mul(kj, bx[c])), A.gammas[c]));
+                pd[c] = gl_mul(pd[c], gl_add(gl_add(wv, gl_mul(A.betas[c], sg)), A.gammas[c]));
+            }
+        }
+        for (u32 c = 0; c < A.n_challenges; ++c) { num[c][k] = pn[c]; den[c][k] = pd[c]; }
+    }
+    for (u32 c = 0; c < A.n_challenges; ++c) {
+        // one inversion for the row's n_chunks denominators: prefix products, invert, walk back
+        u64 pre[ZK_PLONK_MAX_CHUNKS];
+        u64 run = 1;
+        for (u32 k = 0; k < A.n_chunks; ++k) { pre[k] = run; run = gl_mul(run, den[c][k]); }
+        u64 inv = gl_inv(run);
+        u64 total = 1;
+        u64 qk[ZK_PLONK_MAX_CHUNKS];
+        for (u32 k = A.n_chunks; k-- > 0;) {
+            qk[k] = gl_mul(num[c][k], gl_mul(inv, pre[k]));
+            inv = gl_mul(inv, den[c][k]);
+        }
+        for (u32 k = 0; k < A.n_chunks; ++k) {
+            A.q[((size_t)c * A.n_chunks + k) * n + i] = gl_canon(qk[k]);
+            total = gl_mul(total, qk[k]);
+        }
+        A.totals[(size_t)c * n + i] = gl_canon(total);
+    }
+}
+
+// ---- exclusive prefix PRODUCT over rows (Z(x_i) = prod_{r < i} totals[r]) ----------------------------------------------
+#define ZK_PSCAN_ITEMS 8
+#define ZK_PSCAN_THREADS 256
+__global__ void __launch_bounds__(ZK_PSCAN_THREADS)
+plonk_scan_block_kernel(const u64 *__restrict__ x, u32 n, u64 *__restrict__ incl, u64 *__restrict__ totals) {
+    __shared__ u64 sh[ZK_PSCAN_THREADS];
+    const u32 base = (blockIdx.x * ZK_PSCAN_THREADS + threadIdx.x) * ZK_PSCAN_ITEMS;
+    u64 loc[ZK_PSCAN_ITEMS];
+    u64 run = 1;
+#pragma unroll
+    for (int k = 0; k < ZK_PSCAN_ITEMS; ++k) {
+        const u32 i = base + k;
+        run = gl_mul(run, i < n ? x[i] : 1);
+        loc[k] = run;
+    }
+    sh[threadIdx.x] = run;
+    __syncthreads();
+    for (u32 off = 1; off < ZK_PSCAN_THREADS; off <<= 1) {
+        const u64 m = threadIdx.x >= off ? sh[threadIdx.x - off] : 1;
+        __syncthreads();
+        sh[threadIdx.x] = gl_mul(sh[threadIdx.x], m);
+        __syncthreads();
+    }
+    const u64 excl = threadIdx.x ? sh[threadIdx.x - 1] : 1;
+#pragma unroll
+    for (int k = 0; k < ZK_PSCAN_ITEMS; ++k) {
+        const u32 i = base + k;
+        if (i < n) incl[i] = gl_mul(loc[k], excl);
+    }
+    if (threadIdx.x == ZK_PSCAN_THREADS - 1) totals[blockIdx.x] = sh[threadIdx.x];
+}
+__global__ void __launch_bounds__(256) plonk_scan_totals_kernel(u64 *totals, u32 n_blocks) {
+    __shared__ u64 sh[256];
+    const u32 per = (n_blocks + 255) / 256;
+    const u32 lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    u64 run = 1;
+    for (u32 i = lo; i < hi; ++i) run = gl_mul(run, totals[i]);
+    sh[threadIdx.x] = run;
+    __syncthreads();
+    for (u32 off = 1; off < 256; off <<= 1) {
+        const u64 m = threadIdx.x >= off ? sh[threadIdx.x - off] : 1;
+        __syncthreads();
+        sh[threadIdx.x] = gl_mul(sh[threadIdx.x], m);
+        __syncthreads();
+    }
+    run = threadIdx.x ? sh[threadIdx.x - 1] : 1;
+    for (u32 i = lo; i < hi; ++i) { const u64 v = totals[i]; totals[i] = run; run = gl_mul(run, v); }
+}
+// out layout (plonky2 `zs_partial_products`): Z of challenge 0, 1, ..; then the (n_chunks - 1) partial products of
+// challenge 0, of challenge 1, ..   incl / block_totals: the scan pieces of challenge c at [c * n], [c * n_blocks].
+__global__ void __launch_bounds__(256)
+plonk_partial_products_finish_kernel(const u64 *__restrict__ incl, const u64 *__restrict__ block_totals, u32 n_blocks,
+                                     const u64 *__restrict__ q, u32 log_n, u32 n_chunks, u32 n_challenges,
+                                     u64 *__restrict__ out, size_t out_stride) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 n = 1u << log_n;
+    if (i >= n) return;
+    for (u32 c = 0; c < n_challenges; ++c) {
+        // Z(x_i) = inclusive product up to row i-1
+        u64 z = 1;
+        if (i) {
+            const u32 p = i - 1;
+            z = gl_mul(incl[(size_t)c * n + p], block_totals[(size_t)c * n_blocks + p / (ZK_PSCAN_THREADS * ZK_PSCAN_ITEMS)]);
+        }
+        out[(size_t)c * out_stride + i] = gl_canon(z);
+        u64 acc = z;
+        for (u32 k = 0; k + 1 < n_chunks; ++k) {
+            acc = gl_mul(acc, q[((size_t)c * n_chunks + k) * n + i]);
+            out[((size_t)n_challenges + (size_t)c * (n_chunks - 1) + k) * out_stride + i] = gl_canon(acc);
+        }
+    }
+}
+
+// ---- quotient: eval_vanishing_poly_base_batch / Z_H on the coset of size n * 2^qd_bits ---------------------------------
+struct PlonkQuotientArgs {
+    const u64 *cs; size_t cs_stride;             // constants ++ sigmas LDE  [num_constants + routed][N]
+    const u64 *wires; size_t wires_stride;       // wires LDE [num_wires][N]
+    const u64 *zs; size_t zs_stride;             // Zs ++ partial products LDE
+    const u64 *k_is;
+    const u64 *tw;                               // w_size^k, k < size/2
+    const PlonkGateDesc *gates;
+    const u64 *alpha_pow[ZK_PLONK_MAX_CHALLENGES];   // alpha_c^k
+    u32 log_n, qd_bits, step_log;
+    u32 num_constants, num_selectors, routed, num_wires, chunk, n_chunks, n_challenges, n_gates, num_gate_constraints;
+    u64 betas[ZK_PLONK_MAX_CHALLENGES], gammas[ZK_PLONK_MAX_CHALLENGES];
+    u64 pi_hash[4];
+    u64 g_pow_n, n_inv;
+    u64 *out; size_t out_stride;
+};
+
+struct PlonkAcc {                                 // sum_k term_k * alpha_c^k for every challenge
+    u64 acc[ZK_PLONK_MAX_CHALLENGES];
+    const u64 *pow[ZK_PLONK_MAX_CHALLENGES];
+    u32 nc;
+    __device__ __forceinline__ void add(u32 k, u64 term) {
+        for (u32 c = 0; c < nc; ++c) acc[c] = gl_add(acc[c], gl_mul(term, pow[c][k]));
+    }
+};
+
+__global__ void __launch_bounds__(256) plonk_quotient_kernel(PlonkQuotientArgs A) {
+    const u32 size_log = A.log_n + A.qd_bits;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> size_log) return;
+    const u32 size = 1u << size_log, half = size >> 1;
+    u64 w = A.tw[i & (half - 1)];
+    if (i & half) w = gl_neg(w);
+    const u64 x = gl_mul(w, GL_GENERATOR);                         // shifted_x = coset_shift * w_size^i
+    u64 wn = 1;                                                    // (w_size^n)^i: a 2^qd_bits-th root of unity
+    {
+        const u32 k = i & ((1u << A.qd_bits) - 1);
+        if (k) {
+            const u32 idx = k << A.log_n;
+            const u64 t = A.tw[idx & (half - 1)];
+            wn = (idx & half) ? gl_neg(t) : t;
+        }
+    }
+    const u64 zh = gl_sub(gl_mul(A.g_pow_n, wn), 1);               // ZeroPolyOnCoset::eval(i)
+    const u64 xm1 = gl_sub(x, 1);
+    const u64 it = gl_inv(gl_mul(zh, xm1));                        // x is never in H: both non-zero
+    const u64 inv_zh = gl_mul(it, xm1);
+    const u64 l0 = gl_mul(gl_mul(zh, gl_mul(it, zh)), A.n_inv);    // eval_l_0 = Z_H(x) / (n (x - 1))
+    const size_t row = (size_t)i << A.step_log;
+    const size_t row_next = (size_t)((i + (1u << A.qd_bits)) & (size - 1)) << A.step_log;
+    PlonkAcc acc;
+    acc.nc = A.n_challenges;
+    for (u32 c = 0; c < A.n_challenges; ++c) { acc.acc[c] = 0; acc.pow[c] = A.alpha_pow[c]; }
+    const u64 *sig = A.cs + (size_t)A.num_constants * A.cs_stride;
+    u32 term = 0;
+    // vanishing_z_1_terms: L_0(x) (Z(x) - 1)
+    for (u32 c = 0; c < A.n_challenges; ++c) acc.add(term++, gl_mul(l0, gl_sub(A.zs[(size_t)c * A.zs_stride + row], 1)));
+    // vanishing_partial_products_terms: check_partial_products, challenge-major
+    {
+        u64 bx[ZK_PLONK_MAX_CHALLENGES];
+        for (u32 c = 0; c < A.n_challenges; ++c) bx[c] = gl_mul(A.betas[c], x);
+        const u32 per_chal = A.n_chunks;
+        for (u32 k = 0; k < A.n_chunks; ++k) {
+            u64 pn[ZK_PLONK_MAX_CHALLENGES], pd[ZK_PLONK_MAX_CHALLENGES];
+            for (u32 c = 0; c < A.n_challenges; ++c) pn[c] = pd[c] = 1;
+            const u32 j1 = (k + 1) * A.chunk < A.routed ? (k + 1) * A.chunk : A.routed;
+            for (u32 j = k * A.chunk; j < j1; ++j) {
+                const u64 wv = A.wires[(size_t)j * A.wires_stride + row];
+                const u64 sg = sig[(size_t)j * A.cs_stride + row];
+                const u64 kj = A.k_is[j];
+                for (u32 c = 0; c < A.n_challenges; ++c) {
+                    pn[c] = gl_mul(pn[c], gl_add(gl_add(wv, gl_mul(kj, bx[c])), A.gammas[c]));
+                    pd[c] = gl_mul(pd[c], gl_add(gl_add(wv, gl_mul(A.betas[c], sg)), A.gammas[c]));
+                }
+            }
+            for (u32 c = 0; c < A.n_challenges; ++c) {
+                // accs = [Z(x), pp_0 .. pp_{m-1}, Z(g x)]
+                const size_t pp0 = (size_t)A.n_challenges + (size_t)c * (A.n_chunks - 1);
+                const u64 prev = k == 0 ? A.zs[(size_t)c * A.zs_stride + row] : A.zs[(pp0 + k - 1) * A.zs_stride + row];
+                const u64 next = k + 1 == A.n_chunks ? A.zs[(size_t)c * A.zs_stride + row_next] : A.zs[(pp0 + k) * A.zs_stride + row];
+                const u64 t = gl_sub(gl_mul(prev, pn[c]), gl_mul(next, pd[c]));
+                for (u32 cc = 0; cc < A.n_challenges; ++cc)
+                    acc.acc[cc] = gl_add(acc.acc[cc], gl_mul(t, acc.pow[cc][term + c * per_chal + k]));
+            }
+        }
+        term += A.n_challenges * per_chal;
+    }
+    // gate constraints: slot j collects filter_g * constraint_{g,j} over all gates (at most one filter is non-zero on H)
+    const bool many = A.num_selectors > 1;
+    const u64 *consts = A.cs + (size_t)A.num_selectors * A.cs_stride;      // gate constants: selectors removed
+    for (u32 g = 0; g < A.n_gates; ++g) {
+        const PlonkGateDesc G = A.gates[g];
+        if (G.kind == 0) continue;                                          // NoopGate: no constraints
+        const u64 s = A.cs[(size_t)G.selector_index * A.cs_stride + row];
+        u64 filt = 1;                                                       // compute_filter
+        for (u32 r = G.group_start; r < G.group_end; ++r)
+            if (r != g) filt = gl_mul(filt, gl_sub((u64)r, s));
+        if (many) filt = gl_mul(filt, gl_sub(ZK_PLONK_UNUSED_SELECTOR, s));
+        if (G.kind == 1) {                                                  // ConstantGate { num_consts }
+            for (u32 j = 0; j < G.param; ++j)
+                acc.add(term + j, gl_mul(filt, gl_sub(consts[(size_t)j * A.cs_stride + row], A.wires[(size_t)j * A.wires_stride + row])));
+        } else if (G.kind == 2) {                                           // PublicInputGate
+            for (u32 j = 0; j < 4; ++j)
+                acc.add(term + j, gl_mul(filt, gl_sub(A.wires[(size_t)j * A.wires_stride + row], A.pi_hash[j])));
+        } else if (G.kind == 3) {                                           // ArithmeticGate { num_ops }
+            const u64 c0 = consts[row], c1 = consts[A.cs_stride + row];
+            for (u32 j = 0; j < G.param; ++j) {
+                const u64 *wp = A.wires + (size_t)(4 * j) * A.wires_stride + row;
+                const u64 m0 = wp[0], m1 = wp[A.wires_stride], ad = wp[2 * A.wires_stride], out = wp[3 * A.wires_stride];
+                const u64 v = gl_sub(out, gl_add(gl_mul(gl_mul(m0, m1), c0), gl_mul(ad, c1)));
+                acc.add(term + j, gl_mul(filt, v));
+            }
+        }
+    }
+    for (u32 c = 0; c < A.n_challenges; ++c) A.out[(size_t)c * A.out_stride + i] = gl_canon(gl_mul(acc.acc[c], inv_zh));
+}
+
+// out[c * cap + k] = alpha_c^k
+__global__ void plonk_alpha_pow_kernel(u64 *out, u32 cap, u32 count, u32 n_challenges, u64 a0, u64 a1) {
+    const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    out[j] = gl_canon(gl_pow(a0, j));
+    if (n_challenges > 1) out[(size_t)cap + j] = gl_canon(gl_pow(a1, j));
+}

@@ -29,6 +29,7 @@
 #include "quotient.cuh"
 #include "airs.cuh"
 #include "tracegen.cuh"
+#include "plonk.cuh"
 #include "memtrace.cuh"
 #include "arithtrace.cuh"
 #include "host_hash.hpp"
@@ -511,5 +512,6 @@ extern "C" int zk_batch_merkle_path(const zk_batch *b, size_t leaf_index, uint64
 #include "stark_host.inc"
 #include "quotient_host.inc"
 #include "segment_host.inc"
+#include "plonk_host.inc"
 #include "tracegen_host.inc"
 #include "memtrace_host.inc"
