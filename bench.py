@@ -496,6 +496,70 @@ def h2d_profile(dev, trace_bytes, step_s):
     return res
 
 
+def plonk_recursion_profile(ctx, dev, with_cpu, sizes=(12, 13, 14), reps=8):
+    """Secondary object (SURVEY 8(f) item 1): the recursion layer's PLONK proofs -- `CircuitConfig::
+    standard_recursion_config()` (135 wires, 80 routed, FRI rate_bits 3, 28 queries, 16 PoW bits), circuits of 2^12 ..
+    2^14 rows (THRESHOLD_DEGREE_BITS = 13, fixed_recursive_verifier.rs:69), `reps` proofs per size = the chain of
+    `shrink()` proofs the reference runs per table.  Synthetic circuit data (random constants / sigmas / wires with valid
+    selector values: the prover's work does not depend on satisfiability).  With `with_cpu` the oracle's restatement of
+    plonky2's prove() is timed once at 2^13 on the same data and the two proofs are compared word for word."""
+    import numpy as np
+    import torch
+    import zk_evm_amd.plonk as zp
+    P = 0xFFFFFFFF00000001
+    gates = [(0, 0, 0, 0, 4), (1, 2, 0, 0, 4), (2, 0, 0, 0, 4), (3, 20, 0, 0, 4)]
+    out = {"config": "standard_recursion_config, gates {Noop, Constant, PublicInput, Arithmetic}", "proofs_per_size": reps,
+           "sizes": {}}
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    k_is, x = [], 1
+    for _ in range(80):
+        k_is.append(x)
+        x = x * 14293326489335486720 % P
+    for lb in sizes:
+        n = 1 << lb
+        cs = torch.randint(-(1 << 63), (1 << 63) - 1, (83, n), dtype=torch.int64, device=dev, generator=g)
+        cs[0] = torch.randint(0, 4, (n,), dtype=torch.int64, device=dev, generator=g)
+        wires = torch.randint(-(1 << 63), (1 << 63) - 1, (135, n), dtype=torch.int64, device=dev, generator=g)
+        cd = zp.CircuitData(zp.CircuitConfig(), lb, gates, 1, cs, k_is, [1, 2, 3, 4], 20, ctx=ctx)
+        pis = [5, 6, 7]
+        pr = cd.prove(wires, pis)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pr = cd.prove(wires, pis)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / reps
+        out["sizes"]["2^%d" % lb] = {"ms_per_proof": 1e3 * el, "proofs_per_s": 1.0 / el,
+                                     "stages_ms": {k: round(v, 3) for k, v in pr.stage_ms.items()},
+                                     "proof_words": int(pr.opening_proof.size)}
+        if with_cpu and lb == 13:
+            try:
+                import tests.oracle_lib as ol
+                from oracle import plonk as PK
+                o = ol.load_oracle()
+                ol.setup_fri_api(o)
+                host = cs.cpu().numpy().view(np.uint64) % np.uint64(P)
+                og = sorted([PK.NoopGate(), PK.ConstantGate(2), PK.PublicInputGate(), PK.ArithmeticGate(20)],
+                            key=lambda q: (q.degree, q.id))
+                circ = PK.Circuit(PK.CircuitConfig(), lb, og, [0] * 4, [(0, 4)], 1, np.ascontiguousarray(host[:3]),
+                                  np.ascontiguousarray(host[3:]), k_is, [1, 2, 3, 4])
+                PK.commit_circuit(o, circ)
+                tm = {}
+                t0 = time.perf_counter()
+                ep = PK.prove(o, ol, circ, wires.cpu().numpy().view(np.uint64), pis, timing=tm)
+                cpu_s = time.perf_counter() - t0
+                out["cpu_2^13"] = {"seconds": cpu_s, "stages_s": {k: round(v, 3) for k, v in tm.items()}, "kind": "port",
+                                   "cores": ol.usable_cores(), "speedup": cpu_s / el,
+                                   "proofs_identical": bool(np.array_equal(ep["fri"], pr.opening_proof) and
+                                                            np.array_equal(ep["openings"], pr.openings.reshape(-1)))}
+            except Exception as e:
+                out["cpu_2^13"] = {"error": repr(e)}
+        cd.free()
+        del cs, wires
+    return out
+
+
 def self_launch(a) -> int:
     """`python bench.py --gpus N` with no launcher around it: start the N ranks here -- one process per GPU, rank r on
     device r (or --devices), rendezvous on 127.0.0.1 -- and pass rank 0's JSON line through.  The children are this
@@ -736,6 +800,10 @@ def main():
                     out["realistic"] = realistic_profile(ctx, dev, a, all_stark, cfg)
                 except Exception as e:
                     out["realistic"] = {"error": repr(e)}
+                try:
+                    out["plonk_recursion"] = plonk_recursion_profile(ctx, dev, not a.no_cpu_baseline)
+                except Exception as e:
+                    out["plonk_recursion"] = {"error": repr(e)}
         if rank == 0 and not a.no_cpu_baseline and world == 1:
             extrap = None
             try:
