@@ -728,7 +728,9 @@ def main():
                     seg_valu = {"wave_insts_per_launch": pm["leaf_hash_valu_wave_insts_per_launch"],
                                 "achieved_wave_insts_per_s": ach, "peak_wave_insts_per_s": 1024 * 2.4e9 / 4.0,
                                 "frac": ach / (1024 * 2.4e9 / 4.0),
-                                "assumes": "1024 SIMDs x 2.4 GHz / 4 cycles per integer VALU wave-instruction",
+                                "assumes": "1024 SIMDs x 2.4 GHz / 4 cycles per wave-instruction (carry / mad / select class); "
+                                           "v_mov / v_add_u32-class ops issue at ~2.4 cycles (profiles/r01_ubench_valu_issue_rates.txt), "
+                                           "so a mix with many movs can exceed 1.0: the SIMDs are issue-saturated either way",
                                 "source": pm["source"], "source_commit": pm.get("git_commit"),
                                 "measured_in_this_run": False}
             except Exception:

@@ -178,6 +178,13 @@ int zk_challenger_get_extension_challenge(zk_challenger *ch, uint64_t out[2]);
 /* `compact()`: flush pending inputs, drop buffered outputs, return the 12-element sponge state
  * (stored as `init_challenger_state` in StarkProofWithMetadata, prover.rs:335-338) */
 int zk_challenger_compact(zk_challenger *ch, uint64_t state_out[12]);
+/* The whole transcript state as 31 words -- sponge state[12], input buffer[8], its length, output buffer[8], its length,
+ * hasher -- so that a proof whose tables live on different GPUs can hand the Fiat-Shamir chain from one process to the
+ * next (table-parallel segment proofs, SURVEY 8(e) level 2; zk_evm_amd/sharding.py).  import returns ZK_ERR_BAD_ARG on
+ * lengths above 8 or an unknown hasher. */
+#define ZK_CHALLENGER_STATE_WORDS 31
+int zk_challenger_export(const zk_challenger *ch, uint64_t out[31]);
+int zk_challenger_import(zk_challenger *ch, const uint64_t in[31]);
 
 /* ---- openings + FRI ---------------------------------------------------------------------------
  * `FriInstanceInfo` in flat form: a batch is an opening point in F_{p^2} and the list of

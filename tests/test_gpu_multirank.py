@@ -85,3 +85,83 @@ def test_scheduler_two_in_flight_reproduces_direct_proofs(oracle):
         assert sum(s.segments for s in sch.stats) == 6 and all(s.segments > 0 for s in sch.stats)
     for d, g in zip(direct, got):
         assert np.array_equal(d, words(g))
+
+
+def _tp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import zk_evm_amd
+    from tests.gpu_util import to_dev
+    from tests.test_gpu_segment import make_pv, make_traces, to_public_values
+    from zk_evm_amd.all_stark import AllStark
+    from zk_evm_amd.sharding import assign_tables, prove_segment_table_parallel
+    st = AllStark((1, 2, 3, 4))
+    cfg = zk_evm_amd.StarkConfig(fri_config=zk_evm_amd.FriConfig(num_query_rounds=5, proof_of_work_bits=4))
+    log_ns = [9, 8, 10, 7, 8, 8, 11, 8, 8]
+    host = make_traces(np.random.default_rng(77), log_ns)
+    pv = to_public_values(make_pv(np.random.default_rng(78)))
+    in_use = [True, True, True, True, True, True, True, True, False]
+    shapes = [(t.shape[0], l) for t, l in zip(host, log_ns)]
+    mine = assign_tables(shapes, world)[rank]
+    traces = [to_dev(t) if i in mine else None for i, t in enumerate(host)]     # a rank only holds the tables it owns
+    timing = {}
+    proof = prove_segment_table_parallel(st, cfg, traces, in_use, pv, timing=timing)
+    q.put((rank, mine, None if proof is None else _proof_words(proof), timing.get("tables owned")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _proof_words(p):
+    out = [np.array([x for bg in p.multi_proof.ctl_challenges for x in bg], dtype=np.uint64),
+           np.array(p.public_values.mem_before.mem_cap, dtype=np.uint64).ravel(),
+           np.array(p.public_values.mem_after.mem_cap, dtype=np.uint64).ravel()]
+    for tp in p.multi_proof.stark_proofs:
+        if tp is None:
+            out.append(np.zeros(1, dtype=np.uint64))
+            continue
+        pr = tp.proof
+        out += [np.asarray(tp.init_challenger_state).ravel(), np.asarray(pr.trace_cap).ravel(),
+                np.asarray(pr.auxiliary_polys_cap).ravel(), np.asarray(pr.quotient_polys_cap).ravel(),
+                np.asarray(pr.openings).ravel(), np.asarray(pr.opening_proof).ravel()]
+    return np.concatenate([np.asarray(x, dtype=np.uint64) for x in out])
+
+
+def test_table_parallel_segment_equals_single_gpu_proof():
+    """One segment, its tables spread over two ranks (gloo; both on this GPU): caps all-gathered, Fiat-Shamir chain
+    handed from owner to owner -- rank 0's AllProof == zk_prove_segment's, word for word."""
+    import socket
+    import torch.multiprocessing as mp
+    import zk_evm_amd
+    import zk_evm_amd.segment as sg
+    from tests.gpu_util import to_dev
+    from tests.test_gpu_segment import make_pv, make_traces, to_public_values
+    from zk_evm_amd.all_stark import AllStark
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r, mine, words, owned = q.get(timeout=600)
+        res[r] = (mine, words, owned)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(res[0][0] + res[1][0]) == list(range(9)) and res[0][0] and res[1][0]
+    assert res[1][1] is None and res[0][2] == res[0][0]
+    log_ns = [9, 8, 10, 7, 8, 8, 11, 8, 8]
+    host = make_traces(np.random.default_rng(77), log_ns)
+    pv = to_public_values(make_pv(np.random.default_rng(78)))
+    cfg = zk_evm_amd.StarkConfig(fri_config=zk_evm_amd.FriConfig(num_query_rounds=5, proof_of_work_bits=4))
+    in_use = [True, True, True, True, True, True, True, True, False]
+    direct = sg.prove_with_traces(AllStark((1, 2, 3, 4)), cfg, [to_dev(t) for t in host], in_use, pv)
+    assert np.array_equal(_proof_words(direct), res[0][1])

@@ -75,6 +75,8 @@ SIGNATURES = {
     "zk_challenger_get_challenge": (C.c_uint64, [vp]),
     "zk_challenger_get_extension_challenge": (C.c_int, [vp, u64p]),
     "zk_challenger_compact": (C.c_int, [vp, u64p]),
+    "zk_challenger_export": (C.c_int, [vp, u64p]),
+    "zk_challenger_import": (C.c_int, [vp, u64p]),
     "zk_fri_reduction_arity_bits": (sz, [C.POINTER(ZkCfg), ui, vp, sz]),
     "zk_fri_openings": (C.c_int, [vp, vp, sz, vp, sz, u64p]),
     "zk_fri_proof_words": (sz, [C.POINTER(ZkCfg), ui, vp, sz]),

@@ -62,6 +62,20 @@ class Challenger:
         self.lib.zk_challenger_compact(self.handle, out.ctypes.data)
         return out
 
+    def export_state(self) -> np.ndarray:
+        """the whole transcript state (31 words, include/zkstark.h zk_challenger_export)"""
+        out = np.zeros(31, dtype=np.uint64)
+        rc = self.lib.zk_challenger_export(self.handle, out.ctypes.data)
+        if rc != 0:
+            raise ZkStarkError(rc, "zk_challenger_export failed")
+        return out
+
+    def import_state(self, words) -> None:
+        a = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1)
+        if a.size != 31 or self.lib.zk_challenger_import(self.handle, a.ctypes.data) != 0:
+            raise ZkStarkError(-1, "bad challenger state")
+        self.hasher = int(a[30])
+
     def __del__(self):
         try:
             if getattr(self, "handle", None):
