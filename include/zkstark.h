@@ -341,6 +341,16 @@ typedef struct {
     int in_use;                      /* `table_in_use` */
     int optional;                    /* member of OPTIONAL_TABLE_INDICES (all_stark.rs:124-131) */
 } zk_table_in;
+/* Debug mode = the reference's `#[cfg(debug_assertions)] check_ctls` (prover.rs:164-184, [EXT] starky
+ * cross_table_lookup::debug_utils): with the switch on, zk_prove_segment verifies right after `get_ctl_data`, for every
+ * CTL and challenge, that the looking tables' running sums (plus the CTL's extra looking rows) equal the looked table's
+ * -- the logUp form of the multiset equality starky checks row by row -- and fails with ZK_ERR_BAD_ARG naming the CTL
+ * when a witness is inconsistent, instead of emitting a proof the verifier will reject.  Extra looking rows (the Memory
+ * CTL's public-value writes, `get_memory_extra_looking_values`, verifier.rs:547-...) are handed over per CTL index as
+ * n_rows x width field elements, each row contributing 1 / (sum_j beta^j row[j] + gamma); they are consumed by the next
+ * zk_prove_segment on this ctx.  Costs one 8-byte read-back per Z column. */
+int zk_ctx_set_check_ctls(zk_ctx *ctx, int on);
+int zk_ctx_set_ctl_extra_looking(zk_ctx *ctx, size_t ctl_index, const uint64_t *rows, size_t n_rows, size_t width);
 typedef struct zk_segment_proof zk_segment_proof;
 int zk_prove_segment(zk_ctx *ctx, const zk_cfg *cfg, const zk_table_in *tables, size_t n_tables,
                      const uint64_t *ctl_wiring, size_t wiring_words, const uint64_t *public_value_elements,

@@ -81,7 +81,9 @@ def to_public_values(d):
                          d["parent_beacon_root"], list(d["bloom"])),
         sg.BlockHashes(list(d["prev_hashes"]), d["cur_hash"]),
         sg.ExtraBlockData(d["checkpoint_root"], list(d["checkpoint_hash"]), d["txn_before"], d["txn_after"],
-                          d["gas_before"], d["gas_after"]))
+                          d["gas_before"], d["gas_after"]),
+        burn_addr=d.get("burn_addr"), registers_before=dict(d.get("registers_before", {})),
+        registers_after=dict(d.get("registers_after", {})))
 
 
 @pytest.mark.parametrize("hasher,in_use", [(0, [True] * 9),
@@ -488,8 +490,10 @@ def test_cdk_erigon_segment_proof_matches_oracle(oracle, in_use):
     # an eth_mainnet AllStark refuses ten tables; a cdk_erigon one refuses public values without a burn address
     with pytest.raises(zk.ZkStarkError):
         sg.prove_with_traces(AllStark(oairs.CPU_TEST_CONSTS), scfg, dev, in_use, pv)
+    no_burn = to_public_values(pvd)
+    no_burn.burn_addr = None
     with pytest.raises(zk.ZkStarkError):
-        sg.prove_with_traces(st, scfg, dev, in_use, to_public_values(pvd))
+        sg.prove_with_traces(st, scfg, dev, in_use, no_burn)
 
 
 @pytest.mark.parametrize("hasher", [0, 1])
@@ -919,3 +923,33 @@ def test_two_contexts_prove_concurrently():
         t.join(timeout=240)
     assert not errors, errors
     assert results[0] == [serial[0]] * 6 and results[1] == [serial[1]] * 6
+
+
+def test_check_ctls_debug_mode(oracle):
+    """The reference's debug-build `check_ctls` (prover.rs:164-184) as a library switch: a consistent nine-table segment
+    (Cpu executing a kernel program, every table live, the public values' Memory writes as extra looking rows) passes; one
+    changed cell fails BEFORE any table is proven, with the unbalanced CTL named; a wrong kernel hash unbalances Memory."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    from tests import consistent_segment as cs
+    from zk_evm_amd.all_stark import AllStark
+    rng = np.random.default_rng(79)
+    kh = int.from_bytes(rng.bytes(32), "big")
+    traces, pvd, code = cs.build_with_cpu_program(rng, oracle, kh)
+    st = AllStark(cs.CPU_PROGRAM_CONSTS)
+    cfg = zk.StarkConfig(fri_config=zk.FriConfig(num_query_rounds=4, proof_of_work_bits=3))
+
+    def run(trs, check):
+        dev = [torch.from_numpy(np.ascontiguousarray(t).view(np.int64)).cuda() for t in trs]
+        return sg.prove_with_traces(st, cfg, dev, [True] * 9, to_public_values(pvd), check_ctls=check)
+    ref = run(traces, None)
+    got = run(traces, (kh, len(code)))                                 # balanced: the same proof comes out
+    assert np.array_equal(got.multi_proof.stark_proofs[6].proof.opening_proof, ref.multi_proof.stark_proofs[6].proof.opening_proof)
+    bad = [t.copy() for t in traces]
+    bad[2][41 + 5, 4] = 4                                              # 2 + 1 = 4: the Cpu's view of an ADD result
+    with pytest.raises(zk.ZkStarkError, match="check_ctls: CTL 0 is not balanced"):
+        run(bad, (kh, len(code)))
+    with pytest.raises(zk.ZkStarkError, match="check_ctls: CTL 6 is not balanced"):
+        run(traces, (kh ^ 1, len(code)))                               # the Memory CTL's extra looking rows
+    run(bad, None)                                                     # without the switch the prover does not care

@@ -91,6 +91,8 @@ SIGNATURES = {
                                  ui, C.c_int, vp, C.POINTER(vp)]),
     "zk_table_proof_get": (C.c_int, [vp, vp]),
     "zk_table_proof_free": (None, [vp]),
+    "zk_ctx_set_check_ctls": (C.c_int, [vp, C.c_int]),
+    "zk_ctx_set_ctl_extra_looking": (C.c_int, [vp, sz, u64p, sz, sz]),
     "zk_prove_segment": (C.c_int, [vp, C.POINTER(ZkCfg), vp, sz, u64p, sz, u64p, sz, ui, C.c_int, C.c_int,
                                    C.POINTER(vp)]),
     "zk_segment_proof_num_tables": (sz, [vp]),

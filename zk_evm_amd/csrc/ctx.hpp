@@ -34,6 +34,9 @@ struct zk_ctx {
     int cu_count = 0;
     std::set<zk_batch *> live_batches;  // freed by zk_ctx_destroy if the caller leaked them
     DevArena arena;                     // all batch + scratch HBM (arena.hpp)
+    // debug: starky `check_ctls` after get_ctl_data (zk_ctx_set_check_ctls); extra looking rows per CTL index
+    bool check_ctls = false;
+    std::map<size_t, std::pair<size_t, std::vector<u64>>> ctl_extra;   // ctl -> (row width, rows)
     std::map<std::vector<u64>, u32> constraint_counts;   // quotient: constraints yielded per (AIR, lookup/CTL shape)
 };
 

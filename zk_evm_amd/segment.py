@@ -110,6 +110,10 @@ class PublicValues:
     # proof.rs:73-78: "Address to store the base fee to be burnt: only used when `cdk_erigon` is active" (a U256);
     # None = eth_mainnet.  Observed after extra_block_data (get_challenges.rs:146-154,211-219).
     burn_addr: Optional[int] = None
+    # proof.rs:85-87 `RegistersData` before / after the segment (program_counter, is_kernel, stack_len, stack_top,
+    # context, gas_used).  Not part of the transcript; they enter the Memory CTL as extra looking rows (verifier.rs).
+    registers_before: dict = field(default_factory=dict)
+    registers_after: dict = field(default_factory=dict)
 
 
 class PublicValuesError(ZkStarkError):
@@ -183,6 +187,55 @@ def public_values_elements(pv: PublicValues) -> List[int]:
             raise PublicValuesError()
         out += u256_limbs(pv.burn_addr)
     return out
+
+
+# memory/segments.rs:25-77 (unscaled) and cpu/kernel/constants/global_metadata.rs:7-77 ordinals used by the
+# public-value writes of the Memory CTL
+_SEG_GLOBAL_METADATA, _SEG_GLOBAL_BLOCK_BLOOM, _SEG_BLOCK_HASHES, _SEG_REGISTERS_STATES = 5, 24, 32, 33
+_GM = dict(StateTrieRootDigestBefore=6, TransactionTrieRootDigestBefore=7, ReceiptTrieRootDigestBefore=8,
+           StateTrieRootDigestAfter=9, TransactionTrieRootDigestAfter=10, ReceiptTrieRootDigestAfter=11,
+           BlockBeneficiary=12, BlockTimestamp=13, BlockNumber=14, BlockDifficulty=15, BlockRandom=16, BlockGasLimit=17,
+           BlockChainId=18, BlockBaseFee=19, BlockBlobGasUsed=20, BlockExcessBlobGas=21, BlockGasUsed=22,
+           BlockGasUsedBefore=23, BlockGasUsedAfter=24, BlockCurrentHash=25, ParentBeaconBlockRoot=26,
+           TxnNumberBefore=42, TxnNumberAfter=43, KernelHash=45, KernelLen=46, BurnAddr=53)
+REGISTER_FIELDS = ("program_counter", "is_kernel", "stack_len", "stack_top", "context", "gas_used")
+MEMORY_CTL_INDEX = 6                                                    # all_stark.rs:146-172: position of ctl_memory
+
+
+def get_memory_extra_looking_values(pv: PublicValues, kernel_hash: int, kernel_len: int) -> List[List[int]]:
+    """`verifier::debug_utils::get_memory_extra_looking_values` (verifier.rs:547-...): the Memory-CTL rows
+    (is_read = 0, context 0, segment, index, eight 32-bit value limbs, timestamp 2) of the public values the kernel reads
+    from memory -- block metadata, trie roots, block bloom, the 256 previous block hashes, the registers before / after.
+    `KERNEL.code_hash` and `KERNEL.code.len()` are parameters (the assembled kernel is the caller's)."""
+    be = lambda b: int.from_bytes(b, "big")
+    m, e = pv.block_metadata, pv.extra_block_data
+    erigon = pv.burn_addr is not None
+    fields = [("BlockBeneficiary", be(m.block_beneficiary))]
+    if erigon:
+        fields.append(("BurnAddr", pv.burn_addr))
+    fields += [("BlockTimestamp", m.block_timestamp), ("BlockNumber", m.block_number), ("BlockRandom", be(m.block_random)),
+               ("BlockDifficulty", m.block_difficulty), ("BlockGasLimit", m.block_gaslimit), ("BlockChainId", m.block_chain_id),
+               ("BlockBaseFee", m.block_base_fee)]
+    if not erigon:
+        fields.append(("ParentBeaconBlockRoot", be(m.parent_beacon_block_root)))
+    fields += [("BlockCurrentHash", be(pv.block_hashes.cur_hash)), ("BlockGasUsed", m.block_gas_used)]
+    if not erigon:
+        fields += [("BlockBlobGasUsed", m.block_blob_gas_used), ("BlockExcessBlobGas", m.block_excess_blob_gas)]
+    fields += [("TxnNumberBefore", e.txn_number_before), ("TxnNumberAfter", e.txn_number_after),
+               ("BlockGasUsedBefore", e.gas_used_before), ("BlockGasUsedAfter", e.gas_used_after),
+               ("StateTrieRootDigestBefore", be(pv.trie_roots_before.state_root)),
+               ("TransactionTrieRootDigestBefore", be(pv.trie_roots_before.transactions_root)),
+               ("ReceiptTrieRootDigestBefore", be(pv.trie_roots_before.receipts_root)),
+               ("StateTrieRootDigestAfter", be(pv.trie_roots_after.state_root)),
+               ("TransactionTrieRootDigestAfter", be(pv.trie_roots_after.transactions_root)),
+               ("ReceiptTrieRootDigestAfter", be(pv.trie_roots_after.receipts_root)),
+               ("KernelHash", kernel_hash), ("KernelLen", kernel_len)]
+    writes = [(_SEG_GLOBAL_METADATA, _GM[k], v) for k, v in fields]
+    writes += [(_SEG_GLOBAL_BLOCK_BLOOM, i, m.block_bloom[i]) for i in range(8)]
+    writes += [(_SEG_BLOCK_HASHES, i, be(pv.block_hashes.prev_hashes[i])) for i in range(256)]
+    for base, regs in ((0, pv.registers_before), (len(REGISTER_FIELDS), pv.registers_after)):
+        writes += [(_SEG_REGISTERS_STATES, base + i, regs.get(f, 0)) for i, f in enumerate(REGISTER_FIELDS)]
+    return [[0, 0, seg, idx] + u256_limbs(val) + [2] for seg, idx, val in writes]
 
 
 def observe_public_values(challenger: Challenger, pv: PublicValues) -> None:
@@ -308,12 +361,16 @@ def encode_ctl_wiring(ctls: Sequence[CrossTableLookup]) -> np.ndarray:
 
 def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_values: Sequence,
                       table_in_use: Sequence[bool], public_values: PublicValues, abort_signal=None,
-                      hasher: Optional[int] = None, ctx=None, timing: Optional[dict] = None) -> AllProof:
+                      hasher: Optional[int] = None, ctx=None, timing: Optional[dict] = None,
+                      check_ctls: Optional[Tuple[int, int]] = None) -> AllProof:
     """prover.rs:72-194 as ONE C-ABI call (zk_prove_segment; the sequencing is compiled, csrc/segment_host.inc).
     `trace_poly_values[t]`: CUDA int64/uint64 tensor (columns, 2^k) -- the column-major
     `Vec<PolynomialValues<F>>` of table t (values may be non-canonical).  `abort_signal`: a ctypes c_int that
     another thread may set (polled between kernels) or an object with `.is_set()` (checked on entry).
-    `timing`: optional dict receiving the reference's TimingTree scopes in seconds."""
+    `timing`: optional dict receiving the reference's TimingTree scopes in seconds.
+    `check_ctls`: (kernel_hash, kernel_len) switches on the reference's debug-build `check_ctls` (prover.rs:164-184): the
+    library verifies every cross-table lookup (Memory with the public values' extra looking rows) right after the CTL
+    data and raises naming the unbalanced CTL instead of producing a proof the verifier would reject."""
     from .context import default_context
     from .prover import encode_lookup_set, table_proof_from_handle
     from .stark import _trace_args
@@ -355,6 +412,10 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
         ti.lookup_program, ti.lookup_words = (lp.ctypes.data, lp.size) if lp is not None else (None, 0)
         ti.in_use = 1 if table_in_use[t] else 0
         ti.optional = 1 if t in OPTIONAL_TABLE_INDICES else 0
+    if check_ctls is not None:
+        rows = np.array(get_memory_extra_looking_values(public_values, *check_ctls), dtype=np.uint64)
+        ctx.check(ctx.lib.zk_ctx_set_check_ctls(ctx.handle, 1))
+        ctx.check(ctx.lib.zk_ctx_set_ctl_extra_looking(ctx.handle, MEMORY_CTL_INDEX, rows.ctypes.data, rows.shape[0], rows.shape[1]))
     h = C.c_void_p()
     try:
         rc = ctx.lib.zk_prove_segment(ctx.handle, C.byref(cfg), C.cast(tables, C.c_void_p), NUM_TABLES,
@@ -366,6 +427,8 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
     finally:
         if isinstance(abort_signal, C.c_int):
             ctx.set_abort_flag(None)
+        if check_ctls is not None:
+            ctx.lib.zk_ctx_set_check_ctls(ctx.handle, 0)
     lib = ctx.lib
     try:
         nchal = config.num_challenges
