@@ -97,9 +97,83 @@ ARITHMETIC = [("c", 17), ("c", 1), ("c", 1),                    # :214-223 op-fl
               ("l", 1), ("t", _MODULAR_CONSTR_POLY + 32)]       # shift.rs:100-119 SHR = the DIV check
 ARITHMETIC_TOTAL = 707
 
-CPU_TOTAL = 514               # cpu_stark.rs:594-626, 18 modules (eth_mainnet); 531 with the cdk_erigon column set
+# ---- CpuStark: cpu/cpu_stark.rs:594-626, the 18 modules in call order (eth_mainnet feature set) -------------------
+# NUM_GP_CHANNELS = 3; a memory channel carries 8 value limbs; OpsColumnsView field order (cpu/columns/ops.rs:6-47).
+CPU_OPS = ["binary_op", "ternary_op", "fp254_op", "eq_iszero", "logic_op", "not_pop", "shift", "jumpdest_keccak_general",
+           "jumps", "push_prover_input", "dup_swap", "context_op", "m_op_32bytes", "exit_kernel", "m_op_general", "pc_push0",
+           "syscall", "exception"]
 
-TABLES = {1: MEM_CONTINUATION, 2: LOGIC, 3: MEMORY, 4: BYTE_PACKING, 5: ARITHMETIC, 6: KECCAK, 7: KECCAK_SPONGE}
+
+def _stack_one(num_pops, pushes, disable):
+    """cpu/stack.rs:190-306 `eval_packed_one`"""
+    r = []
+    if num_pops > 0:
+        r += [("c", 5 * (num_pops - 1)), ("c", 1)]           # the popped channels 1.., the partial channel is unused
+        if not pushes:
+            r += [("t", 5), ("c", 1), ("t", 1)]              # the new top is read next row unless the stack empties
+    elif pushes:
+        r += [("c", 5 + 1 + 1)]                              # the old top goes out through the partial channel
+    else:
+        r += [("c", 1 + 8 + 1)]                              # nothing moves: same top, no channel
+    if disable:
+        r += [("c", len(range(max(1, num_pops), 3 - int(pushes))))]
+    return r + [("t", 1)]                                    # stack_len update
+
+
+_BINARY, _TERNARY, _UNARY = (2, True, True), (3, True, True), (1, True, True)
+# cpu/stack.rs:120-171 STACK_BEHAVIORS and :20-41 MIGHT_OVERFLOW
+_STACK_BEHAVIORS = dict(binary_op=_BINARY, ternary_op=_TERNARY, fp254_op=_BINARY, logic_op=_BINARY, shift=(2, True, False),
+                        push_prover_input=(0, True, True), pc_push0=(0, True, True), m_op_32bytes=(2, True, False),
+                        exit_kernel=(1, False, True), syscall=(0, True, False), exception=(0, True, False))
+_MIGHT_OVERFLOW = {"push_prover_input", "pc_push0", "dup_swap", "exit_kernel"}
+# cpu/contextops.rs:15-38 KEEPS_CONTEXT: every op except context_op; cpu/gas.rs:20-42 SIMPLE_OPCODES: the `Some` entries
+_KEEPS_CONTEXT = [op for op in CPU_OPS if op != "context_op"]
+_SIMPLE_GAS = ["fp254_op", "eq_iszero", "logic_op", "shift", "pc_push0", "dup_swap", "context_op", "m_op_32bytes", "m_op_general"]
+
+CPU = (
+    [("c", 1 + 2 + 5)]                                       # byte_unpacking.rs:11-46
+    + [("f", 1), ("t", 1)]                                   # clock.rs:15-24
+    # contextops.rs: keep :40-54, get :79-103, set :150-203, top level :277-314
+    + [("t", len(_KEEPS_CONTEXT) + 1)]
+    + [("c", 1 + 7 + 1 + 1 + 1 + 1)]
+    + [("c", 1 + 6 + 1 + 1 + 1 + 8 + 1 + 1)]
+    + [("c", 6)]
+    + [("t", 5), ("c", 1), ("t", 3)]                         # control_flow.rs:50-102
+    # decode.rs:86-221: kernel flag, 8 opcode bits, 5 OPCODES flags, 11 COMBINED_OPCODES flags, their sum, 5 opcode
+    # matches, 12 combined-flag decodings
+    + [("c", 1 + 8 + 5 + 11 + 1 + 5 + 12)]
+    # dup_swap.rs: dup (two channel equalities + two channel descriptions, stack_len, no top read), swap, partial channel
+    + [("c", 8 + 5 + 8 + 5), ("t", 1), ("c", 1)] + [("c", 8 + 5 + 8 + 5 + 1 + 1)] + [("c", 1)]
+    + [("t", 1 + len(_SIMPLE_GAS) + 4 + 1 + 1 + 1)]          # gas.rs:44-139: accumulate (+ jumps, binary, ternary, not_pop,
+                                                             # jumpdest/keccak, push/prover_input), init
+    + [("c", 1), ("t", 1), ("c", 1 + 3), ("l", 1), ("c", 1)]  # halt.rs:16-50
+    # jumps.rs: exit_kernel :16-37; jump_jumpi :66-189 (the JumpdestBits read only exists in eth_mainnet / polygon_pos)
+    + [("t", 3), ("c", 1)]
+    + [("t", 5), ("c", 1), ("t", 1), ("c", 1 + 7 + 4 + 6 + 0 + 1 + 1), ("t", 4)]
+    + [("c", 1 + 3 + 1)]                                     # membus.rs:42-57
+    # memio.rs: load :27-74 (+ MLOAD_GENERAL stack behaviour), store :135-225
+    + [("c", 5 + 8 + 1 + 1)] + _stack_one(1, True, False)
+    + [("c", 5 + 1 + 5 + 1 + 1), ("t", 5), ("c", 2)]
+    + [("c", 8)]                                             # modfp254.rs
+    + [("c", 1 + 7)]                                         # pc.rs
+    + [("c", 8)]                                             # push0.rs
+    + [("c", 6 + 0)]                                         # shift.rs:19-60 (mem_channels[3..NUM_GP_CHANNELS] is empty)
+    + [("c", 8)] + _stack_one(*_UNARY)                       # simple_logic/not.rs
+    + [("c", 1 + 7 + 8 + 8 + 1)] + _stack_one(2, True, True) + _stack_one(1, True, True)   # simple_logic/eq_iszero.rs
+)
+# stack.rs:308-388 `eval_packed`: per op its behaviour and the overflow check, then JUMPDEST / KECCAK_GENERAL, then POP / NOT
+for _op in CPU_OPS:
+    if _op in _STACK_BEHAVIORS:
+        CPU += _stack_one(*_STACK_BEHAVIORS[_op])
+    if _op in _MIGHT_OVERFLOW:
+        CPU += [("t", 1)]
+CPU += _stack_one(0, False, True) + _stack_one(2, True, True)
+CPU += [("c", 2), ("t", 5), ("c", 1 + 2 + 1), ("t", 1)]
+# syscalls_exceptions.rs:29-135
+CPU += [("c", 2 + 1 + 3 + 4 + 2 + 7 + 1), ("t", 3), ("c", 6 + 4)]
+CPU_TOTAL = 514               # 531 with the cdk_erigon column set (not itemised)
+
+TABLES = {1: MEM_CONTINUATION, 2: LOGIC, 3: MEMORY, 4: BYTE_PACKING, 5: ARITHMETIC, 6: KECCAK, 7: KECCAK_SPONGE, 8: CPU}
 
 
 def expand(runs):

@@ -24,7 +24,7 @@ def test_kind_sequence_matches_manifest(air_id):
 
 
 def test_totals():
-    assert len(M.expand(M.ARITHMETIC)) == M.ARITHMETIC_TOTAL
+    assert len(M.expand(M.ARITHMETIC)) == M.ARITHMETIC_TOTAL and len(M.expand(M.CPU)) == M.CPU_TOTAL
     assert len(_kinds(8)) == M.CPU_TOTAL and len(_kinds(10)) == 531
 
 
