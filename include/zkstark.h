@@ -385,6 +385,13 @@ typedef enum {
     ZK_PLONK_GATE_CONSTANT = 1,      /* gates/constant.rs `ConstantGate { num_consts = param }` */
     ZK_PLONK_GATE_PUBLIC_INPUT = 2,  /* gates/public_input.rs */
     ZK_PLONK_GATE_ARITHMETIC = 3,    /* gates/arithmetic_base.rs `ArithmeticGate { num_ops = param }` */
+    ZK_PLONK_GATE_ARITHMETIC_EXTENSION = 4, /* gates/arithmetic_extension.rs `{ num_ops = param }` (D = 2) */
+    ZK_PLONK_GATE_MUL_EXTENSION = 5, /* gates/multiplication_extension.rs `{ num_ops = param }` */
+    ZK_PLONK_GATE_BASE_SUM_2 = 6,    /* gates/base_sum.rs `BaseSumGate<2> { num_limbs = param }` */
+    ZK_PLONK_GATE_REDUCING = 7,      /* gates/reducing.rs `{ num_coeffs = param }` */
+    ZK_PLONK_GATE_REDUCING_EXTENSION = 8, /* gates/reducing_extension.rs `{ num_coeffs = param }` */
+    ZK_PLONK_GATE_EXPONENTIATION = 9,/* gates/exponentiation.rs `{ num_power_bits = param }` */
+    ZK_PLONK_GATE_POSEIDON = 10,     /* gates/poseidon.rs (135 wires, 123 constraints) */
 } zk_plonk_gate_kind;
 /* one entry of `common_data.gates` (sorted by (degree, id) as the builder sorts them) with its selector:
  * `selectors_info.selector_indices[gate]` and `selectors_info.groups[selector_index]` = [group_start, group_end) */

@@ -131,6 +131,194 @@ class ArithmeticGate:
                 for i in range(self.num_ops)]
 
 
+# ---- extension-field helpers on component pairs (elements may be ints, tape symbols or Ext: at zeta plonky2 works in
+# the `ExtensionAlgebra` -- pairs of extension elements with the same X^2 = 7 rule) ---------------------------------
+def _emul(a, b):
+    return (a[0] * b[0] + 7 * (a[1] * b[1]), a[0] * b[1] + a[1] * b[0])
+
+
+def _eadd(a, b):
+    return (a[0] + b[0], a[1] + b[1])
+
+
+def _esub(a, b):
+    return (a[0] - b[0], a[1] - b[1])
+
+
+def _escale(a, k):
+    return (a[0] * k, a[1] * k)
+
+
+class ArithmeticExtensionGate:
+    """gates/arithmetic_extension.rs: num_ops x (output = c0 * m0 * m1 + c1 * addend) over F_{p^2}; wires of op i:
+    8i.. multiplicand_0, +2 multiplicand_1, +4 addend, +6 output (D = 2 wires each)."""
+    degree, num_constants = 3, 2
+    KIND = 4
+
+    def __init__(self, num_ops=10):                      # num_routed_wires / (4 D)
+        self.num_ops = self.PARAM = num_ops
+        self.num_constraints = 2 * num_ops
+        self.id = "ArithmeticExtensionGate { num_ops: %d }" % num_ops
+
+    def eval_unfiltered(self, consts, w, pi_hash):
+        out = []
+        for i in range(self.num_ops):
+            m0, m1, ad, o = [(w[8 * i + 2 * k], w[8 * i + 2 * k + 1]) for k in range(4)]
+            out += list(_esub(o, _eadd(_escale(_emul(m0, m1), consts[0]), _escale(ad, consts[1]))))
+        return out
+
+
+class MulExtensionGate:
+    """gates/multiplication_extension.rs: num_ops x (output = c0 * m0 * m1); wires of op i: 6i.. m0, +2 m1, +4 output."""
+    degree, num_constants = 3, 1
+    KIND = 5
+
+    def __init__(self, num_ops=13):                      # num_routed_wires / (3 D)
+        self.num_ops = self.PARAM = num_ops
+        self.num_constraints = 2 * num_ops
+        self.id = "MulExtensionGate { num_ops: %d }" % num_ops
+
+    def eval_unfiltered(self, consts, w, pi_hash):
+        out = []
+        for i in range(self.num_ops):
+            m0, m1, o = [(w[6 * i + 2 * k], w[6 * i + 2 * k + 1]) for k in range(3)]
+            out += list(_esub(o, _escale(_emul(m0, m1), consts[0])))
+        return out
+
+
+class BaseSumGate:
+    """gates/base_sum.rs `BaseSumGate<2>`: wire 0 = sum_i limb_i 2^i, wires 1.. the limbs, each a bit."""
+    degree, num_constants = 2, 0
+    KIND = 6
+
+    def __init__(self, num_limbs=63):                    # new_from_config: min(log_floor(p - 1, 2), num_routed_wires - 1)
+        self.num_limbs = self.PARAM = num_limbs
+        self.num_constraints = 1 + num_limbs
+        self.id = "BaseSumGate { num_limbs: %d } + Base: 2" % num_limbs
+
+    def eval_unfiltered(self, consts, w, pi_hash):
+        limbs = [w[1 + i] for i in range(self.num_limbs)]
+        acc = 0
+        for l in reversed(limbs):                         # reduce_with_powers(limbs, B)
+            acc = acc * 2 + l
+        return [acc - w[0]] + [l * (l - 1) for l in limbs]
+
+
+class ReducingGate:
+    """gates/reducing.rs: acc_{i} = acc_{i-1} * alpha + coeff_i (base-field coefficients, extension accumulator).
+    wires: output 0..2, alpha 2..4, old_acc 4..6, coeffs 6..6+n, accs (n - 1 pairs; the last accumulator is the output)."""
+    degree, num_constants = 2, 0
+    KIND = 7
+
+    def __init__(self, num_coeffs=43):
+        self.n = self.PARAM = num_coeffs
+        self.num_constraints = 2 * num_coeffs
+        self.id = "ReducingGate { num_coeffs: %d }" % num_coeffs
+
+    def _acc(self, w, i):
+        if i == self.n - 1:
+            return (w[0], w[1])
+        s = 6 + self.n + 2 * i
+        return (w[s], w[s + 1])
+
+    def eval_unfiltered(self, consts, w, pi_hash):
+        alpha, acc, out = (w[2], w[3]), (w[4], w[5]), []
+        for i in range(self.n):
+            t = _emul(acc, alpha)
+            out += list(_esub(self._acc(w, i), (t[0] + w[6 + i], t[1])))
+            acc = self._acc(w, i)
+        return out
+
+
+class ReducingExtensionGate(ReducingGate):
+    """gates/reducing_extension.rs: the same with extension-field coefficients (coeff i at wires 6 + 2i, 7 + 2i)."""
+    KIND = 8
+
+    def __init__(self, num_coeffs=32):
+        self.n = self.PARAM = num_coeffs
+        self.num_constraints = 2 * num_coeffs
+        self.id = "ReducingExtensionGate { num_coeffs: %d }" % num_coeffs
+
+    def _acc(self, w, i):
+        if i == self.n - 1:
+            return (w[0], w[1])
+        s = 6 + 2 * self.n + 2 * i
+        return (w[s], w[s + 1])
+
+    def eval_unfiltered(self, consts, w, pi_hash):
+        alpha, acc, out = (w[2], w[3]), (w[4], w[5]), []
+        for i in range(self.n):
+            out += list(_esub(self._acc(w, i), _eadd(_emul(acc, alpha), (w[6 + 2 * i], w[7 + 2 * i]))))
+            acc = self._acc(w, i)
+        return out
+
+
+class ExponentiationGate:
+    """gates/exponentiation.rs: output = base^(sum power_bit_i 2^i), most significant bit first; wires: base 0, power
+    bits 1..n, output n + 1, intermediate values n + 2 ..."""
+    degree, num_constants = 4, 0
+    KIND = 9
+
+    def __init__(self, num_power_bits=66):               # max_power_bits(135, 80) = min(80 - 2, (135 - 2) / 2)
+        self.n = self.PARAM = num_power_bits
+        self.num_constraints = num_power_bits + 1
+        self.id = "ExponentiationGate { num_power_bits: %d }" % num_power_bits
+
+    def eval_unfiltered(self, consts, w, pi_hash):
+        n, base, out = self.n, w[0], []
+        inter = [w[2 + n + i] for i in range(n)]
+        for i in range(n):
+            prev = 1 if i == 0 else inter[i - 1] * inter[i - 1]
+            bit = w[1 + (n - 1 - i)]                      # power bits are little-endian wires, consumed from the top
+            out.append(inter[i] - prev * (bit * base + (1 - bit)))
+        return out + [w[1 + n] - inter[n - 1]]
+
+
+class PoseidonGate:
+    """gates/poseidon.rs: one permutation per row.  wires: input 0..12, output 12..24, swap 24, delta 25..29, the S-box
+    inputs of full rounds 1..3 (29..65), of the 22 partial rounds (65..87), of the last 4 full rounds (87..135).
+    Evaluated with the plain round function: the same constraint polynomials as plonky2's fast partial rounds (see
+    oracle/poseidon_table.py: between S-boxes both are the same affine maps)."""
+    degree, num_constants, num_constraints = 7, 0, 123
+    KIND, PARAM = 10, 0
+    id = "PoseidonGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)"
+
+    def eval_unfiltered(self, consts, w, pi_hash):
+        from . import poseidon_table as PT
+        RC, mds = PT.RC, PT.mds
+        swap = w[24]
+        out = [swap * (swap - 1)]
+        for i in range(4):
+            out.append(swap * (w[i + 4] - w[i]) - w[25 + i])
+        state = [w[i] + w[25 + i] for i in range(4)] + [w[i + 4] - w[25 + i] for i in range(4)] + [w[i] for i in range(8, 12)]
+        sbox = lambda x: x * x * x * x * x * x * x
+        rnd = 0
+        for r in range(4):
+            state = [state[i] + RC[rnd * 12 + i] for i in range(12)]
+            if r != 0:
+                for i in range(12):
+                    sin = w[29 + 12 * (r - 1) + i]
+                    out.append(state[i] - sin)
+                    state[i] = sin
+            state = mds([sbox(x) for x in state])
+            rnd += 1
+        for r in range(22):
+            state = [state[i] + RC[rnd * 12 + i] for i in range(12)]
+            sin = w[65 + r]
+            out.append(state[0] - sin)
+            state = mds([sbox(sin)] + state[1:])
+            rnd += 1
+        for r in range(4):
+            state = [state[i] + RC[rnd * 12 + i] for i in range(12)]
+            for i in range(12):
+                sin = w[87 + 12 * r + i]
+                out.append(state[i] - sin)
+                state[i] = sin
+            state = mds([sbox(x) for x in state])
+            rnd += 1
+        return out + [state[i] - w[12 + i] for i in range(12)]
+
+
 @dataclass
 class CircuitConfig:
     """CircuitConfig::standard_recursion_config()"""
@@ -334,6 +522,180 @@ def build_arithmetic_circuit(degree_bits, seed, cfg: CircuitConfig = None, n_pub
     circ = Circuit(cfg, degree_bits, gates, selector_indices, groups, len(sel), constants, sigmas, k_is,
                    [rnd() for _ in range(4)])
     return circ, np.array(wires, dtype=np.uint64), public_inputs
+
+
+def build_mixed_circuit(degree_bits, seed, cfg: CircuitConfig = None, n_public_inputs=3):
+    """Like `build_arithmetic_circuit`, with every gate kind of this file on a few rows each, valid witness included:
+    extension arithmetic, bit decompositions, reducing chains, exponentiations and Poseidon permutations whose operands
+    are wired to earlier results.  Eleven gates in three selector groups (degrees 0..7 under max_degree 9)."""
+    from . import poseidon_table as PT
+    cfg = cfg or CircuitConfig()
+    assert (cfg.num_wires, cfg.num_routed_wires) == (135, 80), "the wide gates below assume the standard wire counts"
+    rng = np.random.default_rng(seed)
+    n = 1 << degree_bits
+    gates = sorted([NoopGate(), ConstantGate(cfg.num_constants), PublicInputGate(), ArithmeticGate(20), ArithmeticExtensionGate(10),
+                    MulExtensionGate(13), BaseSumGate(63), ReducingGate(43), ReducingExtensionGate(32), ExponentiationGate(66),
+                    PoseidonGate()], key=lambda g: (g.degree, g.id))
+    gidx = {type(g): i for i, g in enumerate(gates)}
+    rnd = lambda: int(rng.integers(0, P, dtype=np.uint64))
+    wires = [[rnd() for _ in range(n)] for _ in range(cfg.num_wires)]      # everything not set below is free advice
+    gate_of_row = [gidx[NoopGate]] * n
+    gate_consts = [[0] * n for _ in range(cfg.num_constants)]
+    parent = {}
+
+    def find(a):
+        while parent.setdefault(a, a) != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+    pool = []
+
+    def operand(r, col, p_connect=0.6):
+        """value for routed cell (r, col): copied from an earlier result (copy constraint) or fresh"""
+        if pool and col < cfg.num_routed_wires and rng.random() < p_connect:
+            src, v = pool[int(rng.integers(0, len(pool)))]
+            parent[find((r, col))] = find(src)
+        else:
+            v = rnd()
+        wires[col][r] = v
+        return v
+
+    def result(r, col, v):
+        wires[col][r] = v % P
+        if col < cfg.num_routed_wires:
+            pool.append(((r, col), v % P))
+    emul = lambda a, b: ((a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+    public_inputs = [rnd() for _ in range(n_public_inputs)]
+    gate_of_row[0] = gidx[PublicInputGate]
+    row = 1
+    for _ in range(2):                                                     # constants
+        gate_of_row[row] = gidx[ConstantGate]
+        for i in range(cfg.num_constants):
+            v = rnd()
+            gate_consts[i][row] = v
+            result(row, i, v)
+        row += 1
+    budget = n - row
+    per_kind = max(1, budget // 10)
+    for kind in (ArithmeticGate, ArithmeticExtensionGate, MulExtensionGate, BaseSumGate, ReducingGate, ReducingExtensionGate,
+                 ExponentiationGate, PoseidonGate):
+        for _ in range(per_kind):
+            if row >= n:
+                break
+            r = row
+            row += 1
+            gate_of_row[r] = gidx[kind]
+            if kind is ArithmeticGate:
+                c0, c1 = rnd(), rnd()
+                gate_consts[0][r], gate_consts[1][r] = c0, c1
+                for op in range(20):
+                    a, b, c = (operand(r, 4 * op + k) for k in range(3))
+                    result(r, 4 * op + 3, a * b % P * c0 + c * c1)
+            elif kind is ArithmeticExtensionGate:
+                c0, c1 = rnd(), rnd()
+                gate_consts[0][r], gate_consts[1][r] = c0, c1
+                for op in range(10):
+                    v = [operand(r, 8 * op + k) for k in range(6)]
+                    m = emul((v[0], v[1]), (v[2], v[3]))
+                    result(r, 8 * op + 6, m[0] * c0 + v[4] * c1)
+                    result(r, 8 * op + 7, m[1] * c0 + v[5] * c1)
+            elif kind is MulExtensionGate:
+                c0 = rnd()
+                gate_consts[0][r] = c0
+                for op in range(13):
+                    v = [operand(r, 6 * op + k) for k in range(4)]
+                    m = emul((v[0], v[1]), (v[2], v[3]))
+                    result(r, 6 * op + 4, m[0] * c0)
+                    result(r, 6 * op + 5, m[1] * c0)
+            elif kind is BaseSumGate:
+                val = int(rng.integers(0, 1 << 63, dtype=np.uint64))
+                result(r, 0, val)
+                for i in range(63):
+                    wires[1 + i][r] = (val >> i) & 1
+            elif kind in (ReducingGate, ReducingExtensionGate):
+                g = gates[gidx[kind]]
+                alpha = (operand(r, 2), operand(r, 3))
+                acc = (operand(r, 4), operand(r, 5))
+                for i in range(g.n):
+                    if kind is ReducingGate:
+                        co = (operand(r, 6 + i), 0)
+                    else:
+                        co = (operand(r, 6 + 2 * i), operand(r, 7 + 2 * i))
+                    t = emul(acc, alpha)
+                    acc = ((t[0] + co[0]) % P, (t[1] + co[1]) % P)
+                    if i == g.n - 1:
+                        result(r, 0, acc[0])
+                        result(r, 1, acc[1])
+                    else:
+                        st = (6 + g.n if kind is ReducingGate else 6 + 2 * g.n) + 2 * i
+                        wires[st][r], wires[st + 1][r] = acc
+            elif kind is ExponentiationGate:
+                nb = 66
+                base = operand(r, 0)
+                bits = [int(rng.integers(0, 2)) for _ in range(nb)]
+                cur = 1
+                for i in range(nb):
+                    prev = 1 if i == 0 else cur * cur % P
+                    cur = prev * (base if bits[nb - 1 - i] else 1) % P
+                    wires[2 + nb + i][r] = cur
+                for i in range(nb):
+                    wires[1 + i][r] = bits[i]
+                result(r, 1 + nb, cur)
+            else:                                                           # PoseidonGate
+                inp = [operand(r, i) for i in range(12)]
+                swap = int(rng.integers(0, 2))
+                wires[24][r] = swap
+                for i in range(4):
+                    wires[25 + i][r] = swap * (inp[i + 4] - inp[i]) % P
+                st = [(inp[i] + wires[25 + i][r]) % P for i in range(4)] + [(inp[i + 4] - wires[25 + i][r]) % P for i in range(4)] + inp[8:]
+                sb = lambda x: pow(x, 7, P)
+                k = 0
+                for rr in range(4):
+                    st = [(st[i] + PT.RC[k * 12 + i]) % P for i in range(12)]
+                    if rr:
+                        for i in range(12):
+                            wires[29 + 12 * (rr - 1) + i][r] = st[i]
+                    st = [x % P for x in PT.mds([sb(x) for x in st])]
+                    k += 1
+                for rr in range(22):
+                    st = [(st[i] + PT.RC[k * 12 + i]) % P for i in range(12)]
+                    wires[65 + rr][r] = st[0]
+                    st = [x % P for x in PT.mds([sb(st[0])] + st[1:])]
+                    k += 1
+                for rr in range(4):
+                    st = [(st[i] + PT.RC[k * 12 + i]) % P for i in range(12)]
+                    for i in range(12):
+                        wires[87 + 12 * rr + i][r] = st[i]
+                    st = [x % P for x in PT.mds([sb(x) for x in st])]
+                    k += 1
+                for i in range(12):
+                    result(r, 12 + i, st[i])
+            if len(pool) > 4096:
+                pool = pool[-4096:]
+    sel, selector_indices, groups = selector_polynomials(gates, gate_of_row, cfg.max_quotient_degree_factor + 1)
+    constants = np.array(sel + gate_consts, dtype=np.uint64)
+    k_is = get_unique_coset_shifts(cfg.num_routed_wires)
+    sigmas = _sigma_values(degree_bits, cfg.num_routed_wires, k_is, find)
+    circ = Circuit(cfg, degree_bits, gates, selector_indices, groups, len(sel), constants, sigmas, k_is, [rnd() for _ in range(4)])
+    return circ, np.array(wires, dtype=np.uint64), public_inputs
+
+
+def _sigma_values(degree_bits, num_routed, k_is, find):
+    """every copy-constraint class becomes one cycle ([EXT] permutation_argument.rs `get_sigma_polys`)"""
+    n = 1 << degree_bits
+    w = S.root_of_unity(degree_bits)
+    subgroup = [1] * n
+    for i in range(1, n):
+        subgroup[i] = subgroup[i - 1] * w % P
+    classes = {}
+    for r in range(n):
+        for j in range(num_routed):
+            classes.setdefault(find((r, j)), []).append((r, j))
+    sigmas = np.zeros((num_routed, n), dtype=np.uint64)
+    for cells in classes.values():
+        for a, b in zip(cells, cells[1:] + cells[:1]):
+            sigmas[a[1], a[0]] = k_is[b[1]] * subgroup[b[0]] % P
+    return sigmas
 
 
 def set_public_input_wires(o, circ, wires, public_inputs):

@@ -64,8 +64,8 @@ def test_plonk_rejects_bad_circuit_descriptions():
     import zk_evm_amd.plonk as zp
     cs = torch.zeros((83, 64), dtype=torch.int64, device="cuda")
     good = [(0, 0, 0, 0, 4), (1, 2, 0, 0, 4), (2, 0, 0, 0, 4), (3, 20, 0, 0, 4)]
-    with pytest.raises(zk.ZkStarkError, match="gate kind 9"):
-        zp.CircuitData(zp.CircuitConfig(), 6, good[:3] + [(9, 0, 0, 0, 4)], 1, cs, [1] * 80, [0] * 4, 4)
+    with pytest.raises(zk.ZkStarkError, match="gate kind 99"):
+        zp.CircuitData(zp.CircuitConfig(), 6, good[:3] + [(99, 0, 0, 0, 4)], 1, cs, [1] * 80, [0] * 4, 4)
     with pytest.raises(zk.ZkStarkError, match="num_gate_constraints"):
         zp.CircuitData(zp.CircuitConfig(), 6, good, 1, cs, [1] * 80, [0] * 4, 7)
     with pytest.raises(zk.ZkStarkError, match="selector group"):
@@ -73,3 +73,32 @@ def test_plonk_rejects_bad_circuit_descriptions():
     cd = zp.CircuitData(zp.CircuitConfig(), 6, good, 1, cs, [1] * 80, [0] * 4, 20)
     with pytest.raises(zk.ZkStarkError, match="witness must be"):
         cd.prove(torch.zeros((135, 32), dtype=torch.int64, device="cuda"), [])
+
+
+@pytest.mark.parametrize("degree_bits,seed,kw", [(8, 31, dict(proof_of_work_bits=4, num_query_rounds=5)), (12, 32, dict())])
+def test_plonk_mixed_gates_match_oracle(oracle, degree_bits, seed, kw):
+    """Eleven gate kinds in three selector groups -- extension arithmetic, BaseSum, Reducing(+Extension), Exponentiation,
+    Poseidon (123 constraints, plain-round evaluation) next to the four base gates -- with a VALID witness: device proof ==
+    oracle proof word for word, and the oracle's verifier accepts it."""
+    from tests.gpu_util import to_dev
+    ol.setup_fri_api(oracle)
+    circ, wires, pis = PK.build_mixed_circuit(degree_bits, seed=seed, cfg=PK.CircuitConfig(**kw))
+    wires, pi_hash = PK.set_public_input_wires(oracle, circ, wires, pis)
+    exp = PK.prove(oracle, ol, circ, wires, pis)
+    cd = _device_circuit(circ)
+    got = cd.prove(to_dev(wires), pis)
+    assert np.array_equal(got.plonk_zs_partial_products_cap, exp["zs_pp_cap"])
+    assert np.array_equal(got.quotient_polys_cap, exp["quotient_cap"])
+    assert np.array_equal(got.openings.reshape(-1), exp["openings"])
+    assert np.array_equal(got.opening_proof, exp["fri"])
+    ok, why = PK.verify(oracle, ol, circ, dict(wires_cap=got.wires_cap, zs_pp_cap=got.plonk_zs_partial_products_cap,
+                                               quotient_cap=got.quotient_polys_cap, openings=got.openings,
+                                               fri=got.opening_proof, public_inputs=pis))
+    assert ok, why
+    # random (unsatisfying) wires exercise every constraint with non-zero values on both sides
+    rng = np.random.default_rng(seed + 1)
+    junk = rng.integers(0, 1 << 64, size=wires.shape, dtype=np.uint64)
+    got2 = cd.prove(to_dev(junk), pis)
+    exp2 = PK.prove(oracle, ol, circ, junk, pis)
+    assert np.array_equal(got2.quotient_polys_cap, exp2["quotient_cap"]) and np.array_equal(got2.opening_proof, exp2["fri"])
+    cd.free()

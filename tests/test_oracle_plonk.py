@@ -86,3 +86,30 @@ def test_extension_arithmetic():
     assert (a * b) == PK.Ext(3 * 11 + 7 * 5 * 7, 3 * 7 + 5 * 11)
     assert a * a.inverse() == PK.Ext(1)
     assert (2 - a) == PK.Ext(P - 1, P - 5) and a.pow(5) == a * a * a * a * a
+
+
+def test_mixed_gate_circuit_verifies_and_every_gate_bites(oracle):
+    """Eleven gate kinds in three selector groups (extension arithmetic, base sums, reducing chains, exponentiation,
+    Poseidon): the valid witness proves and verifies; breaking one cell of each new gate's row is rejected."""
+    ol.setup_fri_api(oracle)
+    circ, wires, pis = PK.build_mixed_circuit(7, seed=21, cfg=_cfg())
+    assert circ.num_selectors == 3 and circ.groups == [(0, 6), (6, 10), (10, 11)] and circ.num_gate_constraints == 123
+    assert [g.KIND for g in circ.gates] == [0, 1, 2, 6, 8, 7, 4, 3, 5, 9, 10]      # sorted by (degree, id string)
+    wires, _ = PK.set_public_input_wires(oracle, circ, wires, pis)
+    # every gate's constraints vanish on its own rows (generate <-> eval, the reference's test style)
+    for r in range(circ.n):
+        g = circ.gates[min(int(circ.constants[s][r]) for s in range(circ.num_selectors))]
+        vals = g.eval_unfiltered([int(circ.constants[circ.num_selectors + k][r]) for k in range(2)],
+                                 [int(wires[w][r]) for w in range(135)],
+                                 [int(x) for x in oracle.poseidon_hash_no_pad(np.array(pis, dtype=np.uint64))])
+        assert all(v % P == 0 for v in vals), (r, g.id)
+    proof = PK.prove(oracle, ol, circ, wires, pis)
+    ok, why = PK.verify(oracle, ol, circ, proof)
+    assert ok, why
+    for kind, col in ((4, 6), (5, 4), (6, 3), (7, 0), (8, 1), (9, 100), (10, 70)):
+        gi = next(i for i, g in enumerate(circ.gates) if g.KIND == kind)
+        row = next(r for r in range(circ.n) if min(int(circ.constants[s][r]) for s in range(3)) == gi)
+        w2 = wires.copy()
+        w2[col, row] = (int(w2[col, row]) + 1) % P
+        ok, why = PK.verify(oracle, ol, circ, PK.prove(oracle, ol, circ, w2, pis))
+        assert not ok, (kind, col)

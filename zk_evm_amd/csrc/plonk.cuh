@@ -12,6 +12,7 @@
 // divisions of a row share one inversion.
 #pragma once
 #include "gl.cuh"
+#include "poseidon.cuh"
 
 #define ZK_PLONK_MAX_CHALLENGES 2
 #define ZK_PLONK_MAX_CHUNKS 16          // ceil(num_routed_wires / quotient_degree_factor): 10 for the standard config
@@ -181,6 +182,125 @@ struct PlonkAcc {                                 // sum_k term_k * alpha_c^k fo
     }
 };
 
+// wire w of this point's row
+#define PLONK_W(w) (A.wires[(size_t)(w) * A.wires_stride + row])
+__device__ __forceinline__ gl2 plonk_wext(const PlonkQuotientArgs &A, size_t row, u32 w) { return gl2_make(PLONK_W(w), PLONK_W(w + 1)); }
+
+// The gates beyond the four closed-form base-field ones.  Extension elements live in D = 2 consecutive wires; a
+// constraint over F_{p^2} contributes its two components as consecutive terms (`to_basefield_array`).
+__device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, const PlonkGateDesc &G, u64 filt, const u64 *consts,
+                                                  size_t row, u32 term, PlonkAcc &acc) {
+    const u32 n = G.param;
+    auto add2 = [&](u32 k, gl2 v) { acc.add(term + 2 * k, gl_mul(filt, v.a)); acc.add(term + 2 * k + 1, gl_mul(filt, v.b)); };
+    switch (G.kind) {
+        case 4: {   // ArithmeticExtensionGate { num_ops }: output - (c0 m0 m1 + c1 addend)   (gates/arithmetic_extension.rs)
+            const u64 c0 = consts[row], c1 = consts[A.cs_stride + row];
+            for (u32 j = 0; j < n; ++j) {
+                const gl2 m0 = plonk_wext(A, row, 8 * j), m1 = plonk_wext(A, row, 8 * j + 2), ad = plonk_wext(A, row, 8 * j + 4),
+                          o = plonk_wext(A, row, 8 * j + 6);
+                add2(j, gl2_sub(o, gl2_add(gl2_scale(gl2_mul(m0, m1), c0), gl2_scale(ad, c1))));
+            }
+            break;
+        }
+        case 5: {   // MulExtensionGate { num_ops }: output - c0 m0 m1   (gates/multiplication_extension.rs)
+            const u64 c0 = consts[row];
+            for (u32 j = 0; j < n; ++j) {
+                const gl2 m0 = plonk_wext(A, row, 6 * j), m1 = plonk_wext(A, row, 6 * j + 2), o = plonk_wext(A, row, 6 * j + 4);
+                add2(j, gl2_sub(o, gl2_scale(gl2_mul(m0, m1), c0)));
+            }
+            break;
+        }
+        case 6: {   // BaseSumGate<2> { num_limbs }: sum of limb_i 2^i - wire 0, then limb (limb - 1)   (gates/base_sum.rs)
+            u64 s = 0;
+            for (u32 i = n; i-- > 0;) s = gl_add(gl_add(s, s), PLONK_W(1 + i));
+            acc.add(term, gl_mul(filt, gl_sub(s, PLONK_W(0))));
+            for (u32 i = 0; i < n; ++i) {
+                const u64 l = PLONK_W(1 + i);
+                acc.add(term + 1 + i, gl_mul(filt, gl_mul(l, gl_sub(l, 1))));
+            }
+            break;
+        }
+        case 7: case 8: {   // ReducingGate / ReducingExtensionGate { num_coeffs }: acc_i - (acc_{i-1} alpha + coeff_i)
+            const bool ext = G.kind == 8;
+            const gl2 alpha = plonk_wext(A, row, 2);
+            gl2 prev = plonk_wext(A, row, 4);
+            const u32 accs = ext ? 6 + 2 * n : 6 + n;
+            for (u32 i = 0; i < n; ++i) {
+                gl2 t = gl2_mul(prev, alpha);
+                if (ext) t = gl2_add(t, plonk_wext(A, row, 6 + 2 * i));
+                else t.a = gl_add(t.a, PLONK_W(6 + i));
+                const gl2 cur = i + 1 == n ? plonk_wext(A, row, 0) : plonk_wext(A, row, accs + 2 * i);
+                add2(i, gl2_sub(cur, t));
+                prev = cur;
+            }
+            break;
+        }
+        case 9: {   // ExponentiationGate { num_power_bits }   (gates/exponentiation.rs)
+            const u64 base = PLONK_W(0);
+            u64 last = 1;
+            for (u32 i = 0; i < n; ++i) {
+                const u64 prev = i == 0 ? 1 : gl_mul(last, last);
+                const u64 bit = PLONK_W(1 + (n - 1 - i));
+                const u64 cur = PLONK_W(2 + n + i);
+                const u64 sel = gl_add(gl_mul(bit, base), gl_sub(1, bit));
+                acc.add(term + i, gl_mul(filt, gl_sub(cur, gl_mul(prev, sel))));
+                last = cur;
+            }
+            acc.add(term + n, gl_mul(filt, gl_sub(PLONK_W(1 + n), last)));
+            break;
+        }
+        case 10: {  // PoseidonGate   (gates/poseidon.rs): plain rounds -- the same constraint polynomials as plonky2's
+                    // fast partial rounds (between S-boxes both are the same affine maps; oracle/poseidon_table.py)
+            u32 k = term;
+            const u64 swap = PLONK_W(24);
+            acc.add(k++, gl_mul(filt, gl_mul(swap, gl_sub(swap, 1))));
+            u64 s[12];
+            for (u32 i = 0; i < 4; ++i) {
+                const u64 lhs = PLONK_W(i), rhs = PLONK_W(i + 4), d = PLONK_W(25 + i);
+                acc.add(k++, gl_mul(filt, gl_sub(gl_mul(swap, gl_sub(rhs, lhs)), d)));
+                s[i] = gl_add(lhs, d);
+                s[i + 4] = gl_sub(rhs, d);
+            }
+            for (u32 i = 8; i < 12; ++i) s[i] = PLONK_W(i);
+            for (u32 i = 0; i < 12; ++i) s[i] = gl_add_canon(s[i], ZK_RC[i]);
+            int round = 0;
+            for (int r = 0; r < 4; ++r) {                 // first full rounds; rounds 1..3 check their S-box inputs
+                if (r) {
+                    for (u32 i = 0; i < 12; ++i) {
+                        const u64 w = PLONK_W(29 + 12 * (r - 1) + i);
+                        acc.add(k++, gl_mul(filt, gl_sub(s[i], w)));
+                        s[i] = w;
+                    }
+                }
+                for (u32 i = 0; i < 12; ++i) s[i] = pos_sbox(s[i]);
+                ++round;
+                pos_mds<true>(s, &ZK_RCS[round * 12]);    // MDS + the next round's constants = the next S-box input
+            }
+            for (int r = 0; r < 22; ++r) {
+                const u64 w = PLONK_W(65 + r);
+                acc.add(k++, gl_mul(filt, gl_sub(s[0], w)));
+                s[0] = pos_sbox(w);
+                ++round;
+                pos_mds<true>(s, &ZK_RCS[round * 12]);
+            }
+            for (int r = 0; r < 4; ++r) {
+                for (u32 i = 0; i < 12; ++i) {
+                    const u64 w = PLONK_W(87 + 12 * r + i);
+                    acc.add(k++, gl_mul(filt, gl_sub(s[i], w)));
+                    s[i] = pos_sbox(w);
+                }
+                ++round;
+                if (r < 3) pos_mds<true>(s, &ZK_RCS[round * 12]);
+                else pos_mds<false>(s, nullptr);
+            }
+            for (u32 i = 0; i < 12; ++i) acc.add(k++, gl_mul(filt, gl_sub(s[i], PLONK_W(12 + i))));
+            break;
+        }
+        default: break;
+    }
+}
+#undef PLONK_W
+
 __global__ void __launch_bounds__(256) plonk_quotient_kernel(PlonkQuotientArgs A) {
     const u32 size_log = A.log_n + A.qd_bits;
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -267,6 +387,8 @@ __global__ void __launch_bounds__(256) plonk_quotient_kernel(PlonkQuotientArgs A
                 const u64 v = gl_sub(out, gl_add(gl_mul(gl_mul(m0, m1), c0), gl_mul(ad, c1)));
                 acc.add(term + j, gl_mul(filt, v));
             }
+        } else {
+            plonk_eval_wide_gate(A, G, filt, consts, row, term, acc);
         }
     }
     for (u32 c = 0; c < A.n_challenges; ++c) A.out[(size_t)c * A.out_stride + i] = gl_canon(gl_mul(acc.acc[c], inv_zh));
