@@ -555,6 +555,46 @@ def plonk_recursion_profile(ctx, dev, with_cpu, sizes=(12, 13, 14), reps=8):
                                                             np.array_equal(ep["openings"], pr.openings.reshape(-1)))}
             except Exception as e:
                 out["cpu_2^13"] = {"error": repr(e)}
+        if lb == 13:
+            # the per-table shrink chains of one segment are independent of each other: W proofs in flight on this GPU,
+            # one worker thread + Context + HIP stream + CircuitData each (the scheduler's slot model)
+            try:
+                import threading
+                import zk_evm_amd
+                W, per = 4, reps
+                errs = []
+
+                def worker(k):
+                    try:
+                        st = torch.cuda.Stream()
+                        with torch.cuda.stream(st):
+                            c2 = zk_evm_amd.Context(ctx.device)
+                            d2 = zp.CircuitData(zp.CircuitConfig(), lb, gates, 1, cs, k_is, [1, 2, 3, 4], 20, ctx=c2)
+                            d2.prove(wires, pis)
+                            bar.wait()
+                            for _ in range(per):
+                                d2.prove(wires, pis)
+                            st.synchronize()
+                            bar.wait()
+                            d2.free()
+                            c2.close()
+                    except Exception as e:           # pragma: no cover
+                        errs.append(repr(e))
+                        bar.abort()
+                bar = threading.Barrier(W + 1)
+                th = [threading.Thread(target=worker, args=(k,)) for k in range(W)]
+                for t in th:
+                    t.start()
+                bar.wait()
+                t0 = time.perf_counter()
+                bar.wait()
+                elw = time.perf_counter() - t0
+                for t in th:
+                    t.join()
+                out["in_flight_2^13"] = {"error": errs[0]} if errs else {"workers_per_gpu": W, "proofs_per_s": W * per / elw,
+                                                                        "ms_per_proof_effective": 1e3 * elw / (W * per)}
+            except Exception as e:
+                out["in_flight_2^13"] = {"error": repr(e)}
         cd.free()
         del cs, wires
     return out

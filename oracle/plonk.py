@@ -319,6 +319,58 @@ class PoseidonGate:
         return out + [state[i] - w[12 + i] for i in range(12)]
 
 
+class RandomAccessGate:
+    """gates/random_access.rs `RandomAccessGate { bits, num_copies, num_extra_constants }`: per copy the routed wires
+    access_index, claimed_element, 2^bits list items; then the extra-constant wires; the (unrouted) index bits after
+    all routed wires.  Per copy: the bits are boolean, recompose to the index, and folding the list pairwise by the bits
+    (least significant first) leaves the claimed element; the extra constants equal their wires."""
+    KIND = 11
+
+    def __init__(self, bits=4, num_copies=4, num_extra_constants=2):       # new_from_config(standard, 4)
+        self.bits, self.num_copies, self.num_extra = bits, num_copies, num_extra_constants
+        self.PARAM = bits | (num_copies << 8) | (num_extra_constants << 16)
+        self.degree = bits + 1
+        self.num_constants = num_extra_constants
+        self.num_constraints = num_copies * (bits + 2) + num_extra_constants
+        self.id = "RandomAccessGate { bits: %d, num_copies: %d, num_extra_constants: %d }" % (bits, num_copies, num_extra_constants)
+
+    def eval_unfiltered(self, consts, w, pi_hash):
+        vec = 1 << self.bits
+        routed = (2 + vec) * self.num_copies + self.num_extra
+        out = []
+        for c in range(self.num_copies):
+            base = (2 + vec) * c
+            index, claimed = w[base], w[base + 1]
+            items = [w[base + 2 + i] for i in range(vec)]
+            bits = [w[routed + c * self.bits + i] for i in range(self.bits)]
+            out += [b * (b - 1) for b in bits]
+            rec = 0
+            for b in reversed(bits):
+                rec = rec + rec + b
+            out.append(rec - index)
+            for b in bits:
+                items = [items[2 * k] + b * (items[2 * k + 1] - items[2 * k]) for k in range(len(items) // 2)]
+            out.append(items[0] - claimed)
+        return out + [consts[i] - w[(2 + vec) * self.num_copies + i] for i in range(self.num_extra)]
+
+
+class PoseidonMdsGate:
+    """gates/poseidon_mds.rs: outputs = MDS * inputs on twelve F_{p^2} elements (wires 2i, 2i+1 in; 24 + 2i, 25 + 2i out)."""
+    id, degree, num_constants, num_constraints = "PoseidonMdsGate(PhantomData<plonky2_field::goldilocks_field::GoldilocksField>)", 1, 0, 24
+    KIND, PARAM = 12, 0
+
+    def eval_unfiltered(self, consts, w, pi_hash):
+        from . import poseidon_table as PT
+        out = []
+        ins = [(w[2 * i], w[2 * i + 1]) for i in range(12)]
+        for r in range(12):
+            acc = _escale(ins[r], PT.MDS_DIAG[r])
+            for i in range(12):
+                acc = _eadd(acc, _escale(ins[(i + r) % 12], PT.MDS_CIRC[i]))
+            out += list(_esub((w[24 + 2 * r], w[25 + 2 * r]), acc))
+        return out
+
+
 @dataclass
 class CircuitConfig:
     """CircuitConfig::standard_recursion_config()"""
@@ -535,7 +587,7 @@ def build_mixed_circuit(degree_bits, seed, cfg: CircuitConfig = None, n_public_i
     n = 1 << degree_bits
     gates = sorted([NoopGate(), ConstantGate(cfg.num_constants), PublicInputGate(), ArithmeticGate(20), ArithmeticExtensionGate(10),
                     MulExtensionGate(13), BaseSumGate(63), ReducingGate(43), ReducingExtensionGate(32), ExponentiationGate(66),
-                    PoseidonGate()], key=lambda g: (g.degree, g.id))
+                    PoseidonGate(), RandomAccessGate(4, 4, 2), PoseidonMdsGate()], key=lambda g: (g.degree, g.id))
     gidx = {type(g): i for i, g in enumerate(gates)}
     rnd = lambda: int(rng.integers(0, P, dtype=np.uint64))
     wires = [[rnd() for _ in range(n)] for _ in range(cfg.num_wires)]      # everything not set below is free advice
@@ -576,9 +628,9 @@ def build_mixed_circuit(degree_bits, seed, cfg: CircuitConfig = None, n_public_i
             result(row, i, v)
         row += 1
     budget = n - row
-    per_kind = max(1, budget // 10)
+    per_kind = max(1, budget // 12)
     for kind in (ArithmeticGate, ArithmeticExtensionGate, MulExtensionGate, BaseSumGate, ReducingGate, ReducingExtensionGate,
-                 ExponentiationGate, PoseidonGate):
+                 ExponentiationGate, PoseidonGate, RandomAccessGate, PoseidonMdsGate):
         for _ in range(per_kind):
             if row >= n:
                 break
@@ -641,6 +693,24 @@ def build_mixed_circuit(degree_bits, seed, cfg: CircuitConfig = None, n_public_i
                 for i in range(nb):
                     wires[1 + i][r] = bits[i]
                 result(r, 1 + nb, cur)
+            elif kind is RandomAccessGate:
+                c0, c1 = rnd(), rnd()
+                gate_consts[0][r], gate_consts[1][r] = c0, c1
+                for c in range(4):
+                    idx = int(rng.integers(0, 16))
+                    items = [operand(r, 18 * c + 2 + i) for i in range(16)]
+                    wires[18 * c][r] = idx
+                    result(r, 18 * c + 1, items[idx])
+                    for i in range(4):
+                        wires[74 + 4 * c + i][r] = (idx >> i) & 1
+                result(r, 72, c0)
+                result(r, 73, c1)
+            elif kind is PoseidonMdsGate:
+                ins = [(operand(r, 2 * i), operand(r, 2 * i + 1)) for i in range(12)]
+                for rr in range(12):
+                    for comp in range(2):
+                        v = ins[rr][comp] * PT.MDS_DIAG[rr] + sum(ins[(i + rr) % 12][comp] * PT.MDS_CIRC[i] for i in range(12))
+                        result(r, 24 + 2 * rr + comp, v)
             else:                                                           # PoseidonGate
                 inp = [operand(r, i) for i in range(12)]
                 swap = int(rng.integers(0, 2))

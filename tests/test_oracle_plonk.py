@@ -93,8 +93,9 @@ def test_mixed_gate_circuit_verifies_and_every_gate_bites(oracle):
     Poseidon): the valid witness proves and verifies; breaking one cell of each new gate's row is rejected."""
     ol.setup_fri_api(oracle)
     circ, wires, pis = PK.build_mixed_circuit(7, seed=21, cfg=_cfg())
-    assert circ.num_selectors == 3 and circ.groups == [(0, 6), (6, 10), (10, 11)] and circ.num_gate_constraints == 123
-    assert [g.KIND for g in circ.gates] == [0, 1, 2, 6, 8, 7, 4, 3, 5, 9, 10]      # sorted by (degree, id string)
+    assert circ.num_selectors == 3 and circ.num_gate_constraints == 123
+    assert [g.KIND for g in circ.gates] == [0, 1, 12, 2, 6, 8, 7, 4, 3, 5, 9, 11, 10]    # sorted by (degree, id string)
+    assert circ.groups == [(0, 7), (7, 11), (11, 13)]          # greedy: size + next degree < 9
     wires, _ = PK.set_public_input_wires(oracle, circ, wires, pis)
     # every gate's constraints vanish on its own rows (generate <-> eval, the reference's test style)
     for r in range(circ.n):
@@ -106,7 +107,7 @@ def test_mixed_gate_circuit_verifies_and_every_gate_bites(oracle):
     proof = PK.prove(oracle, ol, circ, wires, pis)
     ok, why = PK.verify(oracle, ol, circ, proof)
     assert ok, why
-    for kind, col in ((4, 6), (5, 4), (6, 3), (7, 0), (8, 1), (9, 100), (10, 70)):
+    for kind, col in ((4, 6), (5, 4), (6, 3), (7, 0), (8, 1), (9, 100), (10, 70), (11, 75), (12, 30)):
         gi = next(i for i, g in enumerate(circ.gates) if g.KIND == kind)
         row = next(r for r in range(circ.n) if min(int(circ.constants[s][r]) for s in range(3)) == gi)
         w2 = wires.copy()

@@ -296,6 +296,43 @@ __device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, co
             for (u32 i = 0; i < 12; ++i) acc.add(k++, gl_mul(filt, gl_sub(s[i], PLONK_W(12 + i))));
             break;
         }
+        case 11: {  // RandomAccessGate { bits, num_copies, num_extra_constants } packed as bits | copies << 8 | extra << 16
+            const u32 bits = n & 0xFF, copies = (n >> 8) & 0xFF, extra = (n >> 16) & 0xFF;
+            const u32 vec = 1u << bits, routed = (2 + vec) * copies + extra;
+            u32 k = term;
+            for (u32 c = 0; c < copies; ++c) {
+                const u32 base = (2 + vec) * c;
+                u64 items[32];
+                for (u32 i = 0; i < vec; ++i) items[i] = PLONK_W(base + 2 + i);
+                u64 rec = 0;
+                for (u32 i = 0; i < bits; ++i) {
+                    const u64 b = PLONK_W(routed + c * bits + i);
+                    acc.add(k++, gl_mul(filt, gl_mul(b, gl_sub(b, 1))));
+                }
+                for (u32 i = bits; i-- > 0;) rec = gl_add(gl_add(rec, rec), PLONK_W(routed + c * bits + i));
+                acc.add(k++, gl_mul(filt, gl_sub(rec, PLONK_W(base))));
+                u32 len = vec;
+                for (u32 i = 0; i < bits; ++i) {        // fold pairs by bit i (least significant first)
+                    const u64 b = PLONK_W(routed + c * bits + i);
+                    len >>= 1;
+                    for (u32 j = 0; j < len; ++j) items[j] = gl_add(items[2 * j], gl_mul(b, gl_sub(items[2 * j + 1], items[2 * j])));
+                }
+                acc.add(k++, gl_mul(filt, gl_sub(items[0], PLONK_W(base + 1))));
+            }
+            for (u32 i = 0; i < extra; ++i)
+                acc.add(k++, gl_mul(filt, gl_sub(consts[(size_t)i * A.cs_stride + row], PLONK_W((2 + vec) * copies + i))));
+            break;
+        }
+        case 12: {  // PoseidonMdsGate: outputs - MDS * inputs on twelve extension elements (gates/poseidon_mds.rs)
+            constexpr u32 CIRC[12] = ZK_POSEIDON_MDS_CIRC_INIT;
+            for (u32 r = 0; r < 12; ++r) {
+                gl2 a = gl2_make(0, 0);
+                for (u32 i = 0; i < 12; ++i) a = gl2_add(a, gl2_scale(plonk_wext(A, row, 2 * ((i + r) % 12)), CIRC[i]));
+                if (r == 0) a = gl2_add(a, gl2_scale(plonk_wext(A, row, 0), 8));      // MDS_MATRIX_DIAG = (8, 0, .., 0)
+                add2(r, gl2_sub(plonk_wext(A, row, 24 + 2 * r), a));
+            }
+            break;
+        }
         default: break;
     }
 }
