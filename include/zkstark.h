@@ -394,6 +394,8 @@ typedef enum {
     ZK_PLONK_GATE_POSEIDON = 10,     /* gates/poseidon.rs (135 wires, 123 constraints) */
     ZK_PLONK_GATE_RANDOM_ACCESS = 11,/* gates/random_access.rs; param = bits | num_copies << 8 | num_extra_constants << 16 */
     ZK_PLONK_GATE_POSEIDON_MDS = 12, /* gates/poseidon_mds.rs */
+    ZK_PLONK_GATE_COSET_INTERPOLATION = 13, /* gates/coset_interpolation.rs; param = subgroup_bits | degree << 8 (the
+                                        barycentric weights are recomputed from subgroup_bits) */
 } zk_plonk_gate_kind;
 /* one entry of `common_data.gates` (sorted by (degree, id) as the builder sorts them) with its selector:
  * `selectors_info.selector_indices[gate]` and `selectors_info.groups[selector_index]` = [group_start, group_end) */

@@ -371,6 +371,64 @@ class PoseidonMdsGate:
         return out
 
 
+def barycentric_weights(points):
+    """[EXT] field/src/interpolation.rs `barycentric_weights`: w_i = 1 / prod_{j != i} (x_i - x_j)"""
+    out = []
+    for i, xi in enumerate(points):
+        d = 1
+        for j, xj in enumerate(points):
+            if i != j:
+                d = d * (xi - xj) % P
+        out.append(pow(d, P - 2, P))
+    return out
+
+
+class CosetInterpolationGate:
+    """gates/coset_interpolation.rs `CosetInterpolationGate { subgroup_bits, degree, barycentric_weights }`: the value at
+    `evaluation_point` of the polynomial through 2^subgroup_bits extension values on the coset shift * H, by the
+    barycentric formula accumulated in chunks of (degree - 1) points with the running (eval, partial product) exposed as
+    intermediate wires.  wires: shift 0; values 1 + 2i; evaluation_point, evaluation_value; then the intermediate evals,
+    the intermediate products, and the shifted evaluation point (all D = 2 wide)."""
+    KIND, num_constants = 13, 0
+
+    def __init__(self, subgroup_bits=4, max_degree=8):          # FRI arity 16 under max_quotient_degree_factor 8
+        self.subgroup_bits = subgroup_bits
+        n_points = 1 << subgroup_bits
+        n_inter = (n_points - 2) // (max_degree - 1)
+        self.degree = (n_points - 2) // (n_inter + 1) + 2        # with_max_degree: the smallest degree with that many chunks
+        self.n_points, self.n_inter = n_points, (n_points - 2) // (self.degree - 1)
+        self.PARAM = subgroup_bits | (self.degree << 8)
+        w = S.root_of_unity(subgroup_bits)
+        self.domain = [pow(w, i, P) for i in range(n_points)]
+        self.weights = barycentric_weights(self.domain)
+        self.num_constraints = 2 * (2 + 2 * self.n_inter)
+        self.start_inter = 1 + 2 * n_points + 4
+        self.id = "CosetInterpolationGate { subgroup_bits: %d, degree: %d, barycentric_weights: [..] }" % (subgroup_bits, self.degree)
+
+    def _partial(self, lo, hi, values, x, ev, prod):
+        """interpolation.rs `partial_interpolate`"""
+        for i in range(lo, hi):
+            term = _esub(x, (self.domain[i], 0))
+            ev = _eadd(_emul(ev, term), _emul(_escale(values[i], self.weights[i]), prod))
+            prod = _emul(prod, term)
+        return ev, prod
+
+    def eval_unfiltered(self, consts, w, pi_hash):
+        npnt, d, ni, si = self.n_points, self.degree, self.n_inter, self.start_inter
+        pair = lambda k: (w[k], w[k + 1])
+        shift, point, value = w[0], pair(1 + 2 * npnt), pair(3 + 2 * npnt)
+        shifted = pair(si + 4 * ni)
+        out = list(_esub(point, _escale(shifted, shift)))
+        values = [pair(1 + 2 * i) for i in range(npnt)]
+        ev, prod = self._partial(0, d, values, shifted, (0, 0), (1, 0))
+        for i in range(ni):
+            iev, iprod = pair(si + 2 * i), pair(si + 2 * (ni + i))
+            out += list(_esub(iev, ev)) + list(_esub(iprod, prod))
+            lo = 1 + (d - 1) * (i + 1)
+            ev, prod = self._partial(lo, min(lo + d - 1, npnt), values, shifted, iev, iprod)
+        return out + list(_esub(value, ev))
+
+
 @dataclass
 class CircuitConfig:
     """CircuitConfig::standard_recursion_config()"""
@@ -587,7 +645,8 @@ def build_mixed_circuit(degree_bits, seed, cfg: CircuitConfig = None, n_public_i
     n = 1 << degree_bits
     gates = sorted([NoopGate(), ConstantGate(cfg.num_constants), PublicInputGate(), ArithmeticGate(20), ArithmeticExtensionGate(10),
                     MulExtensionGate(13), BaseSumGate(63), ReducingGate(43), ReducingExtensionGate(32), ExponentiationGate(66),
-                    PoseidonGate(), RandomAccessGate(4, 4, 2), PoseidonMdsGate()], key=lambda g: (g.degree, g.id))
+                    PoseidonGate(), RandomAccessGate(4, 4, 2), PoseidonMdsGate(), CosetInterpolationGate(4, 8)],
+                   key=lambda g: (g.degree, g.id))
     gidx = {type(g): i for i, g in enumerate(gates)}
     rnd = lambda: int(rng.integers(0, P, dtype=np.uint64))
     wires = [[rnd() for _ in range(n)] for _ in range(cfg.num_wires)]      # everything not set below is free advice
@@ -628,9 +687,9 @@ def build_mixed_circuit(degree_bits, seed, cfg: CircuitConfig = None, n_public_i
             result(row, i, v)
         row += 1
     budget = n - row
-    per_kind = max(1, budget // 12)
+    per_kind = max(1, budget // 13)
     for kind in (ArithmeticGate, ArithmeticExtensionGate, MulExtensionGate, BaseSumGate, ReducingGate, ReducingExtensionGate,
-                 ExponentiationGate, PoseidonGate, RandomAccessGate, PoseidonMdsGate):
+                 ExponentiationGate, PoseidonGate, RandomAccessGate, PoseidonMdsGate, CosetInterpolationGate):
         for _ in range(per_kind):
             if row >= n:
                 break
@@ -705,6 +764,25 @@ def build_mixed_circuit(degree_bits, seed, cfg: CircuitConfig = None, n_public_i
                         wires[74 + 4 * c + i][r] = (idx >> i) & 1
                 result(r, 72, c0)
                 result(r, 73, c1)
+            elif kind is CosetInterpolationGate:
+                g = gates[gidx[kind]]
+                shift = operand(r, 0)
+                vals = [(operand(r, 1 + 2 * i), operand(r, 2 + 2 * i)) for i in range(16)]
+                point = (operand(r, 33), operand(r, 34))
+                si = pow(shift, P - 2, P)
+                shifted = (point[0] * si % P, point[1] * si % P)
+                wires[g.start_inter + 4 * g.n_inter][r], wires[g.start_inter + 4 * g.n_inter + 1][r] = shifted
+                red = lambda e: (e[0] % P, e[1] % P)
+                ev, prod = g._partial(0, g.degree, vals, shifted, (0, 0), (1, 0))
+                for i in range(g.n_inter):
+                    ev, prod = red(ev), red(prod)
+                    wires[g.start_inter + 2 * i][r], wires[g.start_inter + 2 * i + 1][r] = ev
+                    wires[g.start_inter + 2 * (g.n_inter + i)][r], wires[g.start_inter + 2 * (g.n_inter + i) + 1][r] = prod
+                    lo = 1 + (g.degree - 1) * (i + 1)
+                    ev, prod = g._partial(lo, min(lo + g.degree - 1, 16), vals, shifted, ev, prod)
+                ev = red(ev)
+                result(r, 35, ev[0])
+                result(r, 36, ev[1])
             elif kind is PoseidonMdsGate:
                 ins = [(operand(r, 2 * i), operand(r, 2 * i + 1)) for i in range(12)]
                 for rr in range(12):

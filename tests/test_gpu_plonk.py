@@ -77,7 +77,7 @@ def test_plonk_rejects_bad_circuit_descriptions():
 
 @pytest.mark.parametrize("degree_bits,seed,kw", [(8, 31, dict(proof_of_work_bits=4, num_query_rounds=5)), (12, 32, dict())])
 def test_plonk_mixed_gates_match_oracle(oracle, degree_bits, seed, kw):
-    """Thirteen gate kinds in three selector groups -- extension arithmetic, BaseSum, Reducing(+Extension), Exponentiation, RandomAccess, PoseidonMds,
+    """Fourteen gate kinds in four selector groups -- extension arithmetic, BaseSum, Reducing(+Extension), Exponentiation, RandomAccess, PoseidonMds, CosetInterpolation,
     Poseidon (123 constraints, plain-round evaluation) next to the four base gates -- with a VALID witness: device proof ==
     oracle proof word for word, and the oracle's verifier accepts it."""
     from tests.gpu_util import to_dev

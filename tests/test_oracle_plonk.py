@@ -93,9 +93,11 @@ def test_mixed_gate_circuit_verifies_and_every_gate_bites(oracle):
     Poseidon): the valid witness proves and verifies; breaking one cell of each new gate's row is rejected."""
     ol.setup_fri_api(oracle)
     circ, wires, pis = PK.build_mixed_circuit(7, seed=21, cfg=_cfg())
-    assert circ.num_selectors == 3 and circ.num_gate_constraints == 123
-    assert [g.KIND for g in circ.gates] == [0, 1, 12, 2, 6, 8, 7, 4, 3, 5, 9, 11, 10]    # sorted by (degree, id string)
-    assert circ.groups == [(0, 7), (7, 11), (11, 13)]          # greedy: size + next degree < 9
+    assert circ.num_selectors == 4 and circ.num_gate_constraints == 123
+    assert [g.KIND for g in circ.gates] == [0, 1, 12, 2, 6, 8, 7, 4, 3, 5, 9, 11, 13, 10]   # sorted by (degree, id string)
+    assert circ.groups == [(0, 7), (7, 11), (11, 13), (13, 14)]  # greedy: size + next degree < 9
+    g = next(g for g in circ.gates if g.KIND == 13)
+    assert (g.degree, g.n_inter, g.num_constraints, g.start_inter + 4 * g.n_inter + 2) == (6, 2, 12, 47)
     wires, _ = PK.set_public_input_wires(oracle, circ, wires, pis)
     # every gate's constraints vanish on its own rows (generate <-> eval, the reference's test style)
     for r in range(circ.n):
@@ -107,10 +109,30 @@ def test_mixed_gate_circuit_verifies_and_every_gate_bites(oracle):
     proof = PK.prove(oracle, ol, circ, wires, pis)
     ok, why = PK.verify(oracle, ol, circ, proof)
     assert ok, why
-    for kind, col in ((4, 6), (5, 4), (6, 3), (7, 0), (8, 1), (9, 100), (10, 70), (11, 75), (12, 30)):
+    for kind, col in ((4, 6), (5, 4), (6, 3), (7, 0), (8, 1), (9, 100), (10, 70), (11, 75), (12, 30), (13, 40)):
         gi = next(i for i, g in enumerate(circ.gates) if g.KIND == kind)
-        row = next(r for r in range(circ.n) if min(int(circ.constants[s][r]) for s in range(3)) == gi)
+        row = next(r for r in range(circ.n) if min(int(circ.constants[s][r]) for s in range(circ.num_selectors)) == gi)
         w2 = wires.copy()
         w2[col, row] = (int(w2[col, row]) + 1) % P
         ok, why = PK.verify(oracle, ol, circ, PK.prove(oracle, ol, circ, w2, pis))
         assert not ok, (kind, col)
+
+
+def test_coset_interpolation_gate_interpolates():
+    """the gate's evaluation_value is the value at `evaluation_point` of the degree < 16 polynomial through the 16 values on
+    shift * H (what FRI's arity-16 fold needs), not merely something self-consistent"""
+    rng = np.random.default_rng(3)
+    g = PK.CosetInterpolationGate(4, 8)
+    coeffs = [PK.Ext(int(rng.integers(0, P, dtype=np.uint64)), int(rng.integers(0, P, dtype=np.uint64))) for _ in range(16)]
+
+    def f(x):
+        acc = PK.Ext(0)
+        for c in reversed(coeffs):
+            acc = acc * x + c
+        return acc
+    shift = int(rng.integers(1, P, dtype=np.uint64))
+    point = PK.Ext(int(rng.integers(0, P, dtype=np.uint64)), int(rng.integers(0, P, dtype=np.uint64)))
+    vals = [f(PK.Ext(shift * h % P)) for h in g.domain]
+    shifted = point * PK.Ext(pow(shift, P - 2, P))
+    ev, prod = g._partial(0, 16, [(v.a, v.b) for v in vals], (shifted.a, shifted.b), (0, 0), (1, 0))
+    assert PK.Ext(ev[0], ev[1]) == f(point)

@@ -157,7 +157,9 @@ plonk_partial_products_finish_kernel(const u64 *__restrict__ incl, const u64 *__
 }
 
 // ---- quotient: eval_vanishing_poly_base_batch / Z_H on the coset of size n * 2^qd_bits ---------------------------------
+#define ZK_PLONK_MAX_INTERP_POINTS 32
 struct PlonkQuotientArgs {
+    const u64 *interp_domain, *interp_weights;   // CosetInterpolationGate: H (2^subgroup_bits points) and barycentric weights
     const u64 *cs; size_t cs_stride;             // constants ++ sigmas LDE  [num_constants + routed][N]
     const u64 *wires; size_t wires_stride;       // wires LDE [num_wires][N]
     const u64 *zs; size_t zs_stride;             // Zs ++ partial products LDE
@@ -331,6 +333,35 @@ __device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, co
                 if (r == 0) a = gl2_add(a, gl2_scale(plonk_wext(A, row, 0), 8));      // MDS_MATRIX_DIAG = (8, 0, .., 0)
                 add2(r, gl2_sub(plonk_wext(A, row, 24 + 2 * r), a));
             }
+            break;
+        }
+        case 13: {  // CosetInterpolationGate { subgroup_bits, degree } packed as bits | degree << 8 (gates/coset_interpolation.rs)
+            const u32 bits = n & 0xFF, deg = (n >> 8) & 0xFF, npnt = 1u << bits, ni = (npnt - 2) / (deg - 1);
+            const u32 si = 1 + 2 * npnt + 4;                       // start_intermediates
+            const u64 shift = PLONK_W(0);
+            const gl2 point = plonk_wext(A, row, 1 + 2 * npnt), value = plonk_wext(A, row, 3 + 2 * npnt);
+            const gl2 x = plonk_wext(A, row, si + 4 * ni);         // shifted evaluation point
+            u32 k = 0;
+            add2(k++, gl2_sub(point, gl2_scale(x, shift)));
+            gl2 ev = gl2_make(0, 0), prod = gl2_make(1, 0);
+            u32 lo = 0, hi = deg;
+            for (u32 c = 0; c <= ni; ++c) {                         // partial_interpolate over chunk [lo, hi)
+                for (u32 i = lo; i < hi; ++i) {
+                    gl2 term = x;
+                    term.a = gl_sub(term.a, A.interp_domain[i]);
+                    const gl2 wv = gl2_scale(plonk_wext(A, row, 1 + 2 * i), A.interp_weights[i]);
+                    ev = gl2_add(gl2_mul(ev, term), gl2_mul(wv, prod));
+                    prod = gl2_mul(prod, term);
+                }
+                if (c == ni) break;
+                const gl2 iev = plonk_wext(A, row, si + 2 * c), iprod = plonk_wext(A, row, si + 2 * (ni + c));
+                add2(k++, gl2_sub(iev, ev));
+                add2(k++, gl2_sub(iprod, prod));
+                ev = iev; prod = iprod;
+                lo = 1 + (deg - 1) * (c + 1);
+                hi = lo + deg - 1 < npnt ? lo + deg - 1 : npnt;
+            }
+            add2(k++, gl2_sub(value, ev));
             break;
         }
         default: break;
