@@ -63,6 +63,10 @@ def parse():
                     help="also report W segments in flight per GPU as a secondary object (1 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the h2d / realistic secondary objects")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not collect the dominant kernel's HBM-traffic / VALU counters with rocprofv3 --pmc child passes "
+                         "(the committed profiles/pmc_latest.json is quoted instead, marked as such)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sample-log-n", type=int, default=18)
     ap.add_argument("--cpu-table-log-n", type=int, default=20,
                     help="height of the ArithmeticStark table proven on the CPU for cpu_baseline (0 = skip, fall back to "
@@ -600,6 +604,48 @@ def plonk_recursion_profile(ctx, dev, with_cpu, sizes=(12, 13, 14), reps=8):
     return out
 
 
+def collect_pmc_in_run(a, timeout_s=240):
+    """`roofline.traffic` / `valu` measured in THIS run: two `rocprofv3 --kernel-trace --pmc` child passes (FETCH_SIZE +
+    SQ_INSTS_VALU, then WRITE_SIZE -- they cannot share a pass; counters only, no sys / hip / memory tracing) of this same
+    script proving ONE segment of the same workload; mean per leaf-hash launch.  FETCH_SIZE is doubled (gfx950 reports half
+    the bytes of a coalesced streaming read: MI355X_MICROARCH.md, HBM section), both are in KiB.  None if rocprofv3 is
+    absent or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    vals = {}
+    for name, ctrs in (("fetch", ["FETCH_SIZE", "SQ_INSTS_VALU"]), ("write", ["WRITE_SIZE"])):
+        d = tempfile.mkdtemp(prefix="zkpmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", *ctrs, "--output-format", "csv", "-d", d, "-o", name, "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-child", "--no-pmc", "--hasher", str(a.hasher), "--log-n", str(a.log_n)]
+            if a.log_ns:
+                cmd += ["--log-ns", a.log_ns]
+            if a.cdk_erigon:
+                cmd += ["--cdk-erigon"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s, capture_output=True)
+            if r.returncode != 0:
+                return None
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(path)):
+                    if "hash_rows_kernel<false>" in row.get("Kernel_Name", ""):
+                        vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if not all(vals.get(k) for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU")):
+        return None
+    mean = lambda k: sum(vals[k]) / len(vals[k])
+    return {"launches": len(vals["FETCH_SIZE"]), "hbm_bytes_per_launch": (2.0 * mean("FETCH_SIZE") + mean("WRITE_SIZE")) * 1024.0,
+            "valu_wave_insts_per_launch": mean("SQ_INSTS_VALU")}
+
+
 def self_launch(a) -> int:
     """`python bench.py --gpus N` with no launcher around it: start the N ranks here -- one process per GPU, rank r on
     device r (or --devices), rendezvous on 127.0.0.1 -- and pass rank 0's JSON line through.  The children are this
@@ -737,6 +783,10 @@ def main():
         def step(timing=None):
             return sg.prove_with_traces(all_stark, cfg, traces, in_use, sg.PublicValues(burn_addr=1 if a.cdk_erigon else None),
                                         ctx=ctx, timing=timing)
+        if a.pmc_child:                       # one segment under rocprofv3 --pmc (collect_pmc_in_run), nothing printed
+            step()
+            torch.cuda.synchronize()
+            return
         for _ in range(a.warmup):
             step()
         barrier()
@@ -846,6 +896,29 @@ def main():
                     out["plonk_recursion"] = plonk_recursion_profile(ctx, dev, not a.no_cpu_baseline)
                 except Exception as e:
                     out["plonk_recursion"] = {"error": repr(e)}
+        if rank == 0 and world == 1 and not a.no_pmc:
+            # counters of the dominant kernel measured in this run (child passes under rocprofv3 --pmc); on any failure the
+            # committed profile's numbers stay, marked measured_in_this_run: false
+            try:
+                ctx.mem_trim()
+                torch.cuda.empty_cache()
+                pmc = collect_pmc_in_run(a)
+            except Exception:
+                pmc = None
+            if pmc:
+                roof = out["roofline"]
+                per_launch_ms = roof["ms_per_launch"]
+                ach = pmc["valu_wave_insts_per_launch"] / (per_launch_ms * 1e-3)
+                roof["traffic"] = pmc["hbm_bytes_per_launch"]
+                roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, two child passes of one "
+                                          "segment each in this run, mean over %d leaf-hash launches" % pmc["launches"])
+                roof["valu"] = {"wave_insts_per_launch": pmc["valu_wave_insts_per_launch"], "achieved_wave_insts_per_s": ach,
+                                "peak_wave_insts_per_s": 1024 * 2.4e9 / 4.0, "frac": ach / (1024 * 2.4e9 / 4.0),
+                                "assumes": "1024 SIMDs x 2.4 GHz / 4 cycles per wave-instruction (carry / mad / select class); v_mov / "
+                                           "v_add_u32-class ops issue at ~2.4 cycles, so a mix with many movs can exceed 1.0: the "
+                                           "SIMDs are issue-saturated either way",
+                                "source": "rocprofv3 --pmc SQ_INSTS_VALU in this run; time per launch from the un-profiled timed region",
+                                "measured_in_this_run": True}
         if rank == 0 and not a.no_cpu_baseline and world == 1:
             extrap = None
             try:

@@ -29,7 +29,7 @@ def _bench(*args, env_extra=None, timeout=900):
 
 
 SMALL = ["--log-n", "12", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--in-flight", "1",
-         "--commit-steps", "0"]
+         "--commit-steps", "0", "--no-pmc", "--no-secondary"]
 
 
 def test_bench_self_launches_two_ranks_on_one_gpu():

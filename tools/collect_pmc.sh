@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 1 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-pmc $*"
 run() { # name counters...
   local name=$1; shift
   rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- python "$ROOT/bench.py" $ARGS > "$OUT/$name.log" 2>&1
