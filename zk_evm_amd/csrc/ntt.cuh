@@ -27,7 +27,7 @@ struct NttPass {
     const u64 *src;      // column c at src + c*src_stride
     u64 *dst;            // column c at dst + c*dst_stride
     size_t src_stride, dst_stride;
-    const u64 *tw;       // tw[k] = w^k, k < 2^(log_tw-1), w of order 2^log_tw (or its inverse)
+    const u64 *tw;       // level layout: tw[D - 1 + k] = (root of order 2D)^k, k < D, for D = 1 .. 2^(log_tw-1) (ntt_host.inc)
     const u64 *in_scale; // optional per-source-index factor applied on load (coset powers)
     const u64 *out_scale;// optional per-index factor applied on store
     u64 out_const;       // constant factor applied on store when apply_out_const
@@ -88,10 +88,10 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
         for (int i = 0; i < K; ++i) {
             const int lm = DIT ? i : (K - 1 - i);       // log2 of the pair distance in m units
             const int hm = 1 << lm;
-            const int sh = p.log_tw - 1 - (log_D0 + lm); // tw index = (x mod D) << sh, D = D0 << lm
+            const u32 lvl = (1u << (log_D0 + lm)) - 1;  // level D = D0 << lm: twiddle of pair (x, x + D) = T_D[x mod D]
 #pragma unroll
             for (int mm = 0; mm < hm; ++mm) {
-                const u64 tw = p.tw[(g + ((u32)mm << log_D0)) << sh];
+                const u64 tw = p.tw[lvl + g + ((u32)mm << log_D0)];
 #pragma unroll
                 for (int m = mm; m < (1 << K); m += 2 * hm) ntt_bfly<DIT>(v[m], v[m + hm], tw);
             }
@@ -174,10 +174,15 @@ __global__ void coset_table_kernel(u64 *out, int log_n, u64 s, u64 c) {
     out[i] = gl_canon(gl_mul(c, gl_pow(s, e)));
 }
 
-// out[k] = w^k for k < count
-__global__ void twiddle_table_kernel(u64 *out, size_t count, u64 w) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) out[i] = gl_canon(gl_pow(w, i));
+// level layout (ntt_host.inc): out[D - 1 + k] = w^(k * N / (2 D)) for D = 1, 2, .., N/2 and k < D; N = 2^log_size
+__global__ void twiddle_levels_kernel(u64 *out, int log_size, u64 w) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // i = D - 1 + k
+    const size_t total = ((size_t)1 << log_size) - 1;
+    if (log_size == 0) { if (i == 0) out[0] = 1; return; }
+    if (i >= total) { if (i == total) out[i] = 0; return; }
+    const int lvl = 63 - __clzll((unsigned long long)(i + 1));     // D = 2^lvl
+    const size_t k = i + 1 - ((size_t)1 << lvl);
+    out[i] = gl_canon(gl_pow(w, k << (log_size - 1 - lvl)));
 }
 
 // element-wise field op (ABI-level access to the device field primitives)
