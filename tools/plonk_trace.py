@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Prove one synthetic recursion-config PLONK circuit `reps` times (for rocprofv3 --kernel-trace --stats: kernel time per
+proof against wall time per proof = how launch- / sync-bound the small proofs are).
+Usage: plonk_trace.py [log_n=13] [reps=20]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+
+import zk_evm_amd
+import zk_evm_amd.plonk as zp
+
+P = 0xFFFFFFFF00000001
+
+
+def main():
+    lb = int(sys.argv[1]) if len(sys.argv) > 1 else 13
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    dev = torch.device("cuda:0")
+    ctx = zk_evm_amd.Context(0)
+    gates = [(0, 0, 0, 0, 4), (1, 2, 0, 0, 4), (2, 0, 0, 0, 4), (3, 20, 0, 0, 4)]
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    k_is, x = [], 1
+    for _ in range(80):
+        k_is.append(x)
+        x = x * 14293326489335486720 % P
+    n = 1 << lb
+    cs = torch.randint(-(1 << 63), (1 << 63) - 1, (83, n), dtype=torch.int64, device=dev, generator=g)
+    cs[0] = torch.randint(0, 4, (n,), dtype=torch.int64, device=dev, generator=g)
+    wires = torch.randint(-(1 << 63), (1 << 63) - 1, (135, n), dtype=torch.int64, device=dev, generator=g)
+    cd = zp.CircuitData(zp.CircuitConfig(), lb, gates, 1, cs, k_is, [1, 2, 3, 4], 20, ctx=ctx)
+    pis = [5, 6, 7]
+    pr = cd.prove(wires, pis)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pr = cd.prove(wires, pis)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / reps
+    print("log_n %d: %.3f ms per proof; stages %s" % (lb, 1e3 * el, {k: round(v, 3) for k, v in pr.stage_ms.items()}))
+
+
+if __name__ == "__main__":
+    main()

@@ -22,7 +22,7 @@ struct zk_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     volatile const int *abort_flag = nullptr;
-    std::map<int, u64 *> tw_fwd, tw_inv;                    // log size -> table
+    std::map<int, u64 *> tw_fwd, tw_inv, tw_inv_br;         // log size -> table (tw_inv_br: block-order levels)
     std::map<std::pair<int, u64>, u64 *> coset_tabs;        // (log_n, shift) -> s^bitrev(i)
     std::map<std::pair<int, u64>, u64 *> coset_inv_tabs;    // (log_n, shift) -> n^-1 s^-bitrev(i)
     hipEvent_t ev[5] = {};

@@ -107,6 +107,40 @@ __device__ __forceinline__ u64 gl_mul(u64 a, u64 b) {
 
 __device__ __forceinline__ u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 
+// gl_mul with the result folded into [0, p) (two compares on top of the lazy form: the only non-canonical outputs of the
+// reduce are 0xFFFFFFFF:lo with lo >= 1 from the no-carry branch, and adding EPS to those wraps them to 0:lo-1 -- the
+// same add the carry branch needs, so the two conditions are merged on the scalar unit).  A canonical product lets the
+// add / sub that consume it use ONE correction instead of two (gl_add_canon / gl_sub_canon): 22 + 5 + 5 instructions for
+// a decimation-in-time butterfly instead of 20 + 8 + 8.
+__device__ __forceinline__ u64 gl_mul_canon(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 P = (u64)a0 * b0;
+    const u64 M = (u64)a0 * b1 + (P >> 32);
+    const u64 M2 = (u64)a1 * b0 + (u32)M;
+    const u64 H = (u64)a1 * b1 + (M >> 32) + (M2 >> 32);
+    u32 lo, hi, t1 = (u32)M2, t2 = (u32)H, t3 = (u32)(H >> 32), e;
+    u64 sa, sb;
+    asm("v_sub_co_u32 %[lo], vcc, %[p0], %[t3]\n\t"
+        "v_subbrev_co_u32 %[t1], vcc, 0, %[t1], vcc\n\t"
+        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"
+        "v_sub_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
+        "v_subbrev_co_u32 %[t1], vcc, 0, %[t1], vcc\n\t"
+        "v_sub_co_u32 %[lo], vcc, %[lo], %[t2]\n\t"
+        "v_subbrev_co_u32 %[e], vcc, 0, %[t2], vcc\n\t"
+        "v_add_co_u32 %[hi], vcc, %[t1], %[e]\n\t"
+        "v_cmp_eq_u32_e64 %[sa], %[hi], -1\n\t"        /* hi:lo >= p  <=>  hi == 2^32-1 and lo != 0 */
+        "v_cmp_ne_u32_e64 %[sb], %[lo], 0\n\t"
+        "s_and_b64 %[sa], %[sa], %[sb]\n\t"
+        "s_or_b64 vcc, vcc, %[sa]\n\t"
+        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"
+        "v_add_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
+        "v_addc_co_u32 %[hi], vcc, 0, %[hi], vcc"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [t1] "+&v"(t1), [t2] "+&v"(t2), [t3] "+&v"(t3), [e] "=&v"(e), [sa] "=&s"(sa), [sb] "=&s"(sb)
+        : [p0] "v"((u32)P)
+        : "vcc", "scc");
+    return ((u64)hi << 32) | lo;
+}
+
 // a, b arbitrary u64 representatives; result arbitrary representative of a+b.
 __device__ __forceinline__ u64 gl_add(u64 a, u64 b) {
     u32 lo, hi, e;
@@ -151,12 +185,27 @@ __device__ __forceinline__ u64 gl_sub(u64 a, u64 b) {
         : "vcc");
     return ((u64)hi << 32) | lo;
 }
+// b must be <= p: one correction is enough.
+__device__ __forceinline__ u64 gl_sub_canon(u64 a, u64 b) {
+    u32 lo, hi, e;
+    asm("v_sub_co_u32 %[lo], vcc, %[a0], %[b0]\n\t"
+        "v_subb_co_u32 %[hi], vcc, %[a1], %[b1], vcc\n\t"
+        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"
+        "v_sub_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
+        "v_subbrev_co_u32 %[hi], vcc, 0, %[hi], vcc"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [e] "=&v"(e)
+        : [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32))
+        : "vcc");
+    return ((u64)hi << 32) | lo;
+}
 #else
 GL_HD u64 gl_add(u64 a, u64 b) { return gl_add_ref(a, b); }
 GL_HD u64 gl_add_canon(u64 a, u64 b) { return gl_add_ref(a, b); }
 GL_HD u64 gl_sub(u64 a, u64 b) { return gl_sub_ref(a, b); }
 GL_HD u64 gl_mul(u64 a, u64 b) { return gl_mul_ref(a, b); }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul_ref(a, a); }
+GL_HD u64 gl_mul_canon(u64 a, u64 b) { return gl_canon(gl_mul_ref(a, b)); }
+GL_HD u64 gl_sub_canon(u64 a, u64 b) { return gl_sub_ref(a, b); }
 #endif
 GL_HD u64 gl_neg(u64 a) { return gl_sub(0, a); }
 

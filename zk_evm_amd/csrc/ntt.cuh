@@ -6,9 +6,13 @@
 //
 // Design (MI355X-first, not the CPU's per-column recursive FFT):
 //   * value-form data is always NATURAL order, coefficient-form data is always kept in
-//     BIT-REVERSED order on the device.  values -> coeffs is decimation-in-frequency (natural in,
-//     bit-reversed out), coeffs -> values is decimation-in-time (bit-reversed in, natural out), so
-//     no pass ever performs a bit-reversal permutation through HBM.
+//     BIT-REVERSED order on the device.  values -> coeffs runs its stages from the largest pair
+//     distance down (natural in, bit-reversed out), coeffs -> values from the smallest up
+//     (bit-reversed in, natural out), so no pass ever performs a bit-reversal permutation through
+//     HBM.  Both use the Cooley-Tukey butterfly (a + w b, a - w b): the natural -> bit-reversed
+//     direction is the remainder tree f mod (y^D -+ c) with one twiddle per block of 2D indices
+//     instead of the textbook Gentleman-Sande (a + b, (a - b) w) -- same outputs, 4 fewer
+//     instructions per butterfly (see ntt_bfly).
 //   * a transform of size 2^L is split into passes of r <= 10/11 consecutive stages.  One
 //     workgroup owns a tile of R = 2^r "rows" spaced d apart (d = smallest butterfly distance of
 //     the pass) times T contiguous elements, stages it in LDS once, runs all r stages there in
@@ -27,7 +31,8 @@ struct NttPass {
     const u64 *src;      // column c at src + c*src_stride
     u64 *dst;            // column c at dst + c*dst_stride
     size_t src_stride, dst_stride;
-    const u64 *tw;       // level layout: tw[D - 1 + k] = (root of order 2D)^k, k < D, for D = 1 .. 2^(log_tw-1) (ntt_host.inc)
+    const u64 *tw;       // DIT: level layout tw[D - 1 + k] = (root of order 2D)^k, k < D, for D = 1 .. 2^(log_tw-1);
+                         // values -> coeffs: block-order levels tw[2^s - 1 + j] = (root of order 2^(s+1))^bitrev_s(j) (ntt_host.inc)
     const u64 *in_scale; // optional per-source-index factor applied on load (coset powers)
     const u64 *out_scale;// optional per-index factor applied on store
     u64 out_const;       // constant factor applied on store when apply_out_const
@@ -41,27 +46,23 @@ struct NttPass {
     int apply_out_const;
 };
 
-// One radix-2 butterfly with the twiddle of global pair (x, x + D), x & D == 0.
-template <bool DIT>
+// One radix-2 butterfly (a, b) -> (a + w b, a - w b).  BOTH directions use this Cooley-Tukey form: the canonical product
+// (gl_mul_canon) lets the add and the sub run with one correction each, 22 + 5 + 5 instructions against 8 + 8 + 20 for
+// the Gentleman-Sande form (a + b, (a - b) w), whose add and sub both see two lazy operands.
 __device__ __forceinline__ void ntt_bfly(u64 &a, u64 &b, u64 w) {
-    if (DIT) {
-        u64 t = gl_mul(b, w);
-        u64 na = gl_add(a, t);
-        b = gl_sub(a, t);
-        a = na;
-    } else {
-        u64 s = gl_add(a, b);
-        b = gl_mul(gl_sub(a, b), w);
-        a = s;
-    }
+    u64 t = gl_mul_canon(b, w);
+    u64 na = gl_add_canon(a, t);
+    b = gl_sub_canon(a, t);
+    a = na;
 }
 
 // One register step of K (<= 3) consecutive stages over the LDS tile.
 // rows of one sub-problem: t0 + m*q, m in [0, 2^K)
-//   DIF: stage half sizes (rows) q*2^(K-1) .. q     DIT: q .. q*2^(K-1)
-// All index math is 32-bit (transforms are <= 2^31 points).  A stage whose pairs are hm apart (in
+//   !DIT: stage half sizes (rows) q*2^(K-1) .. q     DIT: q .. q*2^(K-1)
+// All index math is 32-bit (transforms are <= 2^31 points).  DIT: a stage whose pairs are hm apart (in
 // m units) has only hm distinct twiddles per sub-problem (the twiddle of pair (m, m+hm) depends on
-// m mod hm), so a radix-8 step issues 1+2+4 = 7 twiddle loads, not 12.
+// m mod hm); !DIT: one twiddle per block, 2^(K-1)/hm blocks per sub-problem.  Either way a radix-8 step
+// issues 1+2+4 = 7 twiddle loads, not 12.
 template <bool DIT, int K>
 __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q, u32 base,
                                          u32 elems, u32 tid, u32 nthr) {
@@ -82,18 +83,37 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
 #else
         for (int m = 0; m < (1 << K); ++m) v[m] = tile[((t0 + m * q) << log_t) + u];
 #endif
-        // g = x0 mod D0 (x0 = global index of v[0]); x_m mod D = g + (m mod hm) * D0
-        const u32 g = ((base + (t0 << p.log_d) + u) & ((1u << log_D0) - 1));
+        const u32 x0 = base + (t0 << p.log_d) + u;      // global index of v[0]; bits [log_D0, log_D0 + K) are zero
+        if (DIT) {
+            // pair (x, x + D), D = D0 << lm: twiddle T_D[x mod D]; x_m mod D = g + (m mod hm) * D0
+            const u32 g = x0 & ((1u << log_D0) - 1);
 #pragma unroll
-        for (int i = 0; i < K; ++i) {
-            const int lm = DIT ? i : (K - 1 - i);       // log2 of the pair distance in m units
-            const int hm = 1 << lm;
-            const u32 lvl = (1u << (log_D0 + lm)) - 1;  // level D = D0 << lm: twiddle of pair (x, x + D) = T_D[x mod D]
+            for (int lm = 0; lm < K; ++lm) {
+                const int hm = 1 << lm;
+                const u32 lvl = (1u << (log_D0 + lm)) - 1;
 #pragma unroll
-            for (int mm = 0; mm < hm; ++mm) {
-                const u64 tw = p.tw[lvl + g + ((u32)mm << log_D0)];
+                for (int mm = 0; mm < hm; ++mm) {
+                    const u64 tw = p.tw[lvl + g + ((u32)mm << log_D0)];
 #pragma unroll
-                for (int m = mm; m < (1 << K); m += 2 * hm) ntt_bfly<DIT>(v[m], v[m + hm], tw);
+                    for (int m = mm; m < (1 << K); m += 2 * hm) ntt_bfly(v[m], v[m + hm], tw);
+                }
+            }
+        } else {
+            // natural -> bit-reversed: the block of 2D consecutive indices holding x is reduced modulo y^D -+ c, one
+            // twiddle c per BLOCK: level s = log_n - 1 - log D has 2^s blocks, block j's twiddle at tw[2^s - 1 + j]
+            // (block order, ntt_host.inc) -- uniform over a strided pass, consecutive lanes -> consecutive u64 in the
+            // contiguous one; a radix-8 step reads 1 + 2 + 4 adjacent entries.
+#pragma unroll
+            for (int lm = K - 1; lm >= 0; --lm) {
+                const int hm = 1 << lm;
+                const int log_D = log_D0 + lm;
+                const u32 lvl = (1u << (p.log_n - 1 - log_D)) - 1 + (x0 >> (log_D + 1));
+#pragma unroll
+                for (int hg = 0; hg < (1 << (K - 1 - lm)); ++hg) {
+                    const u64 tw = p.tw[lvl + hg];
+#pragma unroll
+                    for (int mm = 0; mm < hm; ++mm) ntt_bfly(v[hg * 2 * hm + mm], v[hg * 2 * hm + mm + hm], tw);
+                }
             }
         }
 #pragma unroll
@@ -105,8 +125,8 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
     }
 }
 
-// DIT = false: stages from the largest distance down (decimation in frequency).
-// DIT = true : stages from the smallest distance up (decimation in time).
+// DIT = false: stages from the largest distance down (values, natural -> coefficients, bit-reversed).
+// DIT = true : stages from the smallest distance up (coefficients, bit-reversed -> values, natural).
 template <bool DIT>
 __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
     extern __shared__ __attribute__((aligned(16))) u64 tile[];
@@ -172,6 +192,17 @@ __global__ void coset_table_kernel(u64 *out, int log_n, u64 s, u64 c) {
     if (i >> log_n) return;
     u32 e = bitrev32((u32)i, log_n);
     out[i] = gl_canon(gl_mul(c, gl_pow(s, e)));
+}
+
+// block-order levels (ntt_host.inc): out[2^s - 1 + j] = (root of order 2^(s+1))^bitrev_s(j) = w^(bitrev_s(j) * N / 2^(s+1))
+__global__ void twiddle_block_levels_kernel(u64 *out, int log_size, u64 w) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // i = 2^s - 1 + j
+    const size_t total = ((size_t)1 << log_size) - 1;
+    if (log_size == 0) { if (i == 0) out[0] = 1; return; }
+    if (i >= total) { if (i == total) out[i] = 0; return; }
+    const int s = 63 - __clzll((unsigned long long)(i + 1));
+    const u32 j = (u32)(i + 1 - ((size_t)1 << s));
+    out[i] = gl_canon(gl_pow(w, (u64)bitrev32(j, s) << (log_size - 1 - s)));
 }
 
 // level layout (ntt_host.inc): out[D - 1 + k] = w^(k * N / (2 D)) for D = 1, 2, .., N/2 and k < D; N = 2^log_size

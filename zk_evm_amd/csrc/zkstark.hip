@@ -87,6 +87,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     ctx->arena.destroy();
     for (auto &kv : ctx->tw_fwd) hipFree(kv.second);
     for (auto &kv : ctx->tw_inv) hipFree(kv.second);
+    for (auto &kv : ctx->tw_inv_br) hipFree(kv.second);
     for (auto &kv : ctx->coset_tabs) hipFree(kv.second);
     for (auto &kv : ctx->coset_inv_tabs) hipFree(kv.second);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
