@@ -44,6 +44,7 @@ struct NttPass {
     int first_stage;     // DIT: number of leading stages already satisfied by replication
     int log_rep;         // load: dst index x reads src index x >> log_rep
     int apply_out_const;
+    int last_pass;       // the values leave the transform: store canonical representatives
 };
 
 // One radix-2 butterfly (a, b) -> (a + w b, a - w b).  BOTH directions use this Cooley-Tukey form: the canonical product
@@ -143,13 +144,23 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
     const u32 elems = 1u << (r + log_t);
 
     // ---- load (global index x = base + t*d + u  ->  lds[t*T + u]) ----
-    for (u32 e = tid; e < elems; e += nthr) {
-        u32 t = e >> log_t, u = e & (T - 1);
-        u32 x = base + (t << p.log_d) + u;
-        u32 sx = x >> p.log_rep;
-        u64 v = src[sx];
-        if (p.in_scale) v = gl_mul(v, p.in_scale[sx]);
-        tile[e] = v;
+    if (p.log_rep) {
+        // lde's first pass (always the contiguous one, log_d = 0): every coefficient is read and scaled ONCE and written
+        // to its 2^log_rep replicas in the tile (the stages that would have produced them are skipped)
+        const u32 sbase = base >> p.log_rep, rep = 1u << p.log_rep;
+        for (u32 se = tid; se < (elems >> p.log_rep); se += nthr) {
+            u64 v = src[sbase + se];
+            if (p.in_scale) v = gl_mul(v, p.in_scale[sbase + se]);
+            for (u32 k = 0; k < rep; ++k) tile[(se << p.log_rep) + k] = v;
+        }
+    } else {
+        for (u32 e = tid; e < elems; e += nthr) {
+            u32 t = e >> log_t, u = e & (T - 1);
+            u32 x = base + (t << p.log_d) + u;
+            u64 v = src[x];
+            if (p.in_scale) v = gl_mul(v, p.in_scale[x]);
+            tile[e] = v;
+        }
     }
     __syncthreads();
 
@@ -170,9 +181,10 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
         u32 t = e >> log_t, u = e & (T - 1);
         u32 x = base + (t << p.log_d) + u;
         u64 v = tile[e];
-        if (p.out_scale) v = gl_mul(v, p.out_scale[x]);
-        if (p.apply_out_const) v = gl_mul(v, p.out_const);
-        dst[x] = gl_canon(v);
+        if (p.out_scale) v = gl_mul_canon(v, p.out_scale[x]);
+        else if (p.apply_out_const) v = gl_mul_canon(v, p.out_const);
+        else if (p.last_pass) v = gl_canon(v);          // between passes any u64 representative will do
+        dst[x] = v;
     }
 }
 
