@@ -511,9 +511,15 @@ def plonk_recursion_profile(ctx, dev, with_cpu, sizes=(12, 13, 14), reps=8):
     import torch
     import zk_evm_amd.plonk as zp
     P = 0xFFFFFFFF00000001
-    gates = [(0, 0, 0, 0, 4), (1, 2, 0, 0, 4), (2, 0, 0, 0, 4), (3, 20, 0, 0, 4)]
-    out = {"config": "standard_recursion_config, gates {Noop, Constant, PublicInput, Arithmetic}", "proofs_per_size": reps,
-           "sizes": {}}
+    # the gate set of the recursion circuits, as zk_plonk_gate records (kind, param, selector column,
+    # selector group): fourteen kinds sorted by (degree, id), four selector groups under max degree 9
+    gates = [(0, 0, 0, 0, 7), (1, 2, 0, 0, 7), (12, 0, 0, 0, 7), (2, 0, 0, 0, 7), (6, 63, 0, 0, 7), (8, 32, 0, 0, 7),
+             (7, 43, 0, 0, 7), (4, 10, 1, 7, 11), (3, 20, 1, 7, 11), (5, 13, 1, 7, 11), (9, 66, 1, 7, 11),
+             (11, 4 | 4 << 8 | 2 << 16, 2, 11, 13), (13, 4 | 6 << 8, 2, 11, 13), (10, 0, 3, 13, 14)]
+    n_sel, n_gate_constraints = 4, 123                   # PoseidonGate's 123 constraints are the maximum
+    out = {"config": "standard_recursion_config, fourteen gate kinds {Noop, Constant, PoseidonMds, PublicInput, BaseSum, "
+                     "ReducingExtension, Reducing, ArithmeticExtension, Arithmetic, MulExtension, Exponentiation, RandomAccess, "
+                     "CosetInterpolation, Poseidon}, every row one of them at random", "proofs_per_size": reps, "sizes": {}}
     g = torch.Generator(device=dev)
     g.manual_seed(99)
     k_is, x = [], 1
@@ -522,10 +528,13 @@ def plonk_recursion_profile(ctx, dev, with_cpu, sizes=(12, 13, 14), reps=8):
         x = x * 14293326489335486720 % P
     for lb in sizes:
         n = 1 << lb
-        cs = torch.randint(-(1 << 63), (1 << 63) - 1, (83, n), dtype=torch.int64, device=dev, generator=g)
-        cs[0] = torch.randint(0, 4, (n,), dtype=torch.int64, device=dev, generator=g)
+        cs = torch.randint(-(1 << 63), (1 << 63) - 1, (n_sel + 2 + 80, n), dtype=torch.int64, device=dev, generator=g)
+        gate_of_row = torch.randint(0, len(gates), (n,), dtype=torch.int64, device=dev, generator=g)
+        sel_of_gate = torch.tensor([q[2] for q in gates], dtype=torch.int64, device=dev)
+        for sidx in range(n_sel):                        # selector column: the row's gate index, or UNUSED_SELECTOR
+            cs[sidx] = torch.where(sel_of_gate[gate_of_row] == sidx, gate_of_row, torch.full_like(gate_of_row, 0xFFFFFFFF))
         wires = torch.randint(-(1 << 63), (1 << 63) - 1, (135, n), dtype=torch.int64, device=dev, generator=g)
-        cd = zp.CircuitData(zp.CircuitConfig(), lb, gates, 1, cs, k_is, [1, 2, 3, 4], 20, ctx=ctx)
+        cd = zp.CircuitData(zp.CircuitConfig(), lb, gates, n_sel, cs, k_is, [1, 2, 3, 4], n_gate_constraints, ctx=ctx)
         pis = [5, 6, 7]
         pr = cd.prove(wires, pis)
         torch.cuda.synchronize()
@@ -544,10 +553,15 @@ def plonk_recursion_profile(ctx, dev, with_cpu, sizes=(12, 13, 14), reps=8):
                 o = ol.load_oracle()
                 ol.setup_fri_api(o)
                 host = cs.cpu().numpy().view(np.uint64) % np.uint64(P)
-                og = sorted([PK.NoopGate(), PK.ConstantGate(2), PK.PublicInputGate(), PK.ArithmeticGate(20)],
+                og = sorted([PK.NoopGate(), PK.ConstantGate(2), PK.PublicInputGate(), PK.ArithmeticGate(20),
+                             PK.ArithmeticExtensionGate(10), PK.MulExtensionGate(13), PK.BaseSumGate(63), PK.ReducingGate(43),
+                             PK.ReducingExtensionGate(32), PK.ExponentiationGate(66), PK.PoseidonGate(),
+                             PK.RandomAccessGate(4, 4, 2), PK.PoseidonMdsGate(), PK.CosetInterpolationGate(4, 8)],
                             key=lambda q: (q.degree, q.id))
-                circ = PK.Circuit(PK.CircuitConfig(), lb, og, [0] * 4, [(0, 4)], 1, np.ascontiguousarray(host[:3]),
-                                  np.ascontiguousarray(host[3:]), k_is, [1, 2, 3, 4])
+                assert [(q.KIND, q.PARAM) for q in og] == [(q[0], q[1]) for q in gates]
+                circ = PK.Circuit(PK.CircuitConfig(), lb, og, [q[2] for q in gates], sorted({(q[3], q[4]) for q in gates}),
+                                  n_sel, np.ascontiguousarray(host[:n_sel + 2]), np.ascontiguousarray(host[n_sel + 2:]), k_is,
+                                  [1, 2, 3, 4])
                 PK.commit_circuit(o, circ)
                 tm = {}
                 t0 = time.perf_counter()
@@ -575,7 +589,7 @@ def plonk_recursion_profile(ctx, dev, with_cpu, sizes=(12, 13, 14), reps=8):
                             st = torch.cuda.Stream()
                             with torch.cuda.stream(st):
                                 c2 = zk_evm_amd.Context(ctx.device)
-                                d2 = zp.CircuitData(zp.CircuitConfig(), lb, gates, 1, cs, k_is, [1, 2, 3, 4], 20, ctx=c2)
+                                d2 = zp.CircuitData(zp.CircuitConfig(), lb, gates, n_sel, cs, k_is, [1, 2, 3, 4], n_gate_constraints, ctx=c2)
                                 d2.prove(wires, pis)
                                 bar.wait()
                                 for _ in range(per):
