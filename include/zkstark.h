@@ -144,7 +144,9 @@ int zk_coset_ifft(zk_ctx *ctx, uint64_t *d_data, size_t col_stride, size_t n_col
 int zk_lde(zk_ctx *ctx, const uint64_t *d_coeffs, size_t in_stride, uint64_t *d_out,
            size_t out_stride, size_t n_cols, unsigned log_n, unsigned rate_bits);
 /* Element-wise Goldilocks vector op on device arrays: out[i] = a[i] (op) b[i], canonical output.
- * op: 0 = add, 1 = sub, 2 = mul, 3 = square (b ignored), 4 = inverse (b ignored; 0 -> 0).
+ * op: 0 = add, 1 = sub, 2 = mul, 3 = square (b ignored), 4 = inverse (b ignored; 0 -> 0);
+ *     5 = the NTT's canonical-output multiply, stored WITHOUT a final canonicalisation (must be < p on its own),
+ *     6 / 7 = a + b^2 / a - b^2 through the butterfly's one-correction add / sub.
  * (plonky2_field `Field` ops; exists so every field primitive is testable through the ABI.) */
 int zk_gl_vec_op(zk_ctx *ctx, uint32_t op, const uint64_t *d_a, const uint64_t *d_b,
                  uint64_t *d_out, size_t n);

@@ -235,3 +235,54 @@ def test_field_ops_random(ctx):
     for op, exp in ((0, (Ao + Bo) % P), (1, (Ao - Bo) % P), (2, (Ao * Bo) % P), (3, (Ao * Ao) % P)):
         ctx.check(ctx.lib.zk_gl_vec_op(ctx.handle, op, ptr(dA), ptr(dB), ptr(out), n))
         assert np.array_equal(to_host(out), exp.astype(np.uint64)), op
+
+
+def test_canonical_product_and_one_correction_butterfly(ctx):
+    """The NTT butterfly (csrc/ntt.cuh `ntt_bfly`): `gl_mul_canon` must return a value < p for ANY u64 operands -- its
+    extra correction only fires for folds of the form 0xFFFFFFFF:lo, lo >= 1, which random operands never produce -- and
+    the one-correction add / sub must be exact for every lazy first operand.  Edge operands are constructed, not drawn."""
+    from tests.gpu_util import to_dev, to_host, ptr
+    import torch
+    P = 0xFFFFFFFF00000001
+    M = (1 << 64) - 1
+    edge = [0, 1, 2, 0xFFFFFFFF, 1 << 32, (1 << 32) + 1, P - 2, P - 1, P, P + 1, P + 2, M - 1, M, 0xFFFFFFFF00000000,
+            0xFFFFFFFEFFFFFFFF, 1 << 63, (1 << 63) + 1, 1 << 48, P - (1 << 48), 0x00000001FFFFFFFF, 0xFFFFFFFF00000002]
+    pairs = [(a, b) for a in edge for b in edge]
+    # products whose 128-bit value folds to [p, 2^64) without the final carry: T = [0 : Y : X] with X + EPS * Y in range
+    for y in (0xFFFFFFFF, 0xFFFFFFFE, 0x80000000, 1):
+        for x_lo in (1, 2, 0xFFFFFFFF):
+            target = (0xFFFFFFFF << 32) | x_lo              # the non-canonical fold we want
+            x = (target - y * 0xFFFFFFFF) % (1 << 64)
+            t = (y << 64) | x
+            # factor t = a * b with a = 2^32 when divisible, else use (t, 1) only if it fits in 64 bits
+            if t % (1 << 32) == 0 and (t >> 32) < (1 << 64):
+                pairs.append((1 << 32, t >> 32))
+    # the same with a non-zero top limb: (z (2^32 + 1) + 1) * (2^64 - 1) folds to 2^64 - 2 - 3z without a carry
+    pairs += [(z * ((1 << 32) + 1) + 1, M) for z in (1, 2, 12345, 0x55555554)]
+    rng = np.random.default_rng(5)
+    extra = rng.integers(0, 1 << 64, size=(4096, 2), dtype=np.uint64)
+    near = np.array([[(P + int(d)) & M, 1] for d in range(-40, 41)], dtype=np.uint64)   # a * 1: the fold is a itself
+    A = np.concatenate([np.array([p[0] for p in pairs], dtype=np.uint64), extra[:, 0], near[:, 0]])
+    B = np.concatenate([np.array([p[1] for p in pairs], dtype=np.uint64), extra[:, 1], near[:, 1]])
+
+    def folds_non_canonical(a, b):                          # the lazy fold of gl.cuh, no final carry, result >= p
+        t = a * b
+        x, y, z = t & M, (t >> 64) & 0xFFFFFFFF, t >> 96
+        v = x - z
+        if v < 0:
+            v = (v - 0xFFFFFFFF) % (1 << 64)
+        r = v + y * 0xFFFFFFFF
+        return P <= r < (1 << 64)
+    hit = sum(1 for a, b in zip(A.tolist(), B.tolist()) if folds_non_canonical(a, b))
+    assert sum(1 for a, b in pairs[-4:] if folds_non_canonical(a, b)) == 4
+    assert hit >= 40, hit                                   # the no-carry non-canonical fold is really exercised
+    n = A.size
+    dA, dB = to_dev(A), to_dev(B)
+    out = torch.zeros(n, dtype=torch.int64, device="cuda")
+    Ao, Bo = A.astype(object), B.astype(object)
+    for op, exp in ((5, (Ao * Bo) % P), (6, (Ao + Bo * Bo) % P), (7, (Ao - Bo * Bo) % P)):
+        ctx.check(ctx.lib.zk_gl_vec_op(ctx.handle, op, ptr(dA), ptr(dB), ptr(out), n))
+        got = to_host(out)
+        bad = np.nonzero(got != exp.astype(np.uint64))[0]
+        assert bad.size == 0, (op, hex(int(A[bad[0]])), hex(int(B[bad[0]])), hex(int(got[bad[0]])), hex(int(exp[bad[0]])))
+

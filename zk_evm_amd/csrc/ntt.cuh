@@ -238,6 +238,9 @@ __global__ void gl_vec_op_kernel(u32 op, const u64 *a, const u64 *b, u64 *out, s
         case 1: r = gl_sub(x, y); break;
         case 2: r = gl_mul(x, y); break;
         case 3: r = gl_sqr(x); break;
+        case 5: out[i] = gl_mul_canon(x, y); return;                     // RAW: must already be < p
+        case 6: r = gl_add_canon(x, gl_mul_canon(y, y)); break;          // the NTT butterfly's two halves:
+        case 7: r = gl_sub_canon(x, gl_mul_canon(y, y)); break;          //   x +- y^2 with one correction each
         default: r = gl_canon(x) == 0 ? 0 : gl_inv(x); break;
     }
     out[i] = gl_canon(r);

@@ -252,7 +252,7 @@ __device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, co
             break;
         }
         case 10: {  // PoseidonGate   (gates/poseidon.rs): plain rounds -- the same constraint polynomials as plonky2's
-                    // fast partial rounds (between S-boxes both are the same affine maps; oracle/poseidon_table.py)
+                    // fast partial rounds (between S-boxes both are the same affine maps, cf. the Poseidon table AIR in airs.cuh)
             u32 k = term;
             const u64 swap = PLONK_W(24);
             acc.add(k++, gl_mul(filt, gl_mul(swap, gl_sub(swap, 1))));
