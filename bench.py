@@ -500,6 +500,106 @@ def h2d_profile(dev, trace_bytes, step_s):
     return res
 
 
+def from_logs_profile(ctx, dev, all_stark, cfg, reps=3):
+    """Secondary object: operation logs -> witness tables ON THE DEVICE -> segment proof, i.e. the
+    path that replaces the 3.9 GB trace upload of `realistic` by the upload of the interpreter's compact logs
+    (`witness/traces.rs:135-262` `Traces::into_tables`).  Synthetic logs in the C ABI's packed record layouts, sized so
+    the tables come out at the `prove_stdio.rs` heights (Arithmetic 2^17, BytePacking 2^14, Cpu 2^19, Keccak 2^17,
+    KeccakSponge 2^13, Logic 2^16, Memory 2^21, MemBefore 2^19); the Cpu rows are the interpreter's own output and are
+    uploaded as they are.  Logs are random, not an execution: the generators' and the prover's work does not depend on it."""
+    import numpy as np
+    import torch
+    import zk_evm_amd.segment as sg
+    import zk_evm_amd.tracegen as tg
+    rng = np.random.default_rng(7)
+    u64 = lambda *shape: rng.integers(0, 1 << 64, size=shape, dtype=np.uint64)
+    tr = tg.Traces()
+    n_ar = 120000                                           # one-row kinds only: 120 000 rows -> 2^17
+    ar = np.zeros((n_ar, 18), dtype=np.uint64)
+    ar[:, 0] = rng.choice([tg.ARITH_ADD, tg.ARITH_MUL, tg.ARITH_SUB, tg.ARITH_LT, tg.ARITH_GT], size=n_ar)
+    ar[:, 2:10] = u64(n_ar, 8)
+    tr.arithmetic_ops = ar
+    n_bp = 15000
+    bp = np.zeros((n_bp, 10), dtype=np.uint64)
+    bp[:, 0] = rng.integers(0, 2, size=n_bp)
+    bp[:, 2], bp[:, 3], bp[:, 4], bp[:, 5] = 1, rng.integers(0, 1 << 16, size=n_bp), np.arange(2, 2 + n_bp), 32
+    bp[:, 6:10] = u64(n_bp, 4)
+    tr.byte_packing_ops = bp
+    n_cpu_cols = all_stark.table_columns[2]
+    cpu = u64(1 << 19, n_cpu_cols) >> np.uint64(1)
+    pick = rng.integers(0, 19, size=1 << 19)                # CTL filter columns binary, as in synthetic_segment_traces
+    for i, k in enumerate(range(6, 24)):
+        cpu[:, k] = pick == i
+    for k in list(range(24, 33)) + [41, 54, 67, 80]:
+        cpu[:, k] = rng.integers(0, 2, size=1 << 19)
+    tr.cpu = torch.from_numpy(cpu.view(np.int64))
+    n_k = 5400                                              # 24 rows per permutation -> 2^17
+    tr.keccak_inputs = (u64(n_k, 25), np.arange(2, 2 + n_k, dtype=np.uint64))
+    tr.keccak_sponge_ops = [((0, 2, int(a)), 2 + i, rng.bytes(int(l))) for i, (a, l) in
+                            enumerate(zip(rng.integers(0, 1 << 16, size=3500), rng.integers(1, 270, size=3500)))]
+    n_lg = 60000
+    lg = np.zeros((n_lg, 9), dtype=np.uint64)
+    lg[:, 0] = rng.integers(0, 3, size=n_lg)
+    lg[:, 1:9] = u64(n_lg, 8)
+    tr.logic_ops = lg
+    n_bef, n_ops = 400000, 1400000                          # Memory table: initial values + operations + gap rows -> 2^21
+    bef = np.zeros((n_bef, 7), dtype=np.uint64)
+    bef[:, 1], bef[:, 2] = np.arange(n_bef) // 100000, np.arange(n_bef) % 100000
+    bef[:, 3:7] = u64(n_bef, 4)
+    mo = np.zeros((n_ops, 9), dtype=np.uint64)
+    mo[:, 0] = rng.integers(0, 2, size=n_ops).astype(np.uint64) | np.uint64(2)
+    mo[:, 1] = 2 + np.arange(n_ops) // 4
+    mo[:, 3], mo[:, 4] = rng.integers(0, 4, size=n_ops), rng.integers(0, 100000, size=n_ops)
+    mo[:, 5:9] = u64(n_ops, 4)
+    tr.memory_ops = mo
+    log_bytes = ar.nbytes + bp.nbytes + tr.cpu.numel() * 8 + tr.keccak_inputs[0].nbytes + lg.nbytes + bef.nbytes + mo.nbytes + \
+        sum(len(d) for _, _, d in tr.keccak_sponge_ops)
+    gen, prove, tables = [], [], None
+    for _ in range(reps):
+        tables = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tables, _ = tr.into_tables(all_stark, bef, [], cfg, device=ctx.device, ctx=ctx, packed_final=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sg.prove_with_traces(all_stark, cfg, tables, [True] * 9, sg.PublicValues(), ctx=ctx)
+        torch.cuda.synchronize()
+        gen.append(t1 - t0)
+        prove.append(time.perf_counter() - t1)
+    g, pr = min(gen[1:]), min(prove[1:])
+    heights = [int(t.shape[1]).bit_length() - 1 for t in tables]
+    cells = sum(int(t.shape[0]) * int(t.shape[1]) for t in tables)
+    return {"table_heights_log2": heights, "log_GB": log_bytes / 1e9, "cpu_rows_GB": tr.cpu.numel() * 8 / 1e9,
+            "trace_GB": cells * 8 / 1e9, "into_tables_ms": 1e3 * g, "prove_ms": 1e3 * pr,
+            "value": 1.0 / (g + pr), "unit": "segment proofs/s",
+            "note": "logs (pageable host memory, C-ABI record layouts) -> zk_*_generate_trace / zk_memory_trace_* on the device "
+                    "-> prove_with_traces, serial; the Cpu table's rows are uploaded and transposed, every other table is built "
+                    "in HBM from its log"}
+
+
+# the gate set of the recursion circuits (DESIGN.md section 10), as zk_plonk_gate records (kind, param, selector column,
+# selector group): fourteen kinds sorted by (degree, id), four selector groups under max degree 9
+PLONK_RECURSION_GATES = [(0, 0, 0, 0, 7), (1, 2, 0, 0, 7), (12, 0, 0, 0, 7), (2, 0, 0, 0, 7), (6, 63, 0, 0, 7), (8, 32, 0, 0, 7),
+                         (7, 43, 0, 0, 7), (4, 10, 1, 7, 11), (3, 20, 1, 7, 11), (5, 13, 1, 7, 11), (9, 66, 1, 7, 11),
+                         (11, 4 | 4 << 8 | 2 << 16, 2, 11, 13), (13, 4 | 6 << 8, 2, 11, 13), (10, 0, 3, 13, 14)]
+PLONK_K_IS = [pow(14293326489335486720, i, 0xFFFFFFFF00000001) for i in range(80)]   # get_unique_coset_shifts(80)
+
+
+def plonk_synthetic_circuit(dev, lb, g):
+    """(constants ++ sigmas [4 selectors + 2 constants + 80][n], wires [135][n]) of a synthetic 2^lb-row circuit over
+    PLONK_RECURSION_GATES: every row one of the fourteen gates at random (selector columns = the row's gate index in its
+    group's column, UNUSED_SELECTOR elsewhere), everything else uniform."""
+    import torch
+    gates, n_sel, n = PLONK_RECURSION_GATES, 4, 1 << lb
+    cs = torch.randint(-(1 << 63), (1 << 63) - 1, (n_sel + 2 + 80, n), dtype=torch.int64, device=dev, generator=g)
+    gate_of_row = torch.randint(0, len(gates), (n,), dtype=torch.int64, device=dev, generator=g)
+    sel_of_gate = torch.tensor([q[2] for q in gates], dtype=torch.int64, device=dev)
+    for sidx in range(n_sel):
+        cs[sidx] = torch.where(sel_of_gate[gate_of_row] == sidx, gate_of_row, torch.full_like(gate_of_row, 0xFFFFFFFF))
+    wires = torch.randint(-(1 << 63), (1 << 63) - 1, (135, n), dtype=torch.int64, device=dev, generator=g)
+    return cs, wires
+
+
 def plonk_recursion_profile(ctx, dev, with_cpu, sizes=(12, 13, 14), reps=8):
     """Secondary object (SURVEY 8(f) item 1): the recursion layer's PLONK proofs -- `CircuitConfig::
     standard_recursion_config()` (135 wires, 80 routed, FRI rate_bits 3, 28 queries, 16 PoW bits), circuits of 2^12 ..
@@ -511,29 +611,15 @@ def plonk_recursion_profile(ctx, dev, with_cpu, sizes=(12, 13, 14), reps=8):
     import torch
     import zk_evm_amd.plonk as zp
     P = 0xFFFFFFFF00000001
-    # the gate set of the recursion circuits, as zk_plonk_gate records (kind, param, selector column,
-    # selector group): fourteen kinds sorted by (degree, id), four selector groups under max degree 9
-    gates = [(0, 0, 0, 0, 7), (1, 2, 0, 0, 7), (12, 0, 0, 0, 7), (2, 0, 0, 0, 7), (6, 63, 0, 0, 7), (8, 32, 0, 0, 7),
-             (7, 43, 0, 0, 7), (4, 10, 1, 7, 11), (3, 20, 1, 7, 11), (5, 13, 1, 7, 11), (9, 66, 1, 7, 11),
-             (11, 4 | 4 << 8 | 2 << 16, 2, 11, 13), (13, 4 | 6 << 8, 2, 11, 13), (10, 0, 3, 13, 14)]
-    n_sel, n_gate_constraints = 4, 123                   # PoseidonGate's 123 constraints are the maximum
+    gates, n_sel, n_gate_constraints = PLONK_RECURSION_GATES, 4, 123   # PoseidonGate's 123 constraints are the maximum
     out = {"config": "standard_recursion_config, fourteen gate kinds {Noop, Constant, PoseidonMds, PublicInput, BaseSum, "
                      "ReducingExtension, Reducing, ArithmeticExtension, Arithmetic, MulExtension, Exponentiation, RandomAccess, "
                      "CosetInterpolation, Poseidon}, every row one of them at random", "proofs_per_size": reps, "sizes": {}}
     g = torch.Generator(device=dev)
     g.manual_seed(99)
-    k_is, x = [], 1
-    for _ in range(80):
-        k_is.append(x)
-        x = x * 14293326489335486720 % P
+    k_is = PLONK_K_IS
     for lb in sizes:
-        n = 1 << lb
-        cs = torch.randint(-(1 << 63), (1 << 63) - 1, (n_sel + 2 + 80, n), dtype=torch.int64, device=dev, generator=g)
-        gate_of_row = torch.randint(0, len(gates), (n,), dtype=torch.int64, device=dev, generator=g)
-        sel_of_gate = torch.tensor([q[2] for q in gates], dtype=torch.int64, device=dev)
-        for sidx in range(n_sel):                        # selector column: the row's gate index, or UNUSED_SELECTOR
-            cs[sidx] = torch.where(sel_of_gate[gate_of_row] == sidx, gate_of_row, torch.full_like(gate_of_row, 0xFFFFFFFF))
-        wires = torch.randint(-(1 << 63), (1 << 63) - 1, (135, n), dtype=torch.int64, device=dev, generator=g)
+        cs, wires = plonk_synthetic_circuit(dev, lb, g)
         cd = zp.CircuitData(zp.CircuitConfig(), lb, gates, n_sel, cs, k_is, [1, 2, 3, 4], n_gate_constraints, ctx=ctx)
         pis = [5, 6, 7]
         pr = cd.prove(wires, pis)
@@ -911,6 +997,12 @@ def main():
                     out["realistic"] = realistic_profile(ctx, dev, a, all_stark, cfg)
                 except Exception as e:
                     out["realistic"] = {"error": repr(e)}
+                if not a.cdk_erigon:
+                    try:
+                        ctx.mem_trim()
+                        out["from_logs"] = from_logs_profile(ctx, dev, all_stark, cfg)
+                    except Exception as e:
+                        out["from_logs"] = {"error": repr(e)}
                 try:
                     out["plonk_recursion"] = plonk_recursion_profile(ctx, dev, not a.no_cpu_baseline)
                 except Exception as e:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Prove one synthetic recursion-config PLONK circuit `reps` times (for rocprofv3 --kernel-trace --stats: kernel time per
+"""Prove one synthetic recursion-config PLONK circuit (bench.py's: all fourteen gate kinds) `reps` times (for rocprofv3 --kernel-trace --stats: kernel time per
 proof against wall time per proof = how launch- / sync-bound the small proofs are).
 Usage: plonk_trace.py [log_n=13] [reps=20] [workers=1]   (workers > 1: that many proofs in flight, one thread + ctx + stream each)"""
 import os
@@ -20,18 +20,12 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     dev = torch.device("cuda:0")
     ctx = zk_evm_amd.Context(0)
-    gates = [(0, 0, 0, 0, 4), (1, 2, 0, 0, 4), (2, 0, 0, 0, 4), (3, 20, 0, 0, 4)]
+    import bench
+    gates, k_is = bench.PLONK_RECURSION_GATES, bench.PLONK_K_IS
     g = torch.Generator(device=dev)
     g.manual_seed(99)
-    k_is, x = [], 1
-    for _ in range(80):
-        k_is.append(x)
-        x = x * 14293326489335486720 % P
-    n = 1 << lb
-    cs = torch.randint(-(1 << 63), (1 << 63) - 1, (83, n), dtype=torch.int64, device=dev, generator=g)
-    cs[0] = torch.randint(0, 4, (n,), dtype=torch.int64, device=dev, generator=g)
-    wires = torch.randint(-(1 << 63), (1 << 63) - 1, (135, n), dtype=torch.int64, device=dev, generator=g)
-    cd = zp.CircuitData(zp.CircuitConfig(), lb, gates, 1, cs, k_is, [1, 2, 3, 4], 20, ctx=ctx)
+    cs, wires = bench.plonk_synthetic_circuit(dev, lb, g)
+    cd = zp.CircuitData(zp.CircuitConfig(), lb, gates, 4, cs, k_is, [1, 2, 3, 4], 123, ctx=ctx)
     pis = [5, 6, 7]
     pr = cd.prove(wires, pis)
     torch.cuda.synchronize()
@@ -50,7 +44,7 @@ def main():
             st = torch.cuda.Stream()
             with torch.cuda.stream(st):
                 c2 = zk_evm_amd.Context(0)
-                d2 = zp.CircuitData(zp.CircuitConfig(), lb, gates, 1, cs, k_is, [1, 2, 3, 4], 20, ctx=c2)
+                d2 = zp.CircuitData(zp.CircuitConfig(), lb, gates, 4, cs, k_is, [1, 2, 3, 4], 123, ctx=c2)
                 d2.prove(wires, pis)
                 bar.wait()
                 for _ in range(reps):

@@ -195,12 +195,14 @@ def arithmetic_generate_trace(operations, device=0, ctx: Context = None):
 MEMORY_COLUMNS = 30
 
 
-def memory_generate_trace(memory_ops, mem_before_values=(), stale_contexts=(), device=0, ctx: Context = None):
+def memory_generate_trace(memory_ops, mem_before_values=(), stale_contexts=(), device=0, ctx: Context = None,
+                          packed_final: bool = False):
     """`MemoryStark::generate_trace(memory_ops, mem_before_values, stale_contexts)` (memory/memory_stark.rs:405-455)
     on the device: sort, fill_gaps, padding, flags, range-check / frequency / stale-context columns, final memory.
     memory_ops: (filter, timestamp, (context, segment, virt), is_read, value U256); mem_before_values: ((context,
     segment, virt), value).  -> (trace: CUDA int64 (30, 2^k), mem_after: CUDA int64 (12, max(128, pow2)) MemAfter
-    table, final_values: [((context, segment, virt), value)] in row order, unpadded_length)."""
+    table, final_values: [((context, segment, virt), value)] in row order -- or, with packed_final, the C ABI's own (k, 7)
+    uint64 array [context, segment, virt, value limbs], which costs no per-entry Python objects --, unpadded_length)."""
     import torch
     ctx = ctx or default_context(device)
     ctx.use_torch_current_stream()
@@ -243,7 +245,8 @@ def memory_generate_trace(memory_ops, mem_before_values=(), stale_contexts=(), d
                                                         C.c_void_p(after.data_ptr()), rows))
     finally:
         ctx.lib.zk_memory_gen_free(gen)
-    final = [((int(e[0]), int(e[1]), int(e[2])), sum(int(e[3 + l]) << (64 * l) for l in range(4))) for e in flat]
+    final = flat if packed_final else [((int(e[0]), int(e[1]), int(e[2])), sum(int(e[3 + l]) << (64 * l) for l in range(4)))
+                                       for e in flat]
     return trace, after, final, unpadded
 
 
@@ -324,7 +327,8 @@ class Traces:
         self.arithmetic_ops, self.byte_packing_ops, self.cpu, self.logic_ops = [], [], None, []
         self.memory_ops, self.keccak_inputs, self.keccak_sponge_ops, self.poseidon_ops = [], [], [], []
 
-    def into_tables(self, all_stark, mem_before_values, stale_contexts, config, device=0, ctx: Context = None):
+    def into_tables(self, all_stark, mem_before_values, stale_contexts, config, device=0, ctx: Context = None,
+                    packed_final: bool = False):
         """-> (tables in `Table` order, final_values): `Traces::into_tables(all_stark, mem_before_values,
         stale_contexts, trace_lengths, config, timing)`.  min_rows of the optional tables = the number of cap elements,
         as in the reference (:148)."""
@@ -344,7 +348,7 @@ class Traces:
         keccak_sponge = keccak_sponge_generate_trace(self.keccak_sponge_ops, cap_elements, device=device, ctx=ctx)
         logic = logic_generate_trace(self.logic_ops, cap_elements, device=device, ctx=ctx)
         memory, mem_after, final_values, self.unpadded_memory_length = memory_generate_trace(
-            self.memory_ops, mem_before_values, stale_contexts, device=device, ctx=ctx)
+            self.memory_ops, mem_before_values, stale_contexts, device=device, ctx=ctx, packed_final=packed_final)
         mem_before = memory_continuation_generate_trace(mem_before_values, device=device, ctx=ctx)
         tables = [arithmetic, byte_packing, cpu_trace, keccak, keccak_sponge, logic, memory, mem_before, mem_after]
         if all_stark.cdk_erigon:
