@@ -699,7 +699,7 @@ def plonk_recursion_profile(ctx, dev, with_cpu, sizes=(12, 13, 14), reps=8):
                     if errs:
                         return {"error": errs[0]}
                     return {"workers_per_gpu": W, "proofs_per_s": W * per / elw, "ms_per_proof_effective": 1e3 * elw / (W * per)}
-                runs = [run_in_flight(W, reps) for W in (4, 8)]
+                runs = [run_in_flight(W, 2 * reps) for W in (4, 8)]
                 ok = [r for r in runs if "error" not in r]
                 out["in_flight_2^13"] = dict(max(ok, key=lambda r: r["proofs_per_s"]), tried=runs) if ok else runs[0]
             except Exception as e:

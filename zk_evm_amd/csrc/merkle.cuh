@@ -56,6 +56,31 @@ poseidon_hash_rows_kernel(const u64 *__restrict__ cols, size_t col_stride, const
     o[1] = make_ulonglong2(gl_canon(s[2]), gl_canon(s[3]));
 }
 
+// The same for matrices with few rows (FRI commit-phase leaves, the LDE of a 2^12-row table): one row per 16-lane group
+// and the lane-cooperative permutation (poseidon.cuh), so that 2^12 rows are 1024 waves instead of 64 and a sponge step
+// costs the ~16 us latency of the cooperative permutation instead of the ~58 us of a lone wave's.  Lane e < 8 of a group
+// loads column c + e of the chunk being absorbed.
+template <bool GATHER>
+__global__ void __launch_bounds__(256)
+poseidon_hash_rows_coop_kernel(const u64 *__restrict__ cols, size_t col_stride, const u64 *__restrict__ col_off,
+                               u32 n_cols, u32 n_rows, int log_rows, int do_bitrev, u64 *__restrict__ digests) {
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 j = t >> 4, e = t & 15;
+    if (j >= n_rows) return;                           // whole groups leave together
+    const u64 *p = cols + j;
+    const size_t slot = do_bitrev ? (size_t)bitrev32(j, log_rows) : j;
+    if (n_cols <= 4) {                                 // hash_or_noop: the elements themselves, zero padded
+        if (e < 4) digests[4 * slot + e] = e < n_cols ? gl_canon(p[col_offset<GATHER>(e, col_stride, col_off)]) : 0;
+        return;
+    }
+    u64 s = 0;
+    for (u32 c = 0; c < n_cols; c += 8) {
+        if (e < 8 && c + e < n_cols) s = p[col_offset<GATHER>(c + e, col_stride, col_off)];
+        s = poseidon_permute_coop(s, e, threadIdx.x & 63);
+    }
+    if (e < 4) digests[4 * slot + e] = gl_canon(s);
+}
+
 // Poseidon `two_to_one`: parent[i] = P(child[2i] || child[2i+1] || 0^4)[0..4]
 __global__ void __launch_bounds__(256)
 poseidon_merkle_level_kernel(const u64 *__restrict__ child, u64 *__restrict__ parent, size_t n_parent) {

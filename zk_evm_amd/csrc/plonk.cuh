@@ -21,6 +21,7 @@
 
 struct PlonkGateDesc {
     u32 kind, param, selector_index, group_start, group_end;
+    u32 slice;                                   // which of the (at most 2) quotient-kernel slices evaluates this gate
 };
 
 struct PlonkPermArgs {
@@ -173,14 +174,23 @@ struct PlonkQuotientArgs {
     u64 pi_hash[4];
     u64 g_pow_n, n_inv;
     u64 *out; size_t out_stride;
+    u64 *out2;                                   // second slice's partial sums (gridDim.y == 2), added by plonk_add_slices_kernel
 };
 
-struct PlonkAcc {                                 // sum_k term_k * alpha_c^k for every challenge
-    u64 acc[ZK_PLONK_MAX_CHALLENGES];
+// sum_k term_k * alpha_c^k for every challenge.  The terms of ONE gate share its filter, so they are summed unfiltered and
+// the gate's sum is filtered and added once (`end_gate`): one multiply per term and challenge instead of two.
+// (Measured and dropped, r02h: the delayed-reduction accumulator of fri.cuh here -- 8 instructions per term instead of
+// 27, but v_addc on a v_mad_u64_u32 carry-out stalls, and 14 more live VGPRs: the kernel got 40 % SLOWER.)
+struct PlonkAcc {
+    u64 g[ZK_PLONK_MAX_CHALLENGES];               // the current gate's unfiltered sum
+    u64 total[ZK_PLONK_MAX_CHALLENGES];
     const u64 *pow[ZK_PLONK_MAX_CHALLENGES];
     u32 nc;
     __device__ __forceinline__ void add(u32 k, u64 term) {
-        for (u32 c = 0; c < nc; ++c) acc[c] = gl_add(acc[c], gl_mul(term, pow[c][k]));
+        for (u32 c = 0; c < nc; ++c) g[c] = gl_add_canon(g[c], gl_mul_canon(term, pow[c][k]));
+    }
+    __device__ __forceinline__ void end_gate(u64 filt) {
+        for (u32 c = 0; c < nc; ++c) { total[c] = gl_add_canon(total[c], gl_mul_canon(filt, g[c])); g[c] = 0; }
     }
 };
 
@@ -190,10 +200,10 @@ __device__ __forceinline__ gl2 plonk_wext(const PlonkQuotientArgs &A, size_t row
 
 // The gates beyond the four closed-form base-field ones.  Extension elements live in D = 2 consecutive wires; a
 // constraint over F_{p^2} contributes its two components as consecutive terms (`to_basefield_array`).
-__device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, const PlonkGateDesc &G, u64 filt, const u64 *consts,
+__device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, const PlonkGateDesc &G, const u64 *consts,
                                                   size_t row, u32 term, PlonkAcc &acc) {
     const u32 n = G.param;
-    auto add2 = [&](u32 k, gl2 v) { acc.add(term + 2 * k, gl_mul(filt, v.a)); acc.add(term + 2 * k + 1, gl_mul(filt, v.b)); };
+    auto add2 = [&](u32 k, gl2 v) { acc.add(term + 2 * k, v.a); acc.add(term + 2 * k + 1, v.b); };
     switch (G.kind) {
         case 4: {   // ArithmeticExtensionGate { num_ops }: output - (c0 m0 m1 + c1 addend)   (gates/arithmetic_extension.rs)
             const u64 c0 = consts[row], c1 = consts[A.cs_stride + row];
@@ -215,10 +225,10 @@ __device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, co
         case 6: {   // BaseSumGate<2> { num_limbs }: sum of limb_i 2^i - wire 0, then limb (limb - 1)   (gates/base_sum.rs)
             u64 s = 0;
             for (u32 i = n; i-- > 0;) s = gl_add(gl_add(s, s), PLONK_W(1 + i));
-            acc.add(term, gl_mul(filt, gl_sub(s, PLONK_W(0))));
+            acc.add(term, gl_sub(s, PLONK_W(0)));
             for (u32 i = 0; i < n; ++i) {
                 const u64 l = PLONK_W(1 + i);
-                acc.add(term + 1 + i, gl_mul(filt, gl_mul(l, gl_sub(l, 1))));
+                acc.add(term + 1 + i, gl_mul(l, gl_sub(l, 1)));
             }
             break;
         }
@@ -245,21 +255,21 @@ __device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, co
                 const u64 bit = PLONK_W(1 + (n - 1 - i));
                 const u64 cur = PLONK_W(2 + n + i);
                 const u64 sel = gl_add(gl_mul(bit, base), gl_sub(1, bit));
-                acc.add(term + i, gl_mul(filt, gl_sub(cur, gl_mul(prev, sel))));
+                acc.add(term + i, gl_sub(cur, gl_mul(prev, sel)));
                 last = cur;
             }
-            acc.add(term + n, gl_mul(filt, gl_sub(PLONK_W(1 + n), last)));
+            acc.add(term + n, gl_sub(PLONK_W(1 + n), last));
             break;
         }
         case 10: {  // PoseidonGate   (gates/poseidon.rs): plain rounds -- the same constraint polynomials as plonky2's
                     // fast partial rounds (between S-boxes both are the same affine maps, cf. the Poseidon table AIR in airs.cuh)
             u32 k = term;
             const u64 swap = PLONK_W(24);
-            acc.add(k++, gl_mul(filt, gl_mul(swap, gl_sub(swap, 1))));
+            acc.add(k++, gl_mul(swap, gl_sub(swap, 1)));
             u64 s[12];
             for (u32 i = 0; i < 4; ++i) {
                 const u64 lhs = PLONK_W(i), rhs = PLONK_W(i + 4), d = PLONK_W(25 + i);
-                acc.add(k++, gl_mul(filt, gl_sub(gl_mul(swap, gl_sub(rhs, lhs)), d)));
+                acc.add(k++, gl_sub(gl_mul(swap, gl_sub(rhs, lhs)), d));
                 s[i] = gl_add(lhs, d);
                 s[i + 4] = gl_sub(rhs, d);
             }
@@ -270,7 +280,7 @@ __device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, co
                 if (r) {
                     for (u32 i = 0; i < 12; ++i) {
                         const u64 w = PLONK_W(29 + 12 * (r - 1) + i);
-                        acc.add(k++, gl_mul(filt, gl_sub(s[i], w)));
+                        acc.add(k++, gl_sub(s[i], w));
                         s[i] = w;
                     }
                 }
@@ -280,7 +290,7 @@ __device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, co
             }
             for (int r = 0; r < 22; ++r) {
                 const u64 w = PLONK_W(65 + r);
-                acc.add(k++, gl_mul(filt, gl_sub(s[0], w)));
+                acc.add(k++, gl_sub(s[0], w));
                 s[0] = pos_sbox(w);
                 ++round;
                 pos_mds<true>(s, &ZK_RCS[round * 12]);
@@ -288,14 +298,14 @@ __device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, co
             for (int r = 0; r < 4; ++r) {
                 for (u32 i = 0; i < 12; ++i) {
                     const u64 w = PLONK_W(87 + 12 * r + i);
-                    acc.add(k++, gl_mul(filt, gl_sub(s[i], w)));
+                    acc.add(k++, gl_sub(s[i], w));
                     s[i] = pos_sbox(w);
                 }
                 ++round;
                 if (r < 3) pos_mds<true>(s, &ZK_RCS[round * 12]);
                 else pos_mds<false>(s, nullptr);
             }
-            for (u32 i = 0; i < 12; ++i) acc.add(k++, gl_mul(filt, gl_sub(s[i], PLONK_W(12 + i))));
+            for (u32 i = 0; i < 12; ++i) acc.add(k++, gl_sub(s[i], PLONK_W(12 + i)));
             break;
         }
         case 11: {  // RandomAccessGate { bits, num_copies, num_extra_constants } packed as bits | copies << 8 | extra << 16
@@ -309,20 +319,20 @@ __device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, co
                 u64 rec = 0;
                 for (u32 i = 0; i < bits; ++i) {
                     const u64 b = PLONK_W(routed + c * bits + i);
-                    acc.add(k++, gl_mul(filt, gl_mul(b, gl_sub(b, 1))));
+                    acc.add(k++, gl_mul(b, gl_sub(b, 1)));
                 }
                 for (u32 i = bits; i-- > 0;) rec = gl_add(gl_add(rec, rec), PLONK_W(routed + c * bits + i));
-                acc.add(k++, gl_mul(filt, gl_sub(rec, PLONK_W(base))));
+                acc.add(k++, gl_sub(rec, PLONK_W(base)));
                 u32 len = vec;
                 for (u32 i = 0; i < bits; ++i) {        // fold pairs by bit i (least significant first)
                     const u64 b = PLONK_W(routed + c * bits + i);
                     len >>= 1;
                     for (u32 j = 0; j < len; ++j) items[j] = gl_add(items[2 * j], gl_mul(b, gl_sub(items[2 * j + 1], items[2 * j])));
                 }
-                acc.add(k++, gl_mul(filt, gl_sub(items[0], PLONK_W(base + 1))));
+                acc.add(k++, gl_sub(items[0], PLONK_W(base + 1)));
             }
             for (u32 i = 0; i < extra; ++i)
-                acc.add(k++, gl_mul(filt, gl_sub(consts[(size_t)i * A.cs_stride + row], PLONK_W((2 + vec) * copies + i))));
+                acc.add(k++, gl_sub(consts[(size_t)i * A.cs_stride + row], PLONK_W((2 + vec) * copies + i)));
             break;
         }
         case 12: {  // PoseidonMdsGate: outputs - MDS * inputs on twelve extension elements (gates/poseidon_mds.rs)
@@ -369,7 +379,12 @@ __device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, co
 }
 #undef PLONK_W
 
+// One lane per point of the quotient coset.  For circuits of <= 2^14 rows the coset has <= 2^17 points = at most two
+// waves per SIMD, and ONE wave per SIMD issues at half rate whatever its ILP (profiles/r02g_ubench_single_wave_issue.txt):
+// there the launch has gridDim.y == 2 and each slice evaluates the gates the host gave it (cost-balanced; slice 0 also
+// the permutation terms).  The vanishing polynomial is a SUM of terms, so the slices' results just add.
 __global__ void __launch_bounds__(256) plonk_quotient_kernel(PlonkQuotientArgs A) {
+    const u32 sl = blockIdx.y, nsl = gridDim.y;
     const u32 size_log = A.log_n + A.qd_bits;
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >> size_log) return;
@@ -395,13 +410,15 @@ __global__ void __launch_bounds__(256) plonk_quotient_kernel(PlonkQuotientArgs A
     const size_t row_next = (size_t)((i + (1u << A.qd_bits)) & (size - 1)) << A.step_log;
     PlonkAcc acc;
     acc.nc = A.n_challenges;
-    for (u32 c = 0; c < A.n_challenges; ++c) { acc.acc[c] = 0; acc.pow[c] = A.alpha_pow[c]; }
+    for (u32 c = 0; c < A.n_challenges; ++c) { acc.g[c] = 0; acc.total[c] = 0; acc.pow[c] = A.alpha_pow[c]; }
     const u64 *sig = A.cs + (size_t)A.num_constants * A.cs_stride;
     u32 term = 0;
     // vanishing_z_1_terms: L_0(x) (Z(x) - 1)
-    for (u32 c = 0; c < A.n_challenges; ++c) acc.add(term++, gl_mul(l0, gl_sub(A.zs[(size_t)c * A.zs_stride + row], 1)));
+    if (sl == 0)
+        for (u32 c = 0; c < A.n_challenges; ++c) acc.add(term + c, gl_mul(l0, gl_sub(A.zs[(size_t)c * A.zs_stride + row], 1)));
+    term += A.n_challenges;
     // vanishing_partial_products_terms: check_partial_products, challenge-major
-    {
+    if (sl == 0) {
         u64 bx[ZK_PLONK_MAX_CHALLENGES];
         for (u32 c = 0; c < A.n_challenges; ++c) bx[c] = gl_mul(A.betas[c], x);
         const u32 per_chal = A.n_chunks;
@@ -424,18 +441,18 @@ __global__ void __launch_bounds__(256) plonk_quotient_kernel(PlonkQuotientArgs A
                 const u64 prev = k == 0 ? A.zs[(size_t)c * A.zs_stride + row] : A.zs[(pp0 + k - 1) * A.zs_stride + row];
                 const u64 next = k + 1 == A.n_chunks ? A.zs[(size_t)c * A.zs_stride + row_next] : A.zs[(pp0 + k) * A.zs_stride + row];
                 const u64 t = gl_sub(gl_mul(prev, pn[c]), gl_mul(next, pd[c]));
-                for (u32 cc = 0; cc < A.n_challenges; ++cc)
-                    acc.acc[cc] = gl_add(acc.acc[cc], gl_mul(t, acc.pow[cc][term + c * per_chal + k]));
+                acc.add(term + c * per_chal + k, t);
             }
         }
-        term += A.n_challenges * per_chal;
     }
+    if (sl == 0) acc.end_gate(1);
+    term += A.n_challenges * A.n_chunks;
     // gate constraints: slot j collects filter_g * constraint_{g,j} over all gates (at most one filter is non-zero on H)
     const bool many = A.num_selectors > 1;
     const u64 *consts = A.cs + (size_t)A.num_selectors * A.cs_stride;      // gate constants: selectors removed
     for (u32 g = 0; g < A.n_gates; ++g) {
         const PlonkGateDesc G = A.gates[g];
-        if (G.kind == 0) continue;                                          // NoopGate: no constraints
+        if (G.kind == 0 || (nsl > 1 && G.slice != sl)) continue;            // NoopGate: no constraints; other slice's gate
         const u64 s = A.cs[(size_t)G.selector_index * A.cs_stride + row];
         u64 filt = 1;                                                       // compute_filter
         for (u32 r = G.group_start; r < G.group_end; ++r)
@@ -443,23 +460,30 @@ __global__ void __launch_bounds__(256) plonk_quotient_kernel(PlonkQuotientArgs A
         if (many) filt = gl_mul(filt, gl_sub(ZK_PLONK_UNUSED_SELECTOR, s));
         if (G.kind == 1) {                                                  // ConstantGate { num_consts }
             for (u32 j = 0; j < G.param; ++j)
-                acc.add(term + j, gl_mul(filt, gl_sub(consts[(size_t)j * A.cs_stride + row], A.wires[(size_t)j * A.wires_stride + row])));
+                acc.add(term + j, gl_sub(consts[(size_t)j * A.cs_stride + row], A.wires[(size_t)j * A.wires_stride + row]));
         } else if (G.kind == 2) {                                           // PublicInputGate
             for (u32 j = 0; j < 4; ++j)
-                acc.add(term + j, gl_mul(filt, gl_sub(A.wires[(size_t)j * A.wires_stride + row], A.pi_hash[j])));
+                acc.add(term + j, gl_sub(A.wires[(size_t)j * A.wires_stride + row], A.pi_hash[j]));
         } else if (G.kind == 3) {                                           // ArithmeticGate { num_ops }
             const u64 c0 = consts[row], c1 = consts[A.cs_stride + row];
             for (u32 j = 0; j < G.param; ++j) {
                 const u64 *wp = A.wires + (size_t)(4 * j) * A.wires_stride + row;
                 const u64 m0 = wp[0], m1 = wp[A.wires_stride], ad = wp[2 * A.wires_stride], out = wp[3 * A.wires_stride];
                 const u64 v = gl_sub(out, gl_add(gl_mul(gl_mul(m0, m1), c0), gl_mul(ad, c1)));
-                acc.add(term + j, gl_mul(filt, v));
+                acc.add(term + j, v);
             }
         } else {
-            plonk_eval_wide_gate(A, G, filt, consts, row, term, acc);
+            plonk_eval_wide_gate(A, G, consts, row, term, acc);
         }
+        acc.end_gate(filt);
     }
-    for (u32 c = 0; c < A.n_challenges; ++c) A.out[(size_t)c * A.out_stride + i] = gl_canon(gl_mul(acc.acc[c], inv_zh));
+    u64 *out = sl ? A.out2 : A.out;
+    for (u32 c = 0; c < A.n_challenges; ++c) out[(size_t)c * A.out_stride + i] = gl_canon(gl_mul(acc.total[c], inv_zh));
+}
+
+__global__ void plonk_add_slices_kernel(u64 *out, const u64 *out2, size_t count) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = gl_canon(gl_add(out[i], out2[i]));
 }
 
 // out[c * cap + k] = alpha_c^k

@@ -6,6 +6,7 @@
 // There is NO CPU fallback: every entry point either runs the HIP kernels or returns an error.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
