@@ -1,7 +1,7 @@
 """Segments in flight per GPU: W worker threads, each with its own Context + stream, prove the same shape back to back;
 aggregate proofs/s for W = 1, 2, 3 (the input traces are shared and read-only; a W whose arenas would not fit is skipped).  At 2^20 a single segment already keeps the GPU 98.5 % busy; at the realistic table
 heights the small tables leave SIMDs idle that a second in-flight segment can use.
-Usage: python tools/bench_concurrent.py [realistic|<log_n>] [proofs per worker] [stagger seconds]"""
+Usage: python tools/bench_concurrent.py [realistic|<log_n>] [proofs per worker] [stagger seconds] [worker counts, e.g. 1,2,4]"""
 import json
 import os
 import sys
@@ -27,7 +27,7 @@ def main():
     shared = synthetic_segment_traces(log_ns, dev, seed=3)     # read-only inputs, resident once, proven by every worker
     total_hbm = torch.cuda.get_device_properties(0).total_memory
     peak = None
-    for workers in (1, 2, 3):
+    for workers in ([int(x) for x in sys.argv[4].split(",")] if len(sys.argv) > 4 else (1, 2, 3)):
         if peak is not None and workers * peak + torch.cuda.memory_allocated() > 0.88 * total_hbm:
             out["proofs_per_s"][str(workers)] = None         # would not fit: workers x arena peak + inputs
             continue
