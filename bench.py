@@ -952,6 +952,7 @@ def main():
                              "launches": tot["commits"], "ms_per_launch": leaf_ms / max(tot["commits"], 1),
                              "ms_per_step": leaf_ms / a.steps, "share_of_step": leaf_ms / a.steps / ms_per_step,
                              "algorithmic_bytes": tot["leaf_hash_bytes"] / max(tot["commits"], 1),
+                             "permutations_per_launch": tot["leaf_hash_perms"] / max(tot["commits"], 1),
                              "valu": seg_valu,
                              "note": "summed over the %d leaf-hash launches of the timed region (one per commitment: "
                                      "9 trace + 9 auxiliary + 9 quotient per segment); integer-VALU bound, not HBM bound "
@@ -1030,6 +1031,9 @@ def main():
                                            "SIMDs are issue-saturated either way",
                                 "source": "rocprofv3 --pmc SQ_INSTS_VALU in this run; time per launch from the un-profiled timed region",
                                 "measured_in_this_run": True}
+                perms_per_launch = roof.get("permutations_per_launch")
+                if perms_per_launch:
+                    roof["valu"]["instructions_per_permutation"] = pmc["valu_wave_insts_per_launch"] * 64.0 / perms_per_launch
         if rank == 0 and not a.no_cpu_baseline and world == 1:
             extrap = None
             try:
