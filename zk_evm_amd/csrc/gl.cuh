@@ -91,16 +91,44 @@ GL_HD u64 gl_mul_ref(u64 a, u64 b) {
 // ~4.3), so the 128-bit product needs 4 mad + 2 carry adds instead of 4 mad + 6 carry adds.  Measured
 // (tools/ubench_mul.hip): 72.7 cycles per wave-multiply per SIMD against 91.2 for the four-independent-products form
 // and 81.4 for the three-product squaring -- so a square is just gl_mul(a, a).
+// The fold's FIRST correction (the borrow of [T1:T0] - T3) happens with probability ~2^-33 per lane, so its three
+// instructions sit in an unlikely block entered only when some lane of the wave borrowed: the borrow mask leaves the asm
+// in an SGPR pair, the test and branch run on the scalar unit, the common path falls through.  (The second correction
+// fires for every other product and stays inline.)  tools/ubench_mul.hip: 58.7 instead of 74.7 cycles per wave-multiply.
+#define GL_FOLD_HEAD(lo, t1, t3, p0, bm)                                                                           \
+    asm("v_sub_co_u32 %[l], vcc, %[p], %[z]\n\t"         /* [t1:lo] = [T1:T0] - T3 */                              \
+        "v_subbrev_co_u32 %[h], %[b], 0, %[h], vcc"                                                                \
+        : [l] "=&v"(lo), [h] "+&v"(t1), [b] "=&s"(bm)                                                              \
+        : [p] "v"(p0), [z] "v"(t3)                                                                                 \
+        : "vcc");                                                                                                  \
+    if (__builtin_expect(bm != 0, 0)) {                    /* borrow: -= EPS (== += p) */                          \
+        u32 e_;                                                                                                    \
+        asm("v_cndmask_b32_e64 %[e], 0, -1, %[b]\n\t"                                                              \
+            "v_sub_co_u32 %[l], vcc, %[l], %[e]\n\t"                                                               \
+            "v_subbrev_co_u32 %[h], vcc, 0, %[h], vcc"                                                             \
+            : [l] "+&v"(lo), [h] "+&v"(t1), [e] "=&v"(e_)                                                          \
+            : [b] "s"(bm)                                                                                          \
+            : "vcc");                                                                                              \
+    }
+
 __device__ __forceinline__ u64 gl_mul(u64 a, u64 b) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 P = (u64)a0 * b0;
     const u64 M = (u64)a0 * b1 + (P >> 32);            // <= (2^32-1)^2 + 2^32 - 1: no overflow
     const u64 M2 = (u64)a1 * b0 + (u32)M;              // likewise
     const u64 H = (u64)a1 * b1 + (M >> 32) + (M2 >> 32);
-    u32 lo, hi, t1 = (u32)M2, t2 = (u32)H, t3 = (u32)(H >> 32), e;
-    asm(GL_ASM_REDUCE
-        : [lo] "=&v"(lo), [hi] "=&v"(hi), [t1] "+&v"(t1), [t2] "+&v"(t2), [t3] "+&v"(t3), [e] "=&v"(e)
-        : [p0] "v"((u32)P)
+    u32 lo, hi, t1 = (u32)M2, e;
+    const u32 t2 = (u32)H, t3 = (u32)(H >> 32);
+    u64 bm;
+    GL_FOLD_HEAD(lo, t1, t3, (u32)P, bm)
+    asm("v_sub_co_u32 %[lo], vcc, %[lo], %[t2]\n\t"      /* += T2*(2^32-1) = [T2:0] - [0:T2]  */
+        "v_subbrev_co_u32 %[e], vcc, 0, %[t2], vcc\n\t"  /* e = T2 - borrow (>= 0)            */
+        "v_add_co_u32 %[hi], vcc, %[t1], %[e]\n\t"
+        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"         /* carry: += EPS                     */
+        "v_add_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
+        "v_addc_co_u32 %[hi], vcc, 0, %[hi], vcc"
+        : [lo] "+&v"(lo), [hi] "=&v"(hi), [e] "=&v"(e)
+        : [t1] "v"(t1), [t2] "v"(t2)
         : "vcc");
     return ((u64)hi << 32) | lo;
 }
@@ -112,6 +140,8 @@ __device__ __forceinline__ u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 // same add the carry branch needs, so the two conditions are merged on the scalar unit).  A canonical product lets the
 // add / sub that consume it use ONE correction instead of two (gl_add_canon / gl_sub_canon): 22 + 5 + 5 instructions for
 // a decimation-in-time butterfly instead of 20 + 8 + 8.
+// (No unlikely block for the first correction here: in the NTT's register step the branch version measured 2 % SLOWER --
+// 1014 vs 1031 GB/s on the 116 x 2^20 commit -- where the same change makes the leaf hashing 13 % faster.)
 __device__ __forceinline__ u64 gl_mul_canon(u64 a, u64 b) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 P = (u64)a0 * b0;

@@ -91,14 +91,19 @@ __device__ __forceinline__ u64 pos_fold(u64 al, u64 ah) {
     // ah1 * 2^64 == ah1 * (2^32 - 1); al + that < 2^45: no overflow
     asm("v_mad_u64_u32 %0, vcc, %1, -1, %0" : "+v"(al) : "v"(ah1) : "vcc");
     u32 l = (u32)al, h = (u32)(al >> 32), e;
-    // h += ah0; on carry-out add 2^64 == EPS (cannot carry twice: the wrapped h is < 2^13)
-    asm("v_add_co_u32 %1, vcc, %1, %3\n\t"
-        "v_cndmask_b32_e64 %2, 0, -1, vcc\n\t"
-        "v_add_co_u32 %0, vcc, %0, %2\n\t"
-        "v_addc_co_u32 %1, vcc, 0, %1, vcc"
-        : "+v"(l), "+v"(h), "=&v"(e)
-        : "v"(ah0)
-        : "vcc");
+    // h += ah0; on carry-out add 2^64 == EPS (cannot carry twice: the wrapped h is < 2^13).  h < 2^13 before the add, so
+    // the carry needs ah0 > 2^32 - 2^13: probability 2^-19 per lane -- the correction is an unlikely block entered when
+    // some lane of the wave carried (test and branch on the scalar unit), and the fold is two VALU instructions.
+    u64 cm;
+    asm("v_add_co_u32 %0, %1, %0, %2" : "+v"(h), "=&s"(cm) : "v"(ah0));
+    if (__builtin_expect(cm != 0, 0)) {
+        asm("v_cndmask_b32_e64 %2, 0, -1, %3\n\t"
+            "v_add_co_u32 %0, vcc, %0, %2\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(l), "+v"(h), "=&v"(e)
+            : "s"(cm)
+            : "vcc");
+    }
     return ((u64)h << 32) | l;
 }
 
