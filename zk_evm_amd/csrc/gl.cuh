@@ -133,6 +133,23 @@ __device__ __forceinline__ u64 gl_mul(u64 a, u64 b) {
     return ((u64)hi << 32) | lo;
 }
 
+// The branch-free form (all eleven fold instructions inline, one asm statement).  The table AIRs use this one: their
+// kernels hold hundreds of live values, and the unlikely blocks of gl_mul cost the 86-column Cpu AIR its occupancy
+// (4 -> 2 waves per SIMD, its quotient 7 -> 17 ms) while gaining nothing measurable on the others.
+__device__ __forceinline__ u64 gl_mul_nb(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 P = (u64)a0 * b0;
+    const u64 M = (u64)a0 * b1 + (P >> 32);
+    const u64 M2 = (u64)a1 * b0 + (u32)M;
+    const u64 H = (u64)a1 * b1 + (M >> 32) + (M2 >> 32);
+    u32 lo, hi, t1 = (u32)M2, t2 = (u32)H, t3 = (u32)(H >> 32), e;
+    asm(GL_ASM_REDUCE
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [t1] "+&v"(t1), [t2] "+&v"(t2), [t3] "+&v"(t3), [e] "=&v"(e)
+        : [p0] "v"((u32)P)
+        : "vcc");
+    return ((u64)hi << 32) | lo;
+}
+
 __device__ __forceinline__ u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 
 // gl_mul with the result folded into [0, p) (two compares on top of the lazy form: the only non-canonical outputs of the
@@ -152,9 +169,11 @@ __device__ __forceinline__ u64 gl_mul_canon(u64 a, u64 b) {
     u64 sa, sb;
     asm("v_sub_co_u32 %[lo], vcc, %[p0], %[t3]\n\t"
         "v_subbrev_co_u32 %[t1], vcc, 0, %[t1], vcc\n\t"
+        "s_cbranch_vccz 1f\n\t"                          /* no lane borrowed (all but ~2^-27 of the waves) */
         "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"
         "v_sub_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
-        "v_subbrev_co_u32 %[t1], vcc, 0, %[t1], vcc\n\t"
+        "v_subbrev_co_u32 %[t1], vcc, 0, %[t1], vcc\n"
+        "1:\n\t"
         "v_sub_co_u32 %[lo], vcc, %[lo], %[t2]\n\t"
         "v_subbrev_co_u32 %[e], vcc, 0, %[t2], vcc\n\t"
         "v_add_co_u32 %[hi], vcc, %[t1], %[e]\n\t"
@@ -171,7 +190,9 @@ __device__ __forceinline__ u64 gl_mul_canon(u64 a, u64 b) {
     return ((u64)hi << 32) | lo;
 }
 
-// a, b arbitrary u64 representatives; result arbitrary representative of a+b.
+// a, b arbitrary u64 representatives; result arbitrary representative of a+b.  (The second wrap is as rare as gl_mul's first
+// correction, but moving it into an unlikely block changed nothing measurable -- 909.5 vs 910.5 ms per segment, the AIR
+// kernels if anything slower -- so add / sub keep the branch-free form.)
 __device__ __forceinline__ u64 gl_add(u64 a, u64 b) {
     u32 lo, hi, e;
     asm("v_add_co_u32 %[lo], vcc, %[a0], %[b0]\n\t"
@@ -234,6 +255,7 @@ GL_HD u64 gl_add_canon(u64 a, u64 b) { return gl_add_ref(a, b); }
 GL_HD u64 gl_sub(u64 a, u64 b) { return gl_sub_ref(a, b); }
 GL_HD u64 gl_mul(u64 a, u64 b) { return gl_mul_ref(a, b); }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul_ref(a, a); }
+GL_HD u64 gl_mul_nb(u64 a, u64 b) { return gl_mul_ref(a, b); }
 GL_HD u64 gl_mul_canon(u64 a, u64 b) { return gl_canon(gl_mul_ref(a, b)); }
 GL_HD u64 gl_sub_canon(u64 a, u64 b) { return gl_sub_ref(a, b); }
 #endif
