@@ -460,16 +460,20 @@ struct AirKeccak {
                 Fe xr = xor3_gen(lv[reg_c(x, z)], lv[reg_c((x + 4) % 5, z)], lv[reg_c((x + 1) % 5, (z + 63) % 64)]);
                 c.constraint(lv[reg_c_prime(x, z)] - xr);
             }
-        for (u32 x = 0; x < 5; ++x)
-            for (u32 y = 0; y < 5; ++y)
+        // xor3_gen(A'[x,y,z], C[x,z], C'[x,z]) = xor_gen(A'[x,y,z], xor_gen(C[x,z], C'[x,z])): the inner xor does not depend
+        // on y, so it is computed once per (x, z) for the five rows (ten Horner accumulators: rows x halves) -- the same
+        // field values, constraints yielded in the reference's (x, y, half) order, 6 instead of 10 multiplies per (x, z).
+        for (u32 x = 0; x < 5; ++x) {
+            Fe acc[5][2];
+            for (int z = 31; z >= 0; --z)
                 for (u32 half = 0; half < 2; ++half) {
-                    Fe acc;
-                    for (int z = 32 * half + 31; z >= (int)(32 * half); --z) {
-                        Fe bit = xor3_gen(lv[reg_a_prime(x, y, z)], lv[reg_c(x, z)], lv[reg_c_prime(x, z)]);
-                        acc = acc + acc + bit;
-                    }
-                    c.constraint(acc - lv[reg_a(x, y) + half]);
+                    const u32 zz = 32 * half + (u32)z;
+                    const Fe t = xor_gen(lv[reg_c(x, zz)], lv[reg_c_prime(x, zz)]);
+                    for (u32 y = 0; y < 5; ++y) acc[y][half] = acc[y][half] + acc[y][half] + xor_gen(lv[reg_a_prime(x, y, zz)], t);
                 }
+            for (u32 y = 0; y < 5; ++y)
+                for (u32 half = 0; half < 2; ++half) c.constraint(acc[y][half] - lv[reg_a(x, y) + half]);
+        }
         for (u32 x = 0; x < 5; ++x)
             for (u32 z = 0; z < 64; ++z) {
                 Fe s;
