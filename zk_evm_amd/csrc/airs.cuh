@@ -460,37 +460,48 @@ struct AirKeccak {
                 Fe xr = xor3_gen(lv[reg_c(x, z)], lv[reg_c((x + 4) % 5, z)], lv[reg_c((x + 1) % 5, (z + 63) % 64)]);
                 c.constraint(lv[reg_c_prime(x, z)] - xr);
             }
-        // xor3_gen(A'[x,y,z], C[x,z], C'[x,z]) = xor_gen(A'[x,y,z], xor_gen(C[x,z], C'[x,z])): the inner xor does not depend
-        // on y, so it is computed once per (x, z) for the five rows (ten Horner accumulators: rows x halves) -- the same
-        // field values, constraints yielded in the reference's (x, y, half) order, 6 instead of 10 multiplies per (x, z).
+        // The next three constraint families of the reference -- 50 x "A = bits of A' ^ C ^ C'", 320 x "sum_y A'[x,y,z] - C'[x,z]
+        // in {0, 2, 4}", 50 x "A'' = bits of B ^ (~B & B)" -- are yielded through constraint_at: this kernel is bound by its
+        // loads (2431 columns, most of them read once per family), and the dot-product consumer does not care about order.
+        //   * A and the sums visit A'[x, 0..4, z] together; xor3_gen(A', C, C') = xor_gen(A', xor_gen(C, C')) and the inner
+        //     xor does not depend on y: 7 loads and 6 multiplies per (x, z) instead of 5 x 3 + 6 loads and 10 + 2;
+        //   * the chi step reads the five lanes B[0..4, y, z] of a row once for its five output bits (5 loads per (y, z)
+        //     instead of 15).
+        // Same field values at the same positions of the alpha-combination as the reference's order.
         for (u32 x = 0; x < 5; ++x) {
             Fe acc[5][2];
             for (int z = 31; z >= 0; --z)
                 for (u32 half = 0; half < 2; ++half) {
                     const u32 zz = 32 * half + (u32)z;
-                    const Fe t = xor_gen(lv[reg_c(x, zz)], lv[reg_c_prime(x, zz)]);
-                    for (u32 y = 0; y < 5; ++y) acc[y][half] = acc[y][half] + acc[y][half] + xor_gen(lv[reg_a_prime(x, y, zz)], t);
-                }
-            for (u32 y = 0; y < 5; ++y)
-                for (u32 half = 0; half < 2; ++half) c.constraint(acc[y][half] - lv[reg_a(x, y) + half]);
-        }
-        for (u32 x = 0; x < 5; ++x)
-            for (u32 z = 0; z < 64; ++z) {
-                Fe s;
-                for (u32 i = 0; i < 5; ++i) s += lv[reg_a_prime(x, i, z)];
-                Fe diff = s - lv[reg_c_prime(x, z)];
-                c.constraint(diff * (diff - fe(2)) * (diff - fe(4)));
-            }
-        for (u32 x = 0; x < 5; ++x)
-            for (u32 y = 0; y < 5; ++y)
-                for (u32 half = 0; half < 2; ++half) {
-                    Fe acc;
-                    for (int z = 32 * half + 31; z >= (int)(32 * half); --z) {
-                        Fe bit = xor_gen(lv[reg_b(x, y, z)], andn_gen(lv[reg_b((x + 1) % 5, y, z)], lv[reg_b((x + 2) % 5, y, z)]));
-                        acc = acc + acc + bit;
+                    const Fe cp = lv[reg_c_prime(x, zz)];
+                    const Fe t = xor_gen(lv[reg_c(x, zz)], cp), t2 = t + t;
+                    Fe sum;
+                    for (u32 y = 0; y < 5; ++y) {
+                        const Fe a = lv[reg_a_prime(x, y, zz)];
+                        sum += a;
+                        acc[y][half] = acc[y][half] + acc[y][half] + (a + t - a * t2);      // xor_gen(a, t)
                     }
-                    c.constraint(acc - lv[reg_a_pp(x, y) + half]);
+                    const Fe diff = sum - cp;
+                    c.constraint_at(50 + x * 64 + zz, diff * (diff - fe(2)) * (diff - fe(4)));
                 }
+            for (u32 y = 0; y < 5; ++y)
+                for (u32 half = 0; half < 2; ++half) c.constraint_at(x * 10 + y * 2 + half, acc[y][half] - lv[reg_a(x, y) + half]);
+        }
+        c.advance(50 + 320);
+        for (u32 y = 0; y < 5; ++y) {
+            Fe acc[5][2];
+            for (int z = 31; z >= 0; --z)
+                for (u32 half = 0; half < 2; ++half) {
+                    const u32 zz = 32 * half + (u32)z;
+                    Fe b[5];
+                    for (u32 x = 0; x < 5; ++x) b[x] = lv[reg_b(x, y, zz)];
+                    for (u32 x = 0; x < 5; ++x)
+                        acc[x][half] = acc[x][half] + acc[x][half] + xor_gen(b[x], andn_gen(b[(x + 1) % 5], b[(x + 2) % 5]));
+                }
+            for (u32 x = 0; x < 5; ++x)
+                for (u32 half = 0; half < 2; ++half) c.constraint_at(x * 10 + y * 2 + half, acc[x][half] - lv[reg_a_pp(x, y) + half]);
+        }
+        c.advance(50);
         for (u32 half = 0; half < 2; ++half) {
             Fe acc;
             for (int z = 32 * half + 31; z >= (int)(32 * half); --z) acc = acc + acc + lv[2365 + z];

@@ -61,10 +61,21 @@ struct DotConsumer {
     __device__ __forceinline__ void constraint_transition(Fe c) { constraint(c * z_last); }
     __device__ __forceinline__ void constraint_first_row(Fe c) { constraint(c * lagrange_first); }
     __device__ __forceinline__ void constraint_last_row(Fe c) { constraint(c * lagrange_last); }
+    // The sum is a dot product, so a block of n constraints may be yielded in ANY order: constraint_at(i, c) is the i-th
+    // (0-based, in the reference's yield order) constraint of the block that starts at the current position, and
+    // advance(n) closes the block.  An AIR uses this to visit its columns once instead of once per constraint family.
+    __device__ __forceinline__ void constraint_at(u32 i, Fe c) {
+        const u64 a = ap0[-1 - (int)i], b = ap1[-1 - (int)i];
+        dot_acc_mac(d0, __builtin_amdgcn_readfirstlane((u32)a), __builtin_amdgcn_readfirstlane((u32)(a >> 32)), c.v);
+        dot_acc_mac(d1, __builtin_amdgcn_readfirstlane((u32)b), __builtin_amdgcn_readfirstlane((u32)(b >> 32)), c.v);
+    }
+    __device__ __forceinline__ void advance(u32 n) { ap0 -= n; ap1 -= n; }
 };
 // same interface, only counts (everything feeding the ignored values is dead code)
 struct CountConsumer {
     u32 count;
+    __device__ __forceinline__ void constraint_at(u32, Fe) {}
+    __device__ __forceinline__ void advance(u32 n) { count += n; }
     __device__ __forceinline__ void constraint(Fe) { ++count; }
     __device__ __forceinline__ void constraint_transition(Fe) { ++count; }
     __device__ __forceinline__ void constraint_first_row(Fe) { ++count; }
