@@ -99,13 +99,49 @@ __device__ __forceinline__ u64 gl_mul_v4(u64 a, u64 b) {
 #endif
 }
 
+// v6 = v4 with the last correction as ONE 64-bit add (v_lshl_add_u64 of {e, 0}) instead of v_add_co + v_addc
+__device__ __forceinline__ u64 gl_mul_v6(u64 a, u64 b) {
+    u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 P = (u64)a0 * b0;
+    u64 M = (u64)a0 * b1 + (P >> 32);
+    u64 M2 = (u64)a1 * b0 + (u32)M;
+    u64 H = (u64)a1 * b1 + (M >> 32) + (M2 >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 lo, hi, t1 = (u32)M2, t2 = (u32)H, t3 = (u32)(H >> 32), e;
+    u64 bm;
+    asm("v_sub_co_u32 %[lo], vcc, %[p0], %[t3]\n\t"
+        "v_subbrev_co_u32 %[t1], %[bm], 0, %[t1], vcc"
+        : [lo] "=&v"(lo), [t1] "+&v"(t1), [bm] "=&s"(bm)
+        : [p0] "v"((u32)P), [t3] "v"(t3)
+        : "vcc");
+    if (__builtin_expect(bm != 0, 0)) {
+        asm("v_cndmask_b32_e64 %[e], 0, -1, %[bm]\n\t"
+            "v_sub_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
+            "v_subbrev_co_u32 %[t1], vcc, 0, %[t1], vcc"
+            : [lo] "+&v"(lo), [t1] "+&v"(t1), [e] "=&v"(e)
+            : [bm] "s"(bm)
+            : "vcc");
+    }
+    asm("v_sub_co_u32 %[lo], vcc, %[lo], %[t2]\n\t"
+        "v_subbrev_co_u32 %[e], vcc, 0, %[t2], vcc\n\t"
+        "v_add_co_u32 %[hi], vcc, %[t1], %[e]\n\t"
+        "v_cndmask_b32_e64 %[e], 0, -1, vcc"
+        : [lo] "+&v"(lo), [hi] "=&v"(hi), [e] "=&v"(e)
+        : [t1] "v"(t1), [t2] "v"(t2)
+        : "vcc");
+    return (((u64)hi << 32) | lo) + (u64)e;
+#else
+    return gl_reduce128(H, (M2 << 32) | (u32)P);
+#endif
+}
+
 template <int V>
 __global__ void k_mul(u64 *out, u64 seed) {
     u64 r[8], w = seed | 1;
     for (int i = 0; i < 8; ++i) r[i] = seed * (threadIdx.x + 7 * i + 1);
     for (int it = 0; it < ITER; ++it) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r[i] = V == 1 ? gl_mul(r[i], w) : V == 2 ? gl_mul_v2(r[i], w) : V == 4 ? gl_mul_v3(r[i], w) : V == 5 ? gl_mul_v4(r[i], w) : gl_sqr(r[i]);
+        for (int i = 0; i < 8; ++i) r[i] = V == 1 ? gl_mul(r[i], w) : V == 2 ? gl_mul_v2(r[i], w) : V == 4 ? gl_mul_v3(r[i], w) : V == 5 ? gl_mul_v4(r[i], w) : V == 6 ? gl_mul_v6(r[i], w) : gl_sqr(r[i]);
     }
     u64 z = 0;
     for (int i = 0; i < 8; ++i) z ^= gl_canon(r[i]);
@@ -141,5 +177,6 @@ int main() {
     run<3>("gl_sqr", d, nullptr);
     run<4>("gl_mul_v3", d, &ref);
     run<5>("gl_mul_v4", d, &ref);
+    run<6>("gl_mul_v6", d, &ref);
     return 0;
 }

@@ -28,6 +28,12 @@
 struct RcSplit { u64 lo, hi; };
 __constant__ u64 ZK_RC[ZK_POSEIDON_ROUNDS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RC_INIT;
 __constant__ RcSplit ZK_RCS[ZK_POSEIDON_ROUNDS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RCS_INIT;
+// Two partial rounds as one linear step (see pos_partial_pair): M^2 = circ(ZK_M2C) away from row 0 / column 0, constants
+// K_p = M rc' + rc'' of pair p split like ZK_RCS.
+__constant__ u32 ZK_M2C[12] = ZK_POSEIDON_M2_CIRC_INIT;
+__constant__ u32 ZK_M2ROW0[12] = ZK_POSEIDON_M2_ROW0_INIT;
+__constant__ u32 ZK_M2COL0[12] = ZK_POSEIDON_M2_COL0_INIT;
+__constant__ RcSplit ZK_RCS2[ZK_POSEIDON_PARTIAL_PAIRS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RCS2_INIT;
 
 __device__ __forceinline__ u64 pos_sbox(u64 x) {
     u64 x2 = gl_sqr(x);
@@ -129,6 +135,79 @@ __device__ __forceinline__ void pos_mds(u64 (&s)[12], const RcSplit *rc) {
     }
 }
 
+// ---- two partial rounds in one linear step -------------------------------------------------------------
+// In a partial round only element 0 goes through the S-box, so with x = the state after that S-box, M = the MDS matrix and
+// rc', rc'' the constants of the next two rounds,
+//     w0    = (M x)_0 + rc'_0                       (the only entry of the intermediate state that is needed)
+//     delta = sbox(w0) - w0
+//     v''   = M^2 x + (M rc' + rc'') + delta M[:, 0]
+// is the state two rounds later (constants of the round after included, as everywhere in this file): one MDS row, two
+// S-boxes and ONE 12 x 12 product with the entries of M^2 (< 2^13: the 32-bit halves still sum to < 2^50 in a 64-bit
+// accumulator) plus a 13th term per row, instead of two full MDS products: 24 + 312 mads per pair instead of 576, the
+// same field values.  The 22 partial rounds are 11 such pairs; ~15 % of the permutation's instructions.
+// acc += sum_j x[j] * k[j] + d * CD   (k: wave-uniform constants in SGPRs, CD inline)
+template <u32 CD>
+__device__ __forceinline__ void pos_row2_half(u64 &acc, const u32 (&x)[12], const u32 (&k)[12], u32 d) {
+    asm("v_mad_u64_u32 %0, vcc, %1, %13, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %2, %14, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %3, %15, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %4, %16, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %5, %17, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %6, %18, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %7, %19, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %8, %20, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %9, %21, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %10, %22, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %11, %23, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %12, %24, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %25, %26, %0"
+        : "+v"(acc)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]), "v"(x[10]),
+          "v"(x[11]), "s"(k[0]), "s"(k[1]), "s"(k[2]), "s"(k[3]), "s"(k[4]), "s"(k[5]), "s"(k[6]), "s"(k[7]), "s"(k[8]), "s"(k[9]),
+          "s"(k[10]), "s"(k[11]), "v"(d), "n"(CD)
+        : "vcc");
+}
+template <int R>
+__device__ __forceinline__ u64 pos_m2_row(const u32 (&lo)[12], const u32 (&hi)[12], u32 dl, u32 dh, const RcSplit *kp) {
+    constexpr u32 C[12] = ZK_POSEIDON_MDS_CIRC_INIT;
+    constexpr u32 CD = C[(12 - R) % 12] + (R == 0 ? 8 : 0);            // M[R][0]
+    u32 k[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) k[j] = R == 0 ? ZK_M2ROW0[j] : j == 0 ? ZK_M2COL0[R] : ZK_M2C[(j - R + 12) % 12];
+    u64 al = kp[R].lo, ah = kp[R].hi;
+    pos_row2_half<CD>(al, lo, k, dl);
+    pos_row2_half<CD>(ah, hi, k, dh);
+    return pos_fold(al, ah);
+}
+// s (constants of round `round` included, `round` a partial round) -> the state two rounds later; pair = (round - 4) / 2
+__device__ __forceinline__ void pos_partial_pair(u64 (&s)[12], int round, int pair) {
+    s[0] = pos_sbox(s[0]);
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+    const RcSplit *rc1 = &ZK_RCS[(round + 1) * 12];
+    u64 al, ah;
+    pos_row<true>(al, ah, rc1[0].lo, rc1[0].hi, lo, hi, 0);
+    pos_mac<8>(al, lo[0]);
+    pos_mac<8>(ah, hi[0]);
+    const u64 w0 = pos_fold(al, ah);
+    const u64 delta = gl_sub(pos_sbox(w0), w0);
+    const u32 dl = (u32)delta, dh = (u32)(delta >> 32);
+    const RcSplit *kp = &ZK_RCS2[pair * 12];
+    s[0] = pos_m2_row<0>(lo, hi, dl, dh, kp);
+    s[1] = pos_m2_row<1>(lo, hi, dl, dh, kp);
+    s[2] = pos_m2_row<2>(lo, hi, dl, dh, kp);
+    s[3] = pos_m2_row<3>(lo, hi, dl, dh, kp);
+    s[4] = pos_m2_row<4>(lo, hi, dl, dh, kp);
+    s[5] = pos_m2_row<5>(lo, hi, dl, dh, kp);
+    s[6] = pos_m2_row<6>(lo, hi, dl, dh, kp);
+    s[7] = pos_m2_row<7>(lo, hi, dl, dh, kp);
+    s[8] = pos_m2_row<8>(lo, hi, dl, dh, kp);
+    s[9] = pos_m2_row<9>(lo, hi, dl, dh, kp);
+    s[10] = pos_m2_row<10>(lo, hi, dl, dh, kp);
+    s[11] = pos_m2_row<11>(lo, hi, dl, dh, kp);
+}
+
 // In/out: arbitrary u64 representatives; callers canonicalise what they emit.
 __device__ __forceinline__ void poseidon_permute(u64 (&s)[12]) {
 #pragma unroll
@@ -141,11 +220,11 @@ __device__ __forceinline__ void poseidon_permute(u64 (&s)[12]) {
         ++round;
         pos_mds<true>(s, &ZK_RCS[round * 12]);
     }
+    static_assert(ZK_POSEIDON_PARTIAL_ROUNDS == 2 * ZK_POSEIDON_PARTIAL_PAIRS, "partial rounds are taken in pairs");
 #pragma unroll 1
-    for (int k = 0; k < ZK_POSEIDON_PARTIAL_ROUNDS; ++k) {
-        s[0] = pos_sbox(s[0]);
-        ++round;
-        pos_mds<true>(s, &ZK_RCS[round * 12]);
+    for (int k = 0; k < ZK_POSEIDON_PARTIAL_PAIRS; ++k) {
+        pos_partial_pair(s, round, k);
+        round += 2;
     }
 #pragma unroll 1
     for (int k = 0; k < ZK_POSEIDON_HALF_FULL_ROUNDS - 1; ++k) {
