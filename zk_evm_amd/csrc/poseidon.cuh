@@ -13,8 +13,9 @@
 //     sum_i C[i]*half[(i+r)%12] in one 64-bit register with 12 v_mad_u64_u32 (inline constants,
 //     no per-term reduction: sums stay < 2^43).  The NEXT round's constant is the accumulator's
 //     initial value (an SGPR pair from constant memory), so constant addition costs nothing.
-//   * the two 43-bit sums are folded to one lazy u64 with 5 instructions (one mad by 2^32-1, one
-//     carry add, one conditional +EPS) -- see pos_fold().
+//   * the two 43-bit sums are folded to one lazy u64 with 2 instructions on the common path (one mad by 2^32-1, one
+//     carry add; the conditional +EPS fires for 2^-19 of the lanes and lives in an unlikely block) -- see pos_fold().
+//   * the 22 partial rounds are taken two at a time as one linear step with the entries of MDS^2 (pos_partial_pair).
 //   * an MFMA formulation was evaluated and rejected: the i8 matrix pipe could do the 12x12
 //     byte-limb products, but re-laying 64-bit lane-private words out as MFMA operands and
 //     recombining 8 i32 partial sums per word costs more VALU work than the 288 mads it replaces
