@@ -95,6 +95,7 @@ GL_HD u64 gl_mul_ref(u64 a, u64 b) {
 // instructions sit in an unlikely block entered only when some lane of the wave borrowed: the borrow mask leaves the asm
 // in an SGPR pair, the test and branch run on the scalar unit, the common path falls through.  (The second correction
 // fires for every other product and stays inline.)  tools/ubench_mul.hip: 58.7 instead of 74.7 cycles per wave-multiply.
+// Used where multiplies dominate and registers are not scarce: the Poseidon S-box (gl_mul_fast).
 #define GL_FOLD_HEAD(lo, t1, t3, p0, bm)                                                                           \
     asm("v_sub_co_u32 %[l], vcc, %[p], %[z]\n\t"         /* [t1:lo] = [T1:T0] - T3 */                              \
         "v_subbrev_co_u32 %[h], %[b], 0, %[h], vcc"                                                                \
@@ -111,7 +112,7 @@ GL_HD u64 gl_mul_ref(u64 a, u64 b) {
             : "vcc");                                                                                              \
     }
 
-__device__ __forceinline__ u64 gl_mul(u64 a, u64 b) {
+__device__ __forceinline__ u64 gl_mul_fast(u64 a, u64 b) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 P = (u64)a0 * b0;
     const u64 M = (u64)a0 * b1 + (P >> 32);            // <= (2^32-1)^2 + 2^32 - 1: no overflow
@@ -133,10 +134,11 @@ __device__ __forceinline__ u64 gl_mul(u64 a, u64 b) {
     return ((u64)hi << 32) | lo;
 }
 
-// The branch-free form (all eleven fold instructions inline, one asm statement).  The table AIRs use this one: their
-// kernels hold hundreds of live values, and the unlikely blocks of gl_mul cost the 86-column Cpu AIR its occupancy
-// (4 -> 2 waves per SIMD, its quotient 7 -> 17 ms) while gaining nothing measurable on the others.
-__device__ __forceinline__ u64 gl_mul_nb(u64 a, u64 b) {
+// The general-purpose multiply: branch-free (all eleven fold instructions inline, one asm statement).  Everything but the
+// Poseidon S-box uses this one: the table AIRs hold hundreds of live values, and the unlikely blocks of gl_mul_fast cost
+// the 86-column Cpu AIR its occupancy (4 -> 2 waves per SIMD, its quotient 7 -> 17 ms) and the Arithmetic AIR 15 %, while
+// gaining nothing measurable elsewhere.
+__device__ __forceinline__ u64 gl_mul(u64 a, u64 b) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 P = (u64)a0 * b0;
     const u64 M = (u64)a0 * b1 + (P >> 32);
@@ -255,7 +257,7 @@ GL_HD u64 gl_add_canon(u64 a, u64 b) { return gl_add_ref(a, b); }
 GL_HD u64 gl_sub(u64 a, u64 b) { return gl_sub_ref(a, b); }
 GL_HD u64 gl_mul(u64 a, u64 b) { return gl_mul_ref(a, b); }
 GL_HD u64 gl_sqr(u64 a) { return gl_mul_ref(a, a); }
-GL_HD u64 gl_mul_nb(u64 a, u64 b) { return gl_mul_ref(a, b); }
+GL_HD u64 gl_mul_fast(u64 a, u64 b) { return gl_mul_ref(a, b); }
 GL_HD u64 gl_mul_canon(u64 a, u64 b) { return gl_canon(gl_mul_ref(a, b)); }
 GL_HD u64 gl_sub_canon(u64 a, u64 b) { return gl_sub_ref(a, b); }
 #endif

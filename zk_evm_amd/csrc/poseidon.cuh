@@ -37,10 +37,10 @@ __constant__ u32 ZK_M2COL0[12] = ZK_POSEIDON_M2_COL0_INIT;
 __constant__ RcSplit ZK_RCS2[ZK_POSEIDON_PARTIAL_PAIRS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RCS2_INIT;
 
 __device__ __forceinline__ u64 pos_sbox(u64 x) {
-    u64 x2 = gl_sqr(x);
-    u64 x4 = gl_sqr(x2);
-    u64 x3 = gl_mul(x, x2);
-    return gl_mul(x3, x4);
+    u64 x2 = gl_mul_fast(x, x);
+    u64 x4 = gl_mul_fast(x2, x2);
+    u64 x3 = gl_mul_fast(x, x2);
+    return gl_mul_fast(x3, x4);
 }
 
 // acc += x * C  (one v_mad_u64_u32)

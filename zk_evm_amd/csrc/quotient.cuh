@@ -25,7 +25,7 @@ struct Fe {
 };
 __device__ __forceinline__ Fe operator+(Fe a, Fe b) { return Fe(gl_add(a.v, b.v)); }
 __device__ __forceinline__ Fe operator-(Fe a, Fe b) { return Fe(gl_sub(a.v, b.v)); }
-__device__ __forceinline__ Fe operator*(Fe a, Fe b) { return Fe(gl_mul_nb(a.v, b.v)); }   // branch-free: see gl.cuh
+__device__ __forceinline__ Fe operator*(Fe a, Fe b) { return Fe(gl_mul(a.v, b.v)); }
 __device__ __forceinline__ Fe operator-(Fe a) { return Fe(gl_neg(a.v)); }
 __device__ __forceinline__ Fe &operator+=(Fe &a, Fe b) { a = a + b; return a; }
 __device__ __forceinline__ Fe &operator-=(Fe &a, Fe b) { a = a - b; return a; }
