@@ -147,6 +147,7 @@ int zk_lde(zk_ctx *ctx, const uint64_t *d_coeffs, size_t in_stride, uint64_t *d_
  * op: 0 = add, 1 = sub, 2 = mul, 3 = square (b ignored), 4 = inverse (b ignored; 0 -> 0);
  *     5 = the NTT's canonical-output multiply, stored WITHOUT a final canonicalisation (must be < p on its own),
  *     6 / 7 = a + b^2 / a - b^2 through the butterfly's one-correction add / sub.
+ *     8 = the multiply of the Poseidon S-box (its first fold correction lives in an unlikely block).
  * (plonky2_field `Field` ops; exists so every field primitive is testable through the ABI.) */
 int zk_gl_vec_op(zk_ctx *ctx, uint32_t op, const uint64_t *d_a, const uint64_t *d_b,
                  uint64_t *d_out, size_t n);

@@ -207,7 +207,7 @@ def test_field_ops_edge_cases(ctx):
     dA, dB = to_dev(A), to_dev(B)
     out = torch.zeros(n, dtype=torch.int64, device="cuda")
     pyops = {0: lambda a, b: (a + b) % P, 1: lambda a, b: (a - b) % P, 2: lambda a, b: (a * b) % P,
-             3: lambda a, b: (a * a) % P}
+             3: lambda a, b: (a * a) % P, 8: lambda a, b: (a * b) % P}   # 8: gl_mul_fast; cov["borrow_T3"] enters its cold block
     for op, f in pyops.items():
         ctx.check(ctx.lib.zk_gl_vec_op(ctx.handle, op, ptr(dA), ptr(dB), ptr(out), n))
         got = to_host(out)
@@ -232,7 +232,7 @@ def test_field_ops_random(ctx):
     dA, dB = to_dev(A), to_dev(B)
     out = torch.zeros(n, dtype=torch.int64, device="cuda")
     Ao, Bo = A.astype(object), B.astype(object)
-    for op, exp in ((0, (Ao + Bo) % P), (1, (Ao - Bo) % P), (2, (Ao * Bo) % P), (3, (Ao * Ao) % P)):
+    for op, exp in ((0, (Ao + Bo) % P), (1, (Ao - Bo) % P), (2, (Ao * Bo) % P), (3, (Ao * Ao) % P), (8, (Ao * Bo) % P)):
         ctx.check(ctx.lib.zk_gl_vec_op(ctx.handle, op, ptr(dA), ptr(dB), ptr(out), n))
         assert np.array_equal(to_host(out), exp.astype(np.uint64)), op
 

@@ -241,6 +241,7 @@ __global__ void gl_vec_op_kernel(u32 op, const u64 *a, const u64 *b, u64 *out, s
         case 5: out[i] = gl_mul_canon(x, y); return;                     // RAW: must already be < p
         case 6: r = gl_add_canon(x, gl_mul_canon(y, y)); break;          // the NTT butterfly's two halves:
         case 7: r = gl_sub_canon(x, gl_mul_canon(y, y)); break;          //   x +- y^2 with one correction each
+        case 8: r = gl_mul_fast(x, y); break;                            // the Poseidon S-box's multiply (rare correction out of line)
         default: r = gl_canon(x) == 0 ? 0 : gl_inv(x); break;
     }
     out[i] = gl_canon(r);

@@ -250,7 +250,7 @@ extern "C" int zk_lde(zk_ctx *ctx, const uint64_t *d_coeffs, size_t in_stride, u
 extern "C" int zk_gl_vec_op(zk_ctx *ctx, uint32_t op, const uint64_t *d_a, const uint64_t *d_b,
                             uint64_t *d_out, size_t n) {
     if (!ctx) return ZK_ERR_BAD_ARG;
-    if (op > 7) return set_err(ctx, ZK_ERR_BAD_ARG, "unknown field op %u", op);
+    if (op > 8) return set_err(ctx, ZK_ERR_BAD_ARG, "unknown field op %u", op);
     if (!n) return ZK_OK;
     if (!d_a || !d_out || (!d_b && op != 3 && op != 4)) return set_err(ctx, ZK_ERR_BAD_ARG, "null pointer");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
