@@ -111,7 +111,28 @@ eval_columns_partial_kernel(const u64 *__restrict__ coeffs, size_t col_stride, u
         on[t] = col >= P.first[t] && col < P.last[t];
         dot_acc_init(acc[t][0]); dot_acc_init(acc[t][1]);
     }
-    for (u32 p = lo + threadIdx.x; p < hi; p += blockDim.x) {
+    // four coefficients (and their weights) in flight per lane: one at a time the loop is bound by the HBM round trip
+    constexpr u32 UN = 4;
+    u32 p = lo + threadIdx.x;
+    for (; p + (UN - 1) * blockDim.x < hi; p += UN * blockDim.x) {
+        u64 v[UN], wa[NP][UN], wb[NP][UN];
+#pragma unroll
+        for (u32 i = 0; i < UN; ++i) {
+            v[i] = c[p + i * blockDim.x];
+#pragma unroll
+            for (int t = 0; t < NP; ++t)
+                if (on[t]) { wa[t][i] = P.wa[t][p + i * blockDim.x]; wb[t][i] = P.wb[t][p + i * blockDim.x]; }
+        }
+#pragma unroll
+        for (u32 i = 0; i < UN; ++i)
+#pragma unroll
+            for (int t = 0; t < NP; ++t)
+                if (on[t]) {
+                    dot_acc_mac_v(acc[t][0], wa[t][i], v[i]);
+                    dot_acc_mac_v(acc[t][1], wb[t][i], v[i]);
+                }
+    }
+    for (; p < hi; p += blockDim.x) {
         const u64 v = c[p];
 #pragma unroll
         for (int t = 0; t < NP; ++t)
