@@ -1,7 +1,7 @@
 """Randomised differential parity: replay every per-table case of tests/test_gpu_stark_prove.py (all eleven AIRs with
 their lookups / CTL shapes) at randomly drawn heights, hashers, FRI shapes and seeds, device prover against the oracle
 prover word for word.  The pinned tests fix one (height, seed) per table; this walks the neighbourhood.
-Usage: python -m tests.fuzz_parity [seconds] [seed] [segment|tracegen]   (GPU box; prints one JSON line)"""
+Usage: python -m tests.fuzz_parity [seconds] [seed] [segment|tracegen|plonk]   (GPU box; prints one JSON line)"""
 import inspect
 import json
 import os
@@ -32,6 +32,8 @@ def main():
     t.FUZZ = draw
     if len(sys.argv) > 3 and sys.argv[3] == "segment":
         return fuzz_segments(oracle, rng, budget)
+    if len(sys.argv) > 3 and sys.argv[3] == "plonk":
+        return fuzz_plonk(oracle, rng, budget)
     if len(sys.argv) > 3 and sys.argv[3] == "tracegen":
         return fuzz_tracegen(rng, budget)
     cases = [(n, f) for n, f in inspect.getmembers(t, inspect.isfunction) if n.startswith("test_")]
@@ -53,6 +55,37 @@ def main():
                 break
     print(json.dumps({"cases": runs, "seconds": round(time.perf_counter() - t0, 1), "per_table_case": per_case,
                       "log_n_range": [min(d[0] for d in drawn), max(d[0] for d in drawn)], "mismatches": 0}))
+
+
+def fuzz_plonk(oracle, rng, budget):
+    """The PLONK slice: circuits with all fourteen gate kinds (valid witness and junk wires alike) at random heights, FRI
+    shapes and seeds, device proof against the oracle's restatement of plonky2's prove() word for word."""
+    import tests.oracle_lib as ol
+    import tests.test_gpu_plonk as tp
+    from oracle import plonk as PK
+    from tests.gpu_util import to_dev
+    ol.setup_fri_api(oracle)
+    t0, cases, heights = time.perf_counter(), 0, set()
+    while time.perf_counter() - t0 < budget:
+        db = int(rng.integers(6, 12))
+        kw = dict(proof_of_work_bits=int(rng.integers(0, 9)), num_query_rounds=int(rng.integers(1, 9)))
+        seed = int(rng.integers(1, 1 << 30))
+        build = PK.build_mixed_circuit if rng.random() < 0.7 else PK.build_arithmetic_circuit
+        circ, wires, pis = build(db, seed=seed, cfg=PK.CircuitConfig(**kw))
+        wires, _ = PK.set_public_input_wires(oracle, circ, wires, pis)
+        if rng.random() < 0.5:                           # unsatisfying wires: every constraint non-zero on both sides
+            wires = np.random.default_rng(seed).integers(0, 1 << 64, size=wires.shape, dtype=np.uint64)
+        exp = PK.prove(oracle, ol, circ, wires, pis)
+        cd = tp._device_circuit(circ)
+        got = cd.prove(to_dev(wires), pis)
+        assert np.array_equal(got.wires_cap, exp["wires_cap"]) and np.array_equal(got.plonk_zs_partial_products_cap, exp["zs_pp_cap"]), (db, seed)
+        assert np.array_equal(got.quotient_polys_cap, exp["quotient_cap"]), (db, seed)
+        assert np.array_equal(got.openings.reshape(-1), exp["openings"]) and np.array_equal(got.opening_proof, exp["fri"]), (db, seed)
+        cd.free()
+        cases += 1
+        heights.add(db)
+    print(json.dumps({"plonk_cases": cases, "seconds": round(time.perf_counter() - t0, 1), "degree_bits": sorted(heights),
+                      "mismatches": 0}))
 
 
 def fuzz_tracegen(rng, budget):
