@@ -276,6 +276,42 @@ __global__ void fri_pow_kernel(PowState inter, int pos, u64 base, u32 bits, unsi
     if (bits == 0 || (r >> (64 - bits)) == 0) atomicMin(best, (unsigned long long)w);
 }
 
+// The same grind for the Keccak challenger (`KeccakGoldilocksConfig`): its permutation is plonky2's hash onion ([EXT]
+// hash/keccak.rs `KeccakPermutation`) -- keccak256 of the 96 state bytes, then keccak256 of each 32-byte output, the u64
+// words < p taken in order -- and the response is the eighth accepted word (the element `get()` pops).  Two Keccak-f
+// per candidate unless a word is rejected (2^-32 each); the host used to walk the candidates one at a time (0.2-0.4 s
+// per table at 16 bits).
+__global__ void fri_pow_keccak_kernel(PowState inter, int pos, u64 base, u32 bits, unsigned long long *best) {
+    u64 w = base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= GL_P) return;
+    u64 a[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) a[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) a[i] = (i == pos) ? w : gl_canon(inter.s[i]);
+    a[12] ^= 0x01ULL;                                  // 96-byte message: pad byte at offset 96, 0x80 at offset 135
+    a[16] ^= 0x8000000000000000ULL;
+    keccak_f1600(a);
+    u64 r = 0;
+    int got = 0;
+    for (int h = 0; h < 16 && got < 8; ++h) {          // (16 hashes without eight words < p cannot happen)
+        const u64 o0 = a[0], o1 = a[1], o2 = a[2], o3 = a[3];
+        if (got < 8 && o0 < GL_P) { r = o0; ++got; }
+        if (got < 8 && o1 < GL_P) { r = o1; ++got; }
+        if (got < 8 && o2 < GL_P) { r = o2; ++got; }
+        if (got < 8 && o3 < GL_P) { r = o3; ++got; }
+        if (got < 8) {
+#pragma unroll
+            for (int i = 0; i < 25; ++i) a[i] = 0;
+            a[0] = o0; a[1] = o1; a[2] = o2; a[3] = o3;
+            a[4] = 0x01ULL;
+            a[16] = 0x8000000000000000ULL;
+            keccak_f1600(a);
+        }
+    }
+    if (bits == 0 || (r >> (64 - bits)) == 0) atomicMin(best, (unsigned long long)w);
+}
+
 // ---- generic gather into the flat proof buffer -------------------------------------------------
 struct GatherDesc { const u64 *src; u64 dst_off; u32 count; u32 pad; u64 stride; };
 __global__ void gather_words_kernel(const GatherDesc *descs, u32 n_desc, u64 *dst) {

@@ -148,8 +148,11 @@ keccak_hash_rows_kernel(const u64 *__restrict__ cols, size_t col_stride, const u
 #pragma unroll
     for (int i = 0; i < 25; ++i) a[i] = 0;
     size_t slot = do_bitrev ? (size_t)bitrev32((u32)j, log_rows) : j;
-    if (n_cols * 8 <= 25) {  // noop: raw bytes
-        for (u32 c = 0; c < n_cols; ++c) a[c] = gl_canon(p[col_offset<GATHER>(c, col_stride, col_off)]);
+    if (n_cols * 8 <= 25) {  // noop: raw bytes.  (Compile-time indices only: one run-time index into a[] puts the whole
+                             // sponge state in scratch memory for every Keccak-f round of the kernel.)
+#pragma unroll
+        for (u32 c = 0; c < 3; ++c)
+            if (c < n_cols) a[c] = gl_canon(p[col_offset<GATHER>(c, col_stride, col_off)]);
         ulonglong2 *o = reinterpret_cast<ulonglong2 *>(digests + 4 * slot);
         o[0] = make_ulonglong2(a[0], a[1]);
         o[1] = make_ulonglong2(a[2], 0);
