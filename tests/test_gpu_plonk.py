@@ -20,7 +20,8 @@ def _device_circuit(circ):
     cfg = circ.config
     pcfg = zp.CircuitConfig(num_wires=cfg.num_wires, num_routed_wires=cfg.num_routed_wires, num_challenges=cfg.num_challenges,
                             rate_bits=cfg.rate_bits, cap_height=cfg.cap_height, proof_of_work_bits=cfg.proof_of_work_bits,
-                            num_query_rounds=cfg.num_query_rounds, arity_bits=cfg.arity_bits, final_poly_bits=cfg.final_poly_bits)
+                            num_query_rounds=cfg.num_query_rounds, arity_bits=cfg.arity_bits, final_poly_bits=cfg.final_poly_bits,
+                            hasher=cfg.hasher)
     cs = to_dev(np.concatenate([circ.constants, circ.sigmas]))
     return zp.CircuitData(pcfg, circ.degree_bits, circ.gate_descriptors(), circ.num_selectors, cs, circ.k_is,
                           circ.circuit_digest, circ.num_gate_constraints, circ.quotient_degree_factor)
@@ -102,3 +103,21 @@ def test_plonk_mixed_gates_match_oracle(oracle, degree_bits, seed, kw):
     exp2 = PK.prove(oracle, ol, circ, junk, pis)
     assert np.array_equal(got2.quotient_polys_cap, exp2["quotient_cap"]) and np.array_equal(got2.opening_proof, exp2["fri"])
     cd.free()
+
+
+@pytest.mark.parametrize("degree_bits,mixed", [(8, False), (10, True)])
+def test_plonk_keccak_config_matches_oracle(oracle, degree_bits, mixed):
+    """`KeccakGoldilocksConfig`: Keccak Merkle trees and challenger (hash-onion permutation, device-side proof-of-work grind),
+    Poseidon for the public-input hash (C::InnerHasher); device proof == oracle proof."""
+    from tests.gpu_util import to_dev
+    ol.setup_fri_api(oracle)
+    build = PK.build_mixed_circuit if mixed else PK.build_arithmetic_circuit
+    circ, wires, pis = build(degree_bits, seed=5, cfg=PK.CircuitConfig(hasher=1, proof_of_work_bits=9, num_query_rounds=6))
+    wires, _ = PK.set_public_input_wires(oracle, circ, wires, pis)
+    exp = PK.prove(oracle, ol, circ, wires, pis)
+    cd = _device_circuit(circ)
+    got = cd.prove(to_dev(wires), pis)
+    assert np.array_equal(got.wires_cap, exp["wires_cap"]) and np.array_equal(got.quotient_polys_cap, exp["quotient_cap"])
+    assert np.array_equal(got.openings.reshape(-1), exp["openings"]) and np.array_equal(got.opening_proof, exp["fri"])
+    cd.free()
+

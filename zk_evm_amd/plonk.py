@@ -47,9 +47,11 @@ class CircuitConfig:
     num_query_rounds: int = 28
     arity_bits: int = 4
     final_poly_bits: int = 5
+    hasher: int = 0                     # 0 = PoseidonGoldilocksConfig, 1 = KeccakGoldilocksConfig (Merkle trees and transcript;
+                                        # the public-input hash is C::InnerHasher = Poseidon in both)
 
     def fri_cfg(self) -> ZkCfg:
-        return ZkCfg(rate_bits=self.rate_bits, cap_height=self.cap_height, hasher=0, num_challenges=self.num_challenges,
+        return ZkCfg(rate_bits=self.rate_bits, cap_height=self.cap_height, hasher=self.hasher, num_challenges=self.num_challenges,
                      proof_of_work_bits=self.proof_of_work_bits, num_query_rounds=self.num_query_rounds,
                      arity_bits=self.arity_bits, final_poly_bits=self.final_poly_bits)
 
