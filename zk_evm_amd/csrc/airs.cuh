@@ -39,20 +39,24 @@ struct AirLogic {
         c.constraint(all_flags * (all_flags - FE_ONE));
         Fe sum_coeff = is_or + is_xor;
         Fe and_coeff = is_and - is_or - is_xor * fe(2);
-        for (u32 i = 0; i < 256; ++i) { Fe b = lv[IN0 + i]; c.constraint(b * (b - FE_ONE)); }
-        for (u32 i = 0; i < 256; ++i) { Fe b = lv[IN1 + i]; c.constraint(b * (b - FE_ONE)); }
+        // The 512 bit checks and the 8 limb recompositions read the same 512 bit columns: one visit (constraint_at keeps the
+        // reference's positions: 256 + 256 bit checks, then the limbs), the three sums of a limb by Horner from the top bit
+        // instead of a multiply by 2^i per term -- the same field values.
         for (u32 limb = 0; limb < 8; ++limb) {
             Fe x, y, x_land_y;
-            for (u32 i = 0; i < 32; ++i) {
-                Fe xb = lv[IN0 + 32 * limb + i], yb = lv[IN1 + 32 * limb + i];
-                Fe w = fe(1ULL << i);
-                x += xb * w;
-                y += yb * w;
-                x_land_y += xb * yb * w;
+            for (int i = 31; i >= 0; --i) {
+                const u32 k = 32 * limb + (u32)i;
+                const Fe xb = lv[IN0 + k], yb = lv[IN1 + k];
+                c.constraint_at(k, xb * (xb - FE_ONE));
+                c.constraint_at(256 + k, yb * (yb - FE_ONE));
+                x = x + x + xb;
+                y = y + y + yb;
+                x_land_y = x_land_y + x_land_y + xb * yb;
             }
-            Fe x_op_y = sum_coeff * (x + y) + and_coeff * x_land_y;
-            c.constraint(lv[RES + limb] - x_op_y);
+            const Fe x_op_y = sum_coeff * (x + y) + and_coeff * x_land_y;
+            c.constraint_at(512 + limb, lv[RES + limb] - x_op_y);
         }
+        c.advance(512 + 8);
     }
 };
 
