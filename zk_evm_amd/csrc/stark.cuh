@@ -152,6 +152,7 @@ __device__ __forceinline__ void cterms_dot(const CBlob &B, u32 t0, u32 t1, LD ld
 template <class LD>
 __device__ __forceinline__ u64 clin_eval(const CBlob &B, u32 l, LD ld) {
     const u64 *L = B.lin(l);
+    if (L[0] == L[1]) return L[2];                   // a constant (e.g. the filter of an unfiltered lookup): nothing to fold
     DotAcc d[1];
     dot_acc_init(d[0]);
     cterms_dot<1>(B, (u32)L[0], (u32)L[1], ld, d);
@@ -160,12 +161,23 @@ __device__ __forceinline__ u64 clin_eval(const CBlob &B, u32 l, LD ld) {
 template <int NCH, class LD>
 __device__ __forceinline__ void centry_eval(const CBlob &B, u32 e, LD ld, u64 (&denom)[NCH], u64 &filt) {
     const u64 *E = B.entry(e);
-    DotAcc d[NCH];
+    bool simple = (u32)E[1] - (u32)E[0] == 1;        // `Column::single`: one term with coefficient 1 for every challenge
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) dot_acc_init(d[k]);
-    cterms_dot<NCH>(B, (u32)E[0], (u32)E[1], ld, d);
+    for (int k = 0; k < NCH; ++k) simple = simple && B.term((u32)E[0])[1 + k] == 1;
+    if (simple) {                                    // (wave-uniform: the blob is the same for every row)
+        const u64 w0 = B.term((u32)E[0])[0];
+        u64 v = 0;
+        if (!ld((u32)w0, (u32)(w0 >> 32), v)) v = 0;
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) denom[k] = gl_canon(gl_add(dot_acc_reduce(d[k]), E[6 + k]));
+        for (int k = 0; k < NCH; ++k) denom[k] = gl_canon(gl_add(v, E[6 + k]));
+    } else {
+        DotAcc d[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) dot_acc_init(d[k]);
+        cterms_dot<NCH>(B, (u32)E[0], (u32)E[1], ld, d);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) denom[k] = gl_canon(gl_add(dot_acc_reduce(d[k]), E[6 + k]));
+    }
     u64 acc = 0;
     for (u32 p = (u32)E[2]; p < (u32)E[3]; ++p) acc = gl_add(acc, gl_mul(clin_eval(B, 2 * p, ld), clin_eval(B, 2 * p + 1, ld)));
     for (u32 c = (u32)E[4]; c < (u32)E[5]; ++c) acc = gl_add(acc, clin_eval(B, c, ld));
@@ -194,10 +206,17 @@ __device__ __forceinline__ void cterms_dot_slot(const CBlob &B, u32 t0, u32 t1, 
 template <class LD>
 __device__ __forceinline__ void centry_eval_slot(const CBlob &B, u32 e, u32 slot, LD ld, u64 &denom, u64 &filt) {
     const u64 *E = B.entry(e);
-    DotAcc d;
-    dot_acc_init(d);
-    cterms_dot_slot(B, (u32)E[0], (u32)E[1], slot, ld, d);
-    denom = gl_add(dot_acc_reduce(d), E[6 + slot]);
+    if ((u32)E[1] - (u32)E[0] == 1 && B.term((u32)E[0])[1 + slot] == 1) {    // `Column::single` (wave-uniform test)
+        const u64 w0 = B.term((u32)E[0])[0];
+        u64 v = 0;
+        if (!ld((u32)w0, (u32)(w0 >> 32), v)) v = 0;
+        denom = gl_add(v, E[6 + slot]);
+    } else {
+        DotAcc d;
+        dot_acc_init(d);
+        cterms_dot_slot(B, (u32)E[0], (u32)E[1], slot, ld, d);
+        denom = gl_add(dot_acc_reduce(d), E[6 + slot]);
+    }
     u64 acc = 0;
     for (u32 p = (u32)E[2]; p < (u32)E[3]; ++p) acc = gl_add(acc, gl_mul(clin_eval(B, 2 * p, ld), clin_eval(B, 2 * p + 1, ld)));
     for (u32 c = (u32)E[4]; c < (u32)E[5]; ++c) acc = gl_add(acc, clin_eval(B, c, ld));
