@@ -200,7 +200,7 @@ __device__ __forceinline__ void quotient_constraints(const QuotientArgs &A, u32 
             const u32 sub = (u32)lp[1 + l];
             const u32 ne = (u32)lp[sub];
             const u32 n_help = (ne + chunk - 1) / chunk + 1;
-            const CBlob LB{A.cblob + A.cblob[l]};
+            const CBlob LB(A.cblob + A.cblob[l]);
             for (u32 c = 0; c < A.n_lookup_challenges; ++c) {
                 const u64 ch = A.lookup_challenges[c];
                 check_helper_columns(LB, c, ne, chunk, ld, alv, start, cons);
@@ -231,7 +231,7 @@ __device__ __forceinline__ void quotient_constraints(const QuotientArgs &A, u32 
             const u32 sub = off + 3;
             const u32 ne = (u32)cp[sub];
             const u32 h0 = A.num_lookup_columns + start_index;
-            const CBlob ZB{A.cblob + A.cblob[n_lookups_total + zi]};
+            const CBlob ZB(A.cblob + A.cblob[n_lookups_total + zi]);
             if (n_help) check_helper_columns(ZB, 0, ne, chunk, ld, alv, h0, cons);
             const u32 zcol = A.num_lookup_columns + A.total_ctl_helper_cols + zi;
             Fe local_z = alv[zcol], next_z = anv[zcol];

@@ -117,8 +117,17 @@ __device__ __forceinline__ u64 prog_eval_filter_dot(const u64 *__restrict__ prog
 // too.  All loop bounds and term descriptors are wave-uniform and independent of each other.
 //   blob := n_entries, lin_off, term_off, entry[n] {t0, t1, fp0, fp1, fc0, fc1, K_0, K_1},
 //           lin[] {t0, t1, constant}, term[] {col | next << 32, coef_0, coef_1}
+// A lin may be a DELTA lin: {t0 | 2^63, t1 | ref << 32, constant} = lin `ref` + its own few terms + constant.  The
+// filters of consecutive CTL entries are often sums that differ by one column (KeccakSponge's 136 memory reads:
+// is_full_input_block + sum_{j > i} is_final_input_len[j] -- 9316 terms as plain sums, 136 + 135 as deltas); the entry
+// compiler (stark_host.inc) emits deltas against the previous entry's filter, and the evaluation remembers the last lin
+// it computed (entries are visited in order, so the reference is always that one).
+#define ZK_LIN_DELTA (1ULL << 63)
 struct CBlob {
     const u64 *w;
+    mutable u32 memo_lin;                          // last lin evaluated by clin_eval for this thread / row, and its value
+    mutable u64 memo_val;
+    __device__ __forceinline__ explicit CBlob(const u64 *p) : w(p), memo_lin(0xFFFFFFFFu), memo_val(0) {}
     __device__ __forceinline__ u32 n_entries() const { return (u32)w[0]; }
     __device__ __forceinline__ const u64 *entry(u32 e) const { return w + 3 + 8 * (size_t)e; }
     __device__ __forceinline__ const u64 *lin(u32 l) const { return w + w[1] + 3 * (size_t)l; }
@@ -151,12 +160,27 @@ __device__ __forceinline__ void cterms_dot(const CBlob &B, u32 t0, u32 t1, LD ld
 }
 template <class LD>
 __device__ __forceinline__ u64 clin_eval(const CBlob &B, u32 l, LD ld) {
-    const u64 *L = B.lin(l);
-    if (L[0] == L[1]) return L[2];                   // a constant (e.g. the filter of an unfiltered lookup): nothing to fold
-    DotAcc d[1];
-    dot_acc_init(d[0]);
-    cterms_dot<1>(B, (u32)L[0], (u32)L[1], ld, d);
-    return gl_add(dot_acc_reduce(d[0]), L[2]);
+    u64 acc = 0;
+    bool have = false;
+    for (u32 cur = l;;) {                            // a delta lin walks to its reference (normally one memo hit away)
+        if (cur == B.memo_lin) { acc = have ? gl_add(acc, B.memo_val) : B.memo_val; break; }
+        const u64 *L = B.lin(cur);
+        const u32 t0 = (u32)L[0], t1 = (u32)L[1];
+        u64 part = L[2];                             // t0 == t1: a constant (e.g. the filter of an unfiltered lookup)
+        if (t0 != t1) {
+            DotAcc d[1];
+            dot_acc_init(d[0]);
+            cterms_dot<1>(B, t0, t1, ld, d);
+            part = gl_add(dot_acc_reduce(d[0]), L[2]);
+        }
+        acc = have ? gl_add(acc, part) : part;
+        have = true;
+        if (!(L[0] & ZK_LIN_DELTA)) break;
+        cur = (u32)(L[1] >> 32);
+    }
+    B.memo_lin = l;
+    B.memo_val = acc;
+    return acc;
 }
 template <int NCH, class LD>
 __device__ __forceinline__ void centry_eval(const CBlob &B, u32 e, LD ld, u64 (&denom)[NCH], u64 &filt) {
@@ -252,7 +276,7 @@ helper_cols_kernel(const u64 *__restrict__ prog, const u64 *__restrict__ compile
                    u32 chunk, HelperOut O, size_t helper_stride, u32 extra_pc, int *__restrict__ err_flag) {
     const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= t.n) return;
-    const CBlob B{compiled};
+    const CBlob B(compiled);
     const u32 n_entries = B.n_entries();
     const bool has_next = row + 1 < t.n;       // "table" semantics: next-row terms are dropped on the last row
     auto ld = [&](u32 col, u32 next, u64 &v) {
