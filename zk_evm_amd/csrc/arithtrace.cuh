@@ -283,7 +283,7 @@ __device__ __forceinline__ u32 rows_of(int code) {
 
 // ops: n_ops x 18 words = code (the IS_* column of the operation, 16 = range check), opcode (range check only),
 // input0, input1, input2, result (range check only) as four 64-bit little-endian limbs each; row_of[i]: first row.
-__global__ void __launch_bounds__(64)
+static __global__ void __launch_bounds__(64)
 arithmetic_trace_kernel(const u64 *__restrict__ ops, const u32 *__restrict__ row_of, const u32 *__restrict__ order, u32 n_ops,
                         u64 *__restrict__ out, size_t cs) {
     using namespace arith;

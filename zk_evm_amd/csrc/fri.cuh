@@ -76,7 +76,7 @@ __device__ __forceinline__ void dot_acc_mac_v(DotAcc &d, u64 c, u64 v) {
 
 // W[p] = z^bitrev(p, log_n);  zpow[k] = z^(2^k) (ext), k < log_n
 struct ZPowers { u64 a[32], b[32]; };
-__global__ void ext_pow_bitrev_table_kernel(u64 *wa, u64 *wb, int log_n, ZPowers zp) {
+static __global__ void ext_pow_bitrev_table_kernel(u64 *wa, u64 *wb, int log_n, ZPowers zp) {
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >> log_n) return;
     u32 e = bitrev32(p, log_n);
@@ -163,7 +163,7 @@ eval_columns_partial_kernel(const u64 *__restrict__ coeffs, size_t col_stride, u
     }
 }
 // out[(t * n_cols + col) * 2 ..] = sum of the chunks (entries of points that skip the column stay 0)
-__global__ void eval_columns_reduce_kernel(const u64 *partial, u32 chunks, u32 n_entries, u64 *out) {
+static __global__ void eval_columns_reduce_kernel(const u64 *partial, u32 chunks, u32 n_entries, u64 *out) {
     u32 c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_entries) return;
     gl2 acc = gl2_make(0, 0);
@@ -248,7 +248,7 @@ __global__ void __launch_bounds__(256) fri_combine_kernel(FriCombineArgs A) {
 // ---- commit-phase fold on bit-reversed coefficients -------------------------------------------
 // out[k'] = sum_{i'} bp[i'] * c[i' * M + k'],  bp[i'] = beta^bitrev(i', arity_bits)
 struct FoldPowers { u64 a[16], b[16]; };
-__global__ void fri_fold_kernel(const u64 *ca, const u64 *cb, u64 *oa, u64 *ob, u32 M, int arity,
+static __global__ void fri_fold_kernel(const u64 *ca, const u64 *cb, u64 *oa, u64 *ob, u32 M, int arity,
                                 FoldPowers bp) {
     u32 k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= M) return;
@@ -265,7 +265,7 @@ __global__ void fri_fold_kernel(const u64 *ca, const u64 *cb, u64 *oa, u64 *ob, 
 // candidate w = base + tid: state = inter with w at `pos`; Poseidon; accept if state[7] has
 // >= bits leading zeros.  atomicMin keeps the smallest accepted candidate of the launch.
 struct PowState { u64 s[12]; };
-__global__ void fri_pow_kernel(PowState inter, int pos, u64 base, u32 bits, unsigned long long *best) {
+static __global__ void fri_pow_kernel(PowState inter, int pos, u64 base, u32 bits, unsigned long long *best) {
     u64 w = base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= GL_P) return;
     u64 s[12];
@@ -281,7 +281,7 @@ __global__ void fri_pow_kernel(PowState inter, int pos, u64 base, u32 bits, unsi
 // words < p taken in order -- and the response is the eighth accepted word (the element `get()` pops).  Two Keccak-f
 // per candidate unless a word is rejected (2^-32 each); the host used to walk the candidates one at a time (0.2-0.4 s
 // per table at 16 bits).
-__global__ void fri_pow_keccak_kernel(PowState inter, int pos, u64 base, u32 bits, unsigned long long *best) {
+static __global__ void fri_pow_keccak_kernel(PowState inter, int pos, u64 base, u32 bits, unsigned long long *best) {
     u64 w = base + (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= GL_P) return;
     u64 a[25];
@@ -314,7 +314,7 @@ __global__ void fri_pow_keccak_kernel(PowState inter, int pos, u64 base, u32 bit
 
 // ---- generic gather into the flat proof buffer -------------------------------------------------
 struct GatherDesc { const u64 *src; u64 dst_off; u32 count; u32 pad; u64 stride; };
-__global__ void gather_words_kernel(const GatherDesc *descs, u32 n_desc, u64 *dst) {
+static __global__ void gather_words_kernel(const GatherDesc *descs, u32 n_desc, u64 *dst) {
     u32 d = blockIdx.x;
     if (d >= n_desc) return;
     GatherDesc g = descs[d];

@@ -4,7 +4,7 @@
 #pragma once
 #include "gl.cuh"
 
-__constant__ u64 ZK_KECCAK_RC[24] = {
+static __constant__ u64 ZK_KECCAK_RC[24] = {
     0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
     0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
     0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,

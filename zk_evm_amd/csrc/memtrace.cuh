@@ -31,7 +31,7 @@ enum : u32 {
 
 // ops: n_ops x 9 words {flags, timestamp, context, segment, virt, value as four 64-bit limbs};
 // before: n_before x 7 words {context, segment, virt, value limbs}: a filtered write at timestamp 0 (:405-414)
-__global__ void mem_pack_kernel(const u64 *__restrict__ ops, u32 n_ops, const u64 *__restrict__ before, u32 n_before,
+static __global__ void mem_pack_kernel(const u64 *__restrict__ ops, u32 n_ops, const u64 *__restrict__ before, u32 n_before,
                                 MemOpRec *__restrict__ recs, u64 *__restrict__ key_lo, u64 *__restrict__ key_hi,
                                 u32 *__restrict__ idx) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,11 +60,11 @@ __global__ void mem_pack_kernel(const u64 *__restrict__ ops, u32 n_ops, const u6
     idx[i] = i;
 }
 
-__global__ void mem_gather_keys_kernel(const u64 *__restrict__ key_hi, const u32 *__restrict__ idx, u32 m, u64 *__restrict__ out) {
+static __global__ void mem_gather_keys_kernel(const u64 *__restrict__ key_hi, const u32 *__restrict__ idx, u32 m, u64 *__restrict__ out) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) out[i] = key_hi[idx[i]];
 }
-__global__ void mem_gather_recs_kernel(const MemOpRec *__restrict__ recs, const u32 *__restrict__ perm, u32 m, MemOpRec *__restrict__ out) {
+static __global__ void mem_gather_recs_kernel(const MemOpRec *__restrict__ recs, const u32 *__restrict__ perm, u32 m, MemOpRec *__restrict__ out) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) out[i] = recs[perm[i]];
 }
@@ -95,7 +95,7 @@ __device__ __forceinline__ u64 mem_gap_dummies(const MemOpRec &c, const MemOpRec
 }
 
 // pos[j] = j + (dummies before element j); pos has big+1 entries, pos[big] = unpadded length
-__global__ void mem_gap_count_kernel(const MemOpRec *__restrict__ sorted, u32 front, u32 big, u64 max_rc, u64 *__restrict__ cnt,
+static __global__ void mem_gap_count_kernel(const MemOpRec *__restrict__ sorted, u32 front, u32 big, u64 max_rc, u64 *__restrict__ cnt,
                                      int *__restrict__ err) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j > big) return;
@@ -109,7 +109,7 @@ __global__ void mem_gap_count_kernel(const MemOpRec *__restrict__ sorted, u32 fr
 }
 
 // rows[r] for r in [0, n): operation, gap dummy or padding, in final sorted order
-__global__ void mem_expand_kernel(const MemOpRec *__restrict__ sorted, u32 front, u32 big, u64 max_rc, const u64 *__restrict__ pos,
+static __global__ void mem_expand_kernel(const MemOpRec *__restrict__ sorted, u32 front, u32 big, u64 max_rc, const u64 *__restrict__ pos,
                                   u32 unpadded, u32 n, MemOpRec *__restrict__ rows) {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n) return;
@@ -154,7 +154,7 @@ __global__ void mem_expand_kernel(const MemOpRec *__restrict__ sorted, u32 front
 }
 
 // insert_stale_contexts (:385-403): row index = the context number
-__global__ void mem_stale_kernel(const u64 *__restrict__ stale, u32 n_stale, u64 *__restrict__ out, size_t cs) {
+static __global__ void mem_stale_kernel(const u64 *__restrict__ stale, u32 n_stale, u64 *__restrict__ out, size_t cs) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_stale) return;
     const u64 ctx = stale[i];
@@ -164,7 +164,7 @@ __global__ void mem_stale_kernel(const u64 *__restrict__ stale, u32 n_stale, u64
 
 // MemoryOp::into_row, generate_first_change_flags_and_rc, generate_trace_col_major (:104-199, :236-281).
 // The frequency columns, stale_contexts and is_pruned must be zeroed / scattered before this kernel.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 mem_rows_kernel(const MemOpRec *__restrict__ rows, u32 n, u64 *__restrict__ out, size_t cs, u32 *__restrict__ after_flag,
                 int *__restrict__ err) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -223,7 +223,7 @@ mem_rows_kernel(const MemOpRec *__restrict__ rows, u32 n, u64 *__restrict__ out,
 }
 
 // final memory, row order: entries k x 7 words {context, segment, virt, value as four 64-bit limbs}
-__global__ void mem_after_scatter_kernel(const MemOpRec *__restrict__ rows, const u32 *__restrict__ flag, const u32 *__restrict__ off,
+static __global__ void mem_after_scatter_kernel(const MemOpRec *__restrict__ rows, const u32 *__restrict__ flag, const u32 *__restrict__ off,
                                          u32 n, u64 *__restrict__ entries) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || !flag[i]) return;

@@ -82,7 +82,7 @@ poseidon_hash_rows_coop_kernel(const u64 *__restrict__ cols, size_t col_stride, 
 }
 
 // Poseidon `two_to_one`: parent[i] = P(child[2i] || child[2i+1] || 0^4)[0..4]
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 poseidon_merkle_level_kernel(const u64 *__restrict__ child, u64 *__restrict__ parent, size_t n_parent) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_parent) return;
@@ -96,7 +96,7 @@ poseidon_merkle_level_kernel(const u64 *__restrict__ child, u64 *__restrict__ pa
 }
 
 // two_to_one for the small levels near the cap: one parent per 16-lane group (poseidon.cuh, cooperative permutation)
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 poseidon_merkle_level_coop_kernel(const u64 *__restrict__ child, u64 *__restrict__ parent, u32 n_parent) {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 node = t >> 4, e = t & 15;
@@ -106,7 +106,7 @@ poseidon_merkle_level_coop_kernel(const u64 *__restrict__ child, u64 *__restrict
     if (e < 4) parent[(size_t)4 * node + e] = gl_canon(s);
 }
 
-__global__ void poseidon_permute_states_kernel(u64 *states, size_t n_states) {
+static __global__ void poseidon_permute_states_kernel(u64 *states, size_t n_states) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_states) return;
     u64 s[12];
@@ -117,7 +117,7 @@ __global__ void poseidon_permute_states_kernel(u64 *states, size_t n_states) {
     for (int k = 0; k < 12; ++k) states[12 * i + k] = gl_canon(s[k]);
 }
 
-__global__ void keccak_f1600_states_kernel(u64 *states, size_t n_states) {
+static __global__ void keccak_f1600_states_kernel(u64 *states, size_t n_states) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_states) return;
     u64 a[25];
@@ -177,7 +177,7 @@ keccak_hash_rows_kernel(const u64 *__restrict__ cols, size_t col_stride, const u
 }
 
 // KeccakHash<25>::two_to_one: keccak256(left[0..25] || right[0..25])[0..25]
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 keccak_merkle_level_kernel(const u64 *__restrict__ child, u64 *__restrict__ parent, size_t n_parent) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_parent) return;

@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
 
 // In-place bit-reversal permutation of each column (only used by the natural<->natural API
 // entry points; the commit path never calls it).
-__global__ void bitrev_permute_kernel(u64 *data, size_t stride, int log_n) {
+static __global__ void bitrev_permute_kernel(u64 *data, size_t stride, int log_n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >> log_n) return;
     u64 *col = data + (size_t)blockIdx.y * stride;
@@ -199,7 +199,7 @@ __global__ void bitrev_permute_kernel(u64 *data, size_t stride, int log_n) {
 }
 
 // out[i] = c * s^(bitrev(i, log_n))    (coset power tables in coefficient (bit-reversed) order)
-__global__ void coset_table_kernel(u64 *out, int log_n, u64 s, u64 c) {
+static __global__ void coset_table_kernel(u64 *out, int log_n, u64 s, u64 c) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >> log_n) return;
     u32 e = bitrev32((u32)i, log_n);
@@ -207,7 +207,7 @@ __global__ void coset_table_kernel(u64 *out, int log_n, u64 s, u64 c) {
 }
 
 // block-order levels (ntt_host.inc): out[2^s - 1 + j] = (root of order 2^(s+1))^bitrev_s(j) = w^(bitrev_s(j) * N / 2^(s+1))
-__global__ void twiddle_block_levels_kernel(u64 *out, int log_size, u64 w) {
+static __global__ void twiddle_block_levels_kernel(u64 *out, int log_size, u64 w) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // i = 2^s - 1 + j
     const size_t total = ((size_t)1 << log_size) - 1;
     if (log_size == 0) { if (i == 0) out[0] = 1; return; }
@@ -218,7 +218,7 @@ __global__ void twiddle_block_levels_kernel(u64 *out, int log_size, u64 w) {
 }
 
 // level layout (ntt_host.inc): out[D - 1 + k] = w^(k * N / (2 D)) for D = 1, 2, .., N/2 and k < D; N = 2^log_size
-__global__ void twiddle_levels_kernel(u64 *out, int log_size, u64 w) {
+static __global__ void twiddle_levels_kernel(u64 *out, int log_size, u64 w) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // i = D - 1 + k
     const size_t total = ((size_t)1 << log_size) - 1;
     if (log_size == 0) { if (i == 0) out[0] = 1; return; }
@@ -229,7 +229,7 @@ __global__ void twiddle_levels_kernel(u64 *out, int log_size, u64 w) {
 }
 
 // element-wise field op (ABI-level access to the device field primitives)
-__global__ void gl_vec_op_kernel(u32 op, const u64 *a, const u64 *b, u64 *out, size_t n) {
+static __global__ void gl_vec_op_kernel(u32 op, const u64 *a, const u64 *b, u64 *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u64 x = a[i], y = (op == 3 || op == 4) ? 0 : b[i], r;

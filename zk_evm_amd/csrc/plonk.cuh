@@ -36,7 +36,7 @@ struct PlonkPermArgs {
 };
 
 // per row: quotient_chunk_products of `wires_permutation_partial_products_and_zs`
-__global__ void __launch_bounds__(256) plonk_chunk_quotients_kernel(PlonkPermArgs A) {
+static __global__ void __launch_bounds__(256) plonk_chunk_quotients_kernel(PlonkPermArgs A) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     const u32 n = 1u << A.log_n;
     if (i >= n) return;
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) plonk_chunk_quotients_kernel(PlonkPermArg
 // ---- exclusive prefix PRODUCT over rows (Z(x_i) = prod_{r < i} totals[r]) ----------------------------------------------
 #define ZK_PSCAN_ITEMS 8
 #define ZK_PSCAN_THREADS 256
-__global__ void __launch_bounds__(ZK_PSCAN_THREADS)
+static __global__ void __launch_bounds__(ZK_PSCAN_THREADS)
 plonk_scan_block_kernel(const u64 *__restrict__ x, u32 n, u64 *__restrict__ incl, u64 *__restrict__ totals) {
     __shared__ u64 sh[ZK_PSCAN_THREADS];
     const u32 base = (blockIdx.x * ZK_PSCAN_THREADS + threadIdx.x) * ZK_PSCAN_ITEMS;
@@ -115,7 +115,7 @@ plonk_scan_block_kernel(const u64 *__restrict__ x, u32 n, u64 *__restrict__ incl
     }
     if (threadIdx.x == ZK_PSCAN_THREADS - 1) totals[blockIdx.x] = sh[threadIdx.x];
 }
-__global__ void __launch_bounds__(256) plonk_scan_totals_kernel(u64 *totals, u32 n_blocks) {
+static __global__ void __launch_bounds__(256) plonk_scan_totals_kernel(u64 *totals, u32 n_blocks) {
     __shared__ u64 sh[256];
     const u32 per = (n_blocks + 255) / 256;
     const u32 lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) plonk_scan_totals_kernel(u64 *totals, u32
 }
 // out layout (plonky2 `zs_partial_products`): Z of challenge 0, 1, ..; then the (n_chunks - 1) partial products of
 // challenge 0, of challenge 1, ..   incl / block_totals: the scan pieces of challenge c at [c * n], [c * n_blocks].
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 plonk_partial_products_finish_kernel(const u64 *__restrict__ incl, const u64 *__restrict__ block_totals, u32 n_blocks,
                                      const u64 *__restrict__ q, u32 log_n, u32 n_chunks, u32 n_challenges,
                                      u64 *__restrict__ out, size_t out_stride) {
@@ -383,7 +383,7 @@ __device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, co
 // waves per SIMD, and ONE wave per SIMD issues at half rate whatever its ILP (profiles/r02g_ubench_single_wave_issue.txt):
 // there the launch has gridDim.y == 2 and each slice evaluates the gates the host gave it (cost-balanced; slice 0 also
 // the permutation terms).  The vanishing polynomial is a SUM of terms, so the slices' results just add.
-__global__ void __launch_bounds__(256) plonk_quotient_kernel(PlonkQuotientArgs A) {
+static __global__ void __launch_bounds__(256) plonk_quotient_kernel(PlonkQuotientArgs A) {
     const u32 sl = blockIdx.y, nsl = gridDim.y;
     const u32 size_log = A.log_n + A.qd_bits;
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -481,13 +481,13 @@ __global__ void __launch_bounds__(256) plonk_quotient_kernel(PlonkQuotientArgs A
     for (u32 c = 0; c < A.n_challenges; ++c) out[(size_t)c * A.out_stride + i] = gl_canon(gl_mul(acc.total[c], inv_zh));
 }
 
-__global__ void plonk_add_slices_kernel(u64 *out, const u64 *out2, size_t count) {
+static __global__ void plonk_add_slices_kernel(u64 *out, const u64 *out2, size_t count) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) out[i] = gl_canon(gl_add(out[i], out2[i]));
 }
 
 // out[c * cap + k] = alpha_c^k
-__global__ void plonk_alpha_pow_kernel(u64 *out, u32 cap, u32 count, u32 n_challenges, u64 a0, u64 a1) {
+static __global__ void plonk_alpha_pow_kernel(u64 *out, u32 cap, u32 count, u32 n_challenges, u64 a0, u64 a1) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     out[j] = gl_canon(gl_pow(a0, j));

@@ -27,14 +27,14 @@
 // Round constants split into zero-extended 32-bit halves: ZK_RCS[round*12+i] = {lo32, hi32} as two
 // u64, directly usable as the 64-bit addend of v_mad_u64_u32.
 struct RcSplit { u64 lo, hi; };
-__constant__ u64 ZK_RC[ZK_POSEIDON_ROUNDS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RC_INIT;
-__constant__ RcSplit ZK_RCS[ZK_POSEIDON_ROUNDS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RCS_INIT;
+static __constant__ u64 ZK_RC[ZK_POSEIDON_ROUNDS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RC_INIT;
+static __constant__ RcSplit ZK_RCS[ZK_POSEIDON_ROUNDS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RCS_INIT;
 // Two partial rounds as one linear step (see pos_partial_pair): M^2 = circ(ZK_M2C) away from row 0 / column 0, constants
 // K_p = M rc' + rc'' of pair p split like ZK_RCS.
-__constant__ u32 ZK_M2C[12] = ZK_POSEIDON_M2_CIRC_INIT;
-__constant__ u32 ZK_M2ROW0[12] = ZK_POSEIDON_M2_ROW0_INIT;
-__constant__ u32 ZK_M2COL0[12] = ZK_POSEIDON_M2_COL0_INIT;
-__constant__ RcSplit ZK_RCS2[ZK_POSEIDON_PARTIAL_PAIRS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RCS2_INIT;
+static __constant__ u32 ZK_M2C[12] = ZK_POSEIDON_M2_CIRC_INIT;
+static __constant__ u32 ZK_M2ROW0[12] = ZK_POSEIDON_M2_ROW0_INIT;
+static __constant__ u32 ZK_M2COL0[12] = ZK_POSEIDON_M2_COL0_INIT;
+static __constant__ RcSplit ZK_RCS2[ZK_POSEIDON_PARTIAL_PAIRS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RCS2_INIT;
 
 __device__ __forceinline__ u64 pos_sbox(u64 x) {
     u64 x2 = gl_mul_fast(x, x);

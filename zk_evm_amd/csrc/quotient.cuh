@@ -318,7 +318,7 @@ __global__ void quotient_count_kernel(QuotientArgs A) {
     *A.count_out = cons.count;
 }
 // out[k * cap + j] = alpha_k^j
-__global__ void alpha_power_table_kernel(u64 *out, u32 cap, u32 count, u64 a0, u64 a1) {
+static __global__ void alpha_power_table_kernel(u64 *out, u32 cap, u32 count, u64 a0, u64 a1) {
     const u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     out[j] = gl_canon(gl_pow(a0, j));
@@ -328,7 +328,7 @@ __global__ void alpha_power_table_kernel(u64 *out, u32 cap, u32 count, u64 a0, u
 // de-interleave the bit-reversed coefficients of a size-(n*Q) polynomial into its Q degree-n
 // chunks (chunk j = coefficients [j*n, (j+1)*n)): in bit-reversed order chunk j is the positions
 // p with (p mod Q) == bitrev(j, log Q), already in bit-reversed order of size n.
-__global__ void split_quotient_chunks_kernel(const u64 *__restrict__ coef, size_t coef_stride, u32 n_polys,
+static __global__ void split_quotient_chunks_kernel(const u64 *__restrict__ coef, size_t coef_stride, u32 n_polys,
                                              u32 log_n, u32 qd_bits, u64 *__restrict__ out, size_t out_stride) {
     const u32 p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >> log_n) return;

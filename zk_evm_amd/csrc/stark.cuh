@@ -406,7 +406,7 @@ lookup_singles_kernel(const u32 *__restrict__ cols, u32 n_entries, u32 table_col
 }
 
 // x[row] = sum_h helpers[h][row]  ( - freq(row) * table_inv[row]  when freq_pc != 0 )
-__global__ void helper_row_sums_kernel(const u64 *__restrict__ helpers, size_t helper_stride, u32 n_helpers,
+static __global__ void helper_row_sums_kernel(const u64 *__restrict__ helpers, size_t helper_stride, u32 n_helpers,
                                        const u64 *__restrict__ prog, u32 freq_pc, TraceView t,
                                        const u64 *__restrict__ table_inv, u64 *__restrict__ x) {
     const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
@@ -428,7 +428,7 @@ __global__ void helper_row_sums_kernel(const u64 *__restrict__ helpers, size_t h
 #define ZK_SCAN_THREADS 256
 __device__ __forceinline__ u32 scan_src_index(u32 i, u32 n, int mode) { return mode == 0 ? i : n - 1 - i; }
 
-__global__ void __launch_bounds__(ZK_SCAN_THREADS)
+static __global__ void __launch_bounds__(ZK_SCAN_THREADS)
 scan_block_kernel(const u64 *__restrict__ x, u32 n, int mode, u64 *__restrict__ incl, u64 *__restrict__ totals) {
     __shared__ u64 sh[ZK_SCAN_THREADS];
     const u32 base = (blockIdx.x * ZK_SCAN_THREADS + threadIdx.x) * ZK_SCAN_ITEMS;
@@ -458,7 +458,7 @@ scan_block_kernel(const u64 *__restrict__ x, u32 n, int mode, u64 *__restrict__ 
     if (threadIdx.x == ZK_SCAN_THREADS - 1) totals[blockIdx.x] = sh[threadIdx.x];
 }
 // single block: exclusive scan of the block totals, 256 lanes each owning a contiguous chunk
-__global__ void __launch_bounds__(256) scan_totals_kernel(u64 *totals, u32 n_blocks) {
+static __global__ void __launch_bounds__(256) scan_totals_kernel(u64 *totals, u32 n_blocks) {
     __shared__ u64 sh[256];
     const u32 per = (n_blocks + 255) / 256;
     const u32 lo = threadIdx.x * per, hi = lo + per < n_blocks ? lo + per : n_blocks;
@@ -475,7 +475,7 @@ __global__ void __launch_bounds__(256) scan_totals_kernel(u64 *totals, u32 n_blo
     run = threadIdx.x ? sh[threadIdx.x - 1] : 0;
     for (u32 i = lo; i < hi; ++i) { u64 v = totals[i]; totals[i] = run; run = gl_add(run, v); }
 }
-__global__ void scan_finish_kernel(const u64 *__restrict__ incl, const u64 *__restrict__ totals, u32 n,
+static __global__ void scan_finish_kernel(const u64 *__restrict__ incl, const u64 *__restrict__ totals, u32 n,
                                    int mode, u64 *__restrict__ out) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -47,7 +47,7 @@ __device__ __forceinline__ void keccak_round_parts(const u64 (&a)[5][5], KeccakR
 }
 
 // inputs: [n_perms][25] (reference order: input[y * 5 + x]); out: column-major, column c at out + c * stride
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 keccak_trace_kernel(const u64 *__restrict__ inputs, const u64 *__restrict__ timestamps, u32 n_perms, u32 n_rows,
                     u64 *__restrict__ out, size_t stride) {
     const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
@@ -100,7 +100,7 @@ keccak_trace_kernel(const u64 *__restrict__ inputs, const u64 *__restrict__ time
 // `generate_range_checks` of the Arithmetic / BytePacking / KeccakSponge tables (arithmetic_stark.rs:130-156,
 // byte_packing_stark.rs:254-283, keccak_sponge_stark.rs:503-533 -- the same code three times):
 //   counter[i] = min(i, range_max - 1);  frequencies[x] = number of cells of the checked columns equal to x.
-__global__ void range_counter_kernel(u64 *__restrict__ counter, u64 *__restrict__ freq, u32 n, u32 range_max) {
+static __global__ void range_counter_kernel(u64 *__restrict__ counter, u64 *__restrict__ freq, u32 n, u32 range_max) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     counter[i] = i < range_max ? i : range_max - 1;
@@ -111,7 +111,7 @@ __global__ void range_counter_kernel(u64 *__restrict__ counter, u64 *__restrict_
 // offset auxiliary limbs), which as same-address global atomics would serialise in L2; the rest are spread over the
 // range and go to global atomics directly.
 #define ZK_RC_LDS_BINS 4096
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 range_histogram_kernel(const u64 *__restrict__ cols, size_t stride, u32 n, u32 rows_per_block, u32 range_max,
                        unsigned long long *__restrict__ freq, int *__restrict__ err_flag) {
     __shared__ u32 bins[ZK_RC_LDS_BINS];
@@ -139,7 +139,7 @@ range_histogram_kernel(const u64 *__restrict__ cols, size_t stride, u32 n, u32 r
 // operation a one-hot flag (0 AND, 1 OR, 2 XOR), the 2 x 256 input bits and the 8 x 32-bit result limbs; zero rows up
 // to the padded height.  ops: [n_ops][9] = {operator, input0 limbs[4], input1 limbs[4]} (64-bit little-endian limbs,
 // `U256.0`).  One lane per row, 523 coalesced column stores.
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 logic_trace_kernel(const u64 *__restrict__ ops, u32 n_ops, u32 n_rows, u64 *__restrict__ out, size_t stride) {
     const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
@@ -167,7 +167,7 @@ logic_trace_kernel(const u64 *__restrict__ ops, u32 n_ops, u32 n_rows, u64 *__re
 // `mem_before_values_to_rows` + `MemoryContinuationStark::generate_trace`
 // (memory_continuation/memory_continuation_stark.rs:53-98): FILTER = 1, (context, segment, virt), eight 32-bit value
 // limbs; zero rows up to the padded height.  entries: [n][7] = {context, segment, virt, value as 4 x 64-bit LE limbs}.
-__global__ void mem_continuation_trace_kernel(const u64 *__restrict__ entries, u32 n, u32 n_rows, u64 *__restrict__ out,
+static __global__ void mem_continuation_trace_kernel(const u64 *__restrict__ entries, u32 n, u32 n_rows, u64 *__restrict__ out,
                                               size_t stride) {
     const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
@@ -187,7 +187,7 @@ __global__ void mem_continuation_trace_kernel(const u64 *__restrict__ entries, u
 // range-check columns are added afterwards by range_counter_kernel / range_histogram_kernel.
 // ops: [n][10] = {is_read, context, segment, virt, timestamp, len (1..32), bytes as 4 x u64 (byte k of the sequence
 // at bits 8*(k%8) of word k/8)}.  value_bytes[i] = bytes[len - 1 - i].
-__global__ void byte_packing_trace_kernel(const u64 *__restrict__ ops, u32 n_ops, u32 n_rows, u64 *__restrict__ out,
+static __global__ void byte_packing_trace_kernel(const u64 *__restrict__ ops, u32 n_ops, u32 n_rows, u64 *__restrict__ out,
                                           size_t stride) {
     const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
@@ -235,7 +235,7 @@ __device__ __forceinline__ void keccakf_trace(u64 (&st)[25]) {      // plain kec
 #pragma unroll
         for (int y = 0; y < 5; ++y) st[y * 5 + x] = a[x][y];
 }
-__global__ void keccak_sponge_trace_kernel(const u64 *__restrict__ ops, const unsigned char *__restrict__ data, u32 n_ops,
+static __global__ void keccak_sponge_trace_kernel(const u64 *__restrict__ ops, const unsigned char *__restrict__ data, u32 n_ops,
                                            u64 *__restrict__ out, size_t stride) {
     const u32 op = blockIdx.x * blockDim.x + threadIdx.x;
     if (op >= n_ops) return;
@@ -343,7 +343,7 @@ __device__ inline void poseidon_table_perm_row(u64 *__restrict__ out, size_t cs,
     for (u32 i = 4; i < 12; ++i) put(OUTPUT_PARTIAL + i - 4, s[i]);
 }
 
-__global__ void __launch_bounds__(64)
+static __global__ void __launch_bounds__(64)
 poseidon_table_trace_kernel(const u64 *__restrict__ tab, const unsigned char *__restrict__ data, u32 n_ops, u32 rows_used, u32 n_rows,
                             u64 *__restrict__ out, size_t cs) {
     enum : u32 { CONTEXT = 0, SEGMENT, VIRT, TIMESTAMP, LEN, ALREADY_ABSORBED, IS_FINAL_INPUT_LEN = 6, IS_FULL_INPUT_BLOCK = 14,

@@ -1,5 +1,6 @@
 // libzkstark_hip.so -- host side of the C ABI declared in include/zkstark.h.
-// Single translation unit: the device headers carry __constant__ tables.
+// Core translation unit (context, NTT, Merkle, commit, FRI, STARK columns, quotient driver, segment driver); the table
+// AIR kernels, the PLONK prover and the witness-table generators are separate TUs (internal.hpp, zk_evm_amd/build.py).
 //
 // Host responsibilities: per-context twiddle / coset tables, pass planning for the multi-pass
 // NTT, stage sequencing on one HIP stream, device-memory ownership behind zk_batch handles.
@@ -18,8 +19,6 @@
 #include <utility>
 #include <vector>
 
-#include <rocprim/rocprim.hpp>   // radix sort + scans of the Memory-table generator (memtrace_host.inc)
-
 #include "../../include/zkstark.h"
 #include "arena.hpp"
 #include "gl.cuh"
@@ -28,14 +27,10 @@
 #include "fri.cuh"
 #include "stark.cuh"
 #include "quotient.cuh"
-#include "airs.cuh"
-#include "tracegen.cuh"
-#include "plonk.cuh"
-#include "memtrace.cuh"
-#include "arithtrace.cuh"
 #include "host_hash.hpp"
 
 #include "ctx.hpp"
+#include "internal.hpp"
 
 // ------------------------------------------------------------------------------------------
 extern "C" const char *zk_version(void) { return "zkstark-hip 0.1 (gfx950)"; }
@@ -328,9 +323,6 @@ static int check_cfg(zk_ctx *ctx, const zk_cfg *cfg, size_t n_cols, unsigned log
     return ZK_OK;
 }
 
-// mode: values (from_values), natural-order coefficients (from_coeffs), or coefficients already in
-// the device's bit-reversed order (internal: quotient chunks).
-enum CommitMode { COMMIT_VALUES = 0, COMMIT_COEFFS = 1, COMMIT_COEFFS_BITREV = 2 };
 static int commit_impl(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t in_stride,
                        size_t n_cols, unsigned log_n, CommitMode mode, zk_batch **out) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -514,6 +506,17 @@ extern "C" int zk_batch_merkle_path(const zk_batch *b, size_t leaf_index, uint64
 #include "stark_host.inc"
 #include "quotient_host.inc"
 #include "segment_host.inc"
-#include "plonk_host.inc"
-#include "tracegen_host.inc"
-#include "memtrace_host.inc"
+
+// ---- the cross-TU interface (internal.hpp) ----------------------------------------------------------------------
+int zki_commit(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t in_stride, size_t n_cols, unsigned log_n,
+               CommitMode mode, zk_batch **out) {
+    return commit_impl(ctx, cfg, d_in, in_stride, n_cols, log_n, mode, out);
+}
+int zki_get_twiddles(zk_ctx *ctx, int log_size, bool inverse, const u64 **out) { return get_twiddles(ctx, log_size, inverse, out); }
+int zki_get_coset_table(zk_ctx *ctx, int log_n, u64 shift, bool inverse, const u64 **out) {
+    return get_coset_table(ctx, log_n, shift, inverse, out);
+}
+int zki_ntt_values_to_coeffs(zk_ctx *ctx, const u64 *src, size_t src_stride, u64 *dst, size_t dst_stride, size_t n_cols,
+                             int log_n, const u64 *out_scale) {
+    return ntt_values_to_coeffs(ctx, src, src_stride, dst, dst_stride, n_cols, log_n, out_scale);
+}
