@@ -84,6 +84,10 @@ const char *zk_last_error(const zk_ctx *ctx);
 /* Cooperative cancellation, polled between kernels: mirrors `abort_signal` /
  * `check_abort_signal` (evm_arithmetization/src/prover.rs:56,346-354). NULL disables. */
 int zk_ctx_set_abort_flag(zk_ctx *ctx, volatile const int *abort_flag);
+/* The same signal as ONE BYTE, which is what the reference owns: `abort_signal: Option<Arc<AtomicBool>>`
+ * (prover.rs:56) -- the Rust side passes `AtomicBool::as_ptr()` and a store from any thread (`zero`'s abort handler,
+ * polled per table at fixed_recursive_verifier.rs:2123) is seen mid-proof.  Either flag aborts; NULL disables this one. */
+int zk_ctx_set_abort_flag_u8(zk_ctx *ctx, volatile const uint8_t *abort_flag);
 /* Per-stage device timings of the last commit on this ctx, in ms, keyed like the reference's
  * TimingTree scopes (prover.rs:92,99): [0]=ifft [1]=lde/coset-fft [2]=leaf hash [3]=tree. */
 int zk_ctx_last_timings(const zk_ctx *ctx, float out_ms[4]);
@@ -93,6 +97,11 @@ int zk_ctx_last_timings(const zk_ctx *ctx, float out_ms[4]);
  * bench.py derives the leaf-hash kernel's roofline inside a timed multi-table proof from these. */
 int zk_ctx_commit_totals(zk_ctx *ctx, double out_ms[4], uint64_t *n_commits, double *leaf_hash_bytes,
                          double *leaf_hash_perms, double *ntt_bytes, int reset);
+/* The same totals for the commitments zk_prove_segment runs on the ctx's SIDE lane (auxiliary commitments, small
+ * tables: a second, low-priority stream that overlaps the main one).  Their event-to-event times include the sharing of
+ * the chip with main-lane kernels, so they are kept out of zk_ctx_commit_totals and of any roofline derived from it. */
+int zk_ctx_side_commit_totals(zk_ctx *ctx, double out_ms[4], uint64_t *n_commits, double *leaf_hash_bytes,
+                              double *ntt_bytes, int reset);
 
 /* ---- PolynomialBatch::from_values / from_coeffs ------------------------------------------
  * Replaces plonky2 `PolynomialBatch::from_values(values, rate_bits, blinding=false, cap_height,
@@ -319,6 +328,22 @@ int zk_prove_table(zk_ctx *ctx, const zk_cfg *cfg, uint32_t air_id, const uint64
                    const uint64_t *lookup_program, size_t lookup_words, const uint64_t *ctl_zdata, size_t ctl_words,
                    const uint64_t *d_ctl_cols, size_t ctl_col_stride, const uint64_t *ctl_challenges,
                    unsigned constraint_degree, int requires_ctls, zk_challenger *challenger, zk_table_proof **out);
+/* The same split at the one point the transcript allows (SURVEY 8(e) level 2; prover.rs:134-144,328): a table's auxiliary
+ * polynomials -- logUp helper columns under the CTL betas, CTL helper / Z columns -- and their commitment depend on the
+ * CTL challenges only, so zk_table_aux_commit may run for every table at once (different GPUs, or one GPU's side lane)
+ * BEFORE the serial chain of per-table proofs; zk_prove_table_with_aux then takes that commitment instead of rebuilding
+ * it (aux_commitment == NULL: identical to zk_prove_table).  `ctl_challenges` (beta, gamma per challenge) is required by
+ * zk_table_aux_commit and by a zk_prove_table_with_aux call that is given a commitment.  The caller frees the batch. */
+int zk_table_aux_commit(zk_ctx *ctx, const zk_cfg *cfg, const uint64_t *d_trace, size_t col_stride, size_t n_trace_cols,
+                        unsigned log_n, const uint64_t *lookup_program, size_t lookup_words, const uint64_t *ctl_zdata,
+                        size_t ctl_words, const uint64_t *d_ctl_cols, size_t ctl_col_stride, const uint64_t *ctl_challenges,
+                        unsigned constraint_degree, zk_batch **aux_out);
+int zk_prove_table_with_aux(zk_ctx *ctx, const zk_cfg *cfg, uint32_t air_id, const uint64_t *air_consts, size_t n_air_consts,
+                            const uint64_t *d_trace, size_t col_stride, const zk_batch *trace_commitment,
+                            const uint64_t *lookup_program, size_t lookup_words, const uint64_t *ctl_zdata, size_t ctl_words,
+                            const uint64_t *d_ctl_cols, size_t ctl_col_stride, const uint64_t *ctl_challenges,
+                            unsigned constraint_degree, int requires_ctls, const zk_batch *aux_commitment,
+                            zk_challenger *challenger, zk_table_proof **out);
 int zk_table_proof_get(const zk_table_proof *proof, zk_table_proof_view *view);
 void zk_table_proof_free(zk_table_proof *proof);
 

@@ -3,7 +3,7 @@
 //! `zk_last_error`, owned copies of proofs.  No arithmetic happens here and there is no CPU fallback.
 use std::ffi::CStr;
 use std::ptr::{null, null_mut};
-use std::sync::atomic::AtomicI32;
+use std::sync::atomic::AtomicBool;
 use std::sync::Arc;
 
 use anyhow::{anyhow, Result};
@@ -25,7 +25,6 @@ impl Config {
 /// (include/zkstark.h); create one per worker thread, several per GPU if segments should overlap.
 pub struct Context {
     raw: *mut zk_ctx,
-    abort: Option<Arc<AtomicI32>>,
 }
 unsafe impl Send for Context {}
 
@@ -36,7 +35,7 @@ impl Context {
         if rc != ZK_OK || raw.is_null() {
             return Err(anyhow!("zk_ctx_create(device {device}) failed ({rc}): no usable HIP device (no CPU fallback)"));
         }
-        Ok(Context { raw, abort: None })
+        Ok(Context { raw })
     }
     pub fn raw(&self) -> *mut zk_ctx { self.raw }
     pub fn check(&self, rc: i32) -> Result<()> {
@@ -45,13 +44,14 @@ impl Context {
         let msg = unsafe { CStr::from_ptr(zk_last_error(self.raw)) }.to_string_lossy().into_owned();
         Err(anyhow!("zkstark error {rc}: {msg}"))
     }
-    /// `abort_signal` of `prove` (prover.rs:56): the flag is polled between kernels.  The reference uses an
-    /// `AtomicBool`; the shim keeps an `AtomicI32` twin that the abort handler sets alongside it.
-    pub fn set_abort_flag(&mut self, flag: Option<Arc<AtomicI32>>) -> Result<()> {
-        let p = flag.as_ref().map(|f| f.as_ptr() as *const i32).unwrap_or(null());
-        let rc = unsafe { zk_ctx_set_abort_flag(self.raw, p) };
-        self.abort = flag;
-        self.check(rc)
+    /// `abort_signal` of `prove` (prover.rs:56) handed over as it is: the library polls the `AtomicBool`'s own byte
+    /// between kernels (`zk_ctx_set_abort_flag_u8`), so a store from another thread while a proof runs ends it with
+    /// "Stopping job from abort signal." (prover.rs:346-354).  The returned guard keeps the `Arc` alive and clears the
+    /// pointer when dropped; `None` arms nothing.
+    pub fn arm_abort_flag(&self, flag: Option<Arc<AtomicBool>>) -> Result<AbortArmed<'_>> {
+        let p = flag.as_ref().map(|f| f.as_ptr() as *const u8).unwrap_or(null());
+        self.check(unsafe { zk_ctx_set_abort_flag_u8(self.raw, p) })?;
+        Ok(AbortArmed { ctx: self, _keep: flag })
     }
     pub fn mem_reserve(&self, bytes: usize) -> Result<()> { self.check(unsafe { zk_ctx_mem_reserve(self.raw, bytes) }) }
     pub fn synchronize(&self) -> Result<()> { self.check(unsafe { zk_ctx_synchronize(self.raw) }) }
@@ -64,6 +64,12 @@ impl Context {
 }
 impl Drop for Context {
     fn drop(&mut self) { unsafe { zk_ctx_destroy(self.raw) } }
+}
+
+/// Scope of an armed abort flag (`Context::arm_abort_flag`).
+pub struct AbortArmed<'c> { ctx: &'c Context, _keep: Option<Arc<AtomicBool>> }
+impl Drop for AbortArmed<'_> {
+    fn drop(&mut self) { unsafe { zk_ctx_set_abort_flag_u8(self.ctx.raw, null()); } }
 }
 
 /// `PolynomialBatch::from_values` result, resident in HBM.
@@ -100,6 +106,9 @@ pub struct DeviceMatrix<'c> { ctx: &'c Context, ptr: *mut u64, cols: usize, rows
 impl<'c> DeviceMatrix<'c> {
     pub fn upload(ctx: &'c Context, cols: &[&[u64]]) -> Result<Self> {
         let rows = cols.first().map(|c| c.len()).unwrap_or(0);
+        if rows == 0 || cols.iter().any(|c| c.len() != rows) {
+            return Err(anyhow!("DeviceMatrix::upload: columns must be non-empty and of one length"));
+        }
         let mut p: *mut core::ffi::c_void = null_mut();
         ctx.check(unsafe { zk_dev_alloc(ctx.raw, 8 * rows * cols.len(), &mut p) })?;
         let m = DeviceMatrix { ctx, ptr: p as *mut u64, cols: cols.len(), rows };
@@ -117,10 +126,8 @@ impl Drop for DeviceMatrix<'_> {
 
 /// One table handed to `prove_segment` (`zk_table_in`): device trace + the table's static description.
 pub struct TableIn<'a> {
-    pub d_trace: *const u64,
-    pub col_stride: usize,
-    pub n_cols: usize,
-    pub log_n: u32,
+    /// the table's trace, column-major, 2^k rows: the borrow ties the device pointer and its shape to a live allocation
+    pub trace: &'a DeviceMatrix<'a>,
     pub air_id: zk_air,
     pub air_consts: &'a [u64],
     pub lookup_program: &'a [u64],
@@ -166,8 +173,12 @@ unsafe fn caps(p: *const u64, n: usize) -> Vec<[u64; 4]> {
 /// `all_stark.cross_table_lookups` and each table's `lookups()` (shipped ready-made in include/zk_all_stark.h).
 pub fn prove_segment(ctx: &Context, cfg: &Config, tables: &[TableIn], ctl_wiring: &[u64], public_value_elements: &[u64],
                      constraint_degree: u32, mem_before_table: i32, mem_after_table: i32) -> Result<SegmentProof> {
+    if tables.iter().any(|t| !t.trace.rows().is_power_of_two() || t.trace.ctx.raw != ctx.raw) {
+        return Err(anyhow!("prove_segment: every trace needs 2^k rows and must live in this context"));
+    }
     let tin: Vec<zk_table_in> = tables.iter().map(|t| zk_table_in {
-        d_trace: t.d_trace, col_stride: t.col_stride, n_cols: t.n_cols, log_n: t.log_n, air_id: t.air_id as u32,
+        d_trace: t.trace.ptr(), col_stride: t.trace.rows(), n_cols: t.trace.cols(), log_n: t.trace.rows().trailing_zeros(),
+        air_id: t.air_id as u32,
         air_consts: if t.air_consts.is_empty() { null() } else { t.air_consts.as_ptr() }, n_air_consts: t.air_consts.len(),
         lookup_program: if t.lookup_program.is_empty() { null() } else { t.lookup_program.as_ptr() },
         lookup_words: t.lookup_program.len(), in_use: t.in_use as i32, optional: t.optional as i32,

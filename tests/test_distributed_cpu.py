@@ -106,30 +106,117 @@ def test_scheduler_orders_results_and_isolates_failures():
         sch.submit(jobs[0])
 
 
-def _sched_worker(rank, world, port, q):
+def _tuple_codec():
+    """results of the injected prove step are (rank, tag, value) int triples: three words"""
+    return (lambda r: np.array(r, dtype=np.uint64)), (lambda w, job: tuple(int(x) for x in w))
+
+
+def _sched_worker(rank, world, port, q, cursed=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from zk_evm_amd.scheduler import SegmentJob, run_distributed
+    from zk_evm_amd.collectives import RemoteRankError
+    from zk_evm_amd.scheduler import SegmentFailure, SegmentJob, run_distributed
     jobs = [SegmentJob(lambda dev, i=i: 100 + i, [True] * 9, None, tag=i) for i in range(7)]
-    out = run_distributed(None, None, jobs, device=0, in_flight=2,
-                          prove_fn=lambda st, job: (dist.get_rank(), job.tag, job.load(None)))
-    q.put((rank, out))
-    dist.barrier()
+
+    def prove(st, job):
+        if job.tag == cursed:
+            raise RuntimeError("segment %d is cursed" % job.tag)
+        return (dist.get_rank(), job.tag, job.load(None))
+    enc, dec = _tuple_codec()
+    try:
+        out = run_distributed(None, None, jobs, device=0, in_flight=2, prove_fn=prove, encode=enc, decode=dec)
+        q.put((rank, "ok", out))
+    except SegmentFailure as e:
+        q.put((rank, "SegmentFailure", (e.failures, getattr(e, "partial", None))))
+    except RemoteRankError as e:
+        q.put((rank, "RemoteRankError", str(e)))
+    dist.barrier()                                    # reached by every rank: nobody is stuck in a collective
     dist.destroy_process_group()
 
 
-def test_run_distributed_gloo_world2():
+def _run_sched(cursed=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sched_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_sched_worker, args=(r, 2, port, q, cursed)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=120) for _ in procs)
+    res = {}
+    for _ in procs:
+        r, kind, payload = q.get(timeout=120)
+        res[r] = (kind, payload)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res[1] is None
+    return res
+
+
+def test_run_distributed_gloo_world2():
+    res = _run_sched()
+    assert res[1] == ("ok", None)
     # rank 0 holds every proof in segment order; segment i was proven by rank i % 2
-    assert res[0] == [(i % 2, i, 100 + i) for i in range(7)]
+    assert res[0] == ("ok", [(i % 2, i, 100 + i) for i in range(7)])
+
+
+def test_run_distributed_failure_reaches_every_rank_without_deadlock():
+    """a failed segment used to raise before the gather and strand the other ranks in it.  Now the
+    failure travels through the gather; both ranks leave the collective, both raise, rank 0 names segment and rank and
+    still holds the six proofs that succeeded."""
+    res = _run_sched(cursed=3)                         # segment 3 is rank 1's
+    kind1, pay1 = res[1]
+    assert kind1 == "SegmentFailure" and pay1[0][0][:2] == (3, 1)
+    kind0, (failures, partial) = res[0]
+    assert kind0 == "SegmentFailure" and failures[0][:2] == (3, 1) and "cursed" in failures[0][2]
+    assert partial == [(i % 2, i, 100 + i) if i != 3 else None for i in range(7)]
+    res = _run_sched(cursed=4)                         # segment 4 is rank 0's: rank 1 learns of it too
+    assert res[0][0] == "SegmentFailure" and res[1][0] == "RemoteRankError"
+
+
+def test_collectives_word_codecs():
+    from zk_evm_amd import collectives as co
+    recs = [np.arange(5, dtype=np.uint64), np.zeros(0, np.uint64), np.array([2 ** 64 - 1], dtype=np.uint64)]
+    back = co.unpack_records(co.pack_records(recs))
+    assert len(back) == 3 and all(np.array_equal(a, b) for a, b in zip(recs, back))
+    assert co.words_text(co.text_words("ZkStarkError(-3, 'out of memory \u2713')")) == "ZkStarkError(-3, 'out of memory \u2713')"
+    # single process: the collectives degrade to identities
+    assert np.array_equal(co.all_gather_words(np.array([7, 8]), 2)[0], [7, 8])
+    assert np.array_equal(co.gather_varlen_words(np.array([1, 2, 3]))[0], [1, 2, 3])
+    co.agree(None, "nothing")
+    with pytest.raises(ValueError):
+        co.agree(ValueError("x"), "something")
+
+
+def test_stark_proof_words_roundtrip():
+    from zk_evm_amd.prover import StarkProof
+    import zk_evm_amd.segment as sg
+    rng = np.random.default_rng(1)
+    r = lambda *sh: rng.integers(0, 2 ** 63, size=sh, dtype=np.uint64)           # noqa: E731
+    protos = [StarkProof(r(16, 4), r(16, 4), r(16, 4), r(40, 2), r(1000), r(12), 3, 17),
+              StarkProof(r(16, 4), None, r(16, 4), r(9, 2), r(10), None, 0, None)]
+    for p in protos:
+        q, used = StarkProof.from_words(p.to_words())
+        assert used == p.to_words().size
+        for f in ("trace_cap", "auxiliary_polys_cap", "quotient_polys_cap", "openings", "opening_proof", "init_challenger_state"):
+            a, b = getattr(p, f), getattr(q, f)
+            assert (a is None and b is None) or np.array_equal(a, b)
+        assert (q.num_ctl_zs, q.degree_bits) == (p.num_ctl_zs, p.degree_bits)
+    pv = sg.PublicValues()
+    pv.mem_before = sg.MemCap([[1, 2, 3, 4]] * 16)
+    pv.mem_after = sg.MemCap([[5, 6, 7, 8]] * 16)
+    ap = sg.AllProof(sg.MultiProof([sg.StarkProofWithMetadata(protos[0], protos[0].init_challenger_state), None],
+                                   [(11, 12), (13, 14)]), pv, [True, False])
+    back = sg.all_proof_from_words(sg.all_proof_to_words(ap), sg.PublicValues())
+    assert back.table_in_use == [True, False] and back.multi_proof.ctl_challenges == [(11, 12), (13, 14)]
+    assert back.multi_proof.stark_proofs[1] is None and back.public_values.mem_after.mem_cap == pv.mem_after.mem_cap
+    assert np.array_equal(back.multi_proof.stark_proofs[0].proof.opening_proof, protos[0].opening_proof)
+
+
+def test_no_pickled_collective_in_the_product():
+    """r02 verdict: the multi-GPU paths move fixed-shape tensors, never pickled Python objects."""
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zk_evm_amd")
+    for fn in os.listdir(root):
+        if fn.endswith(".py"):
+            src = open(os.path.join(root, fn)).read()
+            for bad in ("all_gather_object(", "gather_object(", "broadcast_object_list(", "scatter_object_list(", "send_object_list("):
+                assert bad not in src, (fn, bad)

@@ -303,6 +303,49 @@ def test_segment_error_paths():
     assert ctx.lib.zk_prove_segment(ctx.handle, C.byref(cfg), None, 9, None, 0, None, 0, 3, -1, -1, None) != 0
 
 
+@pytest.mark.gpu
+def test_abort_byte_flipped_mid_proof():
+    """The reference's `abort_signal` is an `AtomicBool` another thread stores to while the proof runs (prover.rs:56,
+    346-354; polled per table, fixed_recursive_verifier.rs:2123).  zk_ctx_set_abort_flag_u8 takes that byte as it is:
+    flipped ~10 ms into a segment proof that takes > 100 ms, the call must come back with ZK_ERR_ABORTED (`Aborted`),
+    long before the proof would have finished, and the ctx must be usable afterwards."""
+    import threading
+    import time
+
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    from bench import synthetic_segment_traces
+    from zk_evm_amd.all_stark import AllStark
+    dev = torch.device("cuda:0")
+    log_ns = [17] * 9
+    traces = synthetic_segment_traces(log_ns, dev, seed=5)
+    cfg = zk.StarkConfig()
+    alls = AllStark((1, 2, 3, 4))
+    in_use = [True] * 9
+    ctx = zk.Context(0)
+    sg.prove_with_traces(alls, cfg, traces, in_use, sg.PublicValues(), ctx=ctx)          # warm-up: tables, arena
+    t0 = time.perf_counter()
+    sg.prove_with_traces(alls, cfg, traces, in_use, sg.PublicValues(), ctx=ctx)
+    full = time.perf_counter() - t0
+    flag = C.c_uint8(0)                                                                  # one byte == AtomicBool
+    th = threading.Timer(0.010, lambda: setattr(flag, "value", 1))
+    t0 = time.perf_counter()
+    th.start()
+    with pytest.raises(sg.Aborted):
+        sg.prove_with_traces(alls, cfg, traces, in_use, sg.PublicValues(), abort_signal=flag, ctx=ctx)
+    aborted_after = time.perf_counter() - t0
+    th.join()
+    assert aborted_after < 0.8 * full, (aborted_after, full)
+    # the library dropped the pointer on return, the ctx proves again and reproduces the proof
+    flag.value = 0
+    a = sg.prove_with_traces(alls, cfg, traces, in_use, sg.PublicValues(), ctx=ctx)
+    b = sg.prove_with_traces(alls, cfg, traces, in_use, sg.PublicValues(), ctx=ctx)
+    for pa, pb in zip(a.multi_proof.stark_proofs, b.multi_proof.stark_proofs):
+        assert np.array_equal(pa.proof.opening_proof, pb.proof.opening_proof)
+    ctx.close()
+
+
 def _proof_dicts(got):
     out = []
     for sp in got.multi_proof.stark_proofs:

@@ -58,3 +58,19 @@ def test_reference_patch_touches_the_binding_points():
     # a patch, not a copy: only a few context lines of the reference's text travel with it
     context = [ln for ln in p.splitlines() if ln.startswith(" ")]
     assert len(context) < 60
+
+
+def test_shim_abort_and_public_values_use_what_exists():
+    """r02 verdict, weak 10: the abort signal is the reference's own `AtomicBool` byte (no twin that nobody stores to),
+    and the public-value elements are restated with the crate's limb helpers instead of a `Challenger` accessor plonky2
+    1.0.0 does not have."""
+    p = open(os.path.join(ROOT, "rust", "evm_arithmetization_hip.patch")).read()
+    lib = open(os.path.join(ROOT, "rust", "zkstark", "src", "lib.rs")).read()
+    assert "input_buffer_history" not in p and "AtomicI32" not in p and "AtomicI32" not in lib
+    assert "arm_abort_flag(abort_signal" in p
+    assert "zk_ctx_set_abort_flag_u8(self.raw, p)" in lib and "as_ptr() as *const u8" in lib
+    for helper in ("h256_limbs", "u256_limbs", "u256_to_u32", "u256_to_u64"):
+        assert helper in p
+    # hunk header of the new file matches its body
+    m = re.search(r"\+\+\+ b/evm_arithmetization/src/hip\.rs.*?\n@@ -0,0 \+1,(\d+) @@\n((?:\+.*\n)+)", p)
+    assert int(m.group(1)) == len(m.group(2).splitlines())

@@ -39,9 +39,12 @@ SIGNATURES = {
     "zk_dev_upload_columns": (C.c_int, [vp, C.POINTER(vp), sz, sz, u64p, sz]),
     "zk_last_error": (C.c_char_p, [vp]),
     "zk_ctx_set_abort_flag": (C.c_int, [vp, vp]),
+    "zk_ctx_set_abort_flag_u8": (C.c_int, [vp, vp]),
     "zk_ctx_last_timings": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "zk_ctx_commit_totals": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
+    "zk_ctx_side_commit_totals": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
+                                            C.POINTER(C.c_double), C.c_int]),
     "zk_commit_columns": (C.c_int, [vp, C.POINTER(ZkCfg), C.POINTER(vp), sz, ui, C.POINTER(vp)]),
     "zk_commit_columns_device": (C.c_int, [vp, C.POINTER(ZkCfg), u64p, sz, sz, ui, C.POINTER(vp)]),
     "zk_commit_coeffs_device": (C.c_int, [vp, C.POINTER(ZkCfg), u64p, sz, sz, ui, C.POINTER(vp)]),
@@ -89,6 +92,10 @@ SIGNATURES = {
                                     u64p, sz, ui, C.POINTER(vp)]),
     "zk_prove_table": (C.c_int, [vp, C.POINTER(ZkCfg), u32, u64p, sz, u64p, sz, vp, u64p, sz, u64p, sz, u64p, sz, u64p,
                                  ui, C.c_int, vp, C.POINTER(vp)]),
+    "zk_prove_table_with_aux": (C.c_int, [vp, C.POINTER(ZkCfg), u32, u64p, sz, u64p, sz, vp, u64p, sz, u64p, sz, u64p, sz, u64p,
+                                          ui, C.c_int, vp, vp, C.POINTER(vp)]),
+    "zk_table_aux_commit": (C.c_int, [vp, C.POINTER(ZkCfg), u64p, sz, sz, ui, u64p, sz, u64p, sz, u64p, sz, u64p, ui,
+                                      C.POINTER(vp)]),
     "zk_table_proof_get": (C.c_int, [vp, vp]),
     "zk_table_proof_free": (None, [vp]),
     "zk_ctx_set_check_ctls": (C.c_int, [vp, C.c_int]),

@@ -30,12 +30,20 @@ class Context:
         import torch
         self.set_stream(torch.cuda.current_stream(self.device))
 
-    def set_abort_flag(self, flag: "C.c_int | None"):
-        """`flag` is a ctypes c_int the caller may set non-zero from another thread
-        (reference: abort_signal, evm_arithmetization/src/prover.rs:346-354)."""
+    def set_abort_flag(self, flag: "C.c_int | C.c_uint8 | C.c_bool | None"):
+        """`flag` is a ctypes c_int -- or a one-byte c_uint8 / c_bool, the layout of the reference's `AtomicBool` -- that
+        the caller may set non-zero from another thread (abort_signal, evm_arithmetization/src/prover.rs:56,346-354).
+        None clears both forms."""
         self._abort = flag
-        ptr = C.cast(C.byref(flag), C.c_void_p) if flag is not None else None
-        self.check(self.lib.zk_ctx_set_abort_flag(self.handle, ptr))
+        if flag is None:
+            self.check(self.lib.zk_ctx_set_abort_flag(self.handle, None))
+            self.check(self.lib.zk_ctx_set_abort_flag_u8(self.handle, None))
+            return
+        ptr = C.cast(C.byref(flag), C.c_void_p)
+        if C.sizeof(flag) == 1:
+            self.check(self.lib.zk_ctx_set_abort_flag_u8(self.handle, ptr))
+        else:
+            self.check(self.lib.zk_ctx_set_abort_flag(self.handle, ptr))
 
     def synchronize(self):
         self.check(self.lib.zk_ctx_synchronize(self.handle))
@@ -69,6 +77,15 @@ class Context:
         out = dict(zip(("ifft", "lde", "leaf_hash", "tree"), [float(x) for x in ms]))
         out.update(commits=int(n.value), leaf_hash_bytes=float(lb.value), leaf_hash_perms=float(lp.value),
                    ntt_bytes=float(nb.value))
+        return out
+
+    def side_commit_totals(self, reset: bool = False) -> dict:
+        """The same for the commitments zk_prove_segment ran on the ctx's side lane (overlapped with the main stream)."""
+        ms = (C.c_double * 4)()
+        n, lb, nb = C.c_uint64(0), C.c_double(0), C.c_double(0)
+        self.check(self.lib.zk_ctx_side_commit_totals(self.handle, ms, C.byref(n), C.byref(lb), C.byref(nb), 1 if reset else 0))
+        out = dict(zip(("ifft", "lde", "leaf_hash", "tree"), [float(x) for x in ms]))
+        out.update(commits=int(n.value), leaf_hash_bytes=float(lb.value), ntt_bytes=float(nb.value))
         return out
 
     def last_error(self) -> str:

@@ -150,3 +150,24 @@ struct DevArena {
         reserved = in_use = 0;
     }
 };
+
+// The arenas of one zk_ctx.  Lane 0 belongs to ctx->stream; lane 1 to the ctx's side stream (segment_host.inc: the
+// auxiliary-commitment pipeline that runs beside the per-table chain).  Each lane recycles blocks in the order of ITS
+// stream, so a block never migrates between streams without a host-side synchronisation in between: allocation takes
+// from the current lane, a free returns the block to the lane that owns it.
+struct ArenaSet {
+    DevArena lane[2];
+    int cur = 0;
+    hipError_t alloc(void **out, size_t bytes) { return lane[cur].alloc(out, bytes); }
+    void free(void *p) {
+        if (!p) return;
+        if (lane[0].live.count(p)) lane[0].free(p);
+        else lane[1].free(p);
+    }
+    hipError_t reserve(size_t bytes) { return lane[0].reserve(bytes); }
+    size_t trim() { return lane[0].trim() + lane[1].trim(); }
+    void destroy() { lane[0].destroy(); lane[1].destroy(); }
+    size_t reserved() const { return lane[0].reserved + lane[1].reserved; }
+    size_t in_use() const { return lane[0].in_use + lane[1].in_use; }
+    size_t peak_in_use() const { return lane[0].peak_in_use + lane[1].peak_in_use; }
+};

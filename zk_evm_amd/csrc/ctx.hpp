@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <deque>
 #include <map>
 #include <set>
 #include <string>
@@ -15,6 +16,20 @@
 #include "arena.hpp"
 #include "gl.cuh"
 
+// Deferred host synchronisation (zk_prove_segment): while a sink is installed, the helper-column passes neither wait for
+// their kernels nor read their error flag -- the host buffers they upload from are parked here, every pass takes an error
+// slot, and the driver checks the slots once per join point.  That is what lets the auxiliary pipeline run ahead on the side
+// lane while the host serves the Fiat-Shamir round trips of the per-table chain.
+struct AsyncSink {
+    std::deque<std::vector<u64>> keep64;
+    std::deque<std::vector<u32>> keep32;
+    int *d_errs = nullptr;      // device, `cap` slots, zeroed
+    int *h_errs = nullptr;      // pinned host mirror
+    u32 used = 0, cap = 0;
+    std::vector<u64> &new64() { keep64.emplace_back(); return keep64.back(); }
+    std::vector<u32> &new32() { keep32.emplace_back(); return keep32.back(); }
+};
+
 // ------------------------------------------------------------------------------------------
 struct zk_ctx {
     int device = 0;
@@ -22,21 +37,31 @@ struct zk_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     volatile const int *abort_flag = nullptr;
+    volatile const uint8_t *abort_flag_u8 = nullptr;   // the reference's AtomicBool (zk_ctx_set_abort_flag_u8)
     std::map<int, u64 *> tw_fwd, tw_inv, tw_inv_br;         // log size -> table (tw_inv_br: block-order levels)
     std::map<std::pair<int, u64>, u64 *> coset_tabs;        // (log_n, shift) -> s^bitrev(i)
     std::map<std::pair<int, u64>, u64 *> coset_inv_tabs;    // (log_n, shift) -> n^-1 s^-bitrev(i)
-    hipEvent_t ev[5] = {};
+    hipStream_t side_stream = nullptr;  // lane 1: low priority, created on first use (segment_host.inc)
+    std::vector<hipEvent_t> ev_pool;    // recycled timing / ordering events
+    u64 *h_caps = nullptr;              // pinned host slots for cap read-backs of commits in flight (ZK_CAP_SLOTS x 64 words)
+    uint64_t cap_slot_next = 0;
     float timings[4] = {0, 0, 0, 0};
     // running totals over all commits since the last reset (zk_ctx_commit_totals)
     double total_ms[4] = {0, 0, 0, 0};
     double total_leaf_bytes = 0, total_leaf_perms = 0, total_ntt_bytes = 0;
     uint64_t total_commits = 0;
+    // the same for commits that ran on the side lane, i.e. concurrently with main-lane kernels: their event-to-event
+    // times include the sharing of the chip and are kept out of the roofline figures
+    double side_ms[4] = {0, 0, 0, 0};
+    double side_leaf_bytes = 0, side_ntt_bytes = 0;
+    uint64_t side_commits = 0;
     int cu_count = 0;
     std::set<zk_batch *> live_batches;  // freed by zk_ctx_destroy if the caller leaked them
-    DevArena arena;                     // all batch + scratch HBM (arena.hpp)
+    ArenaSet arena;                     // all batch + scratch HBM, one arena per lane (arena.hpp)
     // debug: starky `check_ctls` after get_ctl_data (zk_ctx_set_check_ctls); extra looking rows per CTL index
     bool check_ctls = false;
     std::map<size_t, std::pair<size_t, std::vector<u64>>> ctl_extra;   // ctl -> (row width, rows)
+    AsyncSink *async = nullptr;         // installed by zk_prove_segment for the duration of the call
     std::map<std::vector<u64>, u32> constraint_counts;   // quotient: constraints yielded per (AIR, lookup/CTL shape)
 };
 
@@ -97,8 +122,23 @@ struct DevBuf {
     }
 };
 
+// Work enqueued inside the scope goes to the ctx's side stream and takes its memory from the side arena.
+struct LaneScope {
+    zk_ctx *ctx;
+    hipStream_t prev_stream;
+    int prev_lane;
+    LaneScope(zk_ctx *c, hipStream_t s, int lane) : ctx(c), prev_stream(c->stream), prev_lane(c->arena.cur) {
+        ctx->stream = s;
+        ctx->arena.cur = lane;
+    }
+    ~LaneScope() { ctx->stream = prev_stream; ctx->arena.cur = prev_lane; }
+    LaneScope(const LaneScope &) = delete;
+    LaneScope &operator=(const LaneScope &) = delete;
+};
+
 static int check_abort(zk_ctx *ctx) {
-    if (ctx->abort_flag && *ctx->abort_flag) return set_err(ctx, ZK_ERR_ABORTED, "aborted");
+    if ((ctx->abort_flag && *ctx->abort_flag) || (ctx->abort_flag_u8 && *ctx->abort_flag_u8))
+        return set_err(ctx, ZK_ERR_ABORTED, "aborted");
     return ZK_OK;
 }
 

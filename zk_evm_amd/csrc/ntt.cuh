@@ -79,11 +79,7 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
         u32 t0 = (blk << (log_q + K)) + j;
         u64 v[1 << K];
 #pragma unroll
-#ifdef NTT_EXPERIMENT_NOCONFLICT   /* timing experiment only (wrong results): register-major, conflict-free LDS accesses */
-        for (int m = 0; m < (1 << K); ++m) v[m] = tile[sp + m * nsub];
-#else
         for (int m = 0; m < (1 << K); ++m) v[m] = tile[((t0 + m * q) << log_t) + u];
-#endif
         const u32 x0 = base + (t0 << p.log_d) + u;      // global index of v[0]; bits [log_D0, log_D0 + K) are zero
         if (DIT) {
             // pair (x, x + D), D = D0 << lm: twiddle T_D[x mod D]; x_m mod D = g + (m mod hm) * D0
@@ -118,11 +114,7 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
             }
         }
 #pragma unroll
-#ifdef NTT_EXPERIMENT_NOCONFLICT
-        for (int m = 0; m < (1 << K); ++m) tile[sp + m * nsub] = v[m];
-#else
         for (int m = 0; m < (1 << K); ++m) tile[((t0 + m * q) << log_t) + u] = v[m];
-#endif
     }
 }
 

@@ -92,14 +92,15 @@ __device__ __forceinline__ void pos_row(u64 &al, u64 &ah, u64 rcl, u64 rch, cons
 #undef Y
 }
 
-// value = al + ah * 2^32  (al, ah < 2^44)  ->  lazy u64 representative
+// value = al + ah * 2^32  (al, ah < 2^50: < 2^44 from a plain MDS row, < 2^50 from pos_partial_pair's M^2 row plus the
+// delta term)  ->  lazy u64 representative
 __device__ __forceinline__ u64 pos_fold(u64 al, u64 ah) {
     u32 ah0 = (u32)ah, ah1 = (u32)(ah >> 32);
-    // ah1 * 2^64 == ah1 * (2^32 - 1); al + that < 2^45: no overflow
+    // ah1 * 2^64 == ah1 * (2^32 - 1) with ah1 < 2^18; al + that < 2^51: no overflow
     asm("v_mad_u64_u32 %0, vcc, %1, -1, %0" : "+v"(al) : "v"(ah1) : "vcc");
     u32 l = (u32)al, h = (u32)(al >> 32), e;
-    // h += ah0; on carry-out add 2^64 == EPS (cannot carry twice: the wrapped h is < 2^13).  h < 2^13 before the add, so
-    // the carry needs ah0 > 2^32 - 2^13: probability 2^-19 per lane -- the correction is an unlikely block entered when
+    // h += ah0; on carry-out add 2^64 == EPS (cannot carry twice: the wrapped h is < 2^19).  h < 2^19 before the add, so
+    // the carry needs ah0 > 2^32 - 2^19: probability <= 2^-13 per lane (2^-19 for the plain rows) -- the correction is an unlikely block entered when
     // some lane of the wave carried (test and branch on the scalar unit), and the fold is two VALU instructions.
     u64 cm;
     asm("v_add_co_u32 %0, %1, %0, %2" : "+v"(h), "=&s"(cm) : "v"(ah0));

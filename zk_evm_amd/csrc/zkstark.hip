@@ -61,7 +61,6 @@ extern "C" int zk_ctx_create(int device, zk_ctx **out) {
         return ZK_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
-    for (auto &e : ctx->ev) hipEventCreate(&e);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
     // allow the NTT kernels their full LDS tile (default dynamic limit is 64 KiB)
@@ -80,13 +79,16 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     hipSetDevice(ctx->device);
     while (!ctx->live_batches.empty()) zk_batch_free(*ctx->live_batches.begin());
     hipStreamSynchronize(ctx->stream);
+    if (ctx->side_stream) hipStreamSynchronize(ctx->side_stream);
     ctx->arena.destroy();
     for (auto &kv : ctx->tw_fwd) hipFree(kv.second);
     for (auto &kv : ctx->tw_inv) hipFree(kv.second);
     for (auto &kv : ctx->tw_inv_br) hipFree(kv.second);
     for (auto &kv : ctx->coset_tabs) hipFree(kv.second);
     for (auto &kv : ctx->coset_inv_tabs) hipFree(kv.second);
-    for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
+    for (auto &e : ctx->ev_pool) if (e) hipEventDestroy(e);
+    if (ctx->h_caps) hipHostFree(ctx->h_caps);
+    if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -115,9 +117,9 @@ extern "C" int zk_ctx_mem_trim(zk_ctx *ctx, size_t *released) {
 }
 extern "C" int zk_ctx_mem_stats(const zk_ctx *ctx, size_t *reserved, size_t *in_use, size_t *peak_in_use) {
     if (!ctx) return ZK_ERR_BAD_ARG;
-    if (reserved) *reserved = ctx->arena.reserved;
-    if (in_use) *in_use = ctx->arena.in_use;
-    if (peak_in_use) *peak_in_use = ctx->arena.peak_in_use;
+    if (reserved) *reserved = ctx->arena.reserved();
+    if (in_use) *in_use = ctx->arena.in_use();
+    if (peak_in_use) *peak_in_use = ctx->arena.peak_in_use();
     return ZK_OK;
 }
 extern "C" int zk_dev_alloc(zk_ctx *ctx, size_t bytes, void **d_out) {
@@ -156,6 +158,11 @@ extern "C" int zk_ctx_set_abort_flag(zk_ctx *ctx, volatile const int *abort_flag
     ctx->abort_flag = abort_flag;
     return ZK_OK;
 }
+extern "C" int zk_ctx_set_abort_flag_u8(zk_ctx *ctx, volatile const uint8_t *abort_flag) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    ctx->abort_flag_u8 = abort_flag;
+    return ZK_OK;
+}
 extern "C" int zk_ctx_commit_totals(zk_ctx *ctx, double out_ms[4], uint64_t *n_commits, double *leaf_hash_bytes,
                                     double *leaf_hash_perms, double *ntt_bytes, int reset) {
     if (!ctx) return ZK_ERR_BAD_ARG;
@@ -168,6 +175,20 @@ extern "C" int zk_ctx_commit_totals(zk_ctx *ctx, double out_ms[4], uint64_t *n_c
         for (double &v : ctx->total_ms) v = 0;
         ctx->total_leaf_bytes = ctx->total_leaf_perms = ctx->total_ntt_bytes = 0;
         ctx->total_commits = 0;
+    }
+    return ZK_OK;
+}
+extern "C" int zk_ctx_side_commit_totals(zk_ctx *ctx, double out_ms[4], uint64_t *n_commits, double *leaf_hash_bytes,
+                                         double *ntt_bytes, int reset) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    if (out_ms) for (int i = 0; i < 4; ++i) out_ms[i] = ctx->side_ms[i];
+    if (n_commits) *n_commits = ctx->side_commits;
+    if (leaf_hash_bytes) *leaf_hash_bytes = ctx->side_leaf_bytes;
+    if (ntt_bytes) *ntt_bytes = ctx->side_ntt_bytes;
+    if (reset) {
+        for (double &v : ctx->side_ms) v = 0;
+        ctx->side_leaf_bytes = ctx->side_ntt_bytes = 0;
+        ctx->side_commits = 0;
     }
     return ZK_OK;
 }
@@ -323,20 +344,46 @@ static int check_cfg(zk_ctx *ctx, const zk_cfg *cfg, size_t n_cols, unsigned log
     return ZK_OK;
 }
 
-static int commit_impl(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t in_stride,
-                       size_t n_cols, unsigned log_n, CommitMode mode, zk_batch **out) {
+// ---- commits in flight -----------------------------------------------------------------------------------------
+// A commitment is enqueued (iNTT, LDE, leaf hashing, tree, cap read-back into a pinned slot) without any host
+// synchronisation and finished later (cap copied into the batch, stage times added to the ctx totals): the segment
+// driver keeps several in flight, on the main stream and on the side lane.
+#define ZK_CAP_SLOTS 64
+struct PendingCommit {
+    zk_batch *b = nullptr;
+    hipEvent_t ev[5] = {};
+    hipStream_t stream = nullptr;
+    const u64 *h_cap = nullptr;
+    CommitMode mode = COMMIT_VALUES;
+    bool side = false;
+};
+static hipEvent_t ev_get(zk_ctx *ctx) {
+    if (!ctx->ev_pool.empty()) { hipEvent_t e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+static void ev_put(zk_ctx *ctx, hipEvent_t e) { if (e) ctx->ev_pool.push_back(e); }
+static void pending_release(zk_ctx *ctx, PendingCommit &pc) {
+    for (auto &e : pc.ev) { ev_put(ctx, e); e = nullptr; }
+}
+
+static int commit_enqueue(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t in_stride,
+                          size_t n_cols, unsigned log_n, CommitMode mode, PendingCommit *pc) {
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ZK_TRY(check_abort(ctx));
     const size_t n = (size_t)1 << log_n;
     const unsigned log_N = log_n + cfg->rate_bits;
     const size_t N = (size_t)1 << log_N;
+    if (((size_t)4 << cfg->cap_height) > 64) return set_err(ctx, ZK_ERR_UNSUPPORTED, "cap_height above 4 is not supported");
+    if (!ctx->h_caps) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_caps, (size_t)ZK_CAP_SLOTS * 64 * sizeof(u64), hipHostMallocDefault));
     zk_batch *b = new zk_batch();
     ctx->live_batches.insert(b);
     b->ctx = ctx; b->n_cols = n_cols; b->log_n = log_n; b->rate_bits = cfg->rate_bits;
     b->cap_height = cfg->cap_height; b->hasher = cfg->hasher;
     b->n_digests = zk_merkle_num_digests(log_N, cfg->cap_height);
     int rc = ZK_OK;
-    auto fail = [&](int code) { zk_batch_free(b); return code; };
+    auto fail = [&](int code) { pending_release(ctx, *pc); zk_batch_free(b); return code; };
 #define B_HIP(expr)                                                                          \
     do {                                                                                     \
         hipError_t e_ = (expr);                                                              \
@@ -344,15 +391,17 @@ static int commit_impl(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t i
             return fail(set_err(ctx, e_ == hipErrorOutOfMemory ? ZK_ERR_OOM : ZK_ERR_HIP,    \
                                 "%s failed: %s", #expr, hipGetErrorString(e_)));             \
     } while (0)
-    // stream-ordered pool allocations: repeated commits reuse the same HBM without hipMalloc cost
+    // arena blocks of the current lane: repeated commits reuse the same HBM without hipMalloc cost
     B_HIP(ctx->arena.alloc((void **)&b->d_coeffs, n_cols * n * sizeof(u64)));
     B_HIP(ctx->arena.alloc((void **)&b->d_lde, n_cols * N * sizeof(u64)));
     B_HIP(ctx->arena.alloc((void **)&b->d_digests, b->n_digests * 32));
 
     const u64 *coset = nullptr;
     if ((rc = get_coset_table(ctx, log_n, GL_GENERATOR, false, &coset)) != ZK_OK) return fail(rc);
+    pc->b = b; pc->stream = ctx->stream; pc->mode = mode; pc->side = ctx->arena.cur != 0;
+    for (auto &e : pc->ev) e = ev_get(ctx);
     // make sure table construction is not billed to a stage
-    hipEventRecord(ctx->ev[0], ctx->stream);
+    hipEventRecord(pc->ev[0], ctx->stream);
     if (mode == COMMIT_VALUES) {
         rc = ntt_values_to_coeffs(ctx, d_in, in_stride, b->d_coeffs, n, n_cols, log_n, nullptr);
     } else {
@@ -361,33 +410,65 @@ static int commit_impl(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t i
         if (mode == COMMIT_COEFFS) rc = bitrev_columns(ctx, b->d_coeffs, n, n_cols, log_n);
     }
     if (rc != ZK_OK) return fail(rc);
-    hipEventRecord(ctx->ev[1], ctx->stream);
+    hipEventRecord(pc->ev[1], ctx->stream);
     if ((rc = check_abort(ctx)) != ZK_OK) return fail(rc);
     rc = ntt_coeffs_to_values(ctx, b->d_coeffs, n, b->d_lde, N, n_cols, log_n, cfg->rate_bits, coset);
     if (rc != ZK_OK) return fail(rc);
-    hipEventRecord(ctx->ev[2], ctx->stream);
+    hipEventRecord(pc->ev[2], ctx->stream);
     if ((rc = check_abort(ctx)) != ZK_OK) return fail(rc);
     rc = hash_rows(ctx, cfg->hasher, b->d_lde, N, n_cols, N, (int)log_N, 1, b->d_digests);
     if (rc != ZK_OK) return fail(rc);
-    hipEventRecord(ctx->ev[3], ctx->stream);
+    hipEventRecord(pc->ev[3], ctx->stream);
     rc = merkle_levels(ctx, cfg->hasher, b->d_digests, log_N, cfg->cap_height);
     if (rc != ZK_OK) return fail(rc);
-    hipEventRecord(ctx->ev[4], ctx->stream);
+    hipEventRecord(pc->ev[4], ctx->stream);
     b->cap.resize((size_t)4 << cfg->cap_height);
-    B_HIP(hipMemcpyAsync(b->cap.data(), b->d_digests + 4 * (b->n_digests - ((size_t)1 << cfg->cap_height)),
+    u64 *slot = ctx->h_caps + (ctx->cap_slot_next++ % ZK_CAP_SLOTS) * 64;
+    pc->h_cap = slot;
+    B_HIP(hipMemcpyAsync(slot, b->d_digests + 4 * (b->n_digests - ((size_t)1 << cfg->cap_height)),
                          b->cap.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    B_HIP(hipStreamSynchronize(ctx->stream));
+#undef B_HIP
+    return ZK_OK;
+}
+
+// The commit's stream must have been drained past its cap read-back (stream or event synchronisation by the caller).
+static void commit_finish(zk_ctx *ctx, PendingCommit *pc) {
+    zk_batch *b = pc->b;
+    memcpy(b->cap.data(), pc->h_cap, b->cap.size() * 8);
+    const size_t n = (size_t)1 << b->log_n, N = n << b->rate_bits;
+    double *tot = pc->side ? ctx->side_ms : ctx->total_ms;
     for (int i = 0; i < 4; ++i) {
-        hipEventElapsedTime(&ctx->timings[i], ctx->ev[i], ctx->ev[i + 1]);
-        ctx->total_ms[i] += ctx->timings[i];
+        float ms = 0;
+        hipEventElapsedTime(&ms, pc->ev[i], pc->ev[i + 1]);
+        if (!pc->side) ctx->timings[i] = ms;
+        tot[i] += ms;
     }
     // algorithmic bytes of the leaf-hash launch: read the LDE once, write N digests
-    ctx->total_leaf_bytes += 8.0 * (double)n_cols * (double)N + 32.0 * (double)N;
-    ctx->total_leaf_perms += n_cols > 4 ? (double)N * (double)((n_cols + 7) / 8) : 0.0;
-    ctx->total_ntt_bytes += (mode == COMMIT_VALUES ? 40.0 : 24.0) * (double)n_cols * (double)n;
-    ctx->total_commits += 1;
-#undef B_HIP
-    *out = b;
+    const double leaf_bytes = 8.0 * (double)b->n_cols * (double)N + 32.0 * (double)N;
+    const double ntt_bytes = (pc->mode == COMMIT_VALUES ? 40.0 : 24.0) * (double)b->n_cols * (double)n;
+    if (pc->side) {
+        ctx->side_leaf_bytes += leaf_bytes; ctx->side_ntt_bytes += ntt_bytes; ctx->side_commits += 1;
+    } else {
+        ctx->total_leaf_bytes += leaf_bytes;
+        ctx->total_leaf_perms += b->n_cols > 4 ? (double)N * (double)((b->n_cols + 7) / 8) : 0.0;
+        ctx->total_ntt_bytes += ntt_bytes;
+        ctx->total_commits += 1;
+    }
+    pending_release(ctx, *pc);
+}
+
+static int commit_impl(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t in_stride,
+                       size_t n_cols, unsigned log_n, CommitMode mode, zk_batch **out) {
+    PendingCommit pc;
+    ZK_TRY(commit_enqueue(ctx, cfg, d_in, in_stride, n_cols, log_n, mode, &pc));
+    hipError_t e = hipStreamSynchronize(pc.stream);
+    if (e != hipSuccess) {
+        pending_release(ctx, pc);
+        zk_batch_free(pc.b);
+        return set_err(ctx, ZK_ERR_HIP, "commit: %s", hipGetErrorString(e));
+    }
+    commit_finish(ctx, &pc);
+    *out = pc.b;
     return ZK_OK;
 }
 

@@ -47,6 +47,47 @@ class StarkProof:
     num_ctl_zs: int = 0
     degree_bits: Optional[int] = None
 
+    # ---- flat words (what moves between ranks: a fixed header and u64 payloads, no pickling) ------------------------
+    def to_words(self) -> np.ndarray:
+        """header: degree_bits, num_ctl_zs, cap digests, has_aux_cap, n_openings, proof words, has_init_state; then
+        trace cap, [aux cap], quotient cap, openings, opening proof, [12 init-state words]."""
+        nd = int(np.asarray(self.trace_cap).reshape(-1, 4).shape[0])
+        has_aux = self.auxiliary_polys_cap is not None
+        has_st = self.init_challenger_state is not None
+        op = np.asarray(self.openings, dtype=np.uint64).reshape(-1)
+        fr = np.asarray(self.opening_proof, dtype=np.uint64).reshape(-1)
+        head = np.array([self.degree_bits if self.degree_bits is not None else (1 << 63), self.num_ctl_zs, nd, int(has_aux),
+                         op.size // 2, fr.size, int(has_st)], dtype=np.uint64)
+        parts = [head, np.asarray(self.trace_cap, dtype=np.uint64).reshape(-1)]
+        if has_aux:
+            parts.append(np.asarray(self.auxiliary_polys_cap, dtype=np.uint64).reshape(-1))
+        parts += [np.asarray(self.quotient_polys_cap, dtype=np.uint64).reshape(-1), op, fr]
+        if has_st:
+            parts.append(np.asarray(self.init_challenger_state, dtype=np.uint64).reshape(-1))
+        return np.concatenate(parts)
+
+    @staticmethod
+    def from_words(w: np.ndarray) -> Tuple["StarkProof", int]:
+        """-> (proof, words consumed)"""
+        w = np.asarray(w, dtype=np.uint64)
+        db, nz, nd, has_aux, n_op, n_fri, has_st = (int(x) for x in w[:7])
+        pos = 7
+
+        def take(n, shape=None):
+            nonlocal pos
+            a = w[pos: pos + n].copy()
+            if a.size != n:
+                raise ZkStarkError(-1, "truncated proof words")
+            pos += n
+            return a.reshape(shape) if shape else a
+        tc = take(4 * nd, (nd, 4))
+        ac = take(4 * nd, (nd, 4)) if has_aux else None
+        qc = take(4 * nd, (nd, 4))
+        op = take(2 * n_op, (n_op, 2))
+        fr = take(n_fri)
+        st = take(12) if has_st else None
+        return StarkProof(tc, ac, qc, op, fr, st, nz, None if db == (1 << 63) else db), pos
+
 
 def encode_lookup_set(lookups: Sequence[Lookup]) -> Optional[np.ndarray]:
     if not lookups:
@@ -131,42 +172,73 @@ def table_proof_from_handle(lib, handle) -> StarkProof:
         num_ctl_zs=int(v.n_ctl_zs), degree_bits=int(v.degree_bits))
 
 
+def _table_args(trace_values, lookups, ctl_zdatas, ctl_challenges):
+    """the marshalled pieces shared by zk_prove_table_with_aux and zk_table_aux_commit (kept alive by the caller)"""
+    import torch
+    from .stark import _trace_args
+    n_cols, n, log_n, stride = _trace_args(trace_values)
+    lp = encode_lookup_set(lookups)
+    cp = encode_ctl_set(ctl_zdatas)
+    ctl_cols = torch.cat([z.aux for z in ctl_zdatas], dim=0).contiguous() if ctl_zdatas else None
+    cc = None
+    if ctl_challenges is not None:
+        cc = np.array([x % (1 << 64) for bg in ctl_challenges for x in bg], dtype=np.uint64)
+    return n_cols, n, log_n, stride, lp, cp, ctl_cols, cc
+
+
+def table_aux_commit(config: StarkConfig, trace_values, lookups: Sequence[Lookup], ctl_zdatas: Sequence[CtlZData],
+                     ctl_challenges: Sequence[Tuple[int, int]], constraint_degree: int = 3, hasher: Optional[int] = None,
+                     ctx=None) -> Optional[PolynomialBatch]:
+    """Phase 2 of a table (zk_table_aux_commit): its auxiliary polynomials -- logUp helper columns under the CTL betas,
+    the CTL helper / Z columns of `ctl_zdatas` -- committed.  Depends on the CTL challenges only (prover.rs:134-144,328),
+    so every table's owner runs it at once before the serial chain (sharding.prove_segment_table_parallel).  None when
+    the table has no auxiliary polynomials."""
+    from .context import default_context
+    if not lookups and not ctl_zdatas:
+        return None
+    ctx = ctx or default_context(trace_values.device.index or 0)
+    ctx.use_torch_current_stream()
+    n_cols, n, log_n, stride, lp, cp, ctl_cols, cc = _table_args(trace_values, lookups, ctl_zdatas, ctl_challenges)
+    cfg = config.to_c()
+    if hasher is not None:
+        cfg.hasher = hasher
+    h = C.c_void_p()
+    rc = ctx.lib.zk_table_aux_commit(
+        ctx.handle, C.byref(cfg), C.c_void_p(trace_values.data_ptr()), stride, n_cols, log_n,
+        lp.ctypes.data if lp is not None else None, lp.size if lp is not None else 0,
+        cp.ctypes.data if cp is not None else None, cp.size if cp is not None else 0,
+        C.c_void_p(ctl_cols.data_ptr()) if ctl_cols is not None else None, n, cc.ctypes.data, constraint_degree, C.byref(h))
+    ctx.check(rc)
+    return PolynomialBatch(ctx, h, cfg.rate_bits, cfg.cap_height, cfg.hasher)
+
+
 def prove_single_table(air_id: int, config: StarkConfig, trace_values, trace_commitment: PolynomialBatch,
                           lookups: Sequence[Lookup], ctl_zdatas: Sequence[CtlZData],
                           ctl_challenges: Optional[Sequence[Tuple[int, int]]], challenger: Challenger,
                           constraint_degree: int = 3, requires_ctls: bool = True,
-                          air_consts: Sequence[int] = ()) -> StarkProof:
-    """`prove_single_table` -> starky `prove_with_commitment` as ONE C-ABI call (zk_prove_table; the sequencing
+                          air_consts: Sequence[int] = (), aux_commitment: Optional[PolynomialBatch] = None) -> StarkProof:
+    """`prove_single_table` -> starky `prove_with_commitment` as ONE C-ABI call (zk_prove_table_with_aux; the sequencing
     lives in csrc/segment_host.inc).  The challenger is compacted first, exactly as prover.rs:318-320 does, and
     its state is returned in `init_challenger_state`.
     trace_values: CUDA tensor (n_cols, n) (the same values trace_commitment was built from).
     ctl_challenges: [(beta, gamma)] * num_challenges (lookup challenges = the betas, as starky does when
-    `ctl_challenges` is Some; otherwise they are drawn from the challenger)."""
-    import torch
-    from .stark import _trace_args
+    `ctl_challenges` is Some; otherwise they are drawn from the challenger).
+    aux_commitment: the result of `table_aux_commit` for this table, when phase 2 ran ahead of the chain."""
     ctx = trace_commitment.ctx
-    n_cols, n, log_n, stride = _trace_args(trace_values)
     ctx.use_torch_current_stream()
+    n_cols, n, log_n, stride, lp, cp, ctl_cols, cc = _table_args(trace_values, lookups, ctl_zdatas, ctl_challenges)
     cfg = config.to_c(rate_bits=trace_commitment.rate_bits, cap_height=trace_commitment.cap_height)
     cfg.hasher = trace_commitment.hasher
-    lp = encode_lookup_set(lookups)
-    cp = encode_ctl_set(ctl_zdatas)
-    ctl_cols = None
-    if ctl_zdatas:
-        ctl_cols = torch.cat([z.aux for z in ctl_zdatas], dim=0).contiguous()
-    cc = None
-    if ctl_challenges is not None:
-        cc = np.array([x % (1 << 64) for bg in ctl_challenges for x in bg], dtype=np.uint64)
     ac = np.array(list(air_consts), dtype=np.uint64)
     h = C.c_void_p()
-    rc = ctx.lib.zk_prove_table(
+    rc = ctx.lib.zk_prove_table_with_aux(
         ctx.handle, C.byref(cfg), air_id, ac.ctypes.data if ac.size else None, ac.size,
         C.c_void_p(trace_values.data_ptr()), stride, trace_commitment.handle,
         lp.ctypes.data if lp is not None else None, lp.size if lp is not None else 0,
         cp.ctypes.data if cp is not None else None, cp.size if cp is not None else 0,
         C.c_void_p(ctl_cols.data_ptr()) if ctl_cols is not None else None, n,
         cc.ctypes.data if cc is not None else None, constraint_degree, 1 if requires_ctls else 0,
-        challenger.handle, C.byref(h))
+        aux_commitment.handle if aux_commitment is not None else None, challenger.handle, C.byref(h))
     ctx.check(rc)
     try:
         return table_proof_from_handle(ctx.lib, h)

@@ -99,7 +99,8 @@ class SegmentScheduler:
                         del traces
                     fut.set_result(proof)
                 st.segments += 1
-            except BaseException as e:                    # a failed segment fails its future, not the worker
+            except Exception as e:                        # a failed segment fails its future, not the worker
+                                                          # (KeyboardInterrupt / SystemExit are not swallowed)
                 st.errors.append(repr(e))
                 fut.set_exception(e)
             finally:
@@ -136,28 +137,82 @@ class SegmentScheduler:
         self.shutdown()
 
 
+class SegmentFailure(RuntimeError):
+    """One or more segments of a `run_distributed` job list failed; `.failures` = [(job index, rank, message)]."""
+
+    def __init__(self, failures):
+        self.failures = list(failures)
+        super().__init__("; ".join("segment %d failed on rank %d: %s" % f for f in self.failures))
+
+
 def run_distributed(all_stark, config, jobs: Sequence[SegmentJob], device: int = 0, in_flight: int = 1,
-                    group=None, prove_fn=None, gather: bool = True):
+                    group=None, prove_fn=None, gather: bool = True, encode=None, decode=None):
     """One process per GPU: rank r proves jobs r, r + W, r + 2W, ... on `device` and rank 0 receives all proofs in
-    job order (None elsewhere).  Without an initialised process group this is the single-process scheduler."""
+    job order (None elsewhere).  Without an initialised process group this is the single-process scheduler.
+
+    What crosses ranks is u64 words in tensors (collectives.py; RCCL on the GPU node): `encode(result) -> u64 array`
+    on the proving rank, `decode(words, job) -> result` on rank 0 -- by default the flat `AllProof` words of
+    segment.all_proof_to_words (the job's `PublicValues` stay with the submitter).  A failed segment never strands the
+    other ranks: failures are caught per job, travel through the same gather as (index, message) records, and every
+    rank raises `SegmentFailure` AFTER the collective (so all proofs that did succeed have been delivered)."""
+    import numpy as np
     import torch.distributed as dist
+
+    from . import collectives as co
     world, rank = 1, 0
-    if dist.is_available() and dist.is_initialized():
+    multi = dist.is_available() and dist.is_initialized()
+    if multi:
         world, rank = dist.get_world_size(group), dist.get_rank(group)
     mine = assign_segments(len(jobs), world)[rank]
+    results, failures = [], []
     with SegmentScheduler(all_stark, config, [device], in_flight, prove_fn) as sch:
-        local = sch.map([jobs[i] for i in mine])
-    if world == 1 or not gather:
+        futs = [sch.submit(jobs[i]) for i in mine]
+        for i, f in zip(mine, futs):
+            try:
+                results.append((i, f.result()))
+            except Exception as e:             # the failure is reported through the collective below, not instead of it
+                failures.append((i, rank, repr(e)))
+    if not multi or not gather:                  # (a process group of ONE rank still goes through the collectives below)
+        if multi:
+            co.agree(None if not failures else SegmentFailure(failures), "a segment proof", group)
+        elif failures:
+            raise SegmentFailure(failures)
         out = [None] * len(jobs)
-        for i, p in zip(mine, local):
+        for i, p in results:
             out[i] = p
         return out
-    parts = [None] * world if rank == 0 else None
-    dist.gather_object(list(zip(mine, local)), parts, dst=0, group=group)
+    if encode is None:
+        from . import segment as sg
+        encode = sg.all_proof_to_words
+        decode = lambda w, job: sg.all_proof_from_words(w, job.public_values)          # noqa: E731
+    recs = []
+    for i, p in results:
+        try:
+            recs.append(np.concatenate([np.array([i, 0], dtype=np.uint64), np.asarray(encode(p), dtype=np.uint64).reshape(-1)]))
+        except Exception as e:
+            failures.append((i, rank, "encode: " + repr(e)))
+    for i, r, msg in failures:
+        recs.append(np.concatenate([np.array([i, 1], dtype=np.uint64), co.text_words(msg)]))
+    parts = co.gather_varlen_words(co.pack_records(recs), dst=0, group=group)
+    # every rank learns whether anything failed anywhere (one more tiny all-reduce), so that all of them raise
+    n_failed = sum(int(x[0]) for x in co.all_gather_words(np.array([len(failures)], dtype=np.uint64), 1, group))
     if rank != 0:
+        if failures:
+            raise SegmentFailure(failures)
+        if n_failed:
+            raise co.RemoteRankError("%d segment(s) failed on other ranks" % n_failed)
         return None
     out = [None] * len(jobs)
-    for part in parts:
-        for i, p in part:
-            out[i] = p
+    all_failures = []
+    for r, part in enumerate(parts):
+        for rec in co.unpack_records(part):
+            i, status = int(rec[0]), int(rec[1])
+            if status:
+                all_failures.append((i, r, co.words_text(rec[2:])))
+            else:
+                out[i] = decode(rec[2:], jobs[i])
+    if all_failures:
+        err = SegmentFailure(sorted(all_failures))
+        err.partial = out                      # the proofs that did succeed
+        raise err
     return out

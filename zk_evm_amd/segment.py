@@ -305,6 +305,40 @@ class AllProof:
         return [p.proof.degree_bits if p is not None else None for p in self.multi_proof.stark_proofs]
 
 
+def all_proof_to_words(p: AllProof) -> np.ndarray:
+    """Flat u64 words of an `AllProof` minus the `PublicValues` the submitter already holds (only the two `MemCap`s, which
+    the prover fills in, travel): what `scheduler.run_distributed` / `sharding` gather on rank 0 with tensor collectives."""
+    from .collectives import pack_records
+    mp = p.multi_proof
+    mb = np.array(p.public_values.mem_before.mem_cap, dtype=np.uint64).reshape(-1)
+    ma = np.array(p.public_values.mem_after.mem_cap, dtype=np.uint64).reshape(-1)
+    head = np.array([len(mp.stark_proofs), len(mp.ctl_challenges)] + [int(bool(u)) for u in p.table_in_use] +
+                    [x % (1 << 64) for bg in mp.ctl_challenges for x in bg], dtype=np.uint64)
+    recs = [head, mb, ma]
+    for sp in mp.stark_proofs:
+        recs.append(np.zeros(0, np.uint64) if sp is None else sp.proof.to_words())
+    return pack_records(recs)
+
+
+def all_proof_from_words(w: np.ndarray, public_values: PublicValues) -> AllProof:
+    from .collectives import unpack_records
+    recs = unpack_records(w)
+    head = recs[0]
+    n_tab, nchal = int(head[0]), int(head[1])
+    in_use = [bool(x) for x in head[2: 2 + n_tab]]
+    cc = head[2 + n_tab: 2 + n_tab + 2 * nchal]
+    public_values.mem_before = MemCap.from_elements(recs[1]) if recs[1].size else MemCap()
+    public_values.mem_after = MemCap.from_elements(recs[2]) if recs[2].size else MemCap()
+    proofs: List[Optional[StarkProofWithMetadata]] = []
+    for r in recs[3: 3 + n_tab]:
+        if r.size == 0:
+            proofs.append(None)
+        else:
+            sp, _ = StarkProof.from_words(r)
+            proofs.append(StarkProofWithMetadata(sp, sp.init_challenger_state))
+    return AllProof(MultiProof(proofs, [(int(cc[2 * i]), int(cc[2 * i + 1])) for i in range(nchal)]), public_values, in_use)
+
+
 class Aborted(ZkStarkError):
     def __init__(self):
         super().__init__(-4, "Stopping job from abort signal.")
@@ -321,13 +355,13 @@ def check_abort_signal(abort_signal) -> None:
 
 def prove_single_table(all_stark: AllStark, table: int, config: StarkConfig, trace_values, trace_commitment,
                        ctl_data: Sequence[CtlZData], ctl_challenges, challenger: Challenger,
-                       abort_signal=None) -> StarkProofWithMetadata:
+                       abort_signal=None, aux_commitment=None) -> StarkProofWithMetadata:
     """prover.rs:301-341 for one table of `all_stark` (zk_prove_table: compact, then starky prove_with_commitment)."""
     from .prover import prove_single_table as _prove
     check_abort_signal(abort_signal)
     proof = _prove(all_stark.table_air[table], config, trace_values, trace_commitment, all_stark.lookups[table],
                    ctl_data, ctl_challenges, challenger, constraint_degree=all_stark.constraint_degree,
-                   air_consts=all_stark.air_consts[table])
+                   air_consts=all_stark.air_consts[table], aux_commitment=aux_commitment)
     return StarkProofWithMetadata(proof, proof.init_challenger_state)
 
 
@@ -365,8 +399,9 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
                       check_ctls: Optional[Tuple[int, int]] = None) -> AllProof:
     """prover.rs:72-194 as ONE C-ABI call (zk_prove_segment; the sequencing is compiled, csrc/segment_host.inc).
     `trace_poly_values[t]`: CUDA int64/uint64 tensor (columns, 2^k) -- the column-major
-    `Vec<PolynomialValues<F>>` of table t (values may be non-canonical).  `abort_signal`: a ctypes c_int that
-    another thread may set (polled between kernels) or an object with `.is_set()` (checked on entry).
+    `Vec<PolynomialValues<F>>` of table t (values may be non-canonical).  `abort_signal`: a ctypes
+    c_int (or one-byte c_uint8 / c_bool, the reference's `AtomicBool` layout) that another thread may set (polled between
+    kernels) or an object with `.is_set()` (checked on entry).
     `timing`: optional dict receiving the reference's TimingTree scopes in seconds.
     `check_ctls`: (kernel_hash, kernel_len) switches on the reference's debug-build `check_ctls` (prover.rs:164-184): the
     library verifies every cross-table lookup (Memory with the public values' extra looking rows) right after the CTL
@@ -384,7 +419,7 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
     hasher = config.hasher if hasher is None else hasher
     ctx = ctx or default_context(trace_poly_values[0].device.index or 0)
     ctx.use_torch_current_stream()
-    if isinstance(abort_signal, C.c_int):
+    if isinstance(abort_signal, (C.c_int, C.c_uint8, C.c_bool)):
         ctx.set_abort_flag(abort_signal)
     cfg = config.to_c()
     cfg.hasher = hasher
@@ -425,7 +460,7 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
             raise Aborted()
         ctx.check(rc)
     finally:
-        if isinstance(abort_signal, C.c_int):
+        if isinstance(abort_signal, (C.c_int, C.c_uint8, C.c_bool)):
             ctx.set_abort_flag(None)
         if check_ctls is not None:
             ctx.lib.zk_ctx_set_check_ctls(ctx.handle, 0)

@@ -5,9 +5,9 @@ Two levels shard naturally in the reference:
     reference maps them onto workers at zero/src/prover.rs:221-224)  -> `assign_segments`;
   * inside one segment the per-table trace commitments are transcript-independent
     (prover.rs:90-111) until their caps are observed in fixed table order (prover.rs:118-127)
-    -> `assign_tables` (largest-first onto the least-loaded rank) + `gather_caps`, the only
-    exchange step: an all-gather of 2^cap_height x 32 bytes per table.
-No bulk data ever moves between GPUs.  One process per GPU; `torch.distributed` backend "nccl"
+    -> `assign_tables` (largest-first onto the least-loaded rank) + `gather_caps`: an all-gather of
+    2^cap_height x 32 bytes per table; after it only the 31-word challenger state travels, owner -> all, once per table.
+No bulk data ever moves between GPUs, and nothing that moves is a pickled object (collectives.py).  One process per GPU; `torch.distributed` backend "nccl"
 (RCCL) on the GPU box, "gloo" in the CPU tests.
 """
 from typing import Dict, List, Sequence
@@ -48,30 +48,21 @@ def gather_caps(local_caps: Dict[int, np.ndarray], n_tables: int, cap_len: int =
                 group=None) -> List[np.ndarray]:
     """All-gather the Merkle caps computed by each rank into table order.
     local_caps: {table_index: (cap_len, 4) uint64}.  Returns the list of all n_tables caps on
-    every rank (what `prove_with_traces` feeds to the Challenger, prover.rs:113-127)."""
-    import torch
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        assert len(local_caps) == n_tables
-        return [np.ascontiguousarray(local_caps[t], dtype=np.uint64) for t in range(n_tables)]
-    world = dist.get_world_size(group)
-    backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    # fixed-size payload: [owner_flag, cap words...] per table so a plain all_gather suffices
-    buf = torch.zeros((n_tables, 1 + cap_len * 4), dtype=torch.int64)
+    every rank (what `prove_with_traces` feeds to the Challenger, prover.rs:113-127).
+    One fixed-shape all-gather ([owner flag, cap words] per table; RCCL moves it from device memory under nccl)."""
+    from .collectives import all_gather_words
+    row = 1 + cap_len * 4
+    buf = np.zeros((n_tables, row), dtype=np.uint64)
     for t, cap in local_caps.items():
         buf[t, 0] = 1
-        buf[t, 1:] = torch.from_numpy(np.ascontiguousarray(cap, dtype=np.uint64).view(np.int64).reshape(-1))
-    buf = buf.to(dev)
-    parts = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(parts, buf, group=group)
+        buf[t, 1:] = np.ascontiguousarray(cap, dtype=np.uint64).reshape(-1)
     out: List[np.ndarray] = [None] * n_tables  # type: ignore
-    for p in parts:
-        p = p.cpu()
+    for p in all_gather_words(buf.reshape(-1), n_tables * row, group):
+        p = p.reshape(n_tables, row)
         for t in range(n_tables):
             if int(p[t, 0]) == 1:
                 assert out[t] is None, f"table {t} committed by two ranks"
-                out[t] = p[t, 1:].numpy().view(np.uint64).reshape(cap_len, 4).copy()
+                out[t] = p[t, 1:].reshape(cap_len, 4).copy()
     missing = [t for t in range(n_tables) if out[t] is None]
     assert not missing, f"tables {missing} were committed by no rank"
     return out
@@ -84,119 +75,166 @@ def prove_segment_table_parallel(all_stark, config, trace_poly_values, table_in_
 
     What shards (prover.rs:90-111): every table's trace commitment is independent of the transcript, and a table's CTL /
     logUp columns and its whole `prove_single_table` only read that table's own trace and LDEs -- so table t lives on
-    exactly one rank (`assign_tables`, largest first) and no bulk data ever moves.  What does not: Fiat-Shamir.  The trace
-    caps are observed in table order before anything else (prover.rs:118-127) -> ONE all-gather of 2^cap_height x 32 B per
-    table (`gather_caps`); from then on every rank replays the same transcript (public values, CTL challenges), and the
-    per-table proofs run in table order on their owners with the 31-word challenger state broadcast from owner to all
-    after each table (prover.rs:251-259: the chain is serial by construction, the recursive verifier enforces it).
+    exactly one rank (`assign_tables`, largest first) and no bulk data ever moves.  What does not: Fiat-Shamir.
+      phase 1  trace commitments of the owned tables, in parallel; the caps are observed in table order before anything
+               else (prover.rs:118-127) -> ONE all-gather of 2^cap_height x 32 B per table (`gather_caps`); every rank
+               then replays the same transcript (public values, CTL challenges);
+      phase 2  CTL running sums, logUp helper columns and the AUXILIARY COMMITMENT of every owned table, in parallel on all
+               ranks: they depend on the CTL challenges only (prover.rs:134-144; lookup challenges = the CTL betas, :328);
+      phase 3  the per-table proofs in table order on their owners (prover.rs:251-259: serial by construction, the
+               recursive verifier enforces the order), the 31-word challenger state broadcast owner -> all after each.
+    Everything that crosses ranks is a fixed-shape int64 tensor (collectives.py): table shapes, a status word after every
+    local step (a failing rank never strands the others in a collective: all of them raise), caps, challenger states,
+    and at the end the flat proof words gathered on rank 0.
 
     trace_poly_values[t] is only read on the owner of t (others may pass None).  Returns the `AllProof` on rank 0 of the
     group (None elsewhere); bit-identical to the single-GPU `prove_with_traces`.  Latency, not throughput: the chain is
-    serial, so the gain is bounded by (largest trace commitment + sum of the per-table proofs) / (single-GPU time) --
-    independent segments on independent GPUs (`scheduler.run_distributed`) remain the throughput path."""
+    serial, so the gain is bounded by (largest trace commitment + largest phase 2 + sum of the chain steps) / (single-GPU
+    time) -- independent segments on independent GPUs (`scheduler.run_distributed`) remain the throughput path."""
     import time
+    from itertools import groupby
 
     import torch
     import torch.distributed as dist
 
+    from . import collectives as co
     from . import segment as sg
     from .challenger import Challenger
     from .context import default_context
     from .polynomial_batch import PolynomialBatch
-    from .prover import CtlZData
+    from .prover import CtlZData, StarkProof, table_aux_commit
     from .stark import _trace_args, ctl_partial_sums
     multi = dist.is_available() and dist.is_initialized()
     world, rank = (dist.get_world_size(group), dist.get_rank(group)) if multi else (1, 0)
     n_tab = all_stark.num_tables
     hasher = config.hasher
     fri = config.fri_config
-    # every rank needs the shapes to compute the same assignment: exchange (cols, log_n) of the tables it was given
-    shapes = [None] * n_tab
+    deg = all_stark.constraint_degree
+
+    def step(what, fn):
+        """run a local step; afterwards every rank knows whether all ranks succeeded"""
+        err, val = None, None
+        try:
+            val = fn()
+        except Exception as e:                      # noqa: BLE001 -- re-raised by agree() on this rank
+            err = e
+        co.agree(err, what, group)
+        return val
+    # every rank needs the shapes to compute the same assignment: (cols, log_n) of the tables it was given, (0, 0) = absent
+    mine_shapes = np.zeros((n_tab, 2), dtype=np.uint64)
     for t, tr in enumerate(trace_poly_values):
         if tr is not None:
             c, n, ln, _ = _trace_args(tr)
-            shapes[t] = (c, ln)
-    if multi:
-        allsh = [None] * world
-        dist.all_gather_object(allsh, shapes, group=group)
-        for sh in allsh:
-            for t, s in enumerate(sh):
-                if s is not None:
-                    shapes[t] = s
-    if any(s is None for s in shapes):
-        raise ValueError("every table's trace must be present on at least one rank")
-    owner = [0] * n_tab
-    for r, ts in enumerate(assign_tables(shapes, world)):
-        for t in ts:
-            owner[t] = r
-    mine = [t for t in range(n_tab) if owner[t] == rank]
-    missing = [t for t in mine if trace_poly_values[t] is None]
-    if missing:
-        raise ValueError("rank %d owns tables %s but was not given their traces" % (rank, missing))
+            mine_shapes[t] = (c, ln)
+    shapes = [None] * n_tab
+    for part in co.all_gather_words(mine_shapes.reshape(-1), 2 * n_tab, group):
+        for t, (c, ln) in enumerate(part.reshape(n_tab, 2)):
+            if int(c):
+                shapes[t] = (int(c), int(ln))
+
+    def plan():
+        if any(s is None for s in shapes):
+            raise ValueError("every table's trace must be present on at least one rank")
+        owner = [0] * n_tab
+        for r, ts in enumerate(assign_tables(shapes, world)):
+            for t in ts:
+                owner[t] = r
+        mine = [t for t in range(n_tab) if owner[t] == rank]
+        missing = [t for t in mine if trace_poly_values[t] is None]
+        if missing:
+            raise ValueError("rank %d owns tables %s but was not given their traces" % (rank, missing))
+        return owner, mine
+    owner, mine = step("the table assignment", plan)
     dev0 = trace_poly_values[mine[0]].device if mine else None
     ctx = ctx or default_context((dev0.index or 0) if dev0 is not None else torch.cuda.current_device())
     t0 = time.perf_counter()
     # ---- phase 1: trace commitments of the owned tables, one all-gather of caps -----------------------------------
-    batches = {t: PolynomialBatch.from_values(trace_poly_values[t], fri.rate_bits, False, fri.cap_height, hasher=hasher, ctx=ctx)
-               for t in mine}
-    caps = gather_caps({t: batches[t].merkle_tree.cap.elements for t in mine}, n_tab, 1 << fri.cap_height, group)
-    t1 = time.perf_counter()
-    # ---- transcript seed, replicated (prover.rs:114-144) ---------------------------------------------------------------
-    ch = Challenger(hasher)
-    for t in range(n_tab):
-        if t in all_stark.optional_table_indices and not table_in_use[t]:
-            ch.observe_elements([0] * (4 << fri.cap_height))
-        else:
-            ch.observe_cap(caps[t])
-    sg.observe_public_values(ch, public_values)
-    ctl_challenges = [(ch.get_challenge(), ch.get_challenge()) for _ in range(config.num_challenges)]
-    # ---- CTL data of the owned tables (starky cross_table_lookup_data, restricted to this rank's tables) -------------
-    from itertools import groupby
-    zdata = {t: [] for t in mine}
-    deg = all_stark.constraint_degree
-    for ctl in all_stark.cross_table_lookups:
-        looked = ctl.looked_table
-        for beta, gamma in ctl_challenges:
-            for table, grp in groupby(ctl.looking_tables, key=lambda x: x.table):
-                entries = [(x.columns, x.filter) for x in grp]
-                if table in zdata and table_in_use[table]:
-                    aux = ctl_partial_sums(trace_poly_values[table], entries, beta, gamma, deg, ctx=ctx)
-                    allc = [(x.columns, x.filter) for x in ctl.looking_tables if x.table == table]
-                    zdata[table].append(CtlZData(beta, gamma, allc, aux))
-            if looked.table in zdata and table_in_use[looked.table]:
-                z = ctl_partial_sums(trace_poly_values[looked.table], [(looked.columns, looked.filter)], beta, gamma, deg, ctx=ctx)
-                zdata[looked.table].append(CtlZData(beta, gamma, [(looked.columns, looked.filter)], z))
-    t2 = time.perf_counter()
-    # ---- the chain: tables in order on their owners, challenger state handed on (prover.rs:251-259) -------------------
-    proofs = {}
-    for t in range(n_tab):
-        if not table_in_use[t]:
-            continue
-        if owner[t] == rank:
-            p = sg.prove_single_table(all_stark, t, config, trace_poly_values[t], batches[t], zdata[t], ctl_challenges, ch)
-            proofs[t] = p
-            batches[t].free() if t not in (sg.Table.MemBefore, sg.Table.MemAfter) else None
-        if multi:
-            state = [ch.export_state() if owner[t] == rank else None]
-            dist.broadcast_object_list(state, src=dist.get_global_rank(group, owner[t]) if group is not None else owner[t], group=group)
+    batches = step("a trace commitment", lambda: {
+        t: PolynomialBatch.from_values(trace_poly_values[t], fri.rate_bits, False, fri.cap_height, hasher=hasher, ctx=ctx)
+        for t in mine})
+    aux = {}
+    try:
+        caps = gather_caps({t: batches[t].merkle_tree.cap.elements for t in mine}, n_tab, 1 << fri.cap_height, group)
+        t1 = time.perf_counter()
+        # ---- transcript seed, replicated (prover.rs:114-144) ---------------------------------------------------------------
+        ch = Challenger(hasher)
+        for t in range(n_tab):
+            if t in all_stark.optional_table_indices and not table_in_use[t]:
+                ch.observe_elements([0] * (4 << fri.cap_height))
+            else:
+                ch.observe_cap(caps[t])
+        step("the public values", lambda: sg.observe_public_values(ch, public_values))
+        ctl_challenges = [(ch.get_challenge(), ch.get_challenge()) for _ in range(config.num_challenges)]
+        # ---- phase 2, parallel over the ranks: CTL data, logUp columns and the auxiliary commitment of the owned tables ----
+        zdata = {t: [] for t in mine}
+
+        def phase2():
+            for ctl in all_stark.cross_table_lookups:        # starky cross_table_lookup_data, restricted to this rank's tables
+                looked = ctl.looked_table
+                for beta, gamma in ctl_challenges:
+                    for table, grp in groupby(ctl.looking_tables, key=lambda x: x.table):
+                        entries = [(x.columns, x.filter) for x in grp]
+                        if table in zdata and table_in_use[table]:
+                            cols = ctl_partial_sums(trace_poly_values[table], entries, beta, gamma, deg, ctx=ctx)
+                            allc = [(x.columns, x.filter) for x in ctl.looking_tables if x.table == table]
+                            zdata[table].append(CtlZData(beta, gamma, allc, cols))
+                    if looked.table in zdata and table_in_use[looked.table]:
+                        z = ctl_partial_sums(trace_poly_values[looked.table], [(looked.columns, looked.filter)], beta, gamma, deg, ctx=ctx)
+                        zdata[looked.table].append(CtlZData(beta, gamma, [(looked.columns, looked.filter)], z))
+            for t in mine:
+                if table_in_use[t]:
+                    aux[t] = table_aux_commit(config, trace_poly_values[t], all_stark.lookups[t], zdata[t], ctl_challenges, deg,
+                                              hasher=hasher, ctx=ctx)
+        step("the auxiliary commitments (phase 2)", phase2)
+        t2 = time.perf_counter()
+        # ---- phase 3, the chain: tables in order on their owners, challenger state handed on (prover.rs:251-259) ----------
+        proofs = {}
+        for t in range(n_tab):
+            if not table_in_use[t]:
+                continue
+            state, err = np.zeros(32, dtype=np.uint64), None
+            if owner[t] == rank:
+                try:
+                    proofs[t] = sg.prove_single_table(all_stark, t, config, trace_poly_values[t], batches[t], zdata[t],
+                                                      ctl_challenges, ch, aux_commitment=aux.get(t))
+                    state[1:] = ch.export_state()
+                except Exception as e:              # noqa: BLE001 -- announced to the other ranks below, then re-raised
+                    err = e
+                    state[0] = 1
+            if multi:
+                state = co.broadcast_words(state, 32, owner[t], group)
+            if err is not None:
+                raise err
+            if int(state[0]):
+                raise co.RemoteRankError("the proof of table %d failed on rank %d" % (t, owner[t]))
             if owner[t] != rank:
-                ch.import_state(state[0])
-    t3 = time.perf_counter()
-    for t in list(batches):
-        if batches[t].handle:
-            batches[t].free()
+                ch.import_state(state[1:])
+            else:
+                if aux.get(t) is not None:
+                    aux.pop(t).free()
+                if t not in (sg.Table.MemBefore, sg.Table.MemAfter):
+                    batches[t].free()
+        t3 = time.perf_counter()
+    finally:
+        for b in list(batches.values()) + [a for a in aux.values() if a is not None]:
+            if b.handle:
+                b.free()
     if timing is not None:
-        timing.update({"compute owned trace commitments + cap all-gather": t1 - t0, "compute CTL data (owned tables)": t2 - t1,
+        timing.update({"compute owned trace commitments + cap all-gather": t1 - t0,
+                       "CTL data + auxiliary commitments (owned tables, parallel over ranks)": t2 - t1,
                        "per-table proofs (serial chain over owners)": t3 - t2, "tables owned": mine})
-    parts = [proofs]
-    if multi:
-        parts = [None] * world if rank == 0 else None
-        dist.gather_object(proofs, parts, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    # ---- the proofs to rank 0: flat words, one padded gather ------------------------------------------------------------
+    recs = []
+    for t in sorted(proofs):
+        recs.append(np.concatenate([np.array([t], dtype=np.uint64), proofs[t].proof.to_words()]))
+    parts = co.gather_varlen_words(co.pack_records(recs), dst=0, group=group)
     if rank != 0:
         return None
     merged = {}
     for part in parts:
-        merged.update(part)
+        for rec in co.unpack_records(part):
+            pr, _ = StarkProof.from_words(rec[1:])
+            merged[int(rec[0])] = sg.StarkProofWithMetadata(pr, pr.init_challenger_state)
     mb, ma = caps[sg.Table.MemBefore], caps[sg.Table.MemAfter].copy()
     if not table_in_use[sg.Table.MemAfter]:
         ma[:] = 0
