@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group (and run barrier / MAX all-reduce / cap all-gather through it) even "
                          "with ONE rank: executes the RCCL path of an N-GPU run on a single-GPU box")
+    ap.add_argument("--no-dist-selftest", action="store_true",
+                    help="N = 1 only: do not join a one-rank process group (the `dist` object of the line)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["segment", "commit"], default="segment")
@@ -752,7 +754,8 @@ KERNEL_CLASSES = (   # (class, substring of the rocprofv3 kernel name)
     ("leaf_hash", "hash_rows_kernel<false>"), ("leaf_hash_coop", "hash_rows_coop_kernel"),
     ("ntt_coeffs_to_values", "ntt_pass_kernel<true>"), ("ntt_values_to_coeffs", "ntt_pass_kernel<false>"),
     ("merkle_levels", "merkle_level"), ("fri_combine", "fri_combine_kernel"), ("openings", "eval_columns_partial_kernel"),
-    ("helper_columns", "helper_cols_kernel"), ("lookup_singles", "lookup_singles_kernel"))
+    ("helper_columns", "helper_cols_kernel"), ("lookup_singles", "lookup_singles_kernel"),
+    ("quotient_checks", "quotient_checks_kernel"))
 
 
 def kernel_class(name):
@@ -781,7 +784,7 @@ def collect_kernel_counters(a, timeout_s=300, passes=("trace", "fetch", "write")
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
-    table = {}
+    table, seq = {}, {}
     spec = {"trace": [], "fetch": ["FETCH_SIZE", "SQ_INSTS_VALU", "GRBM_GUI_ACTIVE"], "write": ["WRITE_SIZE"]}
     key = {"FETCH_SIZE": "fetch_kib", "WRITE_SIZE": "write_kib", "SQ_INSTS_VALU": "valu_wave_insts", "GRBM_GUI_ACTIVE": "gui_active"}
     for name in passes:
@@ -799,12 +802,16 @@ def collect_kernel_counters(a, timeout_s=300, passes=("trace", "fetch", "write")
                 return None
             if name == "trace":
                 for path in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
-                    for row in csv.DictReader(open(path)):
+                    rows = sorted(csv.DictReader(open(path)), key=lambda r: float(r["Start_Timestamp"]))
+                    for row in rows:
                         cls = kernel_class(row.get("Kernel_Name", ""))
                         if cls:
+                            ms = (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-6
                             e = table.setdefault(cls, {"launches": 0, "ms": 0.0})
                             e["launches"] += 1
-                            e["ms"] += (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-6
+                            e["ms"] += ms
+                            if cls.startswith("quotient"):          # per dispatch, in launch order (= table order)
+                                seq.setdefault("ms", []).append((cls, ms))
             else:
                 for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                     for row in csv.DictReader(open(path)):
@@ -814,12 +821,19 @@ def collect_kernel_counters(a, timeout_s=300, passes=("trace", "fetch", "write")
                             e[key[row["Counter_Name"]]] = e.get(key[row["Counter_Name"]], 0.0) + float(row["Counter_Value"])
                             if row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                                 e["n_" + key[row["Counter_Name"]]] = e.get("n_" + key[row["Counter_Name"]], 0) + 1
+                                if cls.startswith("quotient"):
+                                    seq.setdefault(key[row["Counter_Name"]], []).append(
+                                        (int(row.get("Dispatch_Id", 0)), cls, float(row["Counter_Value"])))
             if keep_dir:
                 shutil.copytree(d, os.path.join(keep_dir, name), dirs_exist_ok=True)
         except Exception:
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
+    if table and seq:
+        table["_quotient_sequence"] = {"ms": seq.get("ms", []),
+                                       "fetch_kib": [(c, v) for _, c, v in sorted(seq.get("fetch_kib", []))],
+                                       "write_kib": [(c, v) for _, c, v in sorted(seq.get("write_kib", []))]}
     return table or None
 
 
@@ -843,21 +857,43 @@ def kernel_counter_report(kc, log_ns, all_stark, cfg, cdk_erigon):
         # reads (C + A) LDE columns once at each of the 2n coset points, writes 2 challenge values per point
         alg[cls] = alg.get(cls, 0.0) + 8.0 * (c + n_aux[t]) * (2 << log_ns[t]) + 16.0 * (2 << log_ns[t])
     rep = {}
+    qseq = kc.pop("_quotient_sequence", None)
     for cls, e in sorted(kc.items(), key=lambda kv: -kv[1].get("ms", 0.0)):
         r = {"launches": e["launches"], "ms": e["ms"]}
         if e.get("n_fetch_kib") and e.get("n_write_kib"):
             r["fetch_bytes_reported"] = e["fetch_kib"] * 1024.0
             r["write_bytes"] = e["write_kib"] * 1024.0
             r["traffic_bytes"] = (2.0 * e["fetch_kib"] + e["write_kib"]) * 1024.0
-            if cls in alg:
-                r["algorithmic_bytes"] = alg[cls]
-                r["traffic_over_algorithmic"] = r["traffic_bytes"] / alg[cls]
-                r["reported_over_algorithmic"] = (e["fetch_kib"] + e["write_kib"]) * 1024.0 / alg[cls]
             if e["ms"] > 0:
                 r["traffic_GBs"] = r["traffic_bytes"] / e["ms"] / 1e6
         if e.get("valu_wave_insts") and e.get("gui_active"):
             r["cycles_per_wave_instruction"] = e["gui_active"] / 8.0 * 1024.0 / e["valu_wave_insts"]
         rep[cls] = r
+    # The quotient of a table is TWO launches -- its AIR kernel, then the lookup / CTL checks kernel (when it has any) -- in
+    # table order; their traffic together is compared with the table's algorithmic bytes 8 (C + A) 2n + 16 * 2n.
+    if qseq and qseq["ms"]:
+        def per_table(items):
+            out, cur = [], None
+            for cls, v in items:
+                if cls != "quotient_checks":
+                    cur = [cls, v, 0.0]
+                    out.append(cur)
+                elif cur is not None:
+                    cur[2] += v
+            return out
+        ms, fe, wr = per_table(qseq["ms"]), per_table(qseq["fetch_kib"]), per_table(qseq["write_kib"])
+        live = [t for t in range(all_stark.num_tables)]
+        tabs = {}
+        if len(ms) == len(live) and len(fe) == len(live) and len(wr) == len(live):
+            for k, t in enumerate(live):
+                c = all_stark.table_columns[t]
+                algb = 8.0 * (c + n_aux[t]) * (2 << log_ns[t]) + 16.0 * (2 << log_ns[t])
+                traffic = (2.0 * (fe[k][1] + fe[k][2]) + wr[k][1] + wr[k][2]) * 1024.0
+                tabs[names[t]] = {"air_kernel": ms[k][0], "air_ms": ms[k][1], "checks_ms": ms[k][2], "algorithmic_bytes": algb,
+                                  "traffic_bytes": traffic, "traffic_over_algorithmic": traffic / algb,
+                                  "reported_over_algorithmic": ((fe[k][1] + fe[k][2]) + wr[k][1] + wr[k][2]) * 1024.0 / algb}
+            rep["quotient_per_table"] = tabs
+            rep["quotient_ms_total"] = sum(m[1] + m[2] for m in ms)
     rep["_note"] = ("one segment of this workload under rocprofv3, this run: `ms` from a --kernel-trace-only pass; traffic_bytes = "
                     "2 x FETCH_SIZE (gfx950 read correction, MI355X_MICROARCH.md) + WRITE_SIZE; fetch_bytes_reported is FETCH_SIZE "
                     "as rocprofv3 prints it; algorithmic_bytes (quotients) = 8 (C + A) 2n read + 16 * 2n written")
@@ -940,7 +976,11 @@ def main():
         local_dev = [int(x) for x in a.devices.split(",")][local]
     else:
         local_dev = local
-    use_dist = world > 1 or a.force_dist
+    # A single rank joins a process group of one as well (unless --no-dist-selftest / a non-default workload): the N = 1
+    # line then exercises the same init / barrier / all-reduce / collectives as the N > 1 run, on RCCL.  At world size 1 a
+    # failure to initialise is recorded in the line instead of ending the run.
+    use_dist = world > 1 or a.force_dist or (a.workload == "segment" and not a.no_dist_selftest and not a.pmc_child)
+    dist_error = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1 and "MASTER_PORT" not in os.environ:
@@ -949,11 +989,16 @@ def main():
             sk.bind(("127.0.0.1", 0))
             os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             sk.close()
-        if a.dist_backend == "nccl":
-            torch.cuda.set_device(local_dev)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_dev}"))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            if a.dist_backend == "nccl":
+                torch.cuda.set_device(local_dev)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_dev}"))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+        except Exception as e:
+            if world > 1 or a.force_dist:
+                raise
+            use_dist, dist_error = False, repr(e)
     torch.cuda.set_device(local_dev)
     dev = torch.device(f"cuda:{local_dev}")
     local = local_dev
@@ -1200,9 +1245,17 @@ def main():
                                    "cycles_per_wave_instruction of 3.5-3.6 is an issue-saturated SIMD",
                         "source": "rocprofv3 --pmc SQ_INSTS_VALU and GRBM_GUI_ACTIVE (/ 8 XCDs x 1024 SIMDs) of the same launches, "
                                   "this run", "measured_in_this_run": True}
-                    perms_per_launch = roof.get("permutations_per_launch")
-                    if perms_per_launch:
-                        roof["valu"]["instructions_per_permutation"] = insts * 64.0 / perms_per_launch
+                    # all 27 leaf-hash launches of the profiled segment (main and side lane): total instructions / total
+                    # permutations = N * ceil(cols / 8) per commitment with more than 4 columns
+                    seg_perms = 0.0
+                    for t in range(all_stark.num_tables):
+                        h, z, _ = sg.num_ctl_helpers_zs_all(all_stark.cross_table_lookups, t, cfg.num_challenges, all_stark.constraint_degree)
+                        lk = sum(cfg.num_challenges * l.num_helper_columns(all_stark.constraint_degree) for l in all_stark.lookups[t])
+                        for c in (all_stark.table_columns[t], lk + h + z):
+                            if c > 4:
+                                seg_perms += (2 << log_ns[t]) * ((c + 7) // 8)
+                    if seg_perms:
+                        roof["valu"]["instructions_per_permutation"] = lh["valu_wave_insts"] * 64.0 / seg_perms
                 ntt = [kc.get("ntt_coeffs_to_values"), kc.get("ntt_values_to_coeffs")]
                 if all(k and k.get("n_fetch_kib") and k.get("n_write_kib") for k in ntt):
                     tr = sum((2.0 * k["fetch_kib"] + k["write_kib"]) * 1024.0 for k in ntt)
@@ -1244,6 +1297,8 @@ def main():
         selftest = dist_selftest(rank, world, a.dist_backend)
         if rank == 0 and out is not None:
             out["dist"] = selftest
+    if rank == 0 and out is not None and dist_error:
+        out["dist"] = {"ok": False, "error": dist_error, "backend": a.dist_backend, "world": world}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:

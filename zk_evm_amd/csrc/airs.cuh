@@ -125,27 +125,41 @@ struct AirBytePacking {
     static constexpr u32 COLUMNS = 71;
     template <class CONS>
     __device__ static __forceinline__ void eval(const RowView &lv, const RowView &nv, CONS &c, const u64 *) {
+        // Every column is loaded ONCE: the 32 value bytes stay in registers for the 496 pairwise products
+        // index_len[i] * value_bytes[j] (j > i), which are yielded as 31 scaled runs (one dot product over the bytes per
+        // i and challenge, one multiply by index_len[i]) at their reference positions; the order-free constraint_at puts
+        // everything else at its position too.  Positions (byte_packing_stark.rs:296-352): 0 first_row(rc), 1 transition
+        // (incr), 2 last_row(rc), 3 filter binary, 4 first_row(filter - 1), 5 is_read binary, 6..37 index_len binary,
+        // 38 transition(next_filter), 39..534 the pairs -- 535 in all.
         constexpr u32 NUM_BYTES = 32, IDX = 1, VAL = 37;
         const Fe one = FE_ONE;
-        Fe rc1 = lv[69], rc2 = nv[69];
-        c.constraint_first_row(rc1);
-        Fe incr = rc2 - rc1;
-        c.constraint_transition(incr * incr - incr);
-        c.constraint_last_row(rc1 - fe(255));  // BYTE_RANGE_MAX - 1
+        Fe val[NUM_BYTES];
+#pragma unroll
+        for (u32 j = 0; j < NUM_BYTES; ++j) val[j] = lv[VAL + j];
         Fe current_filter;
-        for (u32 i = 0; i < NUM_BYTES; ++i) current_filter += lv[IDX + i];
-        c.constraint(current_filter * (current_filter - one));
-        c.constraint_first_row(current_filter - one);
-        Fe is_read = lv[0];
-        c.constraint(is_read * (is_read - one));
-        for (u32 i = 0; i < NUM_BYTES; ++i) { Fe idx = lv[IDX + i]; c.constraint(idx * (idx - one)); }
-        Fe next_filter;
-        for (u32 i = 0; i < NUM_BYTES; ++i) next_filter += nv[IDX + i];
-        c.constraint_transition(next_filter * (next_filter - current_filter));
-        for (u32 i = 0; i + 1 < NUM_BYTES; ++i) {
-            Fe idx = lv[IDX + i];
-            for (u32 j = i + 1; j < NUM_BYTES; ++j) c.constraint(idx * lv[VAL + j]);
+        u32 pair_pos = 39;
+#pragma unroll
+        for (u32 i = 0; i < NUM_BYTES; ++i) {
+            const Fe idx = lv[IDX + i];
+            current_filter += idx;
+            c.constraint_at(6 + i, idx * (idx - one));
+            if (i + 1 < NUM_BYTES) c.template constraint_scaled_run_at<NUM_BYTES>(pair_pos, idx, val, (int)i + 1);
+            pair_pos += NUM_BYTES - 1 - i;
         }
+        Fe next_filter;
+#pragma unroll
+        for (u32 i = 0; i < NUM_BYTES; ++i) next_filter += nv[IDX + i];
+        const Fe rc1 = lv[69], rc2 = nv[69];
+        const Fe incr = rc2 - rc1;
+        const Fe is_read = lv[0];
+        c.constraint_at_first_row(0, rc1);
+        c.constraint_at_transition(1, incr * incr - incr);
+        c.constraint_at_last_row(2, rc1 - fe(255));  // BYTE_RANGE_MAX - 1
+        c.constraint_at(3, current_filter * (current_filter - one));
+        c.constraint_at_first_row(4, current_filter - one);
+        c.constraint_at(5, is_read * (is_read - one));
+        c.constraint_at_transition(38, next_filter * (next_filter - current_filter));
+        c.advance(535);
     }
 };
 

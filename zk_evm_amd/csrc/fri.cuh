@@ -16,7 +16,9 @@
 //     one output are a stride-M column: fully coalesced.
 #pragma once
 #include "gl.cuh"
+#ifndef ZK_DEVICE_FUNCS_ONLY
 #include "poseidon.cuh"
+#endif
 
 __device__ __forceinline__ gl2 gl2_mul_base(gl2 x, u64 s) { return gl2_make(gl_mul(x.a, s), gl_mul(x.b, s)); }
 __device__ __forceinline__ gl2 gl2_inv_dev(gl2 x) {
@@ -75,6 +77,7 @@ __device__ __forceinline__ void dot_acc_mac_v(DotAcc &d, u64 c, u64 v) {
 }
 
 // W[p] = z^bitrev(p, log_n);  zpow[k] = z^(2^k) (ext), k < log_n
+#ifndef ZK_DEVICE_FUNCS_ONLY   // the kernels of openings + FRI (not needed by units that only use DotAcc)
 struct ZPowers { u64 a[32], b[32]; };
 static __global__ void ext_pow_bitrev_table_kernel(u64 *wa, u64 *wb, int log_n, ZPowers zp) {
     u32 p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -320,3 +323,4 @@ static __global__ void gather_words_kernel(const GatherDesc *descs, u32 n_desc, 
     GatherDesc g = descs[d];
     for (u32 i = threadIdx.x; i < g.count; i += blockDim.x) dst[g.dst_off + i] = g.src[(size_t)i * g.stride];  // raw copy (digest slots may hold bytes)
 }
+#endif  // ZK_DEVICE_FUNCS_ONLY

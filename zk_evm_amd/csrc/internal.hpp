@@ -34,13 +34,13 @@ ZK_INTERNAL int zki_get_coset_table(zk_ctx *ctx, int log_n, u64 shift, bool inve
 ZK_INTERNAL int zki_ntt_values_to_coeffs(zk_ctx *ctx, const u64 *src, size_t src_stride, u64 *dst, size_t dst_stride,
                                          size_t n_cols, int log_n, const u64 *out_scale);
 
-// quotient kernels of the table AIRs, one function per AIR group / TU (zk_airs_*.hip).  Returns ZK_AIR_NOT_MINE when
-// `air_id` belongs to another group.
+// quotient kernels of the table AIRs, one function per AIR group / TU (zk_airs_*.hip): launch the AIR kernel, or with
+// `count` measure the number of constraints the AIR yields.  Returns ZK_AIR_NOT_MINE when `air_id` belongs to another group.
 struct QuotientArgs;
 #define ZK_AIR_NOT_MINE 1
 #define ZK_AIR_GROUP_DECL(name)                                                                                          \
-    ZK_INTERNAL int name(zk_ctx *ctx, uint32_t air_id, const QuotientArgs &A, u32 size, const std::vector<u64> &shape_key, \
-                         DevBuf &scratch, size_t n_trace_cols, size_t n_air_consts)
+    ZK_INTERNAL int name(zk_ctx *ctx, uint32_t air_id, const QuotientArgs &A, u32 size, DevBuf &scratch, size_t n_trace_cols, \
+                         size_t n_air_consts, u32 *count)
 ZK_AIR_GROUP_DECL(zki_quotient_airs_a);
 ZK_AIR_GROUP_DECL(zki_quotient_airs_b);
 ZK_AIR_GROUP_DECL(zki_quotient_airs_c);

@@ -69,12 +69,37 @@ struct DotConsumer {
         dot_acc_mac(d0, __builtin_amdgcn_readfirstlane((u32)a), __builtin_amdgcn_readfirstlane((u32)(a >> 32)), c.v);
         dot_acc_mac(d1, __builtin_amdgcn_readfirstlane((u32)b), __builtin_amdgcn_readfirstlane((u32)(b >> 32)), c.v);
     }
+    // Constraints x * v[j], j0 <= j < N, at block positions first, first + 1, ...: their weighted sum is
+    // x * sum_j coef(first + j - j0) v[j] -- one delayed-reduction dot product per challenge and ONE field multiply by x,
+    // instead of a multiply per constraint (the field is exact: same value).
+    template <int N>
+    __device__ __forceinline__ void constraint_scaled_run_at(u32 first, Fe x, const Fe (&v)[N], int j0) {
+        DotAcc s0, s1;
+        dot_acc_init(s0); dot_acc_init(s1);
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (j >= j0) {
+                const u64 a = ap0[-1 - (int)(first + j - j0)], b = ap1[-1 - (int)(first + j - j0)];
+                dot_acc_mac(s0, __builtin_amdgcn_readfirstlane((u32)a), __builtin_amdgcn_readfirstlane((u32)(a >> 32)), v[j].v);
+                dot_acc_mac(s1, __builtin_amdgcn_readfirstlane((u32)b), __builtin_amdgcn_readfirstlane((u32)(b >> 32)), v[j].v);
+            }
+        const Fe w0 = x * Fe(dot_acc_reduce(s0)), w1 = x * Fe(dot_acc_reduce(s1));
+        dot_acc_mac(d0, 1u, 0u, w0.v);
+        dot_acc_mac(d1, 1u, 0u, w1.v);
+    }
+    __device__ __forceinline__ void constraint_at_transition(u32 i, Fe c) { constraint_at(i, c * z_last); }
+    __device__ __forceinline__ void constraint_at_first_row(u32 i, Fe c) { constraint_at(i, c * lagrange_first); }
+    __device__ __forceinline__ void constraint_at_last_row(u32 i, Fe c) { constraint_at(i, c * lagrange_last); }
     __device__ __forceinline__ void advance(u32 n) { ap0 -= n; ap1 -= n; }
 };
 // same interface, only counts (everything feeding the ignored values is dead code)
 struct CountConsumer {
     u32 count;
     __device__ __forceinline__ void constraint_at(u32, Fe) {}
+    template <int N> __device__ __forceinline__ void constraint_scaled_run_at(u32, Fe, const Fe (&)[N], int) {}
+    __device__ __forceinline__ void constraint_at_transition(u32, Fe) {}
+    __device__ __forceinline__ void constraint_at_first_row(u32, Fe) {}
+    __device__ __forceinline__ void constraint_at_last_row(u32, Fe) {}
     __device__ __forceinline__ void advance(u32 n) { count += n; }
     __device__ __forceinline__ void constraint(Fe) { ++count; }
     __device__ __forceinline__ void constraint_transition(Fe) { ++count; }
@@ -149,6 +174,36 @@ __device__ __forceinline__ void check_helper_columns(const CBlob &B, u32 slot, u
     }
 }
 
+// The same for TWO challenges in one walk: blob compiled with two coefficient slots (quotient_host.inc, "TWINS"); the
+// constraints of challenge k are block positions [k * per, (k + 1) * per) -- helper h at k * per + h -- of the block the
+// caller closes with advance(); h0[k] = first helper column of challenge k.  hs[k] accumulates the helper sums.
+template <class CONS, class LD>
+__device__ __forceinline__ void check_helper_columns_dual(const CBlob &B, u32 n_entries, u32 chunk, LD ld, const RowView &aux_lv,
+                                                          const u32 (&h0)[2], u32 per, CONS &cons, Fe (&hs)[2]) {
+    u32 h = 0;
+    for (u32 e = 0; e < n_entries; e += chunk, ++h) {
+        u64 c0[2], f0;
+        centry_eval<2, false>(B, e, ld, c0, f0);
+        if (chunk == 2 && e + 1 < n_entries) {
+            u64 c1[2], f1;
+            centry_eval<2, false>(B, e + 1, ld, c1, f1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const Fe hv = aux_lv[h0[k] + h];
+                hs[k] += hv;
+                cons.constraint_at(k * per + h, Fe(c1[k]) * Fe(c0[k]) * hv - Fe(f0) * Fe(c1[k]) - Fe(f1) * Fe(c0[k]));
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const Fe hv = aux_lv[h0[k] + h];
+                hs[k] += hv;
+                cons.constraint_at(k * per + h, Fe(c0[k]) * hv - Fe(f0));
+            }
+        }
+    }
+}
+
 // Argument block of the quotient kernel.
 struct QuotientArgs {
     const u64 *trace; size_t trace_stride;   // LDE, [C][N] natural
@@ -172,22 +227,33 @@ struct QuotientArgs {
     // blob of CTL z-data z (slot 0) at cblob + cblob[n_lookups + z]
     const u64 *cblob;
     u32 constraint_degree;
+    u32 lookup_dual;      // both lookup challenges in one walk (two-slot blobs)
     const u64 *air_consts;
     u64 *out; size_t out_stride;  // [n_challenges][size] quotient VALUES on the coset
     const u64 *alpha_pow[ZK_MAX_CHALLENGES];   // alpha_k^j, j < n_constraints
-    u32 n_constraints;    // K (from quotient_count_kernel)
+    u32 n_constraints;    // K = AIR constraints + lookup / CTL check constraints
+    u32 n_air_constraints;   // K_air (quotient_count_kernel<Air>); the checks kernel starts at this position
     u32 *count_out;       // quotient_count_kernel: receives K
     int *err_flag;        // set to 3 when the number of constraints met differs from n_constraints
 };
 
-// every constraint of the table at coset point i, in starky's order: AIR, lookups, CTLs
+// The constraints of the table at coset point i, in starky's order: AIR, lookups, CTLs -- evaluated by TWO kernels.  The
+// weighted sum over constraints is additive, so the table's own AIR (`air_constraints`, one kernel per AIR type, compiled
+// in the zk_airs_*.hip units) and the logUp / cross-table-lookup checks (`check_constraints`: data-driven, ONE kernel for
+// every table) each walk their share of the alpha powers -- positions [0, K_air) and [K_air, K) -- and the second adds the
+// first's partial sums before dividing by Z_H.  Each kernel gets the registers and the occupancy its own code needs.
 template <class Air, class CONS>
-__device__ __forceinline__ void quotient_constraints(const QuotientArgs &A, u32 i, u32 size, CONS &cons) {
+__device__ __forceinline__ void air_constraints(const QuotientArgs &A, u32 i, u32 size, CONS &cons) {
     const u32 row = i << A.step_log;
     const u32 row_next = ((i + (1u << A.qd_bits)) & (size - 1)) << A.step_log;
     RowView lv{A.trace, A.trace_stride, row}, nv{A.trace, A.trace_stride, row_next};
     Air::eval(lv, nv, cons, A.air_consts);
-
+}
+template <class CONS>
+__device__ __forceinline__ void check_constraints(const QuotientArgs &A, u32 i, u32 size, CONS &cons) {
+    const u32 row = i << A.step_log;
+    const u32 row_next = ((i + (1u << A.qd_bits)) & (size - 1)) << A.step_log;
+    RowView lv{A.trace, A.trace_stride, row}, nv{A.trace, A.trace_stride, row_next};
     RowView alv{A.aux, A.aux_stride, row}, anv{A.aux, A.aux_stride, row_next};
     const u32 chunk = A.constraint_degree - 1;
     auto ld = [&](u32 col, u32 next, u64 &v) { v = (next ? nv : lv)[col].v; return true; };   // `eval_with_next`
@@ -201,6 +267,27 @@ __device__ __forceinline__ void quotient_constraints(const QuotientArgs &A, u32 
             const u32 ne = (u32)lp[sub];
             const u32 n_help = (ne + chunk - 1) / chunk + 1;
             const CBlob LB(A.cblob + A.cblob[l]);
+            if (A.lookup_dual) {                     // challenges 0 and 1 in one walk over the looked columns
+                const u32 per = n_help + 1;          // n_help - 1 helper checks, Z on the first row, the transition
+                const u32 h0[2] = {start, start + n_help};
+                Fe hs[2];
+                check_helper_columns_dual(LB, ne, chunk, ld, alv, h0, per, cons, hs);
+                u32 pc = sub + (u32)lp[sub + 1 + ne];
+                const Fe tcol = frame_eval_column(lp, pc, lv, nv, false);        // Column::eval: local row only
+                pc = sub + (u32)lp[sub + 2 + ne];
+                const Fe freq = frame_eval_column(lp, pc, lv, nv, false);
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const Fe z = alv[h0[k] + n_help - 1], next_z = anv[h0[k] + n_help - 1];
+                    const Fe table = tcol + Fe(A.lookup_challenges[k]);
+                    const Fe y = hs[k] * table - freq;
+                    cons.constraint_at_first_row(k * per + n_help - 1, z);
+                    cons.constraint_at(k * per + n_help, (next_z - z) * table - y);
+                }
+                cons.advance(2 * per);
+                start += 2 * n_help;
+                continue;
+            }
             for (u32 c = 0; c < A.n_lookup_challenges; ++c) {
                 const u64 ch = A.lookup_challenges[c];
                 check_helper_columns(LB, c, ne, chunk, ld, alv, start, cons);
@@ -232,6 +319,47 @@ __device__ __forceinline__ void quotient_constraints(const QuotientArgs &A, u32 
             const u32 ne = (u32)cp[sub];
             const u32 h0 = A.num_lookup_columns + start_index;
             const CBlob ZB(A.cblob + A.cblob[n_lookups_total + zi]);
+            if (zi + 1 < n_z && A.cblob[n_lookups_total + zi + 1] == ZK_CBLOB_TWIN) {
+                // this z-data and the next are the two challenges of one looking run: one walk (quotient_host.inc "TWINS")
+                const u32 per = n_help + 2;
+                const u32 hh[2] = {h0, h0 + n_help};
+                const u32 zc[2] = {A.num_lookup_columns + A.total_ctl_helper_cols + zi, A.num_lookup_columns + A.total_ctl_helper_cols + zi + 1};
+                Fe hs[2];
+                if (n_help) {
+                    check_helper_columns_dual(ZB, ne, chunk, ld, alv, hh, per, cons, hs);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const Fe local_z = alv[zc[k]], next_z = anv[zc[k]];
+                        cons.constraint_at_last_row(k * per + n_help, local_z - hs[k]);
+                        cons.constraint_at_transition(k * per + n_help + 1, local_z - next_z - hs[k]);
+                    }
+                } else if (ne > 1) {
+                    u64 d0[2], g0, d1[2], g1;
+                    centry_eval<2, false>(ZB, 0, ld, d0, g0);
+                    centry_eval<2, false>(ZB, 1, ld, d1, g1);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const Fe local_z = alv[zc[k]], next_z = anv[zc[k]];
+                        const Fe c0(d0[k]), f0(g0), c1(d1[k]), f1(g1);
+                        cons.constraint_at_last_row(k * per, c0 * c1 * local_z - f0 * c1 - f1 * c0);
+                        cons.constraint_at_transition(k * per + 1, c0 * c1 * (local_z - next_z) - f0 * c1 - f1 * c0);
+                    }
+                } else {
+                    u64 d0[2], g0;
+                    centry_eval<2, false>(ZB, 0, ld, d0, g0);
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const Fe local_z = alv[zc[k]], next_z = anv[zc[k]];
+                        const Fe c0(d0[k]), f0(g0);
+                        cons.constraint_at_last_row(k * per, c0 * local_z - f0);
+                        cons.constraint_at_transition(k * per + 1, c0 * (local_z - next_z) - f0);
+                    }
+                }
+                cons.advance(2 * per);
+                start_index += 2 * n_help;
+                ++zi;
+                continue;
+            }
             if (n_help) check_helper_columns(ZB, 0, ne, chunk, ld, alv, h0, cons);
             const u32 zcol = A.num_lookup_columns + A.total_ctl_helper_cols + zi;
             Fe local_z = alv[zcol], next_z = anv[zcol];
@@ -259,11 +387,13 @@ __device__ __forceinline__ void quotient_constraints(const QuotientArgs &A, u32 
     }
 }
 
-template <class Air>
-__device__ __forceinline__ void quotient_body(const QuotientArgs &A) {
+// Z_H, the selectors and the consumer of coset point i; `first` = position of the first constraint this kernel yields
+struct PointSetup {
+    DotConsumer cons;
+    Fe inv_zh;
+};
+__device__ __forceinline__ void point_setup(const QuotientArgs &A, u32 i, u32 first, PointSetup &P) {
     const u32 size_log = A.log_n + A.qd_bits;
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >> size_log) return;
     const u32 size = 1u << size_log, half = size >> 1;
     // x = g * w_size^i
     u64 w = A.tw[i & (half - 1)];
@@ -286,35 +416,76 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs &A) {
     Fe inv(gl_inv(p012.v));
     Fe inv_xml = inv * p01;
     Fe inv01 = inv * xml;
-    Fe inv_xm1 = inv01 * zh, inv_zh = inv01 * xm1;
-    DotConsumer cons;
-    cons.ap0 = A.alpha_pow[0] + A.n_constraints;
-    cons.ap1 = A.alpha_pow[1] + A.n_constraints;
-    dot_acc_init(cons.d0); dot_acc_init(cons.d1);
-    cons.z_last = xml;
+    Fe inv_xm1 = inv01 * zh;
+    P.inv_zh = inv01 * xm1;
+    P.cons.ap0 = A.alpha_pow[0] + (A.n_constraints - first);
+    P.cons.ap1 = A.alpha_pow[1] + (A.n_constraints - first);
+    dot_acc_init(P.cons.d0); dot_acc_init(P.cons.d1);
+    P.cons.z_last = xml;
     const Fe zh_over_n = zh * Fe(A.n_inv);
-    cons.lagrange_first = zh_over_n * inv_xm1;                    // L_0(x)     = Z_H(x) / (n (x - 1))
-    cons.lagrange_last = zh_over_n * Fe(A.w_n_inv) * inv_xml;     // L_{n-1}(x) = w^-1 Z_H(x) / (n (x - w^-1))
-    quotient_constraints<Air>(A, i, size, cons);
-    if (cons.ap0 != A.alpha_pow[0] && i == 0) atomicExch(A.err_flag, 3);   // met fewer / more constraints than K
-    A.out[i] = gl_canon(gl_mul(dot_acc_reduce(cons.d0), inv_zh.v));
-    if (A.n_challenges > 1) A.out[A.out_stride + i] = gl_canon(gl_mul(dot_acc_reduce(cons.d1), inv_zh.v));
+    P.cons.lagrange_first = zh_over_n * inv_xm1;                    // L_0(x)     = Z_H(x) / (n (x - 1))
+    P.cons.lagrange_last = zh_over_n * Fe(A.w_n_inv) * inv_xml;     // L_{n-1}(x) = w^-1 Z_H(x) / (n (x - w^-1))
 }
 
+// Kernel 1: the table's AIR.  Writes the partial sums sum_{i < K_air} c_i alpha_k^(K-1-i) (lazy u64) -- or, when the table
+// has neither lookups nor CTLs (A.n_air_constraints == A.n_constraints), the finished quotient values.
+template <class Air>
+__device__ __forceinline__ void quotient_air_body(const QuotientArgs &A) {
+    const u32 size_log = A.log_n + A.qd_bits;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> size_log) return;
+    PointSetup P;
+    point_setup(A, i, 0, P);
+    air_constraints<Air>(A, i, 1u << size_log, P.cons);
+    if (P.cons.ap0 != A.alpha_pow[0] + (A.n_constraints - A.n_air_constraints) && i == 0) atomicExch(A.err_flag, 3);
+    u64 r0 = dot_acc_reduce(P.cons.d0), r1 = dot_acc_reduce(P.cons.d1);
+    if (A.n_air_constraints == A.n_constraints) {       // nothing follows: finish here
+        r0 = gl_canon(gl_mul(r0, P.inv_zh.v));
+        r1 = gl_canon(gl_mul(r1, P.inv_zh.v));
+    }
+    A.out[i] = r0;
+    if (A.n_challenges > 1) A.out[A.out_stride + i] = r1;
+}
 // Two launch-bound flavours of the same body: light AIRs keep their whole working set in VGPRs;
 // heavy AIRs (Arithmetic: ~4k field multiplies and several 32-limb polynomials per point) are
 // capped at 128 VGPRs so that 4 waves per SIMD hide the scratch / L1 latency of their spills.
 template <class Air>
-__global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs A) { quotient_body<Air>(A); }
+__global__ void __launch_bounds__(256) quotient_kernel(QuotientArgs A) { quotient_air_body<Air>(A); }
 template <class Air>
-__global__ void __launch_bounds__(256, 4) quotient_kernel_heavy(QuotientArgs A) { quotient_body<Air>(A); }
-// K = number of constraints the table yields per point (depends only on the AIR and the lookup / CTL shapes)
+__global__ void __launch_bounds__(256, 4) quotient_kernel_heavy(QuotientArgs A) { quotient_air_body<Air>(A); }
+// K_air = number of constraints the AIR yields per point
 template <class Air>
 __global__ void quotient_count_kernel(QuotientArgs A) {
     if (threadIdx.x || blockIdx.x) return;
     CountConsumer cons;
     cons.count = 0;
-    quotient_constraints<Air>(A, 0, 1u << (A.log_n + A.qd_bits), cons);
+    air_constraints<Air>(A, 0, 1u << (A.log_n + A.qd_bits), cons);
+    *A.count_out = cons.count;
+}
+
+#ifndef ZK_DEVICE_FUNCS_ONLY
+// Kernel 2: lookup + CTL checks of any table, on top of kernel 1's partial sums; divides by Z_H.
+static __global__ void __launch_bounds__(256) quotient_checks_kernel(QuotientArgs A) {
+    const u32 size_log = A.log_n + A.qd_bits;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> size_log) return;
+    PointSetup P;
+    point_setup(A, i, A.n_air_constraints, P);
+    check_constraints(A, i, 1u << size_log, P.cons);
+    if (P.cons.ap0 != A.alpha_pow[0] && i == 0) atomicExch(A.err_flag, 3);   // met fewer / more constraints than K
+    const u64 r0 = gl_add(A.out[i], dot_acc_reduce(P.cons.d0));
+    A.out[i] = gl_canon(gl_mul(r0, P.inv_zh.v));
+    if (A.n_challenges > 1) {
+        const u64 r1 = gl_add(A.out[A.out_stride + i], dot_acc_reduce(P.cons.d1));
+        A.out[A.out_stride + i] = gl_canon(gl_mul(r1, P.inv_zh.v));
+    }
+}
+// number of constraints the lookup / CTL description yields per point
+static __global__ void quotient_checks_count_kernel(QuotientArgs A) {
+    if (threadIdx.x || blockIdx.x) return;
+    CountConsumer cons;
+    cons.count = 0;
+    check_constraints(A, 0, 1u << (A.log_n + A.qd_bits), cons);
     *A.count_out = cons.count;
 }
 // out[k * cap + j] = alpha_k^j
@@ -339,3 +510,4 @@ static __global__ void split_quotient_chunks_kernel(const u64 *__restrict__ coef
             out[(size_t)(k * Q + j) * out_stride + p] = coef[(size_t)k * coef_stride + ((size_t)p << qd_bits) + jr];
         }
 }
+#endif  // ZK_DEVICE_FUNCS_ONLY

@@ -115,19 +115,27 @@ __device__ __forceinline__ u64 prog_eval_filter_dot(const u64 *__restrict__ prog
 // combination is linear, sum_j beta^j (sum_i c_ji v_ji + k_j) + gamma becomes ONE dot product over (column, row
 // offset) terms with coefficients beta^j c_ji (one array per challenge) plus a constant; filters become dot products
 // too.  All loop bounds and term descriptors are wave-uniform and independent of each other.
-//   blob := n_entries, lin_off, term_off, entry[n] {t0, t1, fp0, fp1, fc0, fc1, K_0, K_1},
+//   blob := n_entries, lin_off, term_off, entry[n] {t0 | (base + 1) << 32, t1, fp0, fp1, fc0, fc1, K_0, K_1},
 //           lin[] {t0, t1, constant}, term[] {col | next << 32, coef_0, coef_1}
+// `base` (optional) names a lin whose terms -- with the coefficients of every challenge -- are the part of the tuple
+// combination this entry shares with its neighbours (stark_host.inc, "BASES"): its value is computed once per row and
+// challenge and remembered (memo_base), the entry adds its own terms and constant.
 // A lin may be a DELTA lin: {t0 | 2^63, t1 | ref << 32, constant} = lin `ref` + its own few terms + constant.  The
 // filters of consecutive CTL entries are often sums that differ by one column (KeccakSponge's 136 memory reads:
 // is_full_input_block + sum_{j > i} is_final_input_len[j] -- 9316 terms as plain sums, 136 + 135 as deltas); the entry
 // compiler (stark_host.inc) emits deltas against the previous entry's filter, and the evaluation remembers the last lin
 // it computed (entries are visited in order, so the reference is always that one).
 #define ZK_LIN_DELTA (1ULL << 63)
+#define ZK_CBLOB_TWIN (~0ULL)        // index entry of a z-data whose blob is slot 1 of the previous one's (quotient_host.inc)
 struct CBlob {
     const u64 *w;
     mutable u32 memo_lin;                          // last lin evaluated by clin_eval for this thread / row, and its value
     mutable u64 memo_val;
-    __device__ __forceinline__ explicit CBlob(const u64 *p) : w(p), memo_lin(0xFFFFFFFFu), memo_val(0) {}
+    // last base evaluated and its value per challenge slot.  ONE CBlob per (thread, row): the memos hold row values.
+    mutable u32 memo_base, memo_base_ok;           // base lin + 1; bit k of _ok: slot k is valid
+    mutable u64 memo_base_val[2];
+    __device__ __forceinline__ explicit CBlob(const u64 *p)
+        : w(p), memo_lin(0xFFFFFFFFu), memo_val(0), memo_base(0), memo_base_ok(0) { memo_base_val[0] = memo_base_val[1] = 0; }
     __device__ __forceinline__ u32 n_entries() const { return (u32)w[0]; }
     __device__ __forceinline__ const u64 *entry(u32 e) const { return w + 3 + 8 * (size_t)e; }
     __device__ __forceinline__ const u64 *lin(u32 l) const { return w + w[1] + 3 * (size_t)l; }
@@ -182,30 +190,66 @@ __device__ __forceinline__ u64 clin_eval(const CBlob &B, u32 l, LD ld) {
     B.memo_val = acc;
     return acc;
 }
-template <int NCH, class LD>
-__device__ __forceinline__ void centry_eval(const CBlob &B, u32 e, LD ld, u64 (&denom)[NCH], u64 &filt) {
-    const u64 *E = B.entry(e);
-    bool simple = (u32)E[1] - (u32)E[0] == 1;        // `Column::single`: one term with coefficient 1 for every challenge
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) simple = simple && B.term((u32)E[0])[1 + k] == 1;
-    if (simple) {                                    // (wave-uniform: the blob is the same for every row)
-        const u64 w0 = B.term((u32)E[0])[0];
-        u64 v = 0;
-        if (!ld((u32)w0, (u32)(w0 >> 32), v)) v = 0;
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) denom[k] = gl_canon(gl_add(v, E[6 + k]));
-    } else {
-        DotAcc d[NCH];
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) dot_acc_init(d[k]);
-        cterms_dot<NCH>(B, (u32)E[0], (u32)E[1], ld, d);
-#pragma unroll
-        for (int k = 0; k < NCH; ++k) denom[k] = gl_canon(gl_add(dot_acc_reduce(d[k]), E[6 + k]));
-    }
+// the filter of entry E: sum of products of lins + sum of lins (lazy)
+template <class LD>
+__device__ __forceinline__ u64 centry_filter(const CBlob &B, const u64 *E, LD ld) {
     u64 acc = 0;
     for (u32 p = (u32)E[2]; p < (u32)E[3]; ++p) acc = gl_add(acc, gl_mul(clin_eval(B, 2 * p, ld), clin_eval(B, 2 * p + 1, ld)));
     for (u32 c = (u32)E[4]; c < (u32)E[5]; ++c) acc = gl_add(acc, clin_eval(B, c, ld));
-    filt = gl_canon(acc);
+    return acc;
+}
+// value of base lin `base1 - 1` for all NCH challenge slots (memoised: consecutive entries share it)
+template <int NCH, class LD>
+__device__ __forceinline__ void cbase_eval(const CBlob &B, u32 base1, LD ld, u64 (&bv)[NCH]) {
+    if (B.memo_base != base1 || (B.memo_base_ok & ((1u << NCH) - 1)) != ((1u << NCH) - 1)) {     // wave-uniform
+        const u64 *L = B.lin(base1 - 1);
+        DotAcc d[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) dot_acc_init(d[k]);
+        cterms_dot<NCH>(B, (u32)L[0], (u32)L[1], ld, d);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) B.memo_base_val[k] = dot_acc_reduce(d[k]);
+        B.memo_base = base1;
+        B.memo_base_ok = (1u << NCH) - 1;
+    }
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) bv[k] = B.memo_base_val[k];
+}
+// CANON: canonical denominators / filter (the column generators invert and compare them); false = lazy representatives
+template <int NCH, bool CANON = true, class LD>
+__device__ __forceinline__ void centry_eval(const CBlob &B, u32 e, LD ld, u64 (&denom)[NCH], u64 &filt) {
+    const u64 *E = B.entry(e);
+    const u32 t0 = (u32)E[0], t1 = (u32)E[1], base1 = (u32)(E[0] >> 32);
+    u64 k[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) k[c] = E[6 + c];
+    if (base1) {                                     // (wave-uniform: the blob is the same for every row)
+        u64 bv[NCH];
+        cbase_eval<NCH>(B, base1, ld, bv);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) k[c] = gl_add(bv[c], k[c]);
+    }
+    bool simple = t1 - t0 == 1;                      // `Column::single`: one term with coefficient 1 for every challenge
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) simple = simple && B.term(t0)[1 + c] == 1;
+    if (simple) {
+        const u64 w0 = B.term(t0)[0];
+        u64 v = 0;
+        if (!ld((u32)w0, (u32)(w0 >> 32), v)) v = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) denom[c] = CANON ? gl_canon(gl_add(v, k[c])) : gl_add(v, k[c]);
+    } else if (t1 == t0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) denom[c] = CANON ? gl_canon(k[c]) : k[c];
+    } else {
+        DotAcc d[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) dot_acc_init(d[c]);
+        cterms_dot<NCH>(B, t0, t1, ld, d);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) denom[c] = CANON ? gl_canon(gl_add(dot_acc_reduce(d[c]), k[c])) : gl_add(dot_acc_reduce(d[c]), k[c]);
+    }
+    filt = CANON ? gl_canon(centry_filter(B, E, ld)) : centry_filter(B, E, ld);
 }
 
 // one challenge, chosen at run time (wave-uniform slot 0 / 1): the quotient kernel walks lookups challenge by challenge
@@ -230,21 +274,36 @@ __device__ __forceinline__ void cterms_dot_slot(const CBlob &B, u32 t0, u32 t1, 
 template <class LD>
 __device__ __forceinline__ void centry_eval_slot(const CBlob &B, u32 e, u32 slot, LD ld, u64 &denom, u64 &filt) {
     const u64 *E = B.entry(e);
-    if ((u32)E[1] - (u32)E[0] == 1 && B.term((u32)E[0])[1 + slot] == 1) {    // `Column::single` (wave-uniform test)
-        const u64 w0 = B.term((u32)E[0])[0];
+    const u32 t0 = (u32)E[0], t1 = (u32)E[1], base1 = (u32)(E[0] >> 32);
+    u64 k = E[6 + slot];
+    if (base1) {
+        if (B.memo_base != base1 || !((B.memo_base_ok >> slot) & 1)) {
+            const u64 *L = B.lin(base1 - 1);
+            DotAcc d;
+            dot_acc_init(d);
+            cterms_dot_slot(B, (u32)L[0], (u32)L[1], slot, ld, d);
+            if (B.memo_base != base1) B.memo_base_ok = 0;
+            B.memo_base = base1;
+            B.memo_base_ok |= 1u << slot;
+            const u64 v = dot_acc_reduce(d);
+            if (slot) B.memo_base_val[1] = v; else B.memo_base_val[0] = v;          // (no run-time register indexing)
+        }
+        k = gl_add(slot ? B.memo_base_val[1] : B.memo_base_val[0], k);
+    }
+    if (t1 - t0 == 1 && B.term(t0)[1 + slot] == 1) {    // `Column::single` (wave-uniform test)
+        const u64 w0 = B.term(t0)[0];
         u64 v = 0;
         if (!ld((u32)w0, (u32)(w0 >> 32), v)) v = 0;
-        denom = gl_add(v, E[6 + slot]);
+        denom = gl_add(v, k);
+    } else if (t1 == t0) {
+        denom = k;
     } else {
         DotAcc d;
         dot_acc_init(d);
-        cterms_dot_slot(B, (u32)E[0], (u32)E[1], slot, ld, d);
-        denom = gl_add(dot_acc_reduce(d), E[6 + slot]);
+        cterms_dot_slot(B, t0, t1, slot, ld, d);
+        denom = gl_add(dot_acc_reduce(d), k);
     }
-    u64 acc = 0;
-    for (u32 p = (u32)E[2]; p < (u32)E[3]; ++p) acc = gl_add(acc, gl_mul(clin_eval(B, 2 * p, ld), clin_eval(B, 2 * p + 1, ld)));
-    for (u32 c = (u32)E[4]; c < (u32)E[5]; ++c) acc = gl_add(acc, clin_eval(B, c, ld));
-    filt = acc;
+    filt = centry_filter(B, E, ld);
 }
 
 // denominators (one per challenge) and filter of entry e at `row`
@@ -266,6 +325,7 @@ __device__ __forceinline__ void prog_eval_entry(const u64 *__restrict__ prog, u3
     filt = prog_eval_filter_dot(prog, pc, t, row);
 }
 
+#ifndef ZK_DEVICE_FUNCS_ONLY   // the column-generator kernels
 struct HelperOut {
     u64 *helpers[ZK_HELPER_MAX_CHALLENGES];     // challenge k: helper column h at helpers[k] + h * helper_stride
     u64 *extra_inv[ZK_HELPER_MAX_CHALLENGES];   // optional: 1 / (gamma_k + table column)
@@ -487,3 +547,4 @@ static __global__ void scan_finish_kernel(const u64 *__restrict__ incl, const u6
         out[n - 1 - i] = v;
     }
 }
+#endif  // ZK_DEVICE_FUNCS_ONLY
