@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <deque>
 #include <map>
 #include <set>
@@ -62,6 +63,9 @@ struct zk_ctx {
     bool check_ctls = false;
     std::map<size_t, std::pair<size_t, std::vector<u64>>> ctl_extra;   // ctl -> (row width, rows)
     AsyncSink *async = nullptr;         // installed by zk_prove_segment for the duration of the call
+    // pinned staging for small host -> device uploads (stage_upload below)
+    std::vector<char *> stage_chunks;
+    size_t stage_cur = 0, stage_off = 0, stage_since_rewind = 0;
     std::map<std::vector<u64>, u32> constraint_counts;   // quotient: constraints yielded per (AIR, lookup/CTL shape)
 };
 
@@ -135,6 +139,39 @@ struct LaneScope {
     LaneScope(const LaneScope &) = delete;
     LaneScope &operator=(const LaneScope &) = delete;
 };
+
+// Small host -> device uploads (programs, compiled entries, descriptors, coefficient tables).  A hipMemcpyAsync from
+// pageable memory stalls the calling thread on a staging copy and forced "host buffer goes out of scope" synchronisations;
+// here the bytes are copied into pinned memory the ctx owns and the transfer is truly asynchronous on ctx->stream, so the
+// caller's buffer is free again on return and no synchronisation is needed.  The pinned chunks are reused from the start
+// whenever the streams are known idle (stage_rewind: end of a segment proof; or after STAGE_LIMIT bytes, with one sync).
+static constexpr size_t ZK_STAGE_CHUNK = (size_t)1 << 20, ZK_STAGE_LIMIT = (size_t)16 << 20;
+static inline void stage_rewind(zk_ctx *ctx) { ctx->stage_cur = 0; ctx->stage_off = 0; ctx->stage_since_rewind = 0; }
+static hipError_t stage_upload(zk_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    if (bytes > ZK_STAGE_CHUNK / 2) return hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (!ctx->async && ctx->stage_since_rewind + bytes > ZK_STAGE_LIMIT) {   // standalone calls: bound the footprint
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return e;
+        if (ctx->side_stream && (e = hipStreamSynchronize(ctx->side_stream)) != hipSuccess) return e;
+        stage_rewind(ctx);
+    }
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (ctx->stage_chunks.empty() || ctx->stage_off + need > ZK_STAGE_CHUNK) {
+        if (!ctx->stage_chunks.empty()) { ++ctx->stage_cur; ctx->stage_off = 0; }
+        if (ctx->stage_cur >= ctx->stage_chunks.size()) {
+            char *c = nullptr;
+            hipError_t e = hipHostMalloc((void **)&c, ZK_STAGE_CHUNK, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            ctx->stage_chunks.push_back(c);
+        }
+    }
+    char *h = ctx->stage_chunks[ctx->stage_cur] + ctx->stage_off;
+    memcpy(h, h_src, bytes);
+    ctx->stage_off += need;
+    ctx->stage_since_rewind += need;
+    return hipMemcpyAsync(d_dst, h, bytes, hipMemcpyHostToDevice, ctx->stream);
+}
 
 static int check_abort(zk_ctx *ctx) {
     if ((ctx->abort_flag && *ctx->abort_flag) || (ctx->abort_flag_u8 && *ctx->abort_flag_u8))

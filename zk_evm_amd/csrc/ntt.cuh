@@ -45,6 +45,7 @@ struct NttPass {
     int log_rep;         // load: dst index x reads src index x >> log_rep
     int apply_out_const;
     int last_pass;       // the values leave the transform: store canonical representatives
+    int nt;              // stream the tile data with non-temporal loads / stores (the twiddle levels keep the L2)
 };
 
 // One radix-2 butterfly (a, b) -> (a + w b, a - w b).  BOTH directions use this Cooley-Tukey form: the canonical product
@@ -141,7 +142,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
         // to its 2^log_rep replicas in the tile (the stages that would have produced them are skipped)
         const u32 sbase = base >> p.log_rep, rep = 1u << p.log_rep;
         for (u32 se = tid; se < (elems >> p.log_rep); se += nthr) {
-            u64 v = src[sbase + se];
+            u64 v = p.nt ? __builtin_nontemporal_load(src + sbase + se) : src[sbase + se];
             if (p.in_scale) v = gl_mul(v, p.in_scale[sbase + se]);
             for (u32 k = 0; k < rep; ++k) tile[(se << p.log_rep) + k] = v;
         }
@@ -149,7 +150,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
         for (u32 e = tid; e < elems; e += nthr) {
             u32 t = e >> log_t, u = e & (T - 1);
             u32 x = base + (t << p.log_d) + u;
-            u64 v = src[x];
+            u64 v = p.nt ? __builtin_nontemporal_load(src + x) : src[x];
             if (p.in_scale) v = gl_mul(v, p.in_scale[x]);
             tile[e] = v;
         }
@@ -176,7 +177,8 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
         if (p.out_scale) v = gl_mul_canon(v, p.out_scale[x]);
         else if (p.apply_out_const) v = gl_mul_canon(v, p.out_const);
         else if (p.last_pass) v = gl_canon(v);          // between passes any u64 representative will do
-        dst[x] = v;
+        if (p.nt) __builtin_nontemporal_store(v, dst + x);
+        else dst[x] = v;
     }
 }
 
