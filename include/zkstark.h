@@ -454,6 +454,15 @@ int zk_plonk_circuit_cap(const zk_plonk_circuit *circuit, uint64_t *out);
  * the library until zk_plonk_proof_free. */
 int zk_plonk_prove(zk_plonk_circuit *circuit, const uint64_t *d_wires, size_t col_stride, const uint64_t *public_inputs,
                    size_t n_public_inputs, zk_plonk_proof **out);
+/* n_proofs proofs of ONE circuit from ONE call: d_wires[k] / public_inputs[k] as for zk_plonk_prove, out[k] receives proof k.
+ * The reference proves the same few circuits for every segment (one shrink chain per table + the root,
+ * fixed_recursive_verifier.rs:2053-2160, 3167-3179) and a proof at 2^12-2^14 rows cannot fill the GPU, so the library keeps
+ * `in_flight` (0 = 4, at most 16) worker contexts per circuit -- stream + arena each, created on first use -- and runs the
+ * witnesses through them concurrently; the calling thread is one of the workers.  Every proof equals what zk_plonk_prove
+ * returns for the same witness.  On failure: the first error, no proofs. */
+int zk_plonk_prove_batch(zk_plonk_circuit *circuit, const uint64_t *const *d_wires, size_t col_stride,
+                         const uint64_t *const *public_inputs, size_t n_public_inputs, size_t n_proofs, unsigned in_flight,
+                         zk_plonk_proof **out);
 typedef struct {
     size_t cap_digests;
     const uint64_t *wires_cap;                       /* Proof.wires_cap */

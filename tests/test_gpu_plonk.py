@@ -121,3 +121,39 @@ def test_plonk_keccak_config_matches_oracle(oracle, degree_bits, mixed):
     assert np.array_equal(got.openings.reshape(-1), exp["openings"]) and np.array_equal(got.opening_proof, exp["fri"])
     cd.free()
 
+
+
+def test_plonk_prove_batch_equals_single_proofs(oracle):
+    """zk_plonk_prove_batch: twelve witnesses of one mixed-gate circuit through four worker contexts of the library, from one
+    call -- every proof equals `prove` of the same witness word for word (and the first the oracle's), a second batch reuses
+    the workers, and a bad witness fails the whole call."""
+    import torch
+    from tests.gpu_util import to_dev
+    from zk_evm_amd._lib import ZkStarkError
+    ol.setup_fri_api(oracle)
+    circ, wires, pis = PK.build_mixed_circuit(10, seed=41, cfg=PK.CircuitConfig(proof_of_work_bits=6, num_query_rounds=6))
+    wires, _ = PK.set_public_input_wires(oracle, circ, wires, pis)
+    cd = _device_circuit(circ)
+    rng = np.random.default_rng(9)
+    ws, ps = [wires], [pis]
+    for k in range(11):                                  # junk wires: every constraint non-zero; own public inputs
+        p = [int(x) for x in rng.integers(0, 1 << 60, size=len(pis))]
+        w = rng.integers(0, 1 << 64, size=wires.shape, dtype=np.uint64)
+        w, _ = PK.set_public_input_wires(oracle, circ, w, p)
+        ws.append(w)
+        ps.append(p)
+    dev = [to_dev(w) for w in ws]
+    single = [cd.prove(d, p) for d, p in zip(dev, ps)]
+    exp0 = PK.prove(oracle, ol, circ, ws[0], ps[0])
+    assert np.array_equal(single[0].opening_proof, exp0["fri"])
+    for rep in range(2):
+        batch = cd.prove_batch(dev, ps, in_flight=4)
+        assert len(batch) == 12
+        for a, b in zip(single, batch):
+            assert np.array_equal(a.wires_cap, b.wires_cap) and np.array_equal(a.quotient_polys_cap, b.quotient_polys_cap)
+            assert np.array_equal(a.openings, b.openings) and np.array_equal(a.opening_proof, b.opening_proof)
+            assert a.public_inputs_hash == b.public_inputs_hash
+    assert cd.prove_batch([], []) == []
+    with pytest.raises(ZkStarkError):
+        cd.prove_batch(dev[:2] + [torch.zeros((135, 32), dtype=torch.int64, device="cuda")], ps[:3])
+    cd.free()

@@ -112,6 +112,7 @@ SIGNATURES = {
     "zk_plonk_circuit_free": (None, [vp]),
     "zk_plonk_circuit_cap": (C.c_int, [vp, u64p]),
     "zk_plonk_prove": (C.c_int, [vp, u64p, sz, u64p, sz, C.POINTER(vp)]),
+    "zk_plonk_prove_batch": (C.c_int, [vp, vp, sz, vp, sz, sz, ui, vp]),
     "zk_plonk_proof_get": (C.c_int, [vp, vp]),
     "zk_plonk_proof_free": (None, [vp]),
     "zk_keccak_generate_trace": (C.c_int, [vp, u64p, u64p, sz, ui, u64p, sz]),

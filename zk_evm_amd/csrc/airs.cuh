@@ -236,8 +236,8 @@ struct AirArithmetic {
     }
 
     // mul.rs:123-173 (eval_packed_generic_mul); left: accessor, right_s: first column of the right operand
-    template <class CONS, class FL>
-    __device__ static __forceinline__ void mul(const RowView &lv, CONS &c, Fe filt, FL left, u32 right_s) {
+    template <class RV, class CONS, class FL>
+    __device__ static __forceinline__ void mul(const RV &lv, CONS &c, Fe filt, FL left, u32 right_s) {
         auto aux = [&](u32 d) { return lv[AUX0 + d] + lv[AUX1 + d] * fe(BASE) - fe(OFFSET); };   // 2^20 offset undone
         Fe r[NL];
 #pragma unroll
@@ -252,13 +252,14 @@ struct AirArithmetic {
     // modular.rs:419-501 (modular_constr_poly incl. check_reduced), split in two: the constraints it yields
     // itself (modular_checks), and the polynomial it returns, produced coefficient by coefficient (modular_cp).
     //   output(i): 16 limbs; mod_s: first column of the modulus; quot(i): nq limbs (16 or 32)
-    __device__ static __forceinline__ void load_modulus(const RowView &lv, const RowView &nv, u32 mod_s, Fe (&m)[NL]) {
+    template <class RV>
+    __device__ static __forceinline__ void load_modulus(const RV &lv, const RV &nv, u32 mod_s, Fe (&m)[NL]) {
 #pragma unroll
         for (u32 i = 0; i < NL; ++i) m[i] = lv[mod_s + i];
         m[0] += nv[34];                                                 // + MODULAR_MOD_IS_ZERO
     }
-    template <class CONS, class FO, class FQ>
-    __device__ static __forceinline__ void modular_checks(const RowView &lv, const RowView &nv, CONS &c, Fe filt, FO output,
+    template <class RV, class CONS, class FO, class FQ>
+    __device__ static __forceinline__ void modular_checks(const RV &lv, const RV &nv, CONS &c, Fe filt, FO output,
                                                           u32 mod_s, FQ quot, u32 nq) {
         Fe mod_is_zero = nv[34];                                        // MODULAR_MOD_IS_ZERO
         c.constraint_transition(filt * (mod_is_zero * mod_is_zero - mod_is_zero));
@@ -282,8 +283,8 @@ struct AirArithmetic {
         conv16(m, quot, nq, 2 * NL, 3 * NL - 1, [&](u32, Fe p) { c.constraint_transition(filt * p); });
     }
     // f(d, coefficient d of  q*m + output + (x - beta) * s(x)) for d < 2*NL
-    template <class FO, class FQ, class F>
-    __device__ static __forceinline__ void modular_cp(const RowView &lv, const RowView &nv, FO output, u32 mod_s, FQ quot,
+    template <class RV, class FO, class FQ, class F>
+    __device__ static __forceinline__ void modular_cp(const RV &lv, const RV &nv, FO output, u32 mod_s, FQ quot,
                                                       u32 nq, F f) {
         Fe m[NL];
         load_modulus(lv, nv, mod_s, m);
@@ -296,8 +297,8 @@ struct AirArithmetic {
     }
 
     // divmod.rs:86-116 (eval_packed_divmod_helper): the quotient input has 16 limbs (upper half zero)
-    template <class CONS>
-    __device__ static __forceinline__ void divmod_helper(const RowView &lv, const RowView &nv, CONS &c, Fe filt, u32 num_s,
+    template <class RV, class CONS>
+    __device__ static __forceinline__ void divmod_helper(const RV &lv, const RV &nv, CONS &c, Fe filt, u32 num_s,
                                                          u32 den_s, u32 quo_s, u32 rem_s) {
         c.constraint_last_row(filt);
         auto quo = [&](u32 i) { return lv[quo_s + i]; };
@@ -309,8 +310,10 @@ struct AirArithmetic {
         });
     }
 
-    template <class CONS>
-    __device__ static __forceinline__ void eval(const RowView &lv, const RowView &nv, CONS &c, const u64 *) {
+    // ---- the constraint families, in the reference's order (arithmetic_stark.rs:203-252); positions in brackets --------
+    // part0: flags, opcode, range counter [0, 22), MUL [22, 38), ADD / SUB / LT / GT [38, 170)
+    template <class RV, class CONS>
+    __device__ static __forceinline__ void part_head(const RV &lv, const RV &nv, CONS &c) {
         const Fe one = FE_ONE;
         Fe all_flags;
         for (u32 f = 0; f <= IS_RANGE_CHECK; ++f) { Fe fl = lv[f]; c.constraint(fl * (fl - one)); all_flags += fl; }
@@ -323,7 +326,6 @@ struct AirArithmetic {
         c.constraint_last_row(rc1 - fe(65535));
         auto in0 = [&](u32 i) { return lv[IN0 + i]; };
         auto in1 = [&](u32 i) { return lv[IN1 + i]; };
-        auto in2 = [&](u32 i) { return lv[IN2 + i]; };
         auto out = [&](u32 i) { return lv[OUT + i]; };
         auto aux = [&](u32 i) { return lv[AUX0 + i]; };
         mul(lv, c, lv[IS_MUL], in0, IN1);
@@ -331,62 +333,120 @@ struct AirArithmetic {
         addcy(c, lv[IS_SUB], in1, out, in0, aux, false);
         addcy(c, lv[IS_LT], in1, aux, in0, out, false);
         addcy(c, lv[IS_GT], in0, aux, in1, out, false);
-        divmod_helper(lv, nv, c, lv[IS_DIV], IN0, IN1, OUT, AUX0);
-        divmod_helper(lv, nv, c, lv[IS_MOD], IN0, IN1, AUX0, OUT);
-        {   // modular.rs:542-612
-            // BN254 base-field modulus, 16-bit limbs (extension_tower.rs:25-30)
-            constexpr u64 BN[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
-            Fe bn = lv[IS_ADDFP254] + lv[IS_MULFP254] + lv[IS_SUBFP254];
-            Fe filt = lv[IS_ADDMOD] + lv[IS_SUBMOD] + lv[IS_MULMOD] + bn;
-            c.constraint_last_row(filt);
+    }
+    // modular.rs:542-612, in four pieces: [336, 420) filter / BN254 modulus / sign / sub checks, [420, 502) add + mul checks and
+    // the add polynomial, [502, 534) the sub polynomial, [534, 566) the mul polynomial
+    struct ModularFilters { Fe bn, add_f, sub_f, mul_f, sign, sign_ffff; };
+    template <class RV>
+    __device__ static __forceinline__ ModularFilters modular_filters(const RV &lv) {
+        ModularFilters F;
+        F.bn = lv[IS_ADDFP254] + lv[IS_MULFP254] + lv[IS_SUBFP254];
+        F.add_f = lv[IS_ADDMOD] + lv[IS_ADDFP254];
+        F.sub_f = lv[IS_SUBMOD] + lv[IS_SUBFP254];
+        F.mul_f = lv[IS_MULMOD] + lv[IS_MULFP254];
+        F.sign = lv[AUX0 + NL];                                       // quo_input(NL)
+        F.sign_ffff = fe(0xFFFF) * F.sign;
+        return F;
+    }
+    template <class RV, class CONS>
+    __device__ static __forceinline__ void part_modular_a(const RV &lv, const RV &nv, CONS &c) {
+        const Fe one = FE_ONE;
+        // BN254 base-field modulus, 16-bit limbs (extension_tower.rs:25-30)
+        constexpr u64 BN[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+        const ModularFilters F = modular_filters(lv);
+        Fe filt = lv[IS_ADDMOD] + lv[IS_SUBMOD] + lv[IS_MULMOD] + F.bn;
+        c.constraint_last_row(filt);
 #pragma unroll
-            for (u32 i = 0; i < NL; ++i) c.constraint_transition(bn * (in2(i) - fe((BN[i / 4] >> (16 * (i % 4))) & 0xFFFF)));
-            auto quo_input = [&](u32 i) { return lv[AUX0 + i]; };      // 2 * NL limbs
-            Fe add_f = lv[IS_ADDMOD] + lv[IS_ADDFP254], sub_f = lv[IS_SUBMOD] + lv[IS_SUBFP254];
-            Fe mul_f = lv[IS_MULMOD] + lv[IS_MULFP254];
-            // submod_constr_poly (modular.rs:515-539): quotient with the sign limb folded in
-            Fe sign = quo_input(NL);
-            Fe sign_ffff = fe(0xFFFF) * sign;
-            auto q_sub = [&](u32 i) { return i < NL ? quo_input(i) - sign_ffff : (i == NL ? Fe() : quo_input(i)); };
-            c.constraint(sub_f * sign * (sign - one));
+        for (u32 i = 0; i < NL; ++i) c.constraint_transition(F.bn * (lv[IN2 + i] - fe((BN[i / 4] >> (16 * (i % 4))) & 0xFFFF)));
+        auto quo_input = [&](u32 i) { return lv[AUX0 + i]; };      // 2 * NL limbs
+        auto out = [&](u32 i) { return lv[OUT + i]; };
+        // submod_constr_poly (modular.rs:515-539): quotient with the sign limb folded in
+        auto q_sub = [&](u32 i) { return i < NL ? quo_input(i) - F.sign_ffff : (i == NL ? Fe() : quo_input(i)); };
+        c.constraint(F.sub_f * F.sign * (F.sign - one));
 #pragma unroll 1
-            for (u32 i = NL; i < 2 * NL; ++i) c.constraint(sub_f * q_sub(i));
-            modular_checks(lv, nv, c, sub_f, out, IN2, q_sub, 2 * NL);
-            modular_checks(lv, nv, c, add_f + mul_f, out, IN2, quo_input, 2 * NL);
-            modular_cp(lv, nv, out, IN2, quo_input, 2 * NL, [&](u32 d, Fe cp) {       // add: input0 + input1
-                c.constraint_transition(add_f * (d < NL ? cp - (in0(d) + in1(d)) : cp));
-            });
-            modular_cp(lv, nv, out, IN2, q_sub, 2 * NL, [&](u32 d, Fe cp) {           // sub: input0 - input1
-                c.constraint_transition(sub_f * (d < NL ? cp - (in0(d) - in1(d)) : cp));
-            });
-            {   // mul: pol_mul_wide(input0, input1), coefficient d < 2*NL - 1, subtracted from the same polynomial
-                Fe m[NL], r[NL];
-                load_modulus(lv, nv, IN2, m);
+        for (u32 i = NL; i < 2 * NL; ++i) c.constraint(F.sub_f * q_sub(i));
+        modular_checks(lv, nv, c, F.sub_f, out, IN2, q_sub, 2 * NL);
+    }
+    template <class RV, class CONS>
+    __device__ static __forceinline__ void part_modular_b(const RV &lv, const RV &nv, CONS &c) {
+        const ModularFilters F = modular_filters(lv);
+        auto quo_input = [&](u32 i) { return lv[AUX0 + i]; };
+        auto out = [&](u32 i) { return lv[OUT + i]; };
+        modular_checks(lv, nv, c, F.add_f + F.mul_f, out, IN2, quo_input, 2 * NL);
+        modular_cp(lv, nv, out, IN2, quo_input, 2 * NL, [&](u32 d, Fe cp) {       // add: input0 + input1
+            c.constraint_transition(F.add_f * (d < NL ? cp - (lv[IN0 + d] + lv[IN1 + d]) : cp));
+        });
+    }
+    template <class RV, class CONS>
+    __device__ static __forceinline__ void part_modular_c(const RV &lv, const RV &nv, CONS &c) {
+        const ModularFilters F = modular_filters(lv);
+        auto quo_input = [&](u32 i) { return lv[AUX0 + i]; };
+        auto out = [&](u32 i) { return lv[OUT + i]; };
+        auto q_sub = [&](u32 i) { return i < NL ? quo_input(i) - F.sign_ffff : (i == NL ? Fe() : quo_input(i)); };
+        modular_cp(lv, nv, out, IN2, q_sub, 2 * NL, [&](u32 d, Fe cp) {           // sub: input0 - input1
+            c.constraint_transition(F.sub_f * (d < NL ? cp - (lv[IN0 + d] - lv[IN1 + d]) : cp));
+        });
+    }
+    template <class RV, class CONS>
+    __device__ static __forceinline__ void part_modular_d(const RV &lv, const RV &nv, CONS &c) {
+        const ModularFilters F = modular_filters(lv);
+        auto quo_input = [&](u32 i) { return lv[AUX0 + i]; };
+        auto in0 = [&](u32 i) { return lv[IN0 + i]; };
+        auto out = [&](u32 i) { return lv[OUT + i]; };
+        // mul: pol_mul_wide(input0, input1), coefficient d < 2*NL - 1, subtracted from the same polynomial
+        Fe m[NL], r[NL];
+        load_modulus(lv, nv, IN2, m);
 #pragma unroll
-                for (u32 i = 0; i < NL; ++i) r[i] = lv[IN1 + i];
-                auto auxn = [&](u32 i) { return i < 2 * NL - 1 ? nv[35 + i] - fe(OFFSET) + fe(BASE) * nv[66 + i] : Fe(); };
-                Fe wq[NL], wi[NL];                        // two sliding windows: quotient limbs and input0 limbs
+        for (u32 i = 0; i < NL; ++i) r[i] = lv[IN1 + i];
+        auto auxn = [&](u32 i) { return i < 2 * NL - 1 ? nv[35 + i] - fe(OFFSET) + fe(BASE) * nv[66 + i] : Fe(); };
+        Fe wq[NL], wi[NL];                        // two sliding windows: quotient limbs and input0 limbs
 #pragma unroll
-                for (u32 j = 0; j < NL; ++j) { wq[j] = j == 0 ? quo_input(0) : Fe(); wi[j] = j == 0 ? in0(0) : Fe(); }
+        for (u32 j = 0; j < NL; ++j) { wq[j] = j == 0 ? quo_input(0) : Fe(); wi[j] = j == 0 ? in0(0) : Fe(); }
 #pragma unroll 1
-                for (u32 d = 0; d < 2 * NL; ++d) {
-                    DotAcc p, q;
-                    dot_acc_init(p); dot_acc_init(q);
+        for (u32 d = 0; d < 2 * NL; ++d) {
+            DotAcc p, q;
+            dot_acc_init(p); dot_acc_init(q);
 #pragma unroll
-                    for (u32 j = 0; j < NL; ++j) { dot_acc_mac_v(p, wq[j].v, m[j].v); dot_acc_mac_v(q, wi[j].v, r[j].v); }
-                    Fe v(dot_acc_reduce(p));
-                    if (d < NL) v += out(d);
-                    v += adjoin(auxn, d);
-                    if (d < 2 * NL - 1) v -= Fe(dot_acc_reduce(q));
-                    c.constraint_transition(mul_f * v);
+            for (u32 j = 0; j < NL; ++j) { dot_acc_mac_v(p, wq[j].v, m[j].v); dot_acc_mac_v(q, wi[j].v, r[j].v); }
+            Fe v(dot_acc_reduce(p));
+            if (d < NL) v += out(d);
+            v += adjoin(auxn, d);
+            if (d < 2 * NL - 1) v -= Fe(dot_acc_reduce(q));
+            c.constraint_transition(F.mul_f * v);
 #pragma unroll
-                    for (u32 j = NL - 1; j > 0; --j) { wq[j] = wq[j - 1]; wi[j] = wi[j - 1]; }
-                    wq[0] = d + 1 < 2 * NL ? quo_input(d + 1) : Fe();
-                    wi[0] = d + 1 < NL ? in0(d + 1) : Fe();
-                }
-            }
+            for (u32 j = NL - 1; j > 0; --j) { wq[j] = wq[j - 1]; wi[j] = wi[j - 1]; }
+            wq[0] = d + 1 < 2 * NL ? quo_input(d + 1) : Fe();
+            wi[0] = d + 1 < NL ? in0(d + 1) : Fe();
         }
-        {   // byte.rs:201-296
+    }
+    // part_modular_d as two additive halves over the SAME positions [534, 566), for the tiled kernel (arith_quotient.cuh): the
+    // constraint mul_f * (q*m + out + (x - beta) s - in0*in1)_d is linear in the two products, so one wave yields
+    // mul_f * (q*m + out + (x - beta) s)_d and another mul_f * (-(in0*in1)_d); the consumer adds them up.
+    template <class RV, class CONS>
+    __device__ static __forceinline__ void part_modular_d1(const RV &lv, const RV &nv, CONS &c) {
+        const ModularFilters F = modular_filters(lv);
+        auto quo_input = [&](u32 i) { return lv[AUX0 + i]; };
+        auto out = [&](u32 i) { return lv[OUT + i]; };
+        modular_cp(lv, nv, out, IN2, quo_input, 2 * NL, [&](u32, Fe cp) { c.constraint_transition(F.mul_f * cp); });
+    }
+    template <class RV, class CONS>
+    __device__ static __forceinline__ void part_modular_d2(const RV &lv, const RV &nv, CONS &c) {
+        (void)nv;
+        const ModularFilters F = modular_filters(lv);
+        Fe r[NL];
+#pragma unroll
+        for (u32 i = 0; i < NL; ++i) r[i] = lv[IN1 + i];
+        conv16(r, [&](u32 i) { return lv[IN0 + i]; }, NL, 0, 2 * NL - 1, [&](u32, Fe q) { c.constraint_transition(F.mul_f * (-q)); });
+    }
+    // byte.rs:201-296 [566, 608) and SHL = MUL on (IN1, IN2) [608, 624)
+    template <class RV, class CONS>
+    __device__ static __forceinline__ void part_byte_shl(const RV &lv, const RV &nv, CONS &c) {
+        (void)nv;
+        const Fe one = FE_ONE;
+        auto in0 = [&](u32 i) { return lv[IN0 + i]; };
+        auto in1 = [&](u32 i) { return lv[IN1 + i]; };
+        auto out = [&](u32 i) { return lv[OUT + i]; };
+        {
             Fe is_byte = lv[IS_BYTE];
             Fe tree[NL], auxb[6];
             for (u32 i = 0; i < NL; ++i) tree[i] = lv[AUX1 + i];
@@ -424,8 +484,23 @@ struct AirArithmetic {
             c.constraint(is_byte * (out(0) - (one - idx_is_large) * tree[15]));
             for (u32 i = 1; i < NL; ++i) c.constraint(is_byte * out(i));
         }
-        // shift.rs:85-128: SHL = MUL on (IN1, IN2); SHR = DIV helper on (IN1, IN2, OUT, AUX0)
         mul(lv, c, lv[IS_SHL], in1, IN2);
+    }
+    // first positions of the families (707 constraints in all; see part_* above)
+    enum { POS_HEAD = 0, POS_DIV = 170, POS_MOD = 253, POS_MODULAR_A = 336, POS_MODULAR_B = 420, POS_MODULAR_C = 502,
+           POS_MODULAR_D = 534, POS_BYTE_SHL = 566, POS_SHR = 624, N_CONSTRAINTS = 707 };
+
+    template <class CONS>
+    __device__ static __forceinline__ void eval(const RowView &lv, const RowView &nv, CONS &c, const u64 *) {
+        part_head(lv, nv, c);
+        divmod_helper(lv, nv, c, lv[IS_DIV], IN0, IN1, OUT, AUX0);
+        divmod_helper(lv, nv, c, lv[IS_MOD], IN0, IN1, AUX0, OUT);
+        part_modular_a(lv, nv, c);
+        part_modular_b(lv, nv, c);
+        part_modular_c(lv, nv, c);
+        part_modular_d(lv, nv, c);
+        part_byte_shl(lv, nv, c);
+        // shift.rs:85-128: SHL = MUL on (IN1, IN2) (above); SHR = DIV helper on (IN1, IN2, OUT, AUX0)
         divmod_helper(lv, nv, c, lv[IS_SHR], IN1, IN2, OUT, AUX0);
     }
 };

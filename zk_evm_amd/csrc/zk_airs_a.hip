@@ -1,19 +1,30 @@
 // Translation unit of libzkstark_hip.so: the quotient kernels of one group of table AIRs (airs.cuh), see internal.hpp.
 #include "quotient_launch.hpp"
+#include "arith_quotient.cuh"
 #include <cstdlib>
-// ZK_ARITH_HEAVY=0 (tuning only): launch the Arithmetic quotient without the __launch_bounds__(256, 4) cap
-static const bool kArithHeavy = !(getenv("ZK_ARITH_HEAVY") && getenv("ZK_ARITH_HEAVY")[0] == 0x30);
+// ZK_ARITH_TILED=0 (tuning / A-B only): the one-lane-per-point Arithmetic AIR kernel instead of the LDS-tiled one
+static const bool kArithTiled = !(getenv("ZK_ARITH_TILED") && getenv("ZK_ARITH_TILED")[0] == 0x30);
 int zki_quotient_airs_a(zk_ctx *ctx, uint32_t air_id, const QuotientArgs &A, u32 size, DevBuf &scratch, size_t n_trace_cols,
                         size_t n_air_consts, u32 *count) {
     (void)n_air_consts;
     switch (air_id) {
         ZK_AIR_CASE(ZK_AIR_NONE, AirNone, false)
         ZK_AIR_CASE(ZK_AIR_MEM_CONTINUATION, AirMemContinuation, false)
-        case ZK_AIR_ARITHMETIC:
+        case ZK_AIR_ARITHMETIC: {
             if (n_trace_cols != AirArithmetic::COLUMNS)
                 return set_err(ctx, ZK_ERR_BAD_ARG, "AIR %u expects %u trace columns, got %zu", air_id, (unsigned)AirArithmetic::COLUMNS, n_trace_cols);
-            return kArithHeavy ? launch_quotient_air<AirArithmetic, true>(ctx, A, size, scratch, count)
-                               : launch_quotient_air<AirArithmetic, false>(ctx, A, size, scratch, count);
+            if (count || !kArithTiled)        // the constraint count, or ZK_ARITH_TILED=0: the one-lane-per-point form
+                return launch_quotient_air<AirArithmetic, true>(ctx, A, size, scratch, count);
+            static bool attr_set = false;     // (idempotent; a race only repeats the call)
+            const size_t lds = (size_t)ZK_ARITH_LDS_WORDS * sizeof(u64);
+            if (!attr_set) {
+                HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&quotient_arith_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            quotient_arith_kernel<<<(size + ZK_ARITH_POINTS - 1) / ZK_ARITH_POINTS, 64 * ZK_ARITH_WAVES, lds, ctx->stream>>>(A);
+            return check_launch(ctx, "quotient_arith_kernel");
+        }
         default: return ZK_AIR_NOT_MINE;
     }
 }

@@ -2,6 +2,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <chrono>
 #include <cstring>
 #include <memory>

@@ -115,21 +115,59 @@ class CircuitData:
         h = C.c_void_p()
         self.ctx.check(self.ctx.lib.zk_plonk_prove(self.handle, C.c_void_p(wires.data_ptr()), stride,
                                                    pis.ctypes.data if pis.size else None, pis.size, C.byref(h)))
-        lib = self.ctx.lib
         try:
-            v = ZkPlonkProofView()
-            self.ctx.check(lib.zk_plonk_proof_get(h, C.byref(v)))
-
-            def arr(p, words):
-                return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(words,)).copy()
-            nd = int(v.cap_digests)
-            names = ("wires commitment", "partial products and Zs", "quotient", "openings", "FRI")
-            return ProofWithPublicInputs(arr(v.wires_cap, 4 * nd).reshape(nd, 4), arr(v.plonk_zs_partial_products_cap, 4 * nd).reshape(nd, 4),
-                                         arr(v.quotient_polys_cap, 4 * nd).reshape(nd, 4), arr(v.openings, 2 * v.n_openings).reshape(-1, 2),
-                                         arr(v.opening_proof, v.proof_words), [int(x) for x in pis],
-                                         [int(x) for x in v.public_inputs_hash], dict(zip(names, [float(x) for x in v.stage_ms])))
+            return self._proof_from_handle(h, pis)
         finally:
-            lib.zk_plonk_proof_free(h)
+            self.ctx.lib.zk_plonk_proof_free(h)
+
+    def _proof_from_handle(self, h, pis) -> ProofWithPublicInputs:
+        lib = self.ctx.lib
+        v = ZkPlonkProofView()
+        self.ctx.check(lib.zk_plonk_proof_get(h, C.byref(v)))
+
+        def arr(p, words):
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint64)), shape=(words,)).copy()
+        nd = int(v.cap_digests)
+        names = ("wires commitment", "partial products and Zs", "quotient", "openings", "FRI")
+        return ProofWithPublicInputs(arr(v.wires_cap, 4 * nd).reshape(nd, 4), arr(v.plonk_zs_partial_products_cap, 4 * nd).reshape(nd, 4),
+                                     arr(v.quotient_polys_cap, 4 * nd).reshape(nd, 4), arr(v.openings, 2 * v.n_openings).reshape(-1, 2),
+                                     arr(v.opening_proof, v.proof_words), [int(x) for x in pis],
+                                     [int(x) for x in v.public_inputs_hash], dict(zip(names, [float(x) for x in v.stage_ms])))
+
+    def prove_batch(self, wires_list, public_inputs_list, in_flight: int = 0) -> list:
+        """K proofs of this circuit from one call (zk_plonk_prove_batch): the library runs them through `in_flight` worker
+        contexts (0 = its default of 4) so that the small proofs of the recursion layer fill the GPU; every proof equals
+        `prove` of the same witness.  wires_list[k]: CUDA tensor (num_wires, 2^degree_bits)."""
+        from .stark import _trace_args
+        K = len(wires_list)
+        if K == 0:
+            return []
+        if len(public_inputs_list) != K:
+            raise ZkStarkError(-1, "one public-input list per witness")
+        strides = set()
+        for w in wires_list:
+            n_cols, n, log_n, stride = _trace_args(w)
+            if n_cols != self.config.num_wires or log_n != self.degree_bits:
+                raise ZkStarkError(-1, "witness must be (num_wires, 2^degree_bits)")
+            strides.add(stride)
+        if len(strides) != 1:
+            raise ZkStarkError(-1, "the witnesses of one batch must share a column stride")
+        self.ctx.use_torch_current_stream()
+        pis = [np.array([int(x) for x in p], dtype=np.uint64) for p in public_inputs_list]
+        n_pi = pis[0].size
+        if any(p.size != n_pi for p in pis):
+            raise ZkStarkError(-1, "every proof of a circuit has the same number of public inputs")
+        wptr = (C.c_void_p * K)(*[w.data_ptr() for w in wires_list])
+        pptr = (C.c_void_p * K)(*[(p.ctypes.data if n_pi else None) for p in pis])
+        outs = (C.c_void_p * K)()
+        self.ctx.check(self.ctx.lib.zk_plonk_prove_batch(self.handle, wptr, strides.pop(), pptr if n_pi else None, n_pi, K,
+                                                         in_flight, outs))
+        try:
+            return [self._proof_from_handle(C.c_void_p(outs[k]), pis[k]) for k in range(K)]
+        finally:
+            for k in range(K):
+                if outs[k]:
+                    self.ctx.lib.zk_plonk_proof_free(C.c_void_p(outs[k]))
 
     def free(self):
         if getattr(self, "handle", None):
