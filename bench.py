@@ -469,6 +469,73 @@ def realistic_profile(ctx, dev, a, all_stark, cfg, steps=4, in_flight=3):
         out["in_flight"] = {"workers_per_gpu": in_flight, "value": steps * in_flight / el, "unit": "segment proofs/s"}
     except Exception as e:
         out["in_flight"] = {"error": repr(e)}
+    # ---- one segment carried through its recursion layer (fixed_recursive_verifier.rs:2053-2160, 3167-3179) -----------------
+    # prove_segment = the STARK, then per table a StarkWrapperCircuit proof and its shrink() chain down to 2^13 rows, then the
+    # root circuit.  Modelled as 35 PLONK proofs: per table one wrapper proof at 2^14 rows and two shrinking proofs at 2^13
+    # (27), the root at 2^14 and seven more 2^13 steps for the larger tables.  The chains of different tables are
+    # independent, a chain's own steps are serial: step k of all nine tables is ONE zk_plonk_prove_batch call (synthetic
+    # circuits carrying all fourteen gate kinds; witness generation is the Rust side's and is not in this number).
+    try:
+        import zk_evm_amd
+        import zk_evm_amd.plonk as zp
+        g = torch.Generator(device=dev)
+        g.manual_seed(123)
+        circ = {}
+        ctx2 = zk_evm_amd.Context(ctx.device)                              # the recursion layer's own context and stream
+        st2 = torch.cuda.Stream(device=dev)
+        for lb in (13, 14):
+            cs, wires = plonk_synthetic_circuit(dev, lb, g)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(st2):
+                circ[lb] = (zp.CircuitData(zp.CircuitConfig(), lb, PLONK_RECURSION_GATES, 4, cs, PLONK_K_IS, [1, 2, 3, 4], 123, ctx=ctx2), wires)
+        plan = [(14, 9), (13, 9), (13, 9), (13, 7), (14, 1)]               # (circuit rows, proofs in the batch), in chain order
+
+        def recursion():
+            n = 0
+            with torch.cuda.stream(st2):                                   # (thread-local: whichever thread runs this)
+                for lb, k in plan:
+                    cd, wires = circ[lb]
+                    cd.prove_batch([wires] * k, [[5, 6, 7]] * k, in_flight=min(k, 6))
+                    n += k
+            return n
+
+        def stark():
+            sg.prove_with_traces(all_stark, cfg, traces, in_use, pv(), ctx=ctx)
+        stark(); n_rec = recursion()                                         # noqa: E702  (warm: worker contexts, arenas)
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            stark()
+        t_stark = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            recursion()
+        t_rec = (time.perf_counter() - t0) / reps
+        # pipelined: the STARK of segment k + 1 (this thread, ctx) beside the recursion of segment k (a second thread)
+        import threading
+        t0 = time.perf_counter()
+        th = None
+        for _ in range(reps + 1):
+            stark()
+            if th is not None:
+                th.join()
+            th = threading.Thread(target=recursion)
+            th.start()
+        th.join()
+        t_pipe = (time.perf_counter() - t0) / (reps + 1)
+        out["segment_with_recursion"] = {
+            "plonk_proofs_per_segment": n_rec, "stark_ms": 1e3 * t_stark, "recursion_ms": 1e3 * t_rec,
+            "serial": {"value": 1.0 / (t_stark + t_rec), "unit": "segments/s"},
+            "pipelined": {"value": 1.0 / t_pipe, "unit": "segments/s",
+                          "note": "the next segment's STARK runs beside this segment's recursion proofs (two host threads)"},
+            "note": "realistic table heights; 35 synthetic-circuit PLONK proofs per segment in five zk_plonk_prove_batch calls "
+                    "(chain order); circuit witness generation (Rust) not included"}
+        for cd, _ in circ.values():
+            cd.free()
+        ctx2.close()
+    except Exception as e:
+        out["segment_with_recursion"] = {"error": repr(e)}
     del traces
     torch.cuda.empty_cache()
     return out
@@ -791,6 +858,8 @@ def kernel_class(name):
     m = re.search(r"quotient_kernel(?:_heavy)?<(\w+)", name)
     if m:
         return "quotient:" + m.group(1)
+    if "quotient_arith_kernel" in name:            # the LDS-tiled form of the Arithmetic AIR (arith_quotient.cuh)
+        return "quotient:AirArithmetic"
     for cls, sub in KERNEL_CLASSES:
         if sub in name:
             return cls

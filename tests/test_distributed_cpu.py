@@ -220,3 +220,16 @@ def test_no_pickled_collective_in_the_product():
             src = open(os.path.join(root, fn)).read()
             for bad in ("all_gather_object(", "gather_object(", "broadcast_object_list(", "scatter_object_list(", "send_object_list("):
                 assert bad not in src, (fn, bad)
+
+
+def test_split_columns_and_residue_classes():
+    from zk_evm_amd.sharding import _bitrev, split_columns
+    for n, w in [(2431, 8), (116, 2), (5, 4), (12, 16)]:
+        parts = split_columns(n, w)
+        assert [c for p in parts for c in p] == list(range(n)) and max(map(len, parts)) - min(map(len, parts)) <= 1
+    # leaf slot s = q * (N / W) + t  <->  natural row bitrev_N(s) = bitrev(t) * W + bitrev_W(q): the row residue classes
+    log_n, log_w = 6, 2
+    for q in range(1 << log_w):
+        for t in range(1 << (log_n - log_w)):
+            s = (q << (log_n - log_w)) | t
+            assert _bitrev(s, log_n) == _bitrev(t, log_n - log_w) * (1 << log_w) + _bitrev(q, log_w)

@@ -219,3 +219,61 @@ def test_table_parallel_and_scheduler_over_nccl_world1():
     direct = _proof_words(sg.prove_with_traces(AllStark((1, 2, 3, 4)), cfg, [to_dev(t) for t in host], in_use, pv))
     assert np.array_equal(direct, words)
     assert len(extra) == 2 and all(np.array_equal(direct, e) for e in extra)
+
+
+def _l3_worker(rank, world, port, q, shape, hasher):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import zk_evm_amd
+    from tests.oracle_lib import splitmix64
+    from zk_evm_amd.sharding import commit_columns_row_sharded, split_columns
+    n_cols, log_n = shape
+    mine = split_columns(n_cols, world)[rank]
+    vals = np.stack([splitmix64(0xC0FFEE + c, 1 << log_n) for c in mine])        # this rank's columns only
+    dev = torch.from_numpy(vals.view(np.int64)).cuda()
+    timing = {}
+    cap = commit_columns_row_sharded(dev, n_cols, zk_evm_amd.StarkConfig(hasher=hasher), timing=timing)
+    q.put((rank, cap, timing))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape,world,hasher", [((2431, 14), 2, 0), ((37, 10), 4, 0), ((116, 12), 2, 1)])
+def test_row_sharded_commit_equals_single_gpu_cap(shape, world, hasher):
+    """SURVEY 8(e) level 3, commit phase: columns sharded for the NTTs, all-to-all to row residue classes, row-sharded leaf
+    hashing + subtrees, all-gather of the sub-roots -- the cap every rank ends up with is the single-GPU
+    `PolynomialBatch::from_values` cap of the whole matrix (KeccakStark's 2431 columns x 2^14 rows over two ranks; four ranks;
+    the Keccak hasher).  gloo, the ranks share this GPU."""
+    import socket
+    import torch
+    import torch.multiprocessing as mp
+    import zk_evm_amd
+    from tests.oracle_lib import splitmix64
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_l3_worker, args=(r, world, port, q, shape, hasher)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r, cap, timing = q.get(timeout=600)
+        res[r] = (cap, timing)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n_cols, log_n = shape
+    vals = np.stack([splitmix64(0xC0FFEE + c, 1 << log_n) for c in range(n_cols)])
+    full = zk_evm_amd.PolynomialBatch.from_values(torch.from_numpy(vals.view(np.int64)).cuda(), 1, False, 4, hasher=hasher)
+    want = full.merkle_tree.cap.elements
+    for r in range(world):
+        assert np.array_equal(res[r][0], want), r
+        assert res[r][1]["rows"] == (2 << log_n) // world
+    full.free()

@@ -92,77 +92,86 @@ static __global__ void ext_pow_bitrev_table_kernel(u64 *wa, u64 *wb, int log_n, 
 
 // Openings: f_col(z_t) = sum_p c[col][p] * W_t[p] for up to ZK_EVAL_MAX_POINTS points in ONE pass over the
 // coefficients (zeta and g*zeta open the same columns).  Point t only covers columns [first[t], last[t]).
-// partial[((t * n_cols + col) * gridDim.x + chunk) * 2 + {0,1}] = sum over the chunk.
+// partial[((t * n_cols + col) * gridDim.x + chunk) * 2 + {0,1}] = sum over the row chunk.
 #define ZK_EVAL_MAX_POINTS 3
 struct EvalPoints {
     const u64 *wa[ZK_EVAL_MAX_POINTS], *wb[ZK_EVAL_MAX_POINTS];
     u32 first[ZK_EVAL_MAX_POINTS], last[ZK_EVAL_MAX_POINTS];
 };
+// Block = ZK_EVAL_ROWS consecutive coefficient positions x a group of columns.  The weights of the block's positions are
+// staged in LDS ONCE (the r02 form gave every (row chunk, column) pair its own block, which re-read 16 NP bytes of weights
+// per 8-byte coefficient: 3.1x the algorithmic traffic at 2^20, PMC r03d); then every wave walks its share of the group's
+// columns -- 32 coalesced coefficient loads in flight per lane, weights from LDS, delayed-reduction accumulators -- and folds
+// its 64 lanes with DPP-free shuffles.  grid = (row chunks, column groups).
+#define ZK_EVAL_ROWS 2048
+__device__ __forceinline__ u64 wave_sum_gl(u64 v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const u64 o = ((u64)(u32)__shfl_down((int)(u32)(v >> 32), off) << 32) | (u32)__shfl_down((int)(u32)v, off);
+        v = gl_add(v, o);
+    }
+    return v;                                        // lane 0 holds the sum
+}
 template <int NP>
 __global__ void __launch_bounds__(256)
-eval_columns_partial_kernel(const u64 *__restrict__ coeffs, size_t col_stride, u32 n, u32 n_cols, u32 col0,
+eval_columns_partial_kernel(const u64 *__restrict__ coeffs, size_t col_stride, u32 n, u32 n_cols, u32 cols_per_group,
                             EvalPoints P, u64 *__restrict__ partial) {
-    __shared__ u64 sa[256], sb[256];
-    const u32 col = col0 + blockIdx.y;
-    const u64 *c = coeffs + (size_t)col * col_stride;
-    u32 per = (n + gridDim.x - 1) / gridDim.x;
-    u32 lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
-    bool on[NP];
-    DotAcc acc[NP][2];
+    extern __shared__ __attribute__((aligned(16))) u64 wlds[];      // [NP][2][rows]
+    const u32 rows = n < ZK_EVAL_ROWS ? n : ZK_EVAL_ROWS;
+    const u32 lo = blockIdx.x * rows;
+    const u32 c_lo = blockIdx.y * cols_per_group, c_hi = c_lo + cols_per_group < n_cols ? c_lo + cols_per_group : n_cols;
+    for (u32 e = threadIdx.x; e < rows; e += blockDim.x) {
 #pragma unroll
-    for (int t = 0; t < NP; ++t) {
-        on[t] = col >= P.first[t] && col < P.last[t];
-        dot_acc_init(acc[t][0]); dot_acc_init(acc[t][1]);
-    }
-    // four coefficients (and their weights) in flight per lane: one at a time the loop is bound by the HBM round trip
-    constexpr u32 UN = 4;
-    u32 p = lo + threadIdx.x;
-    for (; p + (UN - 1) * blockDim.x < hi; p += UN * blockDim.x) {
-        u64 v[UN], wa[NP][UN], wb[NP][UN];
-#pragma unroll
-        for (u32 i = 0; i < UN; ++i) {
-            v[i] = c[p + i * blockDim.x];
-#pragma unroll
-            for (int t = 0; t < NP; ++t)
-                if (on[t]) { wa[t][i] = P.wa[t][p + i * blockDim.x]; wb[t][i] = P.wb[t][p + i * blockDim.x]; }
+        for (int t = 0; t < NP; ++t) {
+            wlds[(2 * t) * rows + e] = P.wa[t][lo + e];
+            wlds[(2 * t + 1) * rows + e] = P.wb[t][lo + e];
         }
+    }
+    __syncthreads();
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    for (u32 col = c_lo + wave; col < c_hi; col += n_waves) {
+        const u64 *c = coeffs + (size_t)col * col_stride + lo;
+        bool on[NP];
+        DotAcc acc[NP][2];
 #pragma unroll
-        for (u32 i = 0; i < UN; ++i)
+        for (int t = 0; t < NP; ++t) {
+            on[t] = col >= P.first[t] && col < P.last[t];           // wave-uniform
+            dot_acc_init(acc[t][0]); dot_acc_init(acc[t][1]);
+        }
+        constexpr u32 UN = 8;                                       // coefficient loads in flight per lane
+        u32 p = lane;
+        for (; p + (UN - 1) * 64 < rows; p += UN * 64) {
+            u64 v[UN];
+#pragma unroll
+            for (u32 i = 0; i < UN; ++i) v[i] = c[p + i * 64];
+#pragma unroll
+            for (u32 i = 0; i < UN; ++i)
+#pragma unroll
+                for (int t = 0; t < NP; ++t)
+                    if (on[t]) {
+                        dot_acc_mac_v(acc[t][0], wlds[(2 * t) * rows + p + i * 64], v[i]);
+                        dot_acc_mac_v(acc[t][1], wlds[(2 * t + 1) * rows + p + i * 64], v[i]);
+                    }
+        }
+        for (; p < rows; p += 64) {
+            const u64 v = c[p];
 #pragma unroll
             for (int t = 0; t < NP; ++t)
                 if (on[t]) {
-                    dot_acc_mac_v(acc[t][0], wa[t][i], v[i]);
-                    dot_acc_mac_v(acc[t][1], wb[t][i], v[i]);
+                    dot_acc_mac_v(acc[t][0], wlds[(2 * t) * rows + p], v);
+                    dot_acc_mac_v(acc[t][1], wlds[(2 * t + 1) * rows + p], v);
                 }
-    }
-    for (; p < hi; p += blockDim.x) {
-        const u64 v = c[p];
-#pragma unroll
-        for (int t = 0; t < NP; ++t)
-            if (on[t]) {
-                dot_acc_mac_v(acc[t][0], P.wa[t][p], v);
-                dot_acc_mac_v(acc[t][1], P.wb[t][p], v);
-            }
-    }
-#pragma unroll
-    for (int t = 0; t < NP; ++t) {
-        if (!on[t]) continue;          // uniform per block
-        sa[threadIdx.x] = dot_acc_reduce(acc[t][0]);
-        sb[threadIdx.x] = dot_acc_reduce(acc[t][1]);
-        __syncthreads();
-        for (u32 s = blockDim.x / 2; s > 0; s >>= 1) {
-            if (threadIdx.x < s) {
-                sa[threadIdx.x] = gl_add(sa[threadIdx.x], sa[threadIdx.x + s]);
-                sb[threadIdx.x] = gl_add(sb[threadIdx.x], sb[threadIdx.x + s]);
-            }
-            __syncthreads();
         }
-        if (threadIdx.x == 0) {
-            size_t o = (((size_t)t * n_cols + col) * gridDim.x + blockIdx.x) * 2;
-            partial[o] = sa[0];
-            partial[o + 1] = sb[0];
+#pragma unroll
+        for (int t = 0; t < NP; ++t) {
+            if (!on[t]) continue;
+            const u64 a = wave_sum_gl(dot_acc_reduce(acc[t][0])), b = wave_sum_gl(dot_acc_reduce(acc[t][1]));
+            if (lane == 0) {
+                const size_t o = (((size_t)t * n_cols + col) * gridDim.x + blockIdx.x) * 2;
+                partial[o] = a;
+                partial[o + 1] = b;
+            }
         }
-        __syncthreads();
     }
 }
 // out[(t * n_cols + col) * 2 ..] = sum of the chunks (entries of points that skip the column stay 0)
