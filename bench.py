@@ -825,7 +825,7 @@ def plonk_recursion_profile(ctx, dev, with_cpu, sizes=(12, 13, 14), reps=8):
             try:
                 K, best = 48, None
                 tried = []
-                for W in (4, 6):
+                for W in (4, 6, 8):
                     cd.prove_batch([wires] * W, [pis] * W, in_flight=W)          # worker contexts, arenas
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()

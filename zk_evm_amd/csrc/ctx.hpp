@@ -66,6 +66,8 @@ struct zk_ctx {
     // pinned staging for small host -> device uploads (stage_upload below)
     std::vector<char *> stage_chunks;
     size_t stage_cur = 0, stage_off = 0, stage_since_rewind = 0;
+    struct StageReadback { const char *h_pinned; void *h_dst; size_t bytes; };
+    std::vector<StageReadback> stage_pending;   // stage_download results not yet copied to their destinations
     std::map<std::vector<u64>, u32> constraint_counts;   // quotient: constraints yielded per (AIR, lookup/CTL shape)
 };
 
@@ -140,20 +142,29 @@ struct LaneScope {
     LaneScope &operator=(const LaneScope &) = delete;
 };
 
-// Small host -> device uploads (programs, compiled entries, descriptors, coefficient tables).  A hipMemcpyAsync from
-// pageable memory stalls the calling thread on a staging copy and forced "host buffer goes out of scope" synchronisations;
-// here the bytes are copied into pinned memory the ctx owns and the transfer is truly asynchronous on ctx->stream, so the
-// caller's buffer is free again on return and no synchronisation is needed.  The pinned chunks are reused from the start
-// whenever the streams are known idle (stage_rewind: end of a segment proof; or after STAGE_LIMIT bytes, with one sync).
+// Small host <-> device transfers (programs, compiled entries, descriptors, coefficient tables; caps, flags, opening values).
+// On this ROCm a hipMemcpyAsync of a few hundred bytes costs the calling thread ~70 us -- pageable or pinned, either
+// direction (kernel trace r03e: 242 back-to-back copies with 70 us gaps per two realistic-height proofs) -- where a kernel
+// launch costs ~5.  So small transfers go through pinned memory the ctx owns and a copy KERNEL on ctx->stream:
+//   stage_upload:   the bytes are memcpy'd into a pinned chunk, a kernel copies them to the device -- the caller's buffer is
+//                   free again on return, no "host buffer goes out of scope" synchronisation;
+//   stage_download: a kernel copies device words into a pinned chunk; after the caller has synchronised with the stream,
+//                   stage_collect memcpy's them to their (pageable) destinations;
+//   copy_to_pinned: the same for a destination that already is pinned memory.
+// The pinned chunks are reused from the start whenever the streams are known idle (stage_rewind: end of a segment proof;
+// or after ZK_STAGE_LIMIT bytes, with one synchronisation).
 static constexpr size_t ZK_STAGE_CHUNK = (size_t)1 << 20, ZK_STAGE_LIMIT = (size_t)16 << 20;
+static __global__ void zk_copy_words_kernel(u64 *__restrict__ dst, const u64 *__restrict__ src, size_t n_words) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) dst[i] = src[i];
+}
 static inline void stage_rewind(zk_ctx *ctx) { ctx->stage_cur = 0; ctx->stage_off = 0; ctx->stage_since_rewind = 0; }
-static hipError_t stage_upload(zk_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
-    if (!bytes) return hipSuccess;
-    if (bytes > ZK_STAGE_CHUNK / 2) return hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (!ctx->async && ctx->stage_since_rewind + bytes > ZK_STAGE_LIMIT) {   // standalone calls: bound the footprint
-        hipError_t e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return e;
-        if (ctx->side_stream && (e = hipStreamSynchronize(ctx->side_stream)) != hipSuccess) return e;
+// `bytes` of pinned memory (8-byte aligned, rounded up to 64), or nullptr
+static char *stage_alloc(zk_ctx *ctx, size_t bytes, hipError_t *err) {
+    *err = hipSuccess;
+    if (!ctx->async && ctx->stage_pending.empty() && ctx->stage_since_rewind + bytes > ZK_STAGE_LIMIT) {
+        if ((*err = hipStreamSynchronize(ctx->stream)) != hipSuccess) return nullptr;     // standalone calls: bound the footprint
+        if (ctx->side_stream && (*err = hipStreamSynchronize(ctx->side_stream)) != hipSuccess) return nullptr;
         stage_rewind(ctx);
     }
     const size_t need = (bytes + 63) & ~(size_t)63;
@@ -161,16 +172,48 @@ static hipError_t stage_upload(zk_ctx *ctx, void *d_dst, const void *h_src, size
         if (!ctx->stage_chunks.empty()) { ++ctx->stage_cur; ctx->stage_off = 0; }
         if (ctx->stage_cur >= ctx->stage_chunks.size()) {
             char *c = nullptr;
-            hipError_t e = hipHostMalloc((void **)&c, ZK_STAGE_CHUNK, hipHostMallocDefault);
-            if (e != hipSuccess) return e;
+            if ((*err = hipHostMalloc((void **)&c, ZK_STAGE_CHUNK, hipHostMallocDefault)) != hipSuccess) return nullptr;
             ctx->stage_chunks.push_back(c);
         }
     }
     char *h = ctx->stage_chunks[ctx->stage_cur] + ctx->stage_off;
-    memcpy(h, h_src, bytes);
     ctx->stage_off += need;
     ctx->stage_since_rewind += need;
-    return hipMemcpyAsync(d_dst, h, bytes, hipMemcpyHostToDevice, ctx->stream);
+    return h;
+}
+// device destinations come from the ctx arena (512-byte granules): rounding the copy up to whole words stays inside them
+static hipError_t stage_upload(zk_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    if (bytes > ZK_STAGE_CHUNK / 2) return hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e;
+    char *h = stage_alloc(ctx, bytes, &e);
+    if (!h) return e;
+    memcpy(h, h_src, bytes);
+    const size_t words = (bytes + 7) / 8;
+    zk_copy_words_kernel<<<(unsigned)((words + 255) / 256), 256, 0, ctx->stream>>>((u64 *)d_dst, (const u64 *)h, words);
+    return hipGetLastError();
+}
+// `h_pinned_dst` must be pinned (hipHostMalloc) memory with room for the byte count rounded up to whole words
+static hipError_t copy_to_pinned(zk_ctx *ctx, void *h_pinned_dst, const void *d_src, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    const size_t words = (bytes + 7) / 8;
+    zk_copy_words_kernel<<<(unsigned)((words + 255) / 256), 256, 0, ctx->stream>>>((u64 *)h_pinned_dst, (const u64 *)d_src, words);
+    return hipGetLastError();
+}
+// device -> pageable host, small: lands in `h_dst` when stage_collect runs (after the caller's stream synchronisation).
+// `d_src` must be 8-byte aligned with whole words readable (arena blocks are).
+static hipError_t stage_download(zk_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    if (bytes > ZK_STAGE_CHUNK / 2) return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e;
+    char *h = stage_alloc(ctx, bytes, &e);
+    if (!h) return e;
+    ctx->stage_pending.push_back({h, h_dst, bytes});
+    return copy_to_pinned(ctx, h, d_src, bytes);
+}
+static inline void stage_collect(zk_ctx *ctx) {
+    for (auto &r : ctx->stage_pending) memcpy(r.h_dst, r.h_pinned, r.bytes);
+    ctx->stage_pending.clear();
 }
 
 static int check_abort(zk_ctx *ctx) {

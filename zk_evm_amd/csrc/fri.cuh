@@ -103,7 +103,7 @@ struct EvalPoints {
 // per 8-byte coefficient: 3.1x the algorithmic traffic at 2^20, PMC r03d); then every wave walks its share of the group's
 // columns -- 32 coalesced coefficient loads in flight per lane, weights from LDS, delayed-reduction accumulators -- and folds
 // its 64 lanes with DPP-free shuffles.  grid = (row chunks, column groups).
-#define ZK_EVAL_ROWS 2048
+#define ZK_EVAL_ROWS 512          // 16 KiB of weights per block at two points: eight blocks per CU keep the loads in flight
 __device__ __forceinline__ u64 wave_sum_gl(u64 v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {

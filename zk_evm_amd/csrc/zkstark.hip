@@ -426,8 +426,7 @@ static int commit_enqueue(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_
     b->cap.resize((size_t)4 << cfg->cap_height);
     u64 *slot = ctx->h_caps + (ctx->cap_slot_next++ % ZK_CAP_SLOTS) * 64;
     pc->h_cap = slot;
-    B_HIP(hipMemcpyAsync(slot, b->d_digests + 4 * (b->n_digests - ((size_t)1 << cfg->cap_height)),
-                         b->cap.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    B_HIP(copy_to_pinned(ctx, slot, b->d_digests + 4 * (b->n_digests - ((size_t)1 << cfg->cap_height)), b->cap.size() * 8));
 #undef B_HIP
     return ZK_OK;
 }
