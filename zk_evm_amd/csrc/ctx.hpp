@@ -5,9 +5,11 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
 #include <utility>
@@ -68,6 +70,9 @@ struct zk_ctx {
     size_t stage_cur = 0, stage_off = 0, stage_since_rewind = 0;
     struct StageReadback { const char *h_pinned; void *h_dst; size_t bytes; };
     std::vector<StageReadback> stage_pending;   // stage_download results not yet copied to their destinations
+    char *h_big = nullptr;                      // pinned landing buffer for the large downloads (FRI query words)
+    size_t h_big_bytes = 0;
+    std::map<std::pair<u64, u64>, std::shared_ptr<void>> entry_shapes;   // EntryShape per (program hash, words | slots): stark_host.inc
     std::map<std::vector<u64>, u32> constraint_counts;   // quotient: constraints yielded per (AIR, lookup/CTL shape)
 };
 
@@ -182,6 +187,8 @@ static char *stage_alloc(zk_ctx *ctx, size_t bytes, hipError_t *err) {
     return h;
 }
 // device destinations come from the ctx arena (512-byte granules): rounding the copy up to whole words stays inside them
+// ZK_STAGE_KERNEL=0 (A-B runs only): hipMemcpyAsync from / to the pinned chunk instead of the copy kernel
+static const bool kStageKernel = !(getenv("ZK_STAGE_KERNEL") && getenv("ZK_STAGE_KERNEL")[0] == 0x30);
 static hipError_t stage_upload(zk_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     if (!bytes) return hipSuccess;
     if (bytes > ZK_STAGE_CHUNK / 2) return hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream);
@@ -189,6 +196,7 @@ static hipError_t stage_upload(zk_ctx *ctx, void *d_dst, const void *h_src, size
     char *h = stage_alloc(ctx, bytes, &e);
     if (!h) return e;
     memcpy(h, h_src, bytes);
+    if (!kStageKernel) return hipMemcpyAsync(d_dst, h, bytes, hipMemcpyHostToDevice, ctx->stream);
     const size_t words = (bytes + 7) / 8;
     zk_copy_words_kernel<<<(unsigned)((words + 255) / 256), 256, 0, ctx->stream>>>((u64 *)d_dst, (const u64 *)h, words);
     return hipGetLastError();
@@ -196,6 +204,7 @@ static hipError_t stage_upload(zk_ctx *ctx, void *d_dst, const void *h_src, size
 // `h_pinned_dst` must be pinned (hipHostMalloc) memory with room for the byte count rounded up to whole words
 static hipError_t copy_to_pinned(zk_ctx *ctx, void *h_pinned_dst, const void *d_src, size_t bytes) {
     if (!bytes) return hipSuccess;
+    if (!kStageKernel) return hipMemcpyAsync(h_pinned_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
     const size_t words = (bytes + 7) / 8;
     zk_copy_words_kernel<<<(unsigned)((words + 255) / 256), 256, 0, ctx->stream>>>((u64 *)h_pinned_dst, (const u64 *)d_src, words);
     return hipGetLastError();
@@ -204,7 +213,23 @@ static hipError_t copy_to_pinned(zk_ctx *ctx, void *h_pinned_dst, const void *d_
 // `d_src` must be 8-byte aligned with whole words readable (arena blocks are).
 static hipError_t stage_download(zk_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     if (!bytes) return hipSuccess;
-    if (bytes > ZK_STAGE_CHUNK / 2) return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (bytes > ZK_STAGE_CHUNK / 2) {
+        // Large and to pageable memory: the runtime would stage it through its own bounce buffers from the calling thread
+        // (0.5 ms before the copy even starts, kernel trace r03f).  One pinned landing buffer per ctx, one such download
+        // in flight at a time (the caller synchronises and collects before the next).
+        for (auto &r : ctx->stage_pending)
+            if (r.h_pinned == ctx->h_big) return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (ctx->h_big_bytes < bytes) {
+            if (ctx->h_big) (void)hipHostFree(ctx->h_big);
+            ctx->h_big = nullptr; ctx->h_big_bytes = 0;
+            const size_t want = (bytes + (bytes >> 2) + 4095) & ~(size_t)4095;
+            hipError_t e = hipHostMalloc((void **)&ctx->h_big, want, hipHostMallocDefault);
+            if (e != hipSuccess) { (void)hipGetLastError(); return hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream); }
+            ctx->h_big_bytes = want;
+        }
+        ctx->stage_pending.push_back({ctx->h_big, h_dst, bytes});
+        return hipMemcpyAsync(ctx->h_big, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    }
     hipError_t e;
     char *h = stage_alloc(ctx, bytes, &e);
     if (!h) return e;
