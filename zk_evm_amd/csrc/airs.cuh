@@ -505,6 +505,27 @@ struct AirArithmetic {
     }
 };
 
+// 96-bit integer accumulator for sums of up to 2^32 weighted u64 representatives: `step` is one Horner step S <- 2 S + v
+// (32 steps of values < 2^64 stay below 2^96), `add` a plain S <- S + v; `fold` reduces to a lazy field element.
+struct Acc96 {
+    u64 lo;
+    u32 hi;
+    __device__ __forceinline__ Acc96() : lo(0), hi(0) {}
+    __device__ __forceinline__ void step(u64 v) {
+        hi = (hi << 1) | (u32)(lo >> 63);
+        lo <<= 1;
+        const u64 s = lo + v;
+        hi += s < v ? 1u : 0u;
+        lo = s;
+    }
+    __device__ __forceinline__ void add(u64 v) {
+        const u64 s = lo + v;
+        hi += s < v ? 1u : 0u;
+        lo = s;
+    }
+    __device__ __forceinline__ u64 fold() const { return fold96(lo, hi); }
+};
+
 // KeccakStark: keccak/keccak_stark.rs:266-426 + keccak/round_flags.rs:14-60 (xor/andn as polynomials:
 // keccak/logic.rs:15-53); columns keccak/columns.rs:7-134 (2431 columns: 24 round flags, TIMESTAMP,
 // A 25x2 limbs, C and C' 5x64 bits, A' 5x5x64 bits, A'' 25x2 limbs, A''[0,0] bits, A'''[0,0] limbs).
@@ -561,39 +582,51 @@ struct AirKeccak {
         //   * the chi step reads the five lanes B[0..4, y, z] of a row once for its five output bits (5 loads per (y, z)
         //     instead of 15).
         // Same field values at the same positions of the alpha-combination as the reference's order.
-        for (u32 x = 0; x < 5; ++x) {
-            Fe acc[5][2];
-            for (int z = 31; z >= 0; --z)
-                for (u32 half = 0; half < 2; ++half) {
+        // r03: the 32-bit recompositions sum_z 2^z v_z are INTEGER Horner sums in 96-bit accumulators (Acc96: five instructions a
+        // step, one fold to the field at the end) instead of two lazy field additions per bit, and they are split by linearity:
+        // xor_gen(a, t) = a + t - 2 a t  ->  sum 2^z a  +  sum 2^z t (independent of y: once per x)  -  sum 2^z (a * 2t); chi's
+        // xor_gen(b0, n) with n = andn(b1, b2) likewise.  Same field values (the integers are sums of representatives), ~30 % fewer
+        // instructions in a kernel that issues at 3.8 cycles per instruction.
+        for (u32 x = 0; x < 5; ++x)
+            for (u32 half = 0; half < 2; ++half) {
+                Acc96 sa[5], sp[5], st;
+                for (int z = 31; z >= 0; --z) {
                     const u32 zz = 32 * half + (u32)z;
                     const Fe cp = lv[reg_c_prime(x, zz)];
                     const Fe t = xor_gen(lv[reg_c(x, zz)], cp), t2 = t + t;
-                    Fe sum;
+                    st.step(t.v);
+                    Acc96 sum;
                     for (u32 y = 0; y < 5; ++y) {
                         const Fe a = lv[reg_a_prime(x, y, zz)];
-                        sum += a;
-                        acc[y][half] = acc[y][half] + acc[y][half] + (a + t - a * t2);      // xor_gen(a, t)
+                        sum.add(a.v);
+                        sa[y].step(a.v);
+                        sp[y].step((a * t2).v);
                     }
-                    const Fe diff = sum - cp;
+                    const Fe diff = Fe(sum.fold()) - cp;
                     c.constraint_at(50 + x * 64 + zz, diff * (diff - fe(2)) * (diff - fe(4)));
                 }
-            for (u32 y = 0; y < 5; ++y)
-                for (u32 half = 0; half < 2; ++half) c.constraint_at(x * 10 + y * 2 + half, acc[y][half] - lv[reg_a(x, y) + half]);
-        }
+                const Fe tt(st.fold());
+                for (u32 y = 0; y < 5; ++y)
+                    c.constraint_at(x * 10 + y * 2 + half, Fe(sa[y].fold()) + tt - Fe(sp[y].fold()) - lv[reg_a(x, y) + half]);
+            }
         c.advance(50 + 320);
-        for (u32 y = 0; y < 5; ++y) {
-            Fe acc[5][2];
-            for (int z = 31; z >= 0; --z)
-                for (u32 half = 0; half < 2; ++half) {
+        for (u32 y = 0; y < 5; ++y)
+            for (u32 half = 0; half < 2; ++half) {
+                Acc96 sb[5], sn[5], sm[5];
+                for (int z = 31; z >= 0; --z) {
                     const u32 zz = 32 * half + (u32)z;
                     Fe b[5];
-                    for (u32 x = 0; x < 5; ++x) b[x] = lv[reg_b(x, y, zz)];
-                    for (u32 x = 0; x < 5; ++x)
-                        acc[x][half] = acc[x][half] + acc[x][half] + xor_gen(b[x], andn_gen(b[(x + 1) % 5], b[(x + 2) % 5]));
+                    for (u32 x = 0; x < 5; ++x) { b[x] = lv[reg_b(x, y, zz)]; sb[x].step(b[x].v); }
+                    for (u32 x = 0; x < 5; ++x) {
+                        const Fe b2 = b[(x + 2) % 5];
+                        const Fe n = b2 - b[(x + 1) % 5] * b2;               // andn_gen(b1, b2) = (1 - b1) b2
+                        sn[x].step(n.v);
+                        sm[x].step((b[x] * (n + n)).v);                      // xor_gen(b0, n) = b0 + n - b0 * 2n
+                    }
                 }
-            for (u32 x = 0; x < 5; ++x)
-                for (u32 half = 0; half < 2; ++half) c.constraint_at(x * 10 + y * 2 + half, acc[x][half] - lv[reg_a_pp(x, y) + half]);
-        }
+                for (u32 x = 0; x < 5; ++x)
+                    c.constraint_at(x * 10 + y * 2 + half, Fe(sb[x].fold()) + Fe(sn[x].fold()) - Fe(sm[x].fold()) - lv[reg_a_pp(x, y) + half]);
+            }
         c.advance(50);
         for (u32 half = 0; half < 2; ++half) {
             Fe acc;

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -147,6 +148,25 @@ struct LaneScope {
     LaneScope &operator=(const LaneScope &) = delete;
 };
 
+// ZK_HOST_PROFILE=1 (diagnostics): host time per named scope, printed when the ctx is destroyed
+struct HostProf {
+    static bool on() { static const bool v = getenv("ZK_HOST_PROFILE") && getenv("ZK_HOST_PROFILE")[0] == 0x31; return v; }
+    static std::map<std::string, std::pair<double, u64>> &table() { static std::map<std::string, std::pair<double, u64>> t; return t; }
+    const char *name;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostProf(const char *n) : name(n) { if (on()) t0 = std::chrono::steady_clock::now(); }
+    ~HostProf() {
+        if (!on()) return;
+        auto &e = table()[name];
+        e.first += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        e.second += 1;
+    }
+    static void dump() {
+        if (!on()) return;
+        for (auto &kv : table()) fprintf(stderr, "[zk host] %-36s %10.1f us total %8llu calls %8.1f us/call\n", kv.first.c_str(), kv.second.first, (unsigned long long)kv.second.second, kv.second.first / (double)kv.second.second);
+    }
+};
+
 // Small host <-> device transfers (programs, compiled entries, descriptors, coefficient tables; caps, flags, opening values).
 // On this ROCm a hipMemcpyAsync of a few hundred bytes costs the calling thread ~70 us -- pageable or pinned, either
 // direction (kernel trace r03e: 242 back-to-back copies with 70 us gaps per two realistic-height proofs) -- where a kernel
@@ -190,6 +210,7 @@ static char *stage_alloc(zk_ctx *ctx, size_t bytes, hipError_t *err) {
 // ZK_STAGE_KERNEL=0 (A-B runs only): hipMemcpyAsync from / to the pinned chunk instead of the copy kernel
 static const bool kStageKernel = !(getenv("ZK_STAGE_KERNEL") && getenv("ZK_STAGE_KERNEL")[0] == 0x30);
 static hipError_t stage_upload(zk_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    HostProf hp("stage_upload");
     if (!bytes) return hipSuccess;
     if (bytes > ZK_STAGE_CHUNK / 2) return hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream);
     hipError_t e;

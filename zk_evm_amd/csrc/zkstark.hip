@@ -76,6 +76,7 @@ extern "C" void zk_batch_free(zk_batch *b);
 
 extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     if (!ctx) return;
+    HostProf::dump();
     hipSetDevice(ctx->device);
     while (!ctx->live_batches.empty()) zk_batch_free(*ctx->live_batches.begin());
     hipStreamSynchronize(ctx->stream);
@@ -372,6 +373,7 @@ static void pending_release(zk_ctx *ctx, PendingCommit &pc) {
 
 static int commit_enqueue(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t in_stride,
                           size_t n_cols, unsigned log_n, CommitMode mode, PendingCommit *pc) {
+    HostProf hp("commit_enqueue");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ZK_TRY(check_abort(ctx));
     const size_t n = (size_t)1 << log_n;
