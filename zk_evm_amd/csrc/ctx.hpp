@@ -73,7 +73,12 @@ struct zk_ctx {
     std::vector<StageReadback> stage_pending;   // stage_download results not yet copied to their destinations
     char *h_big = nullptr;                      // pinned landing buffer for the large downloads (FRI query words)
     size_t h_big_bytes = 0;
-    std::map<std::pair<u64, u64>, std::shared_ptr<void>> entry_shapes;   // EntryShape per (program hash, words | slots): stark_host.inc
+    std::map<std::pair<u64, u64>, std::shared_ptr<void>> entry_shapes;
+    // device-resident copies of per-table-definition constants (programs, compiled shapes, AIR constants): const_upload
+    struct DevConst { std::vector<u64> words; u64 *d = nullptr; };
+    std::map<std::pair<u64, u64>, DevConst> dev_consts;
+    std::map<std::pair<u64, u64>, std::shared_ptr<void>> dev_shapes;     // DevShape per table description: stark_host.inc
+    size_t dev_const_bytes = 0;   // EntryShape per (program hash, words | slots): stark_host.inc
     std::map<std::vector<u64>, u32> constraint_counts;   // quotient: constraints yielded per (AIR, lookup/CTL shape)
 };
 
@@ -260,6 +265,37 @@ static hipError_t stage_download(zk_ctx *ctx, void *h_dst, const void *d_src, si
 static inline void stage_collect(zk_ctx *ctx) {
     for (auto &r : ctx->stage_pending) memcpy(r.h_dst, r.h_pinned, r.bytes);
     ctx->stage_pending.clear();
+}
+
+// Constants of a table definition -- Column / Filter programs, compiled entry shapes, AIR constants -- are the same words in
+// every proof.  The first use uploads them into device memory the ctx keeps (hipMalloc, synchronously: the copy is complete
+// and visible to both lanes when the call returns); every later use is a hash lookup plus a word-for-word comparison, and NO
+// transfer.  Why it matters: a kernel (or blit) that touches host memory costs the GPU ~60 us of pipeline time around it
+// (kernel trace r03g: 269 such gaps per two realistic-height proofs), 150 small uploads per proof.  Returns nullptr when the
+// cache is full (64 MB) -- the caller then uploads into scratch as before.
+static inline u64 words_hash(const u64 *p, size_t words) {
+    u64 h = 0xcbf29ce484222325ULL;
+    for (size_t i = 0; i < words; ++i) { h ^= p[i]; h *= 0x100000001b3ULL; h ^= h >> 29; }
+    return h;
+}
+static const u64 *const_upload(zk_ctx *ctx, const u64 *words, size_t n_words) {
+    if (!n_words) return nullptr;
+    const std::pair<u64, u64> key{words_hash(words, n_words), (u64)n_words};
+    auto it = ctx->dev_consts.find(key);
+    if (it != ctx->dev_consts.end()) {
+        if (it->second.words.size() == n_words && memcmp(it->second.words.data(), words, n_words * 8) == 0) return it->second.d;
+        return nullptr;                                    // (a hash collision: do not cache the newcomer)
+    }
+    if (ctx->dev_const_bytes + n_words * 8 > ((size_t)64 << 20)) return nullptr;
+    u64 *d = nullptr;
+    if (hipMalloc((void **)&d, n_words * 8) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipMemcpyAsync(d, words, n_words * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(d); return nullptr; }
+    zk_ctx::DevConst &e = ctx->dev_consts[key];
+    e.words.assign(words, words + n_words);
+    e.d = d;
+    ctx->dev_const_bytes += n_words * 8;
+    return d;
 }
 
 static int check_abort(zk_ctx *ctx) {

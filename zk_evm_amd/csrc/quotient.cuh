@@ -313,7 +313,6 @@ __device__ __forceinline__ void check_constraints(const QuotientArgs &A, u32 i, 
         u32 start_index = 0;
         for (u32 zi = 0; zi < n_z; ++zi) {
             const u32 off = (u32)cp[1 + zi];
-            const u64 beta = cp[off], gamma = cp[off + 1];
             const u32 n_help = (u32)cp[off + 2];
             const u32 sub = off + 3;
             const u32 ne = (u32)cp[sub];

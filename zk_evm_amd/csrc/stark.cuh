@@ -326,6 +326,33 @@ __device__ __forceinline__ void prog_eval_entry(const u64 *__restrict__ prog, u3
 }
 
 #ifndef ZK_DEVICE_FUNCS_ONLY   // the column-generator kernels
+// ---- compiled blobs made ON THE DEVICE (stark_host.inc MultiShape) --------------------------------------------------------
+// A table's compiled entries are challenge-independent except for the coefficient words beta^j c and the constants gamma +
+// sum k_j beta^j.  The serialised shape lives in device memory (const_upload); per proof ONE small kernel writes the blob:
+// a template word >= p is a tag (p + 2 * patch + slot) and is replaced by its polynomial evaluated at that slot's challenge,
+// every other word is copied.  The (beta, gamma) pairs of the proof travel as kernel arguments -- no host memory is touched.
+//   ser := blob_words, n_patches, patch_off, mono_off, tmpl[blob_words], patch[n] {mono_start | n_mono << 32, pair | add_gamma << 8},
+//          mono[] {c, j}
+#define ZK_MAX_CH_PAIRS 48
+struct ChTable { u64 beta[ZK_MAX_CH_PAIRS][2], gamma[ZK_MAX_CH_PAIRS][2]; };
+static __global__ void entry_blobs_instantiate_kernel(const u64 *__restrict__ ser, u64 *__restrict__ blob, ChTable T) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (u32)ser[0]) return;
+    u64 w = ser[4 + i];
+    if (w >= GL_P && w != ZK_CBLOB_TWIN) {
+        const u64 idx = w - GL_P;
+        const u32 slot = (u32)idx & 1;
+        const u64 *pa = ser + ser[2] + 2 * (idx >> 1);
+        const u32 ms = (u32)pa[0], nm = (u32)(pa[0] >> 32), pair = (u32)pa[1] & 0xFF;
+        u64 v = ((pa[1] >> 8) & 1) ? T.gamma[pair][slot] : 0;
+        const u64 b = T.beta[pair][slot];
+        const u64 *mo = ser + ser[3] + 2 * (size_t)ms;
+        for (u32 m = 0; m < nm; ++m) v = gl_add(v, gl_mul(mo[2 * m], gl_pow(b, mo[2 * m + 1])));
+        w = gl_canon(v);
+    }
+    blob[i] = w;
+}
+
 struct HelperOut {
     u64 *helpers[ZK_HELPER_MAX_CHALLENGES];     // challenge k: helper column h at helpers[k] + h * helper_stride
     u64 *extra_inv[ZK_HELPER_MAX_CHALLENGES];   // optional: 1 / (gamma_k + table column)

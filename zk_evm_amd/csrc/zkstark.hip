@@ -90,6 +90,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     for (auto &e : ctx->ev_pool) if (e) hipEventDestroy(e);
     if (ctx->h_caps) hipHostFree(ctx->h_caps);
     if (ctx->h_big) hipHostFree(ctx->h_big);
+    for (auto &kv : ctx->dev_consts) if (kv.second.d) hipFree(kv.second.d);
     for (char *c : ctx->stage_chunks) hipHostFree(c);
     if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
