@@ -23,9 +23,16 @@ try:
     print("realistic", b.get("realistic", {}).get("single"), b.get("realistic", {}).get("in_flight"))
     print("in_flight", b.get("in_flight"))
     kc = b.get("kernel_counters") or {}
+    for t, r in (kc.get("quotient_per_table") or {}).items():
+        print("   %-14s air %7.2f ms  checks %7.2f ms  traffic/alg %6.2f  (reported/alg %6.2f)" % (t, r["air_ms"], r["checks_ms"], r["traffic_over_algorithmic"], r["reported_over_algorithmic"]))
+    print("quotient total ms", kc.get("quotient_ms_total"))
     for k, v in kc.items():
-        if isinstance(v, dict):
-            print("  %-32s %4d launches %8.2f ms  traffic/alg %s  cpi %s" % (k, v["launches"], v["ms"], v.get("traffic_over_algorithmic"), v.get("cycles_per_wave_instruction")))
+        if isinstance(v, dict) and "launches" in v:
+            print("  %-32s %4d launches %8.2f ms  traffic %6.2f GB  cpi %s" % (k, v["launches"], v["ms"], v.get("traffic_bytes", 0) / 1e9, v.get("cycles_per_wave_instruction")))
+    pr = b.get("plonk_recursion", {})
+    print("plonk batch", pr.get("batch_2^13"), "threads", (pr.get("in_flight_2^13") or {}).get("proofs_per_s"))
+    print("recursion", (b.get("realistic") or {}).get("segment_with_recursion"))
+    print("dist", b.get("dist"))
     print("ntt", b.get("ntt"))
     print("h2d", b.get("h2d"))
     print("side_lane", b.get("side_lane"))
