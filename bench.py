@@ -1388,9 +1388,11 @@ def main():
                     out["cpu_baseline"]["table_proof_error"] = repr(e)
             else:
                 out["cpu_baseline"] = extrap
-    if use_dist:
+    if use_dist and (world == 1 or a.force_dist or os.environ.get("ZK_BENCH_DIST_SELFTEST") == "1"):
         # the collectives of the product's multi-GPU paths on this backend (RCCL under nccl): cap all-gather, status
-        # all-reduce, challenger-state broadcast, variable-length gather -- every rank takes part, rank 0 reports
+        # all-reduce, challenger-state broadcast, variable-length gather -- every rank takes part, rank 0 reports.  In a
+        # multi-rank run only on request: the scaling line needs nothing but the barrier and the MAX all-reduce above, and
+        # must not depend on anything else.
         selftest = dist_selftest(rank, world, a.dist_backend)
         if rank == 0 and out is not None:
             out["dist"] = selftest
