@@ -4,6 +4,20 @@
 #include <cstdio>
 #include "../zk_evm_amd/csrc/gl.cuh"
 
+// the carry-chain fold used until r03 (gl.cuh now ends the fold with two v_mad_u64_u32: GL_ASM_HEAD / GL_ASM_TAIL)
+#define GL_ASM_REDUCE                                                                            \
+    "v_sub_co_u32 %[lo], vcc, %[p0], %[t3]\n\t"                                                  \
+    "v_subbrev_co_u32 %[t1], vcc, 0, %[t1], vcc\n\t"                                             \
+    "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"                                                     \
+    "v_sub_co_u32 %[lo], vcc, %[lo], %[e]\n\t"                                                   \
+    "v_subbrev_co_u32 %[t1], vcc, 0, %[t1], vcc\n\t"                                             \
+    "v_sub_co_u32 %[lo], vcc, %[lo], %[t2]\n\t"                                                  \
+    "v_subbrev_co_u32 %[e], vcc, 0, %[t2], vcc\n\t"                                              \
+    "v_add_co_u32 %[hi], vcc, %[t1], %[e]\n\t"                                                   \
+    "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"                                                     \
+    "v_add_co_u32 %[lo], vcc, %[lo], %[e]\n\t"                                                   \
+    "v_addc_co_u32 %[hi], vcc, 0, %[hi], vcc"
+
 #ifndef ITER
 #define ITER 2048
 #endif

@@ -71,20 +71,22 @@ GL_HD u64 gl_mul_ref(u64 a, u64 b) {
 // issues at ~4.3 cycles per wave (v_mov/and/or/xor/add_u32 at ~2.4), so the goal is the fewest
 // instructions and no register-pair shuffling (v_mov) around v_mad_u64_u32 results.
 
-// [T3:T2:T1:T0] (T0 = %[p0]) -> lazy u64 in (%[lo], %[hi]); uses 2^64 = 2^32-1, 2^96 = -1.
-// In: %[t1] %[t2] %[t3] (clobbered), %[p0].  Tmp: %[e].
-#define GL_ASM_REDUCE                                                                            \
-    "v_sub_co_u32 %[lo], vcc, %[p0], %[t3]\n\t"      /* [t1:lo] = [T1:T0] - T3            */      \
-    "v_subbrev_co_u32 %[t1], vcc, 0, %[t1], vcc\n\t"                                              \
-    "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"         /* borrow: -= EPS (== += p)          */      \
+// [T3:T2:T1:T0] -> lazy u64, with 2^64 = 2^32 - 1 and 2^96 = -1:   [T1:T0] - T3 + T2 * (2^32 - 1).
+// Head: q = [T1:T0] - T3, a borrow (probability ~2^-33 per lane) repaid by -= EPS (== += p).  Branch-free form; outputs the
+// two halves of q out of place so that they can be allocated as the register pair the tail's mad wants.
+#define GL_ASM_HEAD                                                                               \
+    "v_sub_co_u32 %[lo], vcc, %[p0], %[t3]\n\t"                                                   \
+    "v_subbrev_co_u32 %[h], vcc, 0, %[t1], vcc\n\t"                                               \
+    "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"                                                      \
     "v_sub_co_u32 %[lo], vcc, %[lo], %[e]\n\t"                                                    \
-    "v_subbrev_co_u32 %[t1], vcc, 0, %[t1], vcc\n\t"                                              \
-    "v_sub_co_u32 %[lo], vcc, %[lo], %[t2]\n\t"      /* += T2*(2^32-1) = [T2:0] - [0:T2]  */      \
-    "v_subbrev_co_u32 %[e], vcc, 0, %[t2], vcc\n\t"  /* e = T2 - borrow (>= 0)            */      \
-    "v_add_co_u32 %[hi], vcc, %[t1], %[e]\n\t"                                                    \
-    "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"         /* carry: += EPS                     */      \
-    "v_add_co_u32 %[lo], vcc, %[lo], %[e]\n\t"                                                    \
-    "v_addc_co_u32 %[hi], vcc, 0, %[hi], vcc"
+    "v_subbrev_co_u32 %[h], vcc, 0, %[h], vcc"
+// Tail: r = q + T2 * (2^32 - 1) is ONE v_mad_u64_u32 (64-bit addend, carry out in vcc); the carry (2^64 == 2^32 - 1, every
+// other product) is added by a second one from the 0 / 1 lane mask: three instructions where the carry-chain form (sub,
+// subbrev, add, cndmask, add, addc) needs six.  No second carry: the wrapped r is < (2^32 - 1)^2.
+#define GL_ASM_TAIL                                                                               \
+    "v_mad_u64_u32 %[r], vcc, %[t2], -1, %[r]\n\t"                                                \
+    "v_cndmask_b32_e64 %[c], 0, 1, vcc\n\t"                                                       \
+    "v_mad_u64_u32 %[r], vcc, %[c], -1, %[r]"
 
 // Chained partial products: each v_mad_u64_u32 takes the previous product's high word as its 64-bit addend
 // ({x, 0} pairs cost one v_mov each, and v_mov / v_add_u32 / logic ops issue at ~2.4 cycles where every carry op costs
@@ -96,18 +98,18 @@ GL_HD u64 gl_mul_ref(u64 a, u64 b) {
 // in an SGPR pair, the test and branch run on the scalar unit, the common path falls through.  (The second correction
 // fires for every other product and stays inline.)  tools/ubench_mul.hip: 58.7 instead of 74.7 cycles per wave-multiply.
 // Used where multiplies dominate and registers are not scarce: the Poseidon S-box (gl_mul_fast).
-#define GL_FOLD_HEAD(lo, t1, t3, p0, bm)                                                                           \
-    asm("v_sub_co_u32 %[l], vcc, %[p], %[z]\n\t"         /* [t1:lo] = [T1:T0] - T3 */                              \
-        "v_subbrev_co_u32 %[h], %[b], 0, %[h], vcc"                                                                \
-        : [l] "=&v"(lo), [h] "+&v"(t1), [b] "=&s"(bm)                                                              \
-        : [p] "v"(p0), [z] "v"(t3)                                                                                 \
+#define GL_FOLD_HEAD(lo, h, t1, t3, p0, bm)                                                                        \
+    asm("v_sub_co_u32 %[l], vcc, %[p], %[z]\n\t"         /* [h:lo] = [T1:T0] - T3 */                               \
+        "v_subbrev_co_u32 %[hh], %[b], 0, %[t], vcc"                                                               \
+        : [l] "=&v"(lo), [hh] "=&v"(h), [b] "=&s"(bm)                                                              \
+        : [p] "v"(p0), [z] "v"(t3), [t] "v"(t1)                                                                    \
         : "vcc");                                                                                                  \
     if (__builtin_expect(bm != 0, 0)) {                    /* borrow: -= EPS (== += p) */                          \
         u32 e_;                                                                                                    \
         asm("v_cndmask_b32_e64 %[e], 0, -1, %[b]\n\t"                                                              \
             "v_sub_co_u32 %[l], vcc, %[l], %[e]\n\t"                                                               \
-            "v_subbrev_co_u32 %[h], vcc, 0, %[h], vcc"                                                             \
-            : [l] "+&v"(lo), [h] "+&v"(t1), [e] "=&v"(e_)                                                          \
+            "v_subbrev_co_u32 %[hh], vcc, 0, %[hh], vcc"                                                           \
+            : [l] "+&v"(lo), [hh] "+&v"(h), [e] "=&v"(e_)                                                          \
             : [b] "s"(bm)                                                                                          \
             : "vcc");                                                                                              \
     }
@@ -118,20 +120,13 @@ __device__ __forceinline__ u64 gl_mul_fast(u64 a, u64 b) {
     const u64 M = (u64)a0 * b1 + (P >> 32);            // <= (2^32-1)^2 + 2^32 - 1: no overflow
     const u64 M2 = (u64)a1 * b0 + (u32)M;              // likewise
     const u64 H = (u64)a1 * b1 + (M >> 32) + (M2 >> 32);
-    u32 lo, hi, t1 = (u32)M2, e;
+    u32 lo, h, c;
     const u32 t2 = (u32)H, t3 = (u32)(H >> 32);
     u64 bm;
-    GL_FOLD_HEAD(lo, t1, t3, (u32)P, bm)
-    asm("v_sub_co_u32 %[lo], vcc, %[lo], %[t2]\n\t"      /* += T2*(2^32-1) = [T2:0] - [0:T2]  */
-        "v_subbrev_co_u32 %[e], vcc, 0, %[t2], vcc\n\t"  /* e = T2 - borrow (>= 0)            */
-        "v_add_co_u32 %[hi], vcc, %[t1], %[e]\n\t"
-        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"         /* carry: += EPS                     */
-        "v_add_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
-        "v_addc_co_u32 %[hi], vcc, 0, %[hi], vcc"
-        : [lo] "+&v"(lo), [hi] "=&v"(hi), [e] "=&v"(e)
-        : [t1] "v"(t1), [t2] "v"(t2)
-        : "vcc");
-    return ((u64)hi << 32) | lo;
+    GL_FOLD_HEAD(lo, h, (u32)M2, t3, (u32)P, bm)
+    u64 r = ((u64)h << 32) | lo;
+    asm(GL_ASM_TAIL : [r] "+v"(r), [c] "=&v"(c) : [t2] "v"(t2) : "vcc");
+    return r;
 }
 
 // The general-purpose multiply: branch-free (all eleven fold instructions inline, one asm statement).  Everything but the
@@ -144,12 +139,14 @@ __device__ __forceinline__ u64 gl_mul(u64 a, u64 b) {
     const u64 M = (u64)a0 * b1 + (P >> 32);
     const u64 M2 = (u64)a1 * b0 + (u32)M;
     const u64 H = (u64)a1 * b1 + (M >> 32) + (M2 >> 32);
-    u32 lo, hi, t1 = (u32)M2, t2 = (u32)H, t3 = (u32)(H >> 32), e;
-    asm(GL_ASM_REDUCE
-        : [lo] "=&v"(lo), [hi] "=&v"(hi), [t1] "+&v"(t1), [t2] "+&v"(t2), [t3] "+&v"(t3), [e] "=&v"(e)
-        : [p0] "v"((u32)P)
+    u32 lo, h, e;
+    asm(GL_ASM_HEAD
+        : [lo] "=&v"(lo), [h] "=&v"(h), [e] "=&v"(e)
+        : [p0] "v"((u32)P), [t1] "v"((u32)M2), [t3] "v"((u32)(H >> 32))
         : "vcc");
-    return ((u64)hi << 32) | lo;
+    u64 r = ((u64)h << 32) | lo;
+    asm(GL_ASM_TAIL : [r] "+v"(r), [c] "=&v"(e) : [t2] "v"((u32)H) : "vcc");
+    return r;
 }
 
 __device__ __forceinline__ u64 gl_sqr(u64 a) { return gl_mul(a, a); }
@@ -167,61 +164,71 @@ __device__ __forceinline__ u64 gl_mul_canon(u64 a, u64 b) {
     const u64 M = (u64)a0 * b1 + (P >> 32);
     const u64 M2 = (u64)a1 * b0 + (u32)M;
     const u64 H = (u64)a1 * b1 + (M >> 32) + (M2 >> 32);
-    u32 lo, hi, t1 = (u32)M2, t2 = (u32)H, t3 = (u32)(H >> 32), e;
-    u64 sa, sb;
+    u32 lo, h, e;
+    u64 sa;
     asm("v_sub_co_u32 %[lo], vcc, %[p0], %[t3]\n\t"
-        "v_subbrev_co_u32 %[t1], vcc, 0, %[t1], vcc\n\t"
+        "v_subbrev_co_u32 %[h], vcc, 0, %[t1], vcc\n\t"
         "s_cbranch_vccz 1f\n\t"                          /* no lane borrowed (all but ~2^-27 of the waves) */
         "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"
         "v_sub_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
-        "v_subbrev_co_u32 %[t1], vcc, 0, %[t1], vcc\n"
-        "1:\n\t"
-        "v_sub_co_u32 %[lo], vcc, %[lo], %[t2]\n\t"
-        "v_subbrev_co_u32 %[e], vcc, 0, %[t2], vcc\n\t"
-        "v_add_co_u32 %[hi], vcc, %[t1], %[e]\n\t"
-        "v_cmp_eq_u32_e64 %[sa], %[hi], -1\n\t"        /* hi:lo >= p  <=>  hi == 2^32-1 and lo != 0 */
-        "v_cmp_ne_u32_e64 %[sb], %[lo], 0\n\t"
-        "s_and_b64 %[sa], %[sa], %[sb]\n\t"
+        "v_subbrev_co_u32 %[h], vcc, 0, %[h], vcc\n"
+        "1:"
+        : [lo] "=&v"(lo), [h] "=&v"(h), [e] "=&v"(e)
+        : [p0] "v"((u32)P), [t1] "v"((u32)M2), [t3] "v"((u32)(H >> 32))
+        : "vcc");
+    u64 r = ((u64)h << 32) | lo;
+    // r += T2 * (2^32 - 1); then += EPS (mod 2^64) when that carried (2^64 == EPS) or when r >= p (r - p == r + EPS mod 2^64):
+    // either way the result is < p
+    asm("v_mad_u64_u32 %[r], vcc, %[t2], -1, %[r]\n\t"
+        "v_cmp_gt_u64_e64 %[sa], %[r], %[pm1]\n\t"
         "s_or_b64 vcc, vcc, %[sa]\n\t"
-        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"
-        "v_add_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
-        "v_addc_co_u32 %[hi], vcc, 0, %[hi], vcc"
-        : [lo] "=&v"(lo), [hi] "=&v"(hi), [t1] "+&v"(t1), [t2] "+&v"(t2), [t3] "+&v"(t3), [e] "=&v"(e), [sa] "=&s"(sa), [sb] "=&s"(sb)
-        : [p0] "v"((u32)P)
+        "v_cndmask_b32_e64 %[c], 0, 1, vcc\n\t"
+        "v_mad_u64_u32 %[r], vcc, %[c], -1, %[r]"
+        : [r] "+v"(r), [c] "=&v"(e), [sa] "=&s"(sa)
+        : [t2] "v"((u32)H), [pm1] "s"(GL_P - 1)
         : "vcc", "scc");
-    return ((u64)hi << 32) | lo;
+    return r;
 }
 
 // a, b arbitrary u64 representatives; result arbitrary representative of a+b.  (The second wrap is as rare as gl_mul's first
 // correction, but moving it into an unlikely block changed nothing measurable -- 909.5 vs 910.5 ms per segment, the AIR
 // kernels if anything slower -- so add / sub keep the branch-free form.)
 __device__ __forceinline__ u64 gl_add(u64 a, u64 b) {
-    u32 lo, hi, e;
+    u32 lo, hi, c;
+    u64 cm;                                             // carry mask, handed to the next statement in an SGPR pair
     asm("v_add_co_u32 %[lo], vcc, %[a0], %[b0]\n\t"
-        "v_addc_co_u32 %[hi], vcc, %[a1], %[b1], vcc\n\t"
-        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"
-        "v_add_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
-        "v_addc_co_u32 %[hi], vcc, 0, %[hi], vcc\n\t"
-        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"   // second wrap: only if both inputs >= 2^64-2^32
-        "v_add_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
-        "v_addc_co_u32 %[hi], vcc, 0, %[hi], vcc"
-        : [lo] "=&v"(lo), [hi] "=&v"(hi), [e] "=&v"(e)
+        "v_addc_co_u32 %[hi], %[cm], %[a1], %[b1], vcc"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [cm] "=&s"(cm)
         : [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32))
         : "vcc");
-    return ((u64)hi << 32) | lo;
+    u64 r = ((u64)hi << 32) | lo;
+    // a carry is 2^64 == EPS, added by a mad from the 0 / 1 lane mask (its own carry likewise: the second wrap happens
+    // only if both inputs were >= 2^64 - 2^32)
+    asm("v_cndmask_b32_e64 %[c], 0, 1, %[cm]\n\t"
+        "v_mad_u64_u32 %[r], vcc, %[c], -1, %[r]\n\t"
+        "v_cndmask_b32_e64 %[c], 0, 1, vcc\n\t"
+        "v_mad_u64_u32 %[r], vcc, %[c], -1, %[r]"
+        : [r] "+v"(r), [c] "=&v"(c)
+        : [cm] "s"(cm)
+        : "vcc");
+    return r;
 }
 // b must be canonical (< p): one correction is enough.
 __device__ __forceinline__ u64 gl_add_canon(u64 a, u64 b) {
-    u32 lo, hi, e;
+    u32 lo, hi, c;
+    u64 cm;                                             // carry mask, handed to the next statement in an SGPR pair
     asm("v_add_co_u32 %[lo], vcc, %[a0], %[b0]\n\t"
-        "v_addc_co_u32 %[hi], vcc, %[a1], %[b1], vcc\n\t"
-        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"
-        "v_add_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
-        "v_addc_co_u32 %[hi], vcc, 0, %[hi], vcc"
-        : [lo] "=&v"(lo), [hi] "=&v"(hi), [e] "=&v"(e)
+        "v_addc_co_u32 %[hi], %[cm], %[a1], %[b1], vcc"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [cm] "=&s"(cm)
         : [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32))
         : "vcc");
-    return ((u64)hi << 32) | lo;
+    u64 r = ((u64)hi << 32) | lo;
+    asm("v_cndmask_b32_e64 %[c], 0, 1, %[cm]\n\t"
+        "v_mad_u64_u32 %[r], vcc, %[c], -1, %[r]"
+        : [r] "+v"(r), [c] "=&v"(c)
+        : [cm] "s"(cm)
+        : "vcc");
+    return r;
 }
 __device__ __forceinline__ u64 gl_sub(u64 a, u64 b) {
     u32 lo, hi, e;

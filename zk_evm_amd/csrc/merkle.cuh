@@ -37,16 +37,17 @@ poseidon_hash_rows_kernel(const u64 *__restrict__ cols, size_t col_stride, const
     if (n_cols <= 4) {
         for (u32 c = 0; c < n_cols; ++c) s[c] = gl_canon(p[col_offset<GATHER>(c, col_stride, col_off)]);
     } else {
-        u32 c = 0;
-        for (; c + 8 <= n_cols; c += 8) {
+        // ONE inlined permutation (46 KB of code: two copies would not fit the 64 KB instruction cache a CU pair shares)
+#pragma unroll 1
+        for (u32 c = 0; c < n_cols; c += 8) {
+            if (c + 8 <= n_cols) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s[i] = p[col_offset<GATHER>(c + i, col_stride, col_off)];
-            poseidon_permute(s);
-        }
-        if (c < n_cols) {
+                for (int i = 0; i < 8; ++i) s[i] = p[col_offset<GATHER>(c + i, col_stride, col_off)];
+            } else {                                   // ragged last chunk: overwrite mode keeps the other elements
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                if (c + i < n_cols) s[i] = p[col_offset<GATHER>(c + i, col_stride, col_off)];
+                for (int i = 0; i < 8; ++i)
+                    if (c + i < n_cols) s[i] = p[col_offset<GATHER>(c + i, col_stride, col_off)];
+            }
             poseidon_permute(s);
         }
     }

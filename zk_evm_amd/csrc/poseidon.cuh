@@ -15,7 +15,9 @@
 //     initial value (an SGPR pair from constant memory), so constant addition costs nothing.
 //   * the two 43-bit sums are folded to one lazy u64 with 2 instructions on the common path (one mad by 2^32-1, one
 //     carry add; the conditional +EPS fires for 2^-19 of the lanes and lives in an unlikely block) -- see pos_fold().
-//   * the 22 partial rounds are taken two at a time as one linear step with the entries of MDS^2 (pos_partial_pair).
+//   * the 23 linear layers between the two groups of full S-box layers (the last full round of the first half and the 22
+//     partial rounds) are taken three at a time as ONE 12 x 12 product with the entries of MDS^3 (pos_block3, seven
+//     blocks) and a final pair with MDS^2 (pos_partial_pair).
 //   * an MFMA formulation was evaluated and rejected: the i8 matrix pipe could do the 12x12
 //     byte-limb products, but re-laying 64-bit lane-private words out as MFMA operands and
 //     recombining 8 i32 partial sums per word costs more VALU work than the 288 mads it replaces
@@ -35,6 +37,10 @@ static __constant__ u32 ZK_M2C[12] = ZK_POSEIDON_M2_CIRC_INIT;
 static __constant__ u32 ZK_M2ROW0[12] = ZK_POSEIDON_M2_ROW0_INIT;
 static __constant__ u32 ZK_M2COL0[12] = ZK_POSEIDON_M2_COL0_INIT;
 static __constant__ RcSplit ZK_RCS2[ZK_POSEIDON_PARTIAL_PAIRS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RCS2_INIT;
+// Three linear layers as one step (see pos_block3): M^3 (dense, entries < 2^21), K of block b at ZK_RCS3[12 b ..], KZ at ZK_RCS3Z[b].
+static __constant__ u32 ZK_M3[144] = ZK_POSEIDON_M3_INIT;
+static __constant__ RcSplit ZK_RCS3[ZK_POSEIDON_BLOCK3_COUNT * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RCS3_INIT;
+static __constant__ RcSplit ZK_RCS3Z[ZK_POSEIDON_BLOCK3_COUNT] = ZK_POSEIDON_RCS3Z_INIT;
 
 __device__ __forceinline__ u64 pos_sbox(u64 x) {
     u64 x2 = gl_mul_fast(x, x);
@@ -181,9 +187,11 @@ __device__ __forceinline__ u64 pos_m2_row(const u32 (&lo)[12], const u32 (&hi)[1
     pos_row2_half<CD>(ah, hi, k, dh);
     return pos_fold(al, ah);
 }
-// s (constants of round `round` included, `round` a partial round) -> the state two rounds later; pair = (round - 4) / 2
+// s (constants of round `round` included, `round` a partial round; its S-box already applied unless LEAD) -> the state two
+// rounds later; pair = (round - 4) / 2
+template <bool LEAD>
 __device__ __forceinline__ void pos_partial_pair(u64 (&s)[12], int round, int pair) {
-    s[0] = pos_sbox(s[0]);
+    if (LEAD) s[0] = pos_sbox(s[0]);
     u32 lo[12], hi[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
@@ -210,24 +218,133 @@ __device__ __forceinline__ void pos_partial_pair(u64 (&s)[12], int round, int pa
     s[11] = pos_m2_row<11>(lo, hi, dl, dh, kp);
 }
 
+// ---- three linear layers in one step ---------------------------------------------------------------------
+// The same idea one layer further.  With x = the state after the S-box layer of round r (a full layer for r = 3, element 0
+// only afterwards), rounds r + 1 and r + 2 partial:
+//     w0 = (M x)_0 + rc[r+1]_0,                  d1 = sbox(w0) - w0
+//     z0 = (M^2 x)_0 + KZ + M[0][0] d1,          d2 = sbox(z0) - z0
+//     out = M^3 x + K + d1 M^2[:, 0] + d2 M[:, 0]
+// (KZ, K: tools/gen_poseidon_constants.py, which also checks this schedule against the plain rounds).  The entries of M^3
+// are < 2^21, so a row's two half sums stay < 2^57 in their 64-bit accumulators: 26 + 26 + 12 * 28 = 388 mads for three
+// layers where pairs need 507 and plain MDS products 870.  The wider sums make the fold's carry common (2^-6 per lane), so
+// these rows use the branch-free four-instruction pos_fold_wide.
+__device__ __forceinline__ u64 pos_fold_wide(u64 al, u64 ah) {
+    const u32 ah0 = (u32)ah, ah1 = (u32)(ah >> 32);
+    // ah1 * 2^64 == ah1 * (2^32 - 1), ah1 < 2^25: al + that < 2^58
+    asm("v_mad_u64_u32 %0, vcc, %1, -1, %0" : "+v"(al) : "v"(ah1) : "vcc");
+    u32 l = (u32)al, h = (u32)(al >> 32), c;
+    // h += ah0; a carry out is 2^64 == 2^32 - 1, added by one more mad (the wrapped h is < 2^26: no second carry)
+    asm("v_add_co_u32 %0, vcc, %0, %2\n\t"
+        "v_cndmask_b32_e64 %1, 0, 1, vcc"
+        : "+v"(h), "=&v"(c)
+        : "v"(ah0)
+        : "vcc");
+    u64 t = ((u64)h << 32) | l;
+    asm("v_mad_u64_u32 %0, vcc, %1, -1, %0" : "+v"(t) : "v"(c) : "vcc");
+    return t;
+}
+// acc += sum_j x[j] * k[j] + d1 * kc + d2 * CD   (k, kc: wave-uniform constants in SGPRs, CD inline)
+template <u32 CD>
+__device__ __forceinline__ void pos_row3_half(u64 &acc, const u32 (&x)[12], const u32 (&k)[12], u32 d1, u32 kc, u32 d2) {
+    asm("v_mad_u64_u32 %0, vcc, %1, %13, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %2, %14, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %3, %15, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %4, %16, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %5, %17, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %6, %18, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %7, %19, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %8, %20, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %9, %21, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %10, %22, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %11, %23, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %12, %24, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %25, %26, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %27, %28, %0"
+        : "+v"(acc)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]), "v"(x[10]),
+          "v"(x[11]), "s"(k[0]), "s"(k[1]), "s"(k[2]), "s"(k[3]), "s"(k[4]), "s"(k[5]), "s"(k[6]), "s"(k[7]), "s"(k[8]), "s"(k[9]),
+          "s"(k[10]), "s"(k[11]), "v"(d1), "s"(kc), "v"(d2), "n"(CD)
+        : "vcc");
+}
+template <int R>
+__device__ __forceinline__ u64 pos_m3_row(const u32 (&lo)[12], const u32 (&hi)[12], u32 d1l, u32 d1h, u32 d2l, u32 d2h,
+                                          const RcSplit *kp) {
+    constexpr u32 C[12] = ZK_POSEIDON_MDS_CIRC_INIT;
+    constexpr u32 CD = C[(12 - R) % 12] + (R == 0 ? 8 : 0);            // M[R][0]
+    u32 k[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) k[j] = ZK_M3[R * 12 + j];
+    const u32 kc = ZK_M2COL0[R];                                       // M^2[R][0]
+    u64 al = kp[R].lo, ah = kp[R].hi;
+    pos_row3_half<CD>(al, lo, k, d1l, kc, d2l);
+    pos_row3_half<CD>(ah, hi, k, d1h, kc, d2h);
+    return pos_fold_wide(al, ah);
+}
+// s = the state after the S-box layer of round r = 3 + 3 blk  ->  the state entering round r + 3 (constants included)
+__device__ __forceinline__ void pos_block3(u64 (&s)[12], int blk) {
+    constexpr u32 C[12] = ZK_POSEIDON_MDS_CIRC_INIT;
+    const int r = 3 + 3 * blk;
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { lo[i] = (u32)s[i]; hi[i] = (u32)(s[i] >> 32); }
+    const RcSplit *rc1 = &ZK_RCS[(r + 1) * 12];
+    u64 al, ah;
+    pos_row<true>(al, ah, rc1[0].lo, rc1[0].hi, lo, hi, 0);
+    pos_mac<8>(al, lo[0]);
+    pos_mac<8>(ah, hi[0]);
+    const u64 w0 = pos_fold(al, ah);
+    const u64 d1 = gl_sub(pos_sbox(w0), w0);
+    const u32 d1l = (u32)d1, d1h = (u32)(d1 >> 32);
+    u32 k0[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) k0[j] = ZK_M2ROW0[j];
+    al = ZK_RCS3Z[blk].lo;
+    ah = ZK_RCS3Z[blk].hi;
+    pos_row2_half<C[0] + 8>(al, lo, k0, d1l);                          // sums < 2^49: the narrow fold applies
+    pos_row2_half<C[0] + 8>(ah, hi, k0, d1h);
+    const u64 z0 = pos_fold(al, ah);
+    const u64 d2 = gl_sub(pos_sbox(z0), z0);
+    const u32 d2l = (u32)d2, d2h = (u32)(d2 >> 32);
+    const RcSplit *kp = &ZK_RCS3[blk * 12];
+    s[0] = pos_m3_row<0>(lo, hi, d1l, d1h, d2l, d2h, kp);
+    s[1] = pos_m3_row<1>(lo, hi, d1l, d1h, d2l, d2h, kp);
+    s[2] = pos_m3_row<2>(lo, hi, d1l, d1h, d2l, d2h, kp);
+    s[3] = pos_m3_row<3>(lo, hi, d1l, d1h, d2l, d2h, kp);
+    s[4] = pos_m3_row<4>(lo, hi, d1l, d1h, d2l, d2h, kp);
+    s[5] = pos_m3_row<5>(lo, hi, d1l, d1h, d2l, d2h, kp);
+    s[6] = pos_m3_row<6>(lo, hi, d1l, d1h, d2l, d2h, kp);
+    s[7] = pos_m3_row<7>(lo, hi, d1l, d1h, d2l, d2h, kp);
+    s[8] = pos_m3_row<8>(lo, hi, d1l, d1h, d2l, d2h, kp);
+    s[9] = pos_m3_row<9>(lo, hi, d1l, d1h, d2l, d2h, kp);
+    s[10] = pos_m3_row<10>(lo, hi, d1l, d1h, d2l, d2h, kp);
+    s[11] = pos_m3_row<11>(lo, hi, d1l, d1h, d2l, d2h, kp);
+}
+
 // In/out: arbitrary u64 representatives; callers canonicalise what they emit.
 __device__ __forceinline__ void poseidon_permute(u64 (&s)[12]) {
 #pragma unroll
     for (int i = 0; i < 12; ++i) s[i] = gl_add_canon(s[i], ZK_RC[i]);
     int round = 0;
 #pragma unroll 1
-    for (int k = 0; k < ZK_POSEIDON_HALF_FULL_ROUNDS; ++k) {
+    for (int k = 0; k < ZK_POSEIDON_HALF_FULL_ROUNDS - 1; ++k) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) s[i] = pos_sbox(s[i]);
         ++round;
         pos_mds<true>(s, &ZK_RCS[round * 12]);
     }
-    static_assert(ZK_POSEIDON_PARTIAL_ROUNDS == 2 * ZK_POSEIDON_PARTIAL_PAIRS, "partial rounds are taken in pairs");
+    // linear layers of rounds 3 .. 23 in seven blocks of three, the S-box of rounds 6, 9, .., 24 between them
+    static_assert(ZK_POSEIDON_HALF_FULL_ROUNDS - 1 + 3 * ZK_POSEIDON_BLOCK3_COUNT + 2 ==
+                  ZK_POSEIDON_HALF_FULL_ROUNDS + ZK_POSEIDON_PARTIAL_ROUNDS, "seven blocks of three layers and one pair");
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s[i] = pos_sbox(s[i]);
 #pragma unroll 1
-    for (int k = 0; k < ZK_POSEIDON_PARTIAL_PAIRS; ++k) {
-        pos_partial_pair(s, round, k);
-        round += 2;
+    for (int b = 0; b < ZK_POSEIDON_BLOCK3_COUNT; ++b) {
+        pos_block3(s, b);
+        s[0] = pos_sbox(s[0]);
     }
+    round = ZK_POSEIDON_HALF_FULL_ROUNDS - 1 + 3 * ZK_POSEIDON_BLOCK3_COUNT;           // 24
+    pos_partial_pair<false>(s, round, (round - ZK_POSEIDON_HALF_FULL_ROUNDS) / 2);
+    round += 2;
 #pragma unroll 1
     for (int k = 0; k < ZK_POSEIDON_HALF_FULL_ROUNDS - 1; ++k) {
 #pragma unroll
