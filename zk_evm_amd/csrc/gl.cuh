@@ -245,17 +245,21 @@ __device__ __forceinline__ u64 gl_sub(u64 a, u64 b) {
         : "vcc");
     return ((u64)hi << 32) | lo;
 }
-// b must be <= p: one correction is enough.
+// b must be <= p: one correction is enough.  The borrow is repaid by -= EPS = - 2^32 + 1:  lo += borrow (carry k),
+// hi -= borrow & ~k, the mask arithmetic on the scalar unit: four VALU instructions where cndmask / sub / subbrev needs five.
+// (The NTT butterfly's form.  The same trick in gl_sub and gl_mul's head cost the AIR kernels more in SGPR pairs than the
+// instruction saved: 638 -> 645 ms per segment, r03n.)
 __device__ __forceinline__ u64 gl_sub_canon(u64 a, u64 b) {
-    u32 lo, hi, e;
+    u32 lo, hi;
+    u64 m1;
     asm("v_sub_co_u32 %[lo], vcc, %[a0], %[b0]\n\t"
-        "v_subb_co_u32 %[hi], vcc, %[a1], %[b1], vcc\n\t"
-        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"
-        "v_sub_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
-        "v_subbrev_co_u32 %[hi], vcc, 0, %[hi], vcc"
-        : [lo] "=&v"(lo), [hi] "=&v"(hi), [e] "=&v"(e)
+        "v_subb_co_u32 %[hi], %[m1], %[a1], %[b1], vcc\n\t"
+        "v_addc_co_u32 %[lo], vcc, 0, %[lo], %[m1]\n\t"
+        "s_andn2_b64 %[m1], %[m1], vcc\n\t"
+        "v_subbrev_co_u32 %[hi], vcc, 0, %[hi], %[m1]"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [m1] "=&s"(m1)
         : [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32))
-        : "vcc");
+        : "vcc", "scc");
     return ((u64)hi << 32) | lo;
 }
 #else

@@ -153,10 +153,14 @@ __device__ __forceinline__ void pos_mds(u64 (&s)[12], const RcSplit *rc) {
 // S-boxes and ONE 12 x 12 product with the entries of M^2 (< 2^13: the 32-bit halves still sum to < 2^50 in a 64-bit
 // accumulator) plus a 13th term per row, instead of two full MDS products: 24 + 312 mads per pair instead of 576, the
 // same field values.  The 22 partial rounds are 11 such pairs; ~15 % of the permutation's instructions.
-// acc += sum_j x[j] * k[j] + d * CD   (k: wave-uniform constants in SGPRs, CD inline)
+// kinit + d * CD + sum_j x[j] * k[j]   (kinit, k: wave-uniform constants in SGPRs, CD inline).  The delta term comes FIRST:
+// its multiplier is an inline constant, so that mad can take the SGPR pair kinit as its addend (one constant-bus operand
+// per instruction) and the accumulator needs no v_mov initialisation.
 template <u32 CD>
-__device__ __forceinline__ void pos_row2_half(u64 &acc, const u32 (&x)[12], const u32 (&k)[12], u32 d) {
-    asm("v_mad_u64_u32 %0, vcc, %1, %13, %0\n\t"
+__device__ __forceinline__ u64 pos_row2_half(u64 kinit, const u32 (&x)[12], const u32 (&k)[12], u32 d) {
+    u64 acc;
+    asm("v_mad_u64_u32 %0, vcc, %25, %26, %27\n\t"
+        "v_mad_u64_u32 %0, vcc, %1, %13, %0\n\t"
         "v_mad_u64_u32 %0, vcc, %2, %14, %0\n\t"
         "v_mad_u64_u32 %0, vcc, %3, %15, %0\n\t"
         "v_mad_u64_u32 %0, vcc, %4, %16, %0\n\t"
@@ -167,13 +171,13 @@ __device__ __forceinline__ void pos_row2_half(u64 &acc, const u32 (&x)[12], cons
         "v_mad_u64_u32 %0, vcc, %9, %21, %0\n\t"
         "v_mad_u64_u32 %0, vcc, %10, %22, %0\n\t"
         "v_mad_u64_u32 %0, vcc, %11, %23, %0\n\t"
-        "v_mad_u64_u32 %0, vcc, %12, %24, %0\n\t"
-        "v_mad_u64_u32 %0, vcc, %25, %26, %0"
-        : "+v"(acc)
+        "v_mad_u64_u32 %0, vcc, %12, %24, %0"
+        : "=&v"(acc)
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]), "v"(x[10]),
           "v"(x[11]), "s"(k[0]), "s"(k[1]), "s"(k[2]), "s"(k[3]), "s"(k[4]), "s"(k[5]), "s"(k[6]), "s"(k[7]), "s"(k[8]), "s"(k[9]),
-          "s"(k[10]), "s"(k[11]), "v"(d), "n"(CD)
+          "s"(k[10]), "s"(k[11]), "v"(d), "n"(CD), "s"(kinit)
         : "vcc");
+    return acc;
 }
 template <int R>
 __device__ __forceinline__ u64 pos_m2_row(const u32 (&lo)[12], const u32 (&hi)[12], u32 dl, u32 dh, const RcSplit *kp) {
@@ -182,9 +186,8 @@ __device__ __forceinline__ u64 pos_m2_row(const u32 (&lo)[12], const u32 (&hi)[1
     u32 k[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) k[j] = R == 0 ? ZK_M2ROW0[j] : j == 0 ? ZK_M2COL0[R] : ZK_M2C[(j - R + 12) % 12];
-    u64 al = kp[R].lo, ah = kp[R].hi;
-    pos_row2_half<CD>(al, lo, k, dl);
-    pos_row2_half<CD>(ah, hi, k, dh);
+    const u64 al = pos_row2_half<CD>(kp[R].lo, lo, k, dl);
+    const u64 ah = pos_row2_half<CD>(kp[R].hi, hi, k, dh);
     return pos_fold(al, ah);
 }
 // s (constants of round `round` included, `round` a partial round; its S-box already applied unless LEAD) -> the state two
@@ -243,10 +246,14 @@ __device__ __forceinline__ u64 pos_fold_wide(u64 al, u64 ah) {
     asm("v_mad_u64_u32 %0, vcc, %1, -1, %0" : "+v"(t) : "v"(c) : "vcc");
     return t;
 }
-// acc += sum_j x[j] * k[j] + d1 * kc + d2 * CD   (k, kc: wave-uniform constants in SGPRs, CD inline)
+// kinit + d2 * CD + d1 * kc + sum_j x[j] * k[j]   (kinit, k, kc: wave-uniform constants in SGPRs, CD inline; d2 * CD first,
+// see pos_row2_half)
 template <u32 CD>
-__device__ __forceinline__ void pos_row3_half(u64 &acc, const u32 (&x)[12], const u32 (&k)[12], u32 d1, u32 kc, u32 d2) {
-    asm("v_mad_u64_u32 %0, vcc, %1, %13, %0\n\t"
+__device__ __forceinline__ u64 pos_row3_half(u64 kinit, const u32 (&x)[12], const u32 (&k)[12], u32 d1, u32 kc, u32 d2) {
+    u64 acc;
+    asm("v_mad_u64_u32 %0, vcc, %27, %28, %29\n\t"
+        "v_mad_u64_u32 %0, vcc, %25, %26, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, %1, %13, %0\n\t"
         "v_mad_u64_u32 %0, vcc, %2, %14, %0\n\t"
         "v_mad_u64_u32 %0, vcc, %3, %15, %0\n\t"
         "v_mad_u64_u32 %0, vcc, %4, %16, %0\n\t"
@@ -257,14 +264,13 @@ __device__ __forceinline__ void pos_row3_half(u64 &acc, const u32 (&x)[12], cons
         "v_mad_u64_u32 %0, vcc, %9, %21, %0\n\t"
         "v_mad_u64_u32 %0, vcc, %10, %22, %0\n\t"
         "v_mad_u64_u32 %0, vcc, %11, %23, %0\n\t"
-        "v_mad_u64_u32 %0, vcc, %12, %24, %0\n\t"
-        "v_mad_u64_u32 %0, vcc, %25, %26, %0\n\t"
-        "v_mad_u64_u32 %0, vcc, %27, %28, %0"
-        : "+v"(acc)
+        "v_mad_u64_u32 %0, vcc, %12, %24, %0"
+        : "=&v"(acc)
         : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]), "v"(x[10]),
           "v"(x[11]), "s"(k[0]), "s"(k[1]), "s"(k[2]), "s"(k[3]), "s"(k[4]), "s"(k[5]), "s"(k[6]), "s"(k[7]), "s"(k[8]), "s"(k[9]),
-          "s"(k[10]), "s"(k[11]), "v"(d1), "s"(kc), "v"(d2), "n"(CD)
+          "s"(k[10]), "s"(k[11]), "v"(d1), "s"(kc), "v"(d2), "n"(CD), "s"(kinit)
         : "vcc");
+    return acc;
 }
 template <int R>
 __device__ __forceinline__ u64 pos_m3_row(const u32 (&lo)[12], const u32 (&hi)[12], u32 d1l, u32 d1h, u32 d2l, u32 d2h,
@@ -275,9 +281,8 @@ __device__ __forceinline__ u64 pos_m3_row(const u32 (&lo)[12], const u32 (&hi)[1
 #pragma unroll
     for (int j = 0; j < 12; ++j) k[j] = ZK_M3[R * 12 + j];
     const u32 kc = ZK_M2COL0[R];                                       // M^2[R][0]
-    u64 al = kp[R].lo, ah = kp[R].hi;
-    pos_row3_half<CD>(al, lo, k, d1l, kc, d2l);
-    pos_row3_half<CD>(ah, hi, k, d1h, kc, d2h);
+    const u64 al = pos_row3_half<CD>(kp[R].lo, lo, k, d1l, kc, d2l);
+    const u64 ah = pos_row3_half<CD>(kp[R].hi, hi, k, d1h, kc, d2h);
     return pos_fold_wide(al, ah);
 }
 // s = the state after the S-box layer of round r = 3 + 3 blk  ->  the state entering round r + 3 (constants included)
@@ -298,10 +303,8 @@ __device__ __forceinline__ void pos_block3(u64 (&s)[12], int blk) {
     u32 k0[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) k0[j] = ZK_M2ROW0[j];
-    al = ZK_RCS3Z[blk].lo;
-    ah = ZK_RCS3Z[blk].hi;
-    pos_row2_half<C[0] + 8>(al, lo, k0, d1l);                          // sums < 2^49: the narrow fold applies
-    pos_row2_half<C[0] + 8>(ah, hi, k0, d1h);
+    al = pos_row2_half<C[0] + 8>(ZK_RCS3Z[blk].lo, lo, k0, d1l);       // sums < 2^49: the narrow fold applies
+    ah = pos_row2_half<C[0] + 8>(ZK_RCS3Z[blk].hi, hi, k0, d1h);
     const u64 z0 = pos_fold(al, ah);
     const u64 d2 = gl_sub(pos_sbox(z0), z0);
     const u32 d2l = (u32)d2, d2h = (u32)(d2 >> 32);
