@@ -847,7 +847,7 @@ def plonk_recursion_profile(ctx, dev, with_cpu, sizes=(12, 13, 14), reps=8):
 
 KERNEL_CLASSES = (   # (class, substring of the rocprofv3 kernel name)
     ("leaf_hash", "hash_rows_kernel<false>"), ("leaf_hash_coop", "hash_rows_coop_kernel"),
-    ("ntt_coeffs_to_values", "ntt_pass_kernel<true>"), ("ntt_values_to_coeffs", "ntt_pass_kernel<false>"),
+    ("ntt_coeffs_to_values", "ntt_pass_kernel<true"), ("ntt_values_to_coeffs", "ntt_pass_kernel<false"),
     ("merkle_levels", "merkle_level"), ("fri_combine", "fri_combine_kernel"), ("openings", "eval_columns_partial_kernel"),
     ("helper_columns", "helper_cols_kernel"), ("lookup_singles", "lookup_singles_kernel"),
     ("quotient_checks", "quotient_checks_kernel"))

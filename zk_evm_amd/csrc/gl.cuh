@@ -213,22 +213,21 @@ __device__ __forceinline__ u64 gl_add(u64 a, u64 b) {
         : "vcc");
     return r;
 }
-// b must be canonical (< p): one correction is enough.
+// b must be canonical (< p): one correction is enough.  The carry is repaid by += EPS = + 2^32 - 1:  lo -= carry (borrow k),
+// hi += carry & ~k, the mask arithmetic on the scalar unit (as gl_sub_canon; the halves never have to form a register pair,
+// which the mad form of gl_add costs the NTT butterfly two v_mov).
 __device__ __forceinline__ u64 gl_add_canon(u64 a, u64 b) {
-    u32 lo, hi, c;
-    u64 cm;                                             // carry mask, handed to the next statement in an SGPR pair
+    u32 lo, hi;
+    u64 m;
     asm("v_add_co_u32 %[lo], vcc, %[a0], %[b0]\n\t"
-        "v_addc_co_u32 %[hi], %[cm], %[a1], %[b1], vcc"
-        : [lo] "=&v"(lo), [hi] "=&v"(hi), [cm] "=&s"(cm)
+        "v_addc_co_u32 %[hi], %[m], %[a1], %[b1], vcc\n\t"
+        "v_subbrev_co_u32 %[lo], vcc, 0, %[lo], %[m]\n\t"
+        "s_andn2_b64 %[m], %[m], vcc\n\t"
+        "v_addc_co_u32 %[hi], vcc, 0, %[hi], %[m]"
+        : [lo] "=&v"(lo), [hi] "=&v"(hi), [m] "=&s"(m)
         : [a0] "v"((u32)a), [a1] "v"((u32)(a >> 32)), [b0] "v"((u32)b), [b1] "v"((u32)(b >> 32))
-        : "vcc");
-    u64 r = ((u64)hi << 32) | lo;
-    asm("v_cndmask_b32_e64 %[c], 0, 1, %[cm]\n\t"
-        "v_mad_u64_u32 %[r], vcc, %[c], -1, %[r]"
-        : [r] "+v"(r), [c] "=&v"(c)
-        : [cm] "s"(cm)
-        : "vcc");
-    return r;
+        : "vcc", "scc");
+    return ((u64)hi << 32) | lo;
 }
 __device__ __forceinline__ u64 gl_sub(u64 a, u64 b) {
     u32 lo, hi, e;

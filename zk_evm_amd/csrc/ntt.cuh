@@ -46,6 +46,7 @@ struct NttPass {
     int apply_out_const;
     int last_pass;       // the values leave the transform: store canonical representatives
     int nt;              // stream the tile data with non-temporal loads / stores (the twiddle levels keep the L2)
+    int cols_fastest;    // grid = (columns, tiles): consecutive workgroups run the SAME tile of different columns (ntt_host.inc)
 };
 
 // One radix-2 butterfly (a, b) -> (a + w b, a - w b).  BOTH directions use this Cooley-Tukey form: the canonical product
@@ -65,7 +66,14 @@ __device__ __forceinline__ void ntt_bfly(u64 &a, u64 &b, u64 w) {
 // m units) has only hm distinct twiddles per sub-problem (the twiddle of pair (m, m+hm) depends on
 // m mod hm); !DIT: one twiddle per block, 2^(K-1)/hm blocks per sub-problem.  Either way a radix-8 step
 // issues 1+2+4 = 7 twiddle loads, not 12.
-template <bool DIT, int K>
+// PAD (the contiguous pass, T = 1): tile element i lives at i + (i >> 3).  A step with q = 1 reads rows 8 apart from
+// consecutive lanes (64-byte stride: eight lanes per bank pair), q = 8 two lanes per bank pair; with one pad word per
+// eight the same steps touch every bank once per quarter wave.  (PMC r03n: 48 % of the LDS-active cycles were bank conflicts,
+// and since the shorter field multiply the kernel no longer hides them under VALU issue.)
+template <bool PAD>
+__device__ __forceinline__ u32 ntt_ph(u32 i) { return PAD ? i + (i >> 3) : i; }
+
+template <bool DIT, int K, bool PAD>
 __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q, u32 base,
                                          u32 elems, u32 tid, u32 nthr) {
     const int log_t = p.log_t;
@@ -80,7 +88,7 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
         u32 t0 = (blk << (log_q + K)) + j;
         u64 v[1 << K];
 #pragma unroll
-        for (int m = 0; m < (1 << K); ++m) v[m] = tile[((t0 + m * q) << log_t) + u];
+        for (int m = 0; m < (1 << K); ++m) v[m] = tile[ntt_ph<PAD>(((t0 + m * q) << log_t) + u)];
         const u32 x0 = base + (t0 << p.log_d) + u;      // global index of v[0]; bits [log_D0, log_D0 + K) are zero
         if (DIT) {
             // pair (x, x + D), D = D0 << lm: twiddle T_D[x mod D]; x_m mod D = g + (m mod hm) * D0
@@ -115,13 +123,13 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
             }
         }
 #pragma unroll
-        for (int m = 0; m < (1 << K); ++m) tile[((t0 + m * q) << log_t) + u] = v[m];
+        for (int m = 0; m < (1 << K); ++m) tile[ntt_ph<PAD>(((t0 + m * q) << log_t) + u)] = v[m];
     }
 }
 
 // DIT = false: stages from the largest distance down (values, natural -> coefficients, bit-reversed).
 // DIT = true : stages from the smallest distance up (coefficients, bit-reversed -> values, natural).
-template <bool DIT>
+template <bool DIT, bool PAD = false>
 __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
     extern __shared__ __attribute__((aligned(16))) u64 tile[];
     const int r = p.r, log_t = p.log_t;
@@ -129,11 +137,12 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
     const u32 tid = threadIdx.x, nthr = blockDim.x;
     // tile -> (hi, lo_tile): base = hi * (d * R) + lo_tile * T     (d = 2^log_d)
     const int log_lo_tiles = p.log_d - log_t;
-    const u32 tile_id = blockIdx.x;
+    const u32 tile_id = p.cols_fastest ? blockIdx.y : blockIdx.x;
+    const u32 col_id = p.cols_fastest ? blockIdx.x : blockIdx.y;
     const u32 hi_idx = tile_id >> log_lo_tiles, lo_tile = tile_id & ((1u << log_lo_tiles) - 1);
     const u32 base = (hi_idx << (p.log_d + r)) + (lo_tile << log_t);
-    const u64 *src = p.src + (size_t)blockIdx.y * p.src_stride;
-    u64 *dst = p.dst + (size_t)blockIdx.y * p.dst_stride;
+    const u64 *src = p.src + (size_t)col_id * p.src_stride;
+    u64 *dst = p.dst + (size_t)col_id * p.dst_stride;
     const u32 elems = 1u << (r + log_t);
 
     // ---- load (global index x = base + t*d + u  ->  lds[t*T + u]) ----
@@ -144,7 +153,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
         for (u32 se = tid; se < (elems >> p.log_rep); se += nthr) {
             u64 v = p.nt ? __builtin_nontemporal_load(src + sbase + se) : src[sbase + se];
             if (p.in_scale) v = gl_mul(v, p.in_scale[sbase + se]);
-            for (u32 k = 0; k < rep; ++k) tile[(se << p.log_rep) + k] = v;
+            for (u32 k = 0; k < rep; ++k) tile[ntt_ph<PAD>((se << p.log_rep) + k)] = v;
         }
     } else {
         for (u32 e = tid; e < elems; e += nthr) {
@@ -152,7 +161,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
             u32 x = base + (t << p.log_d) + u;
             u64 v = p.nt ? __builtin_nontemporal_load(src + x) : src[x];
             if (p.in_scale) v = gl_mul(v, p.in_scale[x]);
-            tile[e] = v;
+            tile[ntt_ph<PAD>(e)] = v;
         }
     }
     __syncthreads();
@@ -162,9 +171,9 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
     while (done < r) {
         const int k = r - done < 3 ? r - done : 3;
         const int log_q = DIT ? done : (r - done - k);
-        if (k == 3) ntt_step<DIT, 3>(tile, p, log_q, base, elems, tid, nthr);
-        else if (k == 2) ntt_step<DIT, 2>(tile, p, log_q, base, elems, tid, nthr);
-        else ntt_step<DIT, 1>(tile, p, log_q, base, elems, tid, nthr);
+        if (k == 3) ntt_step<DIT, 3, PAD>(tile, p, log_q, base, elems, tid, nthr);
+        else if (k == 2) ntt_step<DIT, 2, PAD>(tile, p, log_q, base, elems, tid, nthr);
+        else ntt_step<DIT, 1, PAD>(tile, p, log_q, base, elems, tid, nthr);
         __syncthreads();
         done += k;
     }
@@ -173,7 +182,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
     for (u32 e = tid; e < elems; e += nthr) {
         u32 t = e >> log_t, u = e & (T - 1);
         u32 x = base + (t << p.log_d) + u;
-        u64 v = tile[e];
+        u64 v = tile[ntt_ph<PAD>(e)];
         if (p.out_scale) v = gl_mul_canon(v, p.out_scale[x]);
         else if (p.apply_out_const) v = gl_mul_canon(v, p.out_const);
         else if (p.last_pass) v = gl_canon(v);          // between passes any u64 representative will do

@@ -64,9 +64,13 @@ extern "C" int zk_ctx_create(int device, zk_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
     // allow the NTT kernels their full LDS tile (default dynamic limit is 64 KiB)
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false>),
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false, false>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true>),
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true, false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false, true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true, true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = ctx;
     return ZK_OK;
