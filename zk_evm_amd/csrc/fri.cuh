@@ -193,61 +193,83 @@ static __global__ void __launch_bounds__(256) eval_columns_reduce_kernel(const u
     }
 }
 
-// ---- value-domain batch combination ---------------------------------------------------------
-// V[j] = sum_b (prod of later shifts) * (sum_k alpha^k f_{b,k}(x_j) - y_b) / (x_j - z_b).
-// One lane per LDE point.  The loop runs over the DISTINCT columns (the zeta and g*zeta batches open the same
-// trace / auxiliary columns, so each value is loaded once and feeds every batch that opens it), and the
-// alpha-power dot products use delayed reduction: the four 32x32 partial products of coef * value are summed in
-// 96-bit accumulators (v_mad_u64_u32 + carry) and folded mod p once per point -- 8 VALU instructions per
-// (column, batch, component) instead of a 21-instruction field multiply plus an 8-instruction field add.
+// ---- batch combination ------------------------------------------------------------------------------
+// V[j] = sum_b (prod of later shifts) * (G_b(x_j) - y_b) / (x_j - z_b),   G_b = sum_k alpha^k f_{b,k}.
+// G_b is linear in the committed polynomials, so it is formed where they are SHORTEST: on the n bit-reversed coefficients
+// (MODE 1: one lane per coefficient index, every column read once for all batches -- half the bytes and half the multiply-adds
+// of the 2n LDE values the r01-r03 form read), extended to the 2n coset points by ONE low-degree extension of the
+// 2 * n_batches component columns (ntt_host.inc), and divided pointwise (MODE 2).  MODE 0 is the value-domain form (the
+// columns' LDE values, one lane per point, sums and division in one kernel; ZK_FRI_COEFF_COMBINE=0).
+// The loop runs over the DISTINCT columns (the zeta and g*zeta batches open the same trace / auxiliary columns, so each
+// value is loaded once and feeds every batch that opens it), and the alpha-power dot products use delayed reduction: the
+// four 32x32 partial products of coef * value are summed in 96-bit accumulators (v_mad_u64_u32 + carry) and folded mod p
+// once per index -- 8 VALU instructions per (column, batch, component) instead of a field multiply plus a field add.
 #define ZK_FRI_MAX_BATCHES 4
 struct FriCombineArgs {
     int n_batches;
-    int log_N;
+    int log_N;                                  // MODE 0 / 2: points;  MODE 1: log2 of the coefficient count
     const u64 *tw;                              // w_N^k, k < N/2
     u64 coset_shift;                            // g
     u32 n_cols;                                 // distinct columns
-    const u64 *const *cols;                     // device array [n_cols] of column base pointers (LDE, natural)
+    const u64 *const *cols;                     // device array [n_cols] of column base pointers (MODE 0: LDE, natural; MODE 1: coefficients)
     const u64 *coef;                            // device array [n_cols][n_batches][2]: alpha^pos (a, b); (0,0) = not opened
     u64 y[ZK_FRI_MAX_BATCHES][2];               // reduced opening sum_k alpha^k f_k(z_b)
     u64 z[ZK_FRI_MAX_BATCHES][2];               // opening point
     u64 shift[ZK_FRI_MAX_BATCHES][2];           // alpha^(n_polys[b])
     u64 *out_a, *out_b;                         // [N] each
+    u64 *g;                                     // MODE 1 out / MODE 2 in: component (b, c) at g + (2 b + c) * g_stride
+    size_t g_stride;
 };
 
-template <int NB>
+template <int NB, int MODE>
 __global__ void __launch_bounds__(256) fri_combine_kernel(FriCombineArgs A) {
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >> A.log_N) return;
-    DotAcc acc[NB][2];
+    gl2 sums[NB];
+    if (MODE == 2) {
 #pragma unroll
-    for (int b = 0; b < NB; ++b) { dot_acc_init(acc[b][0]); dot_acc_init(acc[b][1]); }
-    const u64 *__restrict__ coef = A.coef;
-    auto consume = [&](u32 k, u64 v) {
+        for (int b = 0; b < NB; ++b) sums[b] = gl2_make(A.g[(size_t)(2 * b) * A.g_stride + j], A.g[(size_t)(2 * b + 1) * A.g_stride + j]);
+    } else {
+        DotAcc acc[NB][2];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const u64 ca = coef[((size_t)k * NB + b) * 2], cb = coef[((size_t)k * NB + b) * 2 + 1];
-            // uniform across the wave: scalar registers, and a scalar branch for batches that skip this column
-            const u32 a0 = __builtin_amdgcn_readfirstlane((u32)ca), a1 = __builtin_amdgcn_readfirstlane((u32)(ca >> 32));
-            const u32 b0 = __builtin_amdgcn_readfirstlane((u32)cb), b1 = __builtin_amdgcn_readfirstlane((u32)(cb >> 32));
-            if ((a0 | a1 | b0 | b1) != 0) {
-                dot_acc_mac(acc[b][0], a0, a1, v);
-                dot_acc_mac(acc[b][1], b0, b1, v);
+        for (int b = 0; b < NB; ++b) { dot_acc_init(acc[b][0]); dot_acc_init(acc[b][1]); }
+        const u64 *__restrict__ coef = A.coef;
+        auto consume = [&](u32 k, u64 v) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const u64 ca = coef[((size_t)k * NB + b) * 2], cb = coef[((size_t)k * NB + b) * 2 + 1];
+                // uniform across the wave: scalar registers, and a scalar branch for batches that skip this column
+                const u32 a0 = __builtin_amdgcn_readfirstlane((u32)ca), a1 = __builtin_amdgcn_readfirstlane((u32)(ca >> 32));
+                const u32 b0 = __builtin_amdgcn_readfirstlane((u32)cb), b1 = __builtin_amdgcn_readfirstlane((u32)(cb >> 32));
+                if ((a0 | a1 | b0 | b1) != 0) {
+                    dot_acc_mac(acc[b][0], a0, a1, v);
+                    dot_acc_mac(acc[b][1], b0, b1, v);
+                }
             }
+        };
+        // The columns are 8-16 MB apart and a wave that waits for one load at a time moves 512 B per HBM round trip (2.9 TB/s
+        // with every wave slot taken): keep FRI_COLS_IN_FLIGHT loads in flight per lane.
+        constexpr u32 FRI_COLS_IN_FLIGHT = 8;
+        u32 k = 0;
+        for (; k + FRI_COLS_IN_FLIGHT <= A.n_cols; k += FRI_COLS_IN_FLIGHT) {
+            u64 v[FRI_COLS_IN_FLIGHT];
+#pragma unroll
+            for (u32 i = 0; i < FRI_COLS_IN_FLIGHT; ++i) v[i] = A.cols[k + i][j];
+#pragma unroll
+            for (u32 i = 0; i < FRI_COLS_IN_FLIGHT; ++i) consume(k + i, v[i]);
         }
-    };
-    // The columns are 16 MB apart and a wave that waits for one load at a time moves 512 B per HBM round trip (2.9 TB/s
-    // with every wave slot taken): keep FRI_COLS_IN_FLIGHT loads in flight per lane.
-    constexpr u32 FRI_COLS_IN_FLIGHT = 8;
-    u32 k = 0;
-    for (; k + FRI_COLS_IN_FLIGHT <= A.n_cols; k += FRI_COLS_IN_FLIGHT) {
-        u64 v[FRI_COLS_IN_FLIGHT];
+        for (; k < A.n_cols; ++k) consume(k, A.cols[k][j]);
 #pragma unroll
-        for (u32 i = 0; i < FRI_COLS_IN_FLIGHT; ++i) v[i] = A.cols[k + i][j];
+        for (int b = 0; b < NB; ++b) sums[b] = gl2_make(dot_acc_reduce(acc[b][0]), dot_acc_reduce(acc[b][1]));
+        if (MODE == 1) {
 #pragma unroll
-        for (u32 i = 0; i < FRI_COLS_IN_FLIGHT; ++i) consume(k + i, v[i]);
+            for (int b = 0; b < NB; ++b) {
+                A.g[(size_t)(2 * b) * A.g_stride + j] = gl_canon(sums[b].a);
+                A.g[(size_t)(2 * b + 1) * A.g_stride + j] = gl_canon(sums[b].b);
+            }
+            return;
+        }
     }
-    for (; k < A.n_cols; ++k) consume(k, A.cols[k][j]);
     const u32 half = 1u << (A.log_N - 1);
     u64 w = A.tw[j & (half - 1)];
     if (j & half) w = gl_neg(w);
@@ -255,8 +277,7 @@ __global__ void __launch_bounds__(256) fri_combine_kernel(FriCombineArgs A) {
     gl2 sum = gl2_make(0, 0);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        gl2 s = gl2_make(dot_acc_reduce(acc[b][0]), dot_acc_reduce(acc[b][1]));
-        gl2 numer = gl2_sub(s, gl2_make(A.y[b][0], A.y[b][1]));
+        gl2 numer = gl2_sub(sums[b], gl2_make(A.y[b][0], A.y[b][1]));
         gl2 denom = gl2_make(gl_sub(x, A.z[b][0]), gl_neg(A.z[b][1]));
         sum = gl2_mul(sum, gl2_make(A.shift[b][0], A.shift[b][1]));
         sum = gl2_add(sum, gl2_mul(numer, gl2_inv_dev(denom)));
