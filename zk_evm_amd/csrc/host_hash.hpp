@@ -19,8 +19,9 @@
 namespace zkhost {
 
 // Host permutation for the transcript.  A wide table's opening set is ~10^4 elements (Keccak: 1200 permutations
-// per proof), so this is on the critical path between kernels: 128-bit products (one mulq each), the MDS rows over a
-// doubled state array (no modulo in the inner loop), constants added once per round.
+// per proof, 2150 per segment), so this is on the critical path between kernels: 128-bit products (one mulq each), the MDS
+// rows over a doubled state array (no modulo in the inner loop), constants added once per round, and the blocked schedule
+// of the device permutation for the partial rounds (poseidon_permute below).
 inline u64 mul_host(u64 a, u64 b) {
     const unsigned __int128 p = (unsigned __int128)a * b;
     return gl_reduce128((u64)(p >> 64), (u64)p);
@@ -67,33 +68,117 @@ __attribute__((target("avx2"))) inline void mds_avx2(u64 (&s)[12], const u64 (&l
     }
 }
 #endif
-inline void poseidon_permute(u64 (&s)[12]) {
-    static const u64 RC[ZK_POSEIDON_ROUNDS * 12] = ZK_POSEIDON_RC_INIT;
 #if defined(__x86_64__)
-    static const bool have_avx2 = __builtin_cpu_supports("avx2");
-#endif
-    for (int i = 0; i < 12; ++i) s[i] = gl_canon(s[i]);
-    for (int round = 0; round < ZK_POSEIDON_ROUNDS; ++round) {
-        const bool full = round < ZK_POSEIDON_HALF_FULL_ROUNDS ||
-                          round >= ZK_POSEIDON_HALF_FULL_ROUNDS + ZK_POSEIDON_PARTIAL_ROUNDS;
-        const u64 *rc = RC + round * 12;
-        u64 lo[24], hi[24];
-        for (int i = 0; i < 12; ++i) {
-            u64 x = gl_add_ref(s[i], rc[i]);
-            if (full || i == 0) {
-                const u64 x2 = mul_host(x, x), x4 = mul_host(x2, x2);
-                x = mul_host(mul_host(x, x2), x4);
-            }
-            lo[i] = lo[i + 12] = x & 0xFFFFFFFFULL;
-            hi[i] = hi[i + 12] = x >> 32;
+// the 12 x 12 product of a block (poseidon_permute below) on the 32-bit halves: al[r] = sum_j T[j][r] * lo[j] etc., four rows
+// per vector; T = the matrix transposed, one u64 lane per entry, rows 12 / 13 = the columns multiplying d1 / d2
+struct Block3Tables { alignas(32) u64 t[14][12]; };
+__attribute__((target("avx2"))) inline void block3_avx2(u64 (&al)[12], u64 (&ah)[12], const Block3Tables &T,
+                                                        const u64 (&lo)[14], const u64 (&hi)[14]) {
+    for (int g = 0; g < 3; ++g) {
+        __m256i vl = _mm256_setzero_si256(), vh = _mm256_setzero_si256();
+#pragma GCC unroll 14
+        for (int j = 0; j < 14; ++j) {
+            const __m256i c = _mm256_load_si256((const __m256i *)(T.t[j] + 4 * g));
+            vl = _mm256_add_epi64(vl, _mm256_mul_epu32(_mm256_set1_epi64x((long long)lo[j]), c));
+            vh = _mm256_add_epi64(vh, _mm256_mul_epu32(_mm256_set1_epi64x((long long)hi[j]), c));
         }
-#if defined(__x86_64__)
-        if (have_avx2) { mds_avx2(s, lo, hi); continue; }
-#endif
-        mds_scalar(s, lo, hi);
+        _mm256_storeu_si256((__m256i *)(al + 4 * g), vl);
+        _mm256_storeu_si256((__m256i *)(ah + 4 * g), vh);
     }
 }
-
+#endif
+inline u64 sbox_host(u64 x) {
+    const u64 x2 = mul_host(x, x), x4 = mul_host(x2, x2);
+    return mul_host(mul_host(x, x2), x4);
+}
+inline u64 red128(unsigned __int128 v) { return gl_canon(gl_reduce128((u64)(v >> 64), (u64)v)); }
+struct RcSplitHost { u64 lo, hi; };
+// The schedule of the device permutation (csrc/poseidon.cuh, pos_block3; constants and the proof that it equals the plain
+// 30 rounds: tools/gen_poseidon_constants.py): full rounds 0 .. 2 as they are, then the 23 linear layers up to round 25 as
+// seven blocks of three (one 12 x 12 product with the entries of MDS^3 < 2^21, here as 128-bit sums) and two plain rounds --
+// 8 + 2 matrix products instead of 23 for the middle of the permutation: 1.32 -> 0.8 us on the GPU box's EPYC 9575F.
+inline void poseidon_permute(u64 (&s)[12]) {
+    static const u64 RC[ZK_POSEIDON_ROUNDS * 12] = ZK_POSEIDON_RC_INIT;
+    static const u32 CIRC[12] = ZK_POSEIDON_MDS_CIRC_INIT;
+    static const u32 M2R0[12] = ZK_POSEIDON_M2_ROW0_INIT, M2C0[12] = ZK_POSEIDON_M2_COL0_INIT;
+    static const u32 M3[144] = ZK_POSEIDON_M3_INIT;
+    static const RcSplitHost K3[ZK_POSEIDON_BLOCK3_COUNT * 12] = ZK_POSEIDON_RCS3_INIT;
+    static const RcSplitHost KZ3[ZK_POSEIDON_BLOCK3_COUNT] = ZK_POSEIDON_RCS3Z_INIT;
+#if defined(__x86_64__)
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    static const Block3Tables T3 = [] {
+        Block3Tables t;
+        for (int i = 0; i < 12; ++i) {
+            for (int j = 0; j < 12; ++j) t.t[j][i] = M3[i * 12 + j];
+            t.t[12][i] = M2C0[i];
+            t.t[13][i] = CIRC[(12 - i) % 12] + (i == 0 ? 8u : 0u);
+        }
+        return t;
+    }();
+#endif
+    typedef unsigned __int128 u128;
+    auto mds = [&](u64 (&x)[12]) {                     // x <- MDS x  (x: S-box layer already applied)
+        u64 lo[24], hi[24];
+        for (int i = 0; i < 12; ++i) {
+            lo[i] = lo[i + 12] = x[i] & 0xFFFFFFFFULL;
+            hi[i] = hi[i + 12] = x[i] >> 32;
+        }
+#if defined(__x86_64__)
+        if (have_avx2) { mds_avx2(x, lo, hi); return; }
+#endif
+        mds_scalar(x, lo, hi);
+    };
+    for (int i = 0; i < 12; ++i) s[i] = gl_canon(s[i]);
+    for (int round = 0; round < ZK_POSEIDON_HALF_FULL_ROUNDS - 1; ++round) {
+        for (int i = 0; i < 12; ++i) s[i] = sbox_host(gl_add_ref(s[i], RC[round * 12 + i]));
+        mds(s);
+    }
+    for (int i = 0; i < 12; ++i) s[i] = sbox_host(gl_add_ref(s[i], RC[(ZK_POSEIDON_HALF_FULL_ROUNDS - 1) * 12 + i]));
+    for (int b = 0; b < ZK_POSEIDON_BLOCK3_COUNT; ++b) {
+        const int r = ZK_POSEIDON_HALF_FULL_ROUNDS - 1 + 3 * b;
+        if (b) s[0] = sbox_host(s[0]);
+        u128 a = RC[(r + 1) * 12], z = KZ3[b].lo | (KZ3[b].hi << 32);
+        for (int j = 0; j < 12; ++j) {
+            a += (u128)s[j] * (CIRC[j] + (j == 0 ? 8u : 0u));          // row 0 of MDS
+            z += (u128)s[j] * M2R0[j];
+        }
+        const u64 w0 = red128(a);
+        const u64 d1 = gl_canon(gl_sub_ref(sbox_host(w0), w0));
+        const u64 z0 = red128(z + (u128)d1 * (CIRC[0] + 8u));
+        const u64 d2 = gl_canon(gl_sub_ref(sbox_host(z0), z0));
+        u64 out[12];
+#if defined(__x86_64__)
+        if (have_avx2) {
+            u64 lo[14], hi[14], al[12], ah[12];
+            for (int j = 0; j < 12; ++j) { lo[j] = s[j] & 0xFFFFFFFFULL; hi[j] = s[j] >> 32; }
+            lo[12] = d1 & 0xFFFFFFFFULL; hi[12] = d1 >> 32;
+            lo[13] = d2 & 0xFFFFFFFFULL; hi[13] = d2 >> 32;
+            block3_avx2(al, ah, T3, lo, hi);               // sums < 2^58
+            for (int i = 0; i < 12; ++i)
+                out[i] = red128((u128)al[i] + ((u128)ah[i] << 32) + (K3[b * 12 + i].lo | (K3[b * 12 + i].hi << 32)));
+        } else
+#endif
+        for (int i = 0; i < 12; ++i) {
+            u128 acc = (K3[b * 12 + i].lo | (K3[b * 12 + i].hi << 32)) + (u128)d1 * M2C0[i] +
+                       (u128)d2 * (CIRC[(12 - i) % 12] + (i == 0 ? 8u : 0u));            // MDS[i][0]
+            for (int j = 0; j < 12; ++j) acc += (u128)s[j] * M3[i * 12 + j];
+            out[i] = red128(acc);
+        }
+        for (int i = 0; i < 12; ++i) s[i] = out[i];
+    }
+    // rounds 24, 25 (partial; the constants of round 24 are in), then the four full rounds
+    int round = ZK_POSEIDON_HALF_FULL_ROUNDS - 1 + 3 * ZK_POSEIDON_BLOCK3_COUNT;
+    s[0] = sbox_host(s[0]);
+    mds(s);
+    ++round;
+    for (int i = 0; i < 12; ++i) s[i] = gl_add_ref(s[i], RC[round * 12 + i]);
+    s[0] = sbox_host(s[0]);
+    mds(s);
+    for (++round; round < ZK_POSEIDON_ROUNDS; ++round) {
+        for (int i = 0; i < 12; ++i) s[i] = sbox_host(gl_add_ref(s[i], RC[round * 12 + i]));
+        mds(s);
+    }
+}
 inline u64 rotl(u64 x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
 
 inline void keccak_f1600(u64 (&a)[25]) {

@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <list>
 #include <map>
 #include <memory>
 #include <set>
