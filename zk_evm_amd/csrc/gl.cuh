@@ -114,16 +114,29 @@ GL_HD u64 gl_mul_ref(u64 a, u64 b) {
             : "vcc");                                                                                              \
     }
 
-__device__ __forceinline__ u64 gl_mul_fast(u64 a, u64 b) {
+// The 128-bit product [T3:T2:T1:T0] of two u64 as a chain of four multiply-adds:
+//     P = a0 b0;  M = a0 b1 + hi(P);  M2 = a1 b0 + M  (the WHOLE pair M as the addend: the low word is what a1 b0 + lo(M)
+//     gives, the high part now also carries hi(M), and the sum's bit 64 leaves in the carry mask);  H = a1 b1 + [c : hi(M2)].
+// Each {x, 0} addend pair costs a v_mov; taking M as it stands saves two of the three and the 64-bit add of hi(M) (r03r).
+__device__ __forceinline__ void gl_prod128(u64 a, u64 b, u32 &t0, u32 &t1, u32 &t2, u32 &t3) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 P = (u64)a0 * b0;
-    const u64 M = (u64)a0 * b1 + (P >> 32);            // <= (2^32-1)^2 + 2^32 - 1: no overflow
-    const u64 M2 = (u64)a1 * b0 + (u32)M;              // likewise
-    const u64 H = (u64)a1 * b1 + (M >> 32) + (M2 >> 32);
-    u32 lo, h, c;
-    const u32 t2 = (u32)H, t3 = (u32)(H >> 32);
+    u64 M = (u64)a0 * b1 + (P >> 32);                  // <= (2^32-1)^2 + 2^32 - 1: no overflow
+    u32 c;
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+        "v_cndmask_b32_e64 %1, 0, 1, vcc"
+        : "+v"(M), "=&v"(c)
+        : "v"(a1), "v"(b0)
+        : "vcc");
+    const u64 H = (u64)a1 * b1 + (((u64)c << 32) | (u32)(M >> 32));
+    t0 = (u32)P; t1 = (u32)M; t2 = (u32)H; t3 = (u32)(H >> 32);
+}
+
+__device__ __forceinline__ u64 gl_mul_fast(u64 a, u64 b) {
+    u32 t0, t1, t2, t3, lo, h, c;
+    gl_prod128(a, b, t0, t1, t2, t3);
     u64 bm;
-    GL_FOLD_HEAD(lo, h, (u32)M2, t3, (u32)P, bm)
+    GL_FOLD_HEAD(lo, h, t1, t3, t0, bm)
     u64 r = ((u64)h << 32) | lo;
     asm(GL_ASM_TAIL : [r] "+v"(r), [c] "=&v"(c) : [t2] "v"(t2) : "vcc");
     return r;
@@ -134,18 +147,14 @@ __device__ __forceinline__ u64 gl_mul_fast(u64 a, u64 b) {
 // the 86-column Cpu AIR its occupancy (4 -> 2 waves per SIMD, its quotient 7 -> 17 ms) and the Arithmetic AIR 15 %, while
 // gaining nothing measurable elsewhere.
 __device__ __forceinline__ u64 gl_mul(u64 a, u64 b) {
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    const u64 P = (u64)a0 * b0;
-    const u64 M = (u64)a0 * b1 + (P >> 32);
-    const u64 M2 = (u64)a1 * b0 + (u32)M;
-    const u64 H = (u64)a1 * b1 + (M >> 32) + (M2 >> 32);
-    u32 lo, h, e;
+    u32 t0, t1, t2, t3, lo, h, e;
+    gl_prod128(a, b, t0, t1, t2, t3);
     asm(GL_ASM_HEAD
         : [lo] "=&v"(lo), [h] "=&v"(h), [e] "=&v"(e)
-        : [p0] "v"((u32)P), [t1] "v"((u32)M2), [t3] "v"((u32)(H >> 32))
+        : [p0] "v"(t0), [t1] "v"(t1), [t3] "v"(t3)
         : "vcc");
     u64 r = ((u64)h << 32) | lo;
-    asm(GL_ASM_TAIL : [r] "+v"(r), [c] "=&v"(e) : [t2] "v"((u32)H) : "vcc");
+    asm(GL_ASM_TAIL : [r] "+v"(r), [c] "=&v"(e) : [t2] "v"(t2) : "vcc");
     return r;
 }
 
@@ -159,12 +168,8 @@ __device__ __forceinline__ u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 // (No unlikely block for the first correction here: in the NTT's register step the branch version measured 2 % SLOWER --
 // 1014 vs 1031 GB/s on the 116 x 2^20 commit -- where the same change makes the leaf hashing 13 % faster.)
 __device__ __forceinline__ u64 gl_mul_canon(u64 a, u64 b) {
-    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
-    const u64 P = (u64)a0 * b0;
-    const u64 M = (u64)a0 * b1 + (P >> 32);
-    const u64 M2 = (u64)a1 * b0 + (u32)M;
-    const u64 H = (u64)a1 * b1 + (M >> 32) + (M2 >> 32);
-    u32 lo, h, e;
+    u32 t0, t1, t2, t3, lo, h, e;
+    gl_prod128(a, b, t0, t1, t2, t3);
     u64 sa;
     asm("v_sub_co_u32 %[lo], vcc, %[p0], %[t3]\n\t"
         "v_subbrev_co_u32 %[h], vcc, 0, %[t1], vcc\n\t"
@@ -174,7 +179,7 @@ __device__ __forceinline__ u64 gl_mul_canon(u64 a, u64 b) {
         "v_subbrev_co_u32 %[h], vcc, 0, %[h], vcc\n"
         "1:"
         : [lo] "=&v"(lo), [h] "=&v"(h), [e] "=&v"(e)
-        : [p0] "v"((u32)P), [t1] "v"((u32)M2), [t3] "v"((u32)(H >> 32))
+        : [p0] "v"(t0), [t1] "v"(t1), [t3] "v"(t3)
         : "vcc");
     u64 r = ((u64)h << 32) | lo;
     // r += T2 * (2^32 - 1); then += EPS (mod 2^64) when that carried (2^64 == EPS) or when r >= p (r - p == r + EPS mod 2^64):
@@ -185,7 +190,7 @@ __device__ __forceinline__ u64 gl_mul_canon(u64 a, u64 b) {
         "v_cndmask_b32_e64 %[c], 0, 1, vcc\n\t"
         "v_mad_u64_u32 %[r], vcc, %[c], -1, %[r]"
         : [r] "+v"(r), [c] "=&v"(e), [sa] "=&s"(sa)
-        : [t2] "v"((u32)H), [pm1] "s"(GL_P - 1)
+        : [t2] "v"(t2), [pm1] "s"(GL_P - 1)
         : "vcc", "scc");
     return r;
 }
