@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 QUICK="--steps 6 --warmup 2 --no-cpu-baseline --no-secondary --commit-steps 0 --in-flight 1 --no-pmc --no-dist-selftest"
-timeout 900 python -m pytest tests -m gpu -x -q -k "poseidon or commit or merkle or kat or segment_proof_matches_oracle" 2>&1 | tail -2
+timeout 900 python -m pytest tests -m gpu -x -q -k "fri or plonk or stark_prove or segment_proof_matches_oracle" 2>&1 | tail -2
 cp zk_evm_amd/libzkstark_hip.so /tmp/new.so
 for rep in 1 2 3; do
   for V in base new; do
