@@ -1339,7 +1339,7 @@ def main():
                         "frac_is": "wave-instructions issued / issue slots, one wave64 VALU op per 2 cycles per SIMD being the floor "
                                    "(MI355X_MICROARCH.md); the kernel's own mix is dominated by v_mad_u64_u32 / carry-chain / "
                                    "v_cndmask ops that issue at ~4.3 cycles each (profiles/r01_ubench_valu_issue_rates.txt), so a "
-                                   "cycles_per_wave_instruction of 3.5-3.6 is an issue-saturated SIMD",
+                                   "cycles_per_wave_instruction of 3.5-3.8 is an issue-saturated SIMD",
                         "source": "rocprofv3 --pmc SQ_INSTS_VALU and GRBM_GUI_ACTIVE (/ 8 XCDs x 1024 SIMDs) of the same launches, "
                                   "this run", "measured_in_this_run": True}
                     # all 27 leaf-hash launches of the profiled segment (main and side lane): total instructions / total
