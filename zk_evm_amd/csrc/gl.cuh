@@ -88,15 +88,14 @@ GL_HD u64 gl_mul_ref(u64 a, u64 b) {
     "v_cndmask_b32_e64 %[c], 0, 1, vcc\n\t"                                                       \
     "v_mad_u64_u32 %[r], vcc, %[c], -1, %[r]"
 
-// Chained partial products: each v_mad_u64_u32 takes the previous product's high word as its 64-bit addend
-// ({x, 0} pairs cost one v_mov each, and v_mov / v_add_u32 / logic ops issue at ~2.4 cycles where every carry op costs
-// ~4.3), so the 128-bit product needs 4 mad + 2 carry adds instead of 4 mad + 6 carry adds.  Measured
-// (tools/ubench_mul.hip): 72.7 cycles per wave-multiply per SIMD against 91.2 for the four-independent-products form
-// and 81.4 for the three-product squaring -- so a square is just gl_mul(a, a).
-// The fold's FIRST correction (the borrow of [T1:T0] - T3) happens with probability ~2^-33 per lane, so its three
-// instructions sit in an unlikely block entered only when some lane of the wave borrowed: the borrow mask leaves the asm
-// in an SGPR pair, the test and branch run on the scalar unit, the common path falls through.  (The second correction
-// fires for every other product and stays inline.)  tools/ubench_mul.hip: 58.7 instead of 74.7 cycles per wave-multiply.
+// Chained partial products (gl_prod128 below): each v_mad_u64_u32 takes the previous product's high part as its 64-bit
+// addend, so the 128-bit product needs no carry adds at all.  History, measured with tools/ubench_mul.hip in cycles per
+// wave-multiply per SIMD: four independent products + six carry adds 91.2; chained with {x, 0} addend pairs (one v_mov
+// each) and two carry adds 72.7; the three-product squaring 81.4 -- so a square is just gl_mul(a, a).
+// The fold's FIRST correction (the borrow of [T1:T0] - T3) happens with probability ~2^-33 per lane, so in gl_mul_fast its
+// three instructions sit in an unlikely block entered only when some lane of the wave borrowed: the borrow mask leaves the
+// asm in an SGPR pair, the test and branch run on the scalar unit, the common path falls through (74.7 -> 58.7 cycles with
+// the carry-chain fold of r02; the fold itself is now GL_ASM_TAIL).
 // Used where multiplies dominate and registers are not scarce: the Poseidon S-box (gl_mul_fast).
 #define GL_FOLD_HEAD(lo, h, t1, t3, p0, bm)                                                                        \
     asm("v_sub_co_u32 %[l], vcc, %[p], %[z]\n\t"         /* [h:lo] = [T1:T0] - T3 */                               \
@@ -163,10 +162,10 @@ __device__ __forceinline__ u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 // gl_mul with the result folded into [0, p) (two compares on top of the lazy form: the only non-canonical outputs of the
 // reduce are 0xFFFFFFFF:lo with lo >= 1 from the no-carry branch, and adding EPS to those wraps them to 0:lo-1 -- the
 // same add the carry branch needs, so the two conditions are merged on the scalar unit).  A canonical product lets the
-// add / sub that consume it use ONE correction instead of two (gl_add_canon / gl_sub_canon): 22 + 5 + 5 instructions for
-// a decimation-in-time butterfly instead of 20 + 8 + 8.
-// (No unlikely block for the first correction here: in the NTT's register step the branch version measured 2 % SLOWER --
-// 1014 vs 1031 GB/s on the 116 x 2^20 commit -- where the same change makes the leaf hashing 13 % faster.)
+// add / sub that consume it use ONE correction instead of two (gl_add_canon / gl_sub_canon): 11 + 4 + 4 full-rate
+// instructions for a decimation-in-time butterfly (22 + 5 + 5 with the carry-chain folds of r02).
+// (The first correction is skipped by a wave-uniform s_cbranch_vccz INSIDE the asm statement: as a compiler-visible
+// branch it measured 2 % slower in the NTT's register step.)
 __device__ __forceinline__ u64 gl_mul_canon(u64 a, u64 b) {
     u32 t0, t1, t2, t3, lo, h, e;
     gl_prod128(a, b, t0, t1, t2, t3);

@@ -50,8 +50,8 @@ struct NttPass {
 };
 
 // One radix-2 butterfly (a, b) -> (a + w b, a - w b).  BOTH directions use this Cooley-Tukey form: the canonical product
-// (gl_mul_canon) lets the add and the sub run with one correction each, 22 + 5 + 5 instructions against 8 + 8 + 20 for
-// the Gentleman-Sande form (a + b, (a - b) w), whose add and sub both see two lazy operands.
+// (gl_mul_canon) lets the add and the sub run with one correction each, 11 + 4 + 4 full-rate instructions (gl.cuh)
+// against 6 + 8 + 10 for the Gentleman-Sande form (a + b, (a - b) w), whose add and sub both see two lazy operands.
 __device__ __forceinline__ void ntt_bfly(u64 &a, u64 &b, u64 w) {
     u64 t = gl_mul_canon(b, w);
     u64 na = gl_add_canon(a, t);
