@@ -53,10 +53,40 @@ __device__ __forceinline__ void dot_acc_mac(DotAcc &d, u32 c0, u32 c1, u64 v) {
 }
 // (lo + hi * 2^64) mod p as a lazy u64; hi < 2^32:  2^64 = 2^32 - 1
 __device__ __forceinline__ u64 fold96(u64 lo, u32 hi) { return gl_add(lo, ((u64)hi << 32) - hi); }
+// The accumulated value W = s00 + s01 2^32 + (s11 + h00) 2^64 + h01 2^96 + h11 2^128 as a lazy u64.  Summed word by word
+// (seven carry adds) it is [w4 : w3 : w2 : w1 : w0], and with 2^64 = 2^32 - 1, 2^96 = -1, 2^128 = -2^32 that is
+// [w1 : w0] - [w4 : w3] + w2 (2^32 - 1): the fold of a 128-bit product (gl.cuh) with a 64-bit subtrahend -- 15 instructions.
+// (r03s folded the three columns separately and recombined them with two field multiplies: 65 instructions, which was most
+// of what a compiled lookup / CTL entry of one or two terms cost.)  Needs fewer than 2^31 accumulated products (w4 < 2^31:
+// one borrow correction is enough); the term counts here are column counts.
 __device__ __forceinline__ u64 dot_acc_reduce(const DotAcc &d) {
-    u64 a = fold96(d.s00, d.h00), b = fold96(d.s01, d.h01), c = fold96(d.s11, d.h11);
-    // a + b * 2^32 + c * (2^32 - 1)
-    return gl_add(a, gl_add(gl_mul(b, (u64)1 << 32), gl_mul(c, 0xFFFFFFFFULL)));
+    const u32 a0 = (u32)d.s00, a1 = (u32)(d.s00 >> 32), b0 = (u32)d.s01, b1 = (u32)(d.s01 >> 32), c0 = (u32)d.s11,
+              c1 = (u32)(d.s11 >> 32);
+    u32 w1, w2, w3, w4, lo, hi, e;
+    asm("v_add_co_u32 %[w1], vcc, %[a1], %[b0]\n\t"
+        "v_addc_co_u32 %[w2], vcc, %[b1], %[c0], vcc\n\t"
+        "v_addc_co_u32 %[w3], vcc, 0, %[c1], vcc\n\t"
+        "v_addc_co_u32 %[w4], vcc, 0, %[h11], vcc\n\t"
+        "v_add_co_u32 %[w2], vcc, %[w2], %[h00]\n\t"
+        "v_addc_co_u32 %[w3], vcc, %[w3], %[h01], vcc\n\t"
+        "v_addc_co_u32 %[w4], vcc, 0, %[w4], vcc\n\t"
+        "v_sub_co_u32 %[lo], vcc, %[a0], %[w3]\n\t"            /* [hi:lo] = [w1:w0] - [w4:w3] */
+        "v_subb_co_u32 %[hi], vcc, %[w1], %[w4], vcc\n\t"
+        "v_cndmask_b32_e64 %[e], 0, -1, vcc\n\t"               /* borrow: -= EPS (== += p) */
+        "v_sub_co_u32 %[lo], vcc, %[lo], %[e]\n\t"
+        "v_subbrev_co_u32 %[hi], vcc, 0, %[hi], vcc"
+        : [w1] "=&v"(w1), [w2] "=&v"(w2), [w3] "=&v"(w3), [w4] "=&v"(w4), [lo] "=&v"(lo), [hi] "=&v"(hi), [e] "=&v"(e)
+        : [a0] "v"(a0), [a1] "v"(a1), [b0] "v"(b0), [b1] "v"(b1), [c0] "v"(c0), [c1] "v"(c1), [h00] "v"(d.h00),
+          [h01] "v"(d.h01), [h11] "v"(d.h11)
+        : "vcc");
+    u64 r = ((u64)hi << 32) | lo;
+    asm("v_mad_u64_u32 %[r], vcc, %[t2], -1, %[r]\n\t"         /* += w2 (2^32 - 1); a carry is 2^64 = 2^32 - 1 again (gl.cuh, GL_ASM_TAIL) */
+        "v_cndmask_b32_e64 %[c], 0, 1, vcc\n\t"
+        "v_mad_u64_u32 %[r], vcc, %[c], -1, %[r]"
+        : [r] "+v"(r), [c] "=&v"(e)
+        : [t2] "v"(w2)
+        : "vcc");
+    return r;
 }
 
 // same with per-lane (VGPR) coefficients
@@ -103,7 +133,10 @@ struct EvalPoints {
 // per 8-byte coefficient: 3.1x the algorithmic traffic at 2^20, PMC r03d); then every wave walks its share of the group's
 // columns -- 32 coalesced coefficient loads in flight per lane, weights from LDS, delayed-reduction accumulators -- and folds
 // its 64 lanes with DPP-free shuffles.  grid = (row chunks, column groups).
-#define ZK_EVAL_ROWS 512          // 16 KiB of weights per block at two points: eight blocks per CU keep the loads in flight
+// Row-chunk size (fri_host.inc kEvalRows, ZK_EVAL_ROWS): every (column, chunk) pair ends in four wave reductions (fold the 96-bit
+// accumulators, six shuffle steps each: ~500 instructions), which at 512 rows = 8 coefficients per lane was 62 of the kernel's 108
+// instructions per coefficient (PMC r03s: 4.4 cycles per instruction, i.e. issue-bound at 2.6 TB/s); at 2048 rows it is 16.
+#define ZK_EVAL_ROWS_MAX 2048     // 64 KiB of weights per block at two points, 96 KiB at three
 __device__ __forceinline__ u64 wave_sum_gl(u64 v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -113,11 +146,11 @@ __device__ __forceinline__ u64 wave_sum_gl(u64 v) {
     return v;                                        // lane 0 holds the sum
 }
 template <int NP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 eval_columns_partial_kernel(const u64 *__restrict__ coeffs, size_t col_stride, u32 n, u32 n_cols, u32 cols_per_group,
-                            EvalPoints P, u64 *__restrict__ partial) {
+                            u32 rows_max, EvalPoints P, u64 *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) u64 wlds[];      // [NP][2][rows]
-    const u32 rows = n < ZK_EVAL_ROWS ? n : ZK_EVAL_ROWS;
+    const u32 rows = n < rows_max ? n : rows_max;
     const u32 lo = blockIdx.x * rows;
     const u32 c_lo = blockIdx.y * cols_per_group, c_hi = c_lo + cols_per_group < n_cols ? c_lo + cols_per_group : n_cols;
     for (u32 e = threadIdx.x; e < rows; e += blockDim.x) {
@@ -221,6 +254,15 @@ struct FriCombineArgs {
     size_t g_stride;
 };
 
+// The column pointers come out of a device array, so the compiler knows nothing about their address space and would emit
+// FLAT loads (address-space check per access, counted in lgkmcnt as well, so that every wait for a scalar coefficient load
+// also waited for the column loads in flight).  They are global memory: say so, and the load takes the wave-uniform base from
+// an SGPR pair plus the lane's 32-bit offset.
+__device__ __forceinline__ u64 fri_col_load(const u64 *col, u32 j) {
+    typedef const u64 __attribute__((address_space(1))) *gcol_t;
+    return ((gcol_t)col)[j];
+}
+
 template <int NB, int MODE>
 __global__ void __launch_bounds__(256) fri_combine_kernel(FriCombineArgs A) {
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -254,11 +296,11 @@ __global__ void __launch_bounds__(256) fri_combine_kernel(FriCombineArgs A) {
         for (; k + FRI_COLS_IN_FLIGHT <= A.n_cols; k += FRI_COLS_IN_FLIGHT) {
             u64 v[FRI_COLS_IN_FLIGHT];
 #pragma unroll
-            for (u32 i = 0; i < FRI_COLS_IN_FLIGHT; ++i) v[i] = A.cols[k + i][j];
+            for (u32 i = 0; i < FRI_COLS_IN_FLIGHT; ++i) v[i] = fri_col_load(A.cols[k + i], j);
 #pragma unroll
             for (u32 i = 0; i < FRI_COLS_IN_FLIGHT; ++i) consume(k + i, v[i]);
         }
-        for (; k < A.n_cols; ++k) consume(k, A.cols[k][j]);
+        for (; k < A.n_cols; ++k) consume(k, fri_col_load(A.cols[k], j));
 #pragma unroll
         for (int b = 0; b < NB; ++b) sums[b] = gl2_make(dot_acc_reduce(acc[b][0]), dot_acc_reduce(acc[b][1]));
         if (MODE == 1) {

@@ -286,7 +286,25 @@ GL_HD u64 gl_pow(u64 b, u64 e) {
     }
     return r;
 }
-GL_HD u64 gl_inv(u64 a) { return gl_pow(a, GL_P - 2); }
+GL_HD u64 gl_sqr_n(u64 x, int n) {
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) x = gl_sqr(x);
+    return x;
+}
+// a^(p - 2) by an addition chain: p - 2 = 2^64 - 2^32 - 1 = (2^31 - 1) 2^33 + (2^32 - 1), and a^(2^k - 1) doubles its k with
+// k squarings and one multiply -- 64 squarings + 10 multiplies where square-and-multiply over the 63 one bits needs 64 + 62.
+GL_HD u64 gl_inv(u64 a) {
+    const u64 t2 = gl_mul(gl_sqr(a), a);                 // a^(2^2 - 1)
+    const u64 t4 = gl_mul(gl_sqr_n(t2, 2), t2);
+    const u64 t8 = gl_mul(gl_sqr_n(t4, 4), t4);
+    const u64 t16 = gl_mul(gl_sqr_n(t8, 8), t8);
+    const u64 t24 = gl_mul(gl_sqr_n(t16, 8), t8);
+    const u64 t28 = gl_mul(gl_sqr_n(t24, 4), t4);
+    const u64 t30 = gl_mul(gl_sqr_n(t28, 2), t2);
+    const u64 t31 = gl_mul(gl_sqr(t30), a);              // a^(2^31 - 1)
+    const u64 t32 = gl_mul(gl_sqr(t31), a);              // a^(2^32 - 1)
+    return gl_mul(gl_sqr_n(t31, 33), t32);
+}
 GL_HD u64 gl_root_of_unity(unsigned log_n) {
     u64 r = GL_POW2_GENERATOR;
     for (unsigned i = log_n; i < 32; ++i) r = gl_sqr(r);
