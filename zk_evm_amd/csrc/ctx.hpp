@@ -46,6 +46,8 @@ struct zk_ctx {
     std::map<std::pair<int, u64>, u64 *> coset_tabs;        // (log_n, shift) -> s^bitrev(i)
     std::map<std::pair<int, u64>, u64 *> coset_inv_tabs;    // (log_n, shift) -> n^-1 s^-bitrev(i)
     hipStream_t side_stream = nullptr;  // lane 1: low priority, created on first use (segment_host.inc)
+    hipStream_t tail_stream = nullptr;  // tree tops of main-lane trace commitments (segment_host.inc), created on first use
+    hipStream_t commit_tail = nullptr;  // != nullptr: commit_enqueue sends the small Merkle levels + cap read-back of main-lane commits there
     std::vector<hipEvent_t> ev_pool;    // recycled timing / ordering events
     u64 *h_caps = nullptr;              // pinned host slots for cap read-backs of commits in flight (ZK_CAP_SLOTS x 64 words)
     uint64_t cap_slot_next = 0;
@@ -195,6 +197,7 @@ static char *stage_alloc(zk_ctx *ctx, size_t bytes, hipError_t *err) {
     if (!ctx->async && ctx->stage_pending.empty() && ctx->stage_since_rewind + bytes > ZK_STAGE_LIMIT) {
         if ((*err = hipStreamSynchronize(ctx->stream)) != hipSuccess) return nullptr;     // standalone calls: bound the footprint
         if (ctx->side_stream && (*err = hipStreamSynchronize(ctx->side_stream)) != hipSuccess) return nullptr;
+        if (ctx->tail_stream && (*err = hipStreamSynchronize(ctx->tail_stream)) != hipSuccess) return nullptr;
         stage_rewind(ctx);
     }
     const size_t need = (bytes + 63) & ~(size_t)63;

@@ -73,6 +73,30 @@ __device__ __forceinline__ void ntt_bfly(u64 &a, u64 &b, u64 w) {
 template <bool PAD>
 __device__ __forceinline__ u32 ntt_ph(u32 i) { return PAD ? i + (i >> 3) : i; }
 
+// Twiddle loads as BUFFER loads: the table's base sits in a resource descriptor (four SGPRs, built once per kernel), the
+// wave-uniform part of the index in the instruction's scalar offset and the lane's part in one 32-bit VGPR -- no 64-bit
+// address arithmetic on the vector unit (a v_lshl_add_u64 per twiddle with global loads: 8 of a radix-8 step's 343 VALU
+// instructions, all at the slow rate), and the compiler issues a step's seven loads together, ahead of the LDS reads.  Raw
+// buffer, no range check in practice (num_records = 2^32 - 1; launch_pass rejects tables above 2^28 entries = 2 GiB).
+// r03t, tools/kbench 116 x 2^20: values -> coefficients 1.39 -> 1.26 ms, coefficients -> values 2.64 -> 2.64 (that direction
+// is not bound by its instruction count).  The same treatment of the tile loads / stores (buffer accesses for the column
+// data as well) measured SLOWER in combination (1.66 ms), so those stay global accesses.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef u32 ntt_v2u32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ntt_tw_rsrc(const u64 *tw) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<u64 *>(tw), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ u64 ntt_tw_load(__amdgpu_buffer_rsrc_t r, u32 lane_byte_off, u32 uniform_index) {
+    const ntt_v2u32 v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_byte_off, uniform_index * 8, 0);
+    return ((u64)v.y << 32) | v.x;
+}
+#else
+typedef const u64 *__amdgpu_buffer_rsrc_t_host;
+#define __amdgpu_buffer_rsrc_t __amdgpu_buffer_rsrc_t_host
+__device__ inline __amdgpu_buffer_rsrc_t ntt_tw_rsrc(const u64 *tw) { return tw; }          // (host pass: parsed, never run)
+__device__ inline u64 ntt_tw_load(__amdgpu_buffer_rsrc_t r, u32 lane_byte_off, u32 uniform_index) { return r[uniform_index + lane_byte_off / 8]; }
+#endif
+
 template <bool DIT, int K, bool PAD>
 __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q, u32 base,
                                          u32 elems, u32 tid, u32 nthr) {
@@ -80,6 +104,9 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
     const u32 T = 1u << log_t, q = 1u << log_q;
     const u32 nsub = elems >> K;
     const int log_D0 = p.log_d + log_q;                 // global distance of adjacent m
+    const u32 stride8 = (q << log_t) * 8;               // bytes between the tile elements of adjacent m (wave-uniform)
+    char *const tile_b = reinterpret_cast<char *>(tile);
+    const __amdgpu_buffer_rsrc_t twr = ntt_tw_rsrc(p.tw);
     for (u32 sp = tid; sp < nsub; sp += nthr) {
         u32 u = sp & (T - 1);
         u32 w = sp >> log_t;
@@ -87,19 +114,22 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
         u32 blk = w >> log_q;
         u32 t0 = (blk << (log_q + K)) + j;
         u64 v[1 << K];
+        // element m lives at ((t0 + m q) << log_t) + u = a0 + m (q << log_t): one add per address
+        const u32 a0 = (t0 << log_t) + u;
 #pragma unroll
-        for (int m = 0; m < (1 << K); ++m) v[m] = tile[ntt_ph<PAD>(((t0 + m * q) << log_t) + u)];
+        for (int m = 0; m < (1 << K); ++m)
+            v[m] = PAD ? tile[ntt_ph<PAD>(((t0 + m * q) << log_t) + u)] : *reinterpret_cast<u64 *>(tile_b + (a0 * 8 + m * stride8));
         const u32 x0 = base + (t0 << p.log_d) + u;      // global index of v[0]; bits [log_D0, log_D0 + K) are zero
         if (DIT) {
             // pair (x, x + D), D = D0 << lm: twiddle T_D[x mod D]; x_m mod D = g + (m mod hm) * D0
-            const u32 g = x0 & ((1u << log_D0) - 1);
+            const u32 g8 = (x0 & ((1u << log_D0) - 1)) * 8;
 #pragma unroll
             for (int lm = 0; lm < K; ++lm) {
                 const int hm = 1 << lm;
                 const u32 lvl = (1u << (log_D0 + lm)) - 1;
 #pragma unroll
                 for (int mm = 0; mm < hm; ++mm) {
-                    const u64 tw = p.tw[lvl + g + ((u32)mm << log_D0)];
+                    const u64 tw = ntt_tw_load(twr, g8, lvl + ((u32)mm << log_D0));
 #pragma unroll
                     for (int m = mm; m < (1 << K); m += 2 * hm) ntt_bfly(v[m], v[m + hm], tw);
                 }
@@ -113,17 +143,21 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
             for (int lm = K - 1; lm >= 0; --lm) {
                 const int hm = 1 << lm;
                 const int log_D = log_D0 + lm;
-                const u32 lvl = (1u << (p.log_n - 1 - log_D)) - 1 + (x0 >> (log_D + 1));
+                const u32 lvl = (1u << (p.log_n - 1 - log_D)) - 1;
+                const u32 blk8 = (x0 >> (log_D + 1)) * 8;
 #pragma unroll
                 for (int hg = 0; hg < (1 << (K - 1 - lm)); ++hg) {
-                    const u64 tw = p.tw[lvl + hg];
+                    const u64 tw = ntt_tw_load(twr, blk8, lvl + hg);
 #pragma unroll
                     for (int mm = 0; mm < hm; ++mm) ntt_bfly(v[hg * 2 * hm + mm], v[hg * 2 * hm + mm + hm], tw);
                 }
             }
         }
 #pragma unroll
-        for (int m = 0; m < (1 << K); ++m) tile[ntt_ph<PAD>(((t0 + m * q) << log_t) + u)] = v[m];
+        for (int m = 0; m < (1 << K); ++m) {
+            if (PAD) tile[ntt_ph<PAD>(((t0 + m * q) << log_t) + u)] = v[m];
+            else *reinterpret_cast<u64 *>(tile_b + (a0 * 8 + m * stride8)) = v[m];
+        }
     }
 }
 

@@ -86,6 +86,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     while (!ctx->live_batches.empty()) zk_batch_free(*ctx->live_batches.begin());
     hipStreamSynchronize(ctx->stream);
     if (ctx->side_stream) hipStreamSynchronize(ctx->side_stream);
+    if (ctx->tail_stream) hipStreamSynchronize(ctx->tail_stream);
     ctx->arena.destroy();
     for (auto &kv : ctx->tw_fwd) hipFree(kv.second);
     for (auto &kv : ctx->tw_inv) hipFree(kv.second);
@@ -98,6 +99,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     for (auto &kv : ctx->dev_consts) if (kv.second.d) hipFree(kv.second.d);
     for (char *c : ctx->stage_chunks) hipHostFree(c);
     if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
+    if (ctx->tail_stream) hipStreamDestroy(ctx->tail_stream);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -361,6 +363,7 @@ static int check_cfg(zk_ctx *ctx, const zk_cfg *cfg, size_t n_cols, unsigned log
 struct PendingCommit {
     zk_batch *b = nullptr;
     hipEvent_t ev[5] = {};
+    hipEvent_t tail_ev = nullptr;       // main stream -> tail stream hand-over inside merkle_levels
     hipStream_t stream = nullptr;
     const u64 *h_cap = nullptr;
     CommitMode mode = COMMIT_VALUES;
@@ -375,6 +378,7 @@ static hipEvent_t ev_get(zk_ctx *ctx) {
 static void ev_put(zk_ctx *ctx, hipEvent_t e) { if (e) ctx->ev_pool.push_back(e); }
 static void pending_release(zk_ctx *ctx, PendingCommit &pc) {
     for (auto &e : pc.ev) { ev_put(ctx, e); e = nullptr; }
+    ev_put(ctx, pc.tail_ev); pc.tail_ev = nullptr;
 }
 
 static int commit_enqueue(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t in_stride,
@@ -429,13 +433,22 @@ static int commit_enqueue(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_
     rc = hash_rows(ctx, cfg->hasher, b->d_lde, N, n_cols, N, (int)log_N, 1, b->d_digests);
     if (rc != ZK_OK) return fail(rc);
     hipEventRecord(pc->ev[3], ctx->stream);
-    rc = merkle_levels(ctx, cfg->hasher, b->d_digests, log_N, cfg->cap_height);
+    // The levels of <= 2^kTreeTailLog nodes are latency-bound (one or two waves per SIMD at best, then the cooperative
+    // kernels): when the caller enqueues several commitments back to back on the main lane (the trace commitments of a
+    // segment) they and the cap read-back move to the tail stream, and the next commitment's NTT starts under them.
+    hipStream_t tail = ctx->commit_tail && !pc->side ? ctx->commit_tail : nullptr;
+    if (tail) pc->tail_ev = ev_get(ctx);
+    rc = merkle_levels(ctx, cfg->hasher, b->d_digests, log_N, cfg->cap_height, tail, pc->tail_ev);
     if (rc != ZK_OK) return fail(rc);
+    hipStream_t const main_stream = ctx->stream;
+    if (tail) ctx->stream = tail;                       // (the tree ended there: merkle_levels hands over at its first small level)
     hipEventRecord(pc->ev[4], ctx->stream);
     b->cap.resize((size_t)4 << cfg->cap_height);
     u64 *slot = ctx->h_caps + (ctx->cap_slot_next++ % ZK_CAP_SLOTS) * 64;
     pc->h_cap = slot;
-    B_HIP(copy_to_pinned(ctx, slot, b->d_digests + 4 * (b->n_digests - ((size_t)1 << cfg->cap_height)), b->cap.size() * 8));
+    hipError_t cap_rc = copy_to_pinned(ctx, slot, b->d_digests + 4 * (b->n_digests - ((size_t)1 << cfg->cap_height)), b->cap.size() * 8);
+    ctx->stream = main_stream;
+    B_HIP(cap_rc);
 #undef B_HIP
     return ZK_OK;
 }
