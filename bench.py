@@ -1251,6 +1251,10 @@ def main():
                                      "(profiles/pmc_latest.json)"
                                      % (tot["commits"], tot["leaf_hash_perms"] / (leaf_ms * 1e-3))},
                 "commit_stages_ms_per_step": {k: tot[k] / a.steps for k in ("ifft", "lde", "leaf_hash", "tree")},
+                "commit_stages_note": "HIP events around each stage of the main-lane commitments; since r03t the levels of <= 2^17 "
+                                      "nodes of a trace commitment's tree run on the ctx's tail stream under the NEXT commitment's "
+                                      "NTT, so `tree` is an event-to-event span across two streams (an upper bound), and the stages "
+                                      "no longer add up to the wall time of the commit phase (segment_timing_s has that)",
                 "ntt": {"achieved_GBs": tot["ntt_bytes"] / (ntt_ms * 1e-3) / 1e9,
                         "algorithmic_bytes_per_step": tot["ntt_bytes"] / a.steps,
                         "frac_of_hbm_peak": tot["ntt_bytes"] / (ntt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
