@@ -464,7 +464,10 @@ __global__ void quotient_count_kernel(QuotientArgs A) {
 
 #ifndef ZK_DEVICE_FUNCS_ONLY
 // Kernel 2: lookup + CTL checks of any table, on top of kernel 1's partial sums; divides by Z_H.
-static __global__ void __launch_bounds__(256) quotient_checks_kernel(QuotientArgs A) {
+#ifndef ZK_CHECKS_WAVES
+#define ZK_CHECKS_WAVES 1
+#endif
+static __global__ void __launch_bounds__(256, ZK_CHECKS_WAVES) quotient_checks_kernel(QuotientArgs A) {
     const u32 size_log = A.log_n + A.qd_bits;
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >> size_log) return;

@@ -68,7 +68,15 @@ __device__ __forceinline__ u64 prog_eval_filter(const u64 *__restrict__ prog, u3
 // not depend on the challenge, only the combination sum_j beta_k^j col_j + gamma_k does.  Linear combinations
 // (`Column`) and the tuple combination are dot products with wave-uniform coefficients, accumulated unreduced
 // (DotAcc: 8 VALU instructions per term instead of a field multiply + add); beta_k^j comes precomputed.
+#ifndef ZK_HELPER_BATCH
 #define ZK_HELPER_BATCH 16
+#endif
+#ifndef ZK_HELPER_WAVES
+#define ZK_HELPER_WAVES 1
+#endif
+#ifndef ZK_HELPER_UNROLL
+#define ZK_HELPER_UNROLL 1
+#endif
 #define ZK_HELPER_MAX_CHALLENGES 2
 #define ZK_HELPER_MAX_TUPLE 64
 struct HelperChallenges {
@@ -358,7 +366,7 @@ struct HelperOut {
     u64 *extra_inv[ZK_HELPER_MAX_CHALLENGES];   // optional: 1 / (gamma_k + table column)
 };
 template <int NCH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, ZK_HELPER_WAVES)
 helper_cols_kernel(const u64 *__restrict__ prog, const u64 *__restrict__ compiled, TraceView t, HelperChallenges H,
                    u32 chunk, HelperOut O, size_t helper_stride, u32 extra_pc, int *__restrict__ err_flag) {
     const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
@@ -377,7 +385,7 @@ helper_cols_kernel(const u64 *__restrict__ prog, const u64 *__restrict__ compile
         u64 run[NCH];
 #pragma unroll
         for (int k = 0; k < NCH; ++k) run[k] = 1;
-#pragma unroll
+#pragma unroll ZK_HELPER_UNROLL
         for (int i = 0; i < ZK_HELPER_BATCH; ++i) {
             flt[i] = 0;
 #pragma unroll
