@@ -68,9 +68,17 @@ __device__ __forceinline__ u64 prog_eval_filter(const u64 *__restrict__ prog, u3
 // not depend on the challenge, only the combination sum_j beta_k^j col_j + gamma_k does.  Linear combinations
 // (`Column`) and the tuple combination are dot products with wave-uniform coefficients, accumulated unreduced
 // (DotAcc: 8 VALU instructions per term instead of a field multiply + add); beta_k^j comes precomputed.
+// Entries per Montgomery batch inversion.  helper_cols_kernel: 4 -- with 16 the (denominator, prefix product) arrays of the two
+// challenges do not fit the registers next to the entry evaluator and live in scratch (528 bytes per lane; r03u: the kernel at
+// 10.5 cycles per instruction, i.e. waiting, not issuing); with 8 or 4 the batch loop unrolls and they are registers (no scratch;
+// 144 / 94 VGPRs).  The kernel has issue slots to spare, so four times the inversions (74 multiplies each since r03t) still come
+// out ahead -- A/B in one call (profiles/r03u_ab_helper_batch.log): CTL data 15.2 / 13.7 / 11.8 ms for 16 / 8 / 4 at 2^20
+// (578 -> 575 ms per segment), 112.6 -> 110.2 ms per realistic-height segment.  lookup_singles_kernel (no interpreter,
+// everything in registers anyway): 16.
 #ifndef ZK_HELPER_BATCH
-#define ZK_HELPER_BATCH 16
+#define ZK_HELPER_BATCH 4
 #endif
+#define ZK_SINGLES_BATCH 16
 #ifndef ZK_HELPER_WAVES
 #define ZK_HELPER_WAVES 1
 #endif
@@ -452,16 +460,16 @@ lookup_singles_kernel(const u32 *__restrict__ cols, u32 n_entries, u32 table_col
                       HelperOut O, size_t helper_stride, int *__restrict__ err_flag) {
     const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= t.n) return;
-    for (u32 e0 = 0; e0 < n_entries; e0 += ZK_HELPER_BATCH) {
-        u64 x[ZK_HELPER_BATCH];
+    for (u32 e0 = 0; e0 < n_entries; e0 += ZK_SINGLES_BATCH) {
+        u64 x[ZK_SINGLES_BATCH];
 #pragma unroll
-        for (int i = 0; i < ZK_HELPER_BATCH; ++i) x[i] = e0 + i < n_entries ? t.base[(size_t)cols[e0 + i] * t.stride + row] : 0;
+        for (int i = 0; i < ZK_SINGLES_BATCH; ++i) x[i] = e0 + i < n_entries ? t.base[(size_t)cols[e0 + i] * t.stride + row] : 0;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
-            u64 v[ZK_HELPER_BATCH], pre[ZK_HELPER_BATCH];
+            u64 v[ZK_SINGLES_BATCH], pre[ZK_SINGLES_BATCH];
             u64 run = 1;
 #pragma unroll
-            for (int i = 0; i < ZK_HELPER_BATCH; ++i) {
+            for (int i = 0; i < ZK_SINGLES_BATCH; ++i) {
                 u64 d = gl_canon(gl_add(x[i], H.gamma[k]));
                 if (e0 + i >= n_entries) d = 1;
                 else if (d == 0) { atomicExch(err_flag, 2); d = 1; }     // 1/0: plonky2 would panic
@@ -471,7 +479,7 @@ lookup_singles_kernel(const u32 *__restrict__ cols, u32 n_entries, u32 table_col
             }
             u64 inv = gl_inv(run);
 #pragma unroll
-            for (int i = ZK_HELPER_BATCH - 1; i >= 0; --i) {
+            for (int i = ZK_SINGLES_BATCH - 1; i >= 0; --i) {
                 const u64 vi = v[i];
                 v[i] = gl_mul(inv, pre[i]);
                 inv = gl_mul(inv, vi);
@@ -479,11 +487,11 @@ lookup_singles_kernel(const u32 *__restrict__ cols, u32 n_entries, u32 table_col
             u64 *out = O.helpers[k];
             if (chunk == 1) {
 #pragma unroll
-                for (int i = 0; i < ZK_HELPER_BATCH; ++i)
+                for (int i = 0; i < ZK_SINGLES_BATCH; ++i)
                     if (e0 + i < n_entries) out[(size_t)(e0 + i) * helper_stride + row] = gl_canon(v[i]);
             } else {
 #pragma unroll
-                for (int i = 0; i < ZK_HELPER_BATCH; i += 2)
+                for (int i = 0; i < ZK_SINGLES_BATCH; i += 2)
                     if (e0 + i < n_entries) {
                         u64 s = e0 + i + 1 < n_entries ? gl_add(v[i], v[i + 1]) : v[i];
                         out[(size_t)((e0 + i) >> 1) * helper_stride + row] = gl_canon(s);
