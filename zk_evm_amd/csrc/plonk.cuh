@@ -186,22 +186,32 @@ struct PlonkAcc {
     u64 total[ZK_PLONK_MAX_CHALLENGES];
     const u64 *pow[ZK_PLONK_MAX_CHALLENGES];
     u32 nc;
+    // (compile-time indices only: a loop over the run-time challenge count indexes g / total / pow dynamically, which puts
+    //  the accumulators in scratch memory -- every term then went through a scratch load and store, r03v)
+    static_assert(ZK_PLONK_MAX_CHALLENGES == 2, "PlonkAcc::add / end_gate are written out for two challenges");
     __device__ __forceinline__ void add(u32 k, u64 term) {
-        for (u32 c = 0; c < nc; ++c) g[c] = gl_add_canon(g[c], gl_mul_canon(term, pow[c][k]));
+        g[0] = gl_add_canon(g[0], gl_mul_canon(term, pow[0][k]));
+        if (nc > 1) g[1] = gl_add_canon(g[1], gl_mul_canon(term, pow[1][k]));
     }
     __device__ __forceinline__ void end_gate(u64 filt) {
-        for (u32 c = 0; c < nc; ++c) { total[c] = gl_add_canon(total[c], gl_mul_canon(filt, g[c])); g[c] = 0; }
+        total[0] = gl_add_canon(total[0], gl_mul_canon(filt, g[0])); g[0] = 0;
+        if (nc > 1) { total[1] = gl_add_canon(total[1], gl_mul_canon(filt, g[1])); g[1] = 0; }
     }
 };
 
 // wire w of this point's row
-#define PLONK_W(w) (A.wires[(size_t)(w) * A.wires_stride + row])
+// (global-memory pointers said to be so: inside the non-inlined wide-gate evaluator the argument block arrives by reference
+//  and the compiler would otherwise emit FLAT loads for every wire)
+typedef const u64 __attribute__((address_space(1))) *plonk_gptr;
+#define PLONK_W(w) (((plonk_gptr)A.wires)[(size_t)(w) * A.wires_stride + row])
 __device__ __forceinline__ gl2 plonk_wext(const PlonkQuotientArgs &A, size_t row, u32 w) { return gl2_make(PLONK_W(w), PLONK_W(w + 1)); }
 
 // The gates beyond the four closed-form base-field ones.  Extension elements live in D = 2 consecutive wires; a
 // constraint over F_{p^2} contributes its two components as consecutive terms (`to_basefield_array`).
-__device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, const PlonkGateDesc &G, const u64 *consts,
-                                                  size_t row, u32 term, PlonkAcc &acc) {
+__device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, const PlonkGateDesc &G, const u64 *consts_generic,
+                                                  size_t row, u32 term, PlonkAcc &acc_io) {
+    PlonkAcc acc = acc_io;                 // the accumulators in registers for the gate, written back once at the end
+    const plonk_gptr consts = (plonk_gptr)consts_generic;
     const u32 n = G.param;
     auto add2 = [&](u32 k, gl2 v) { acc.add(term + 2 * k, v.a); acc.add(term + 2 * k + 1, v.b); };
     switch (G.kind) {
@@ -376,6 +386,7 @@ __device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, co
         }
         default: break;
     }
+    acc_io = acc;
 }
 #undef PLONK_W
 
@@ -410,7 +421,8 @@ static __global__ void __launch_bounds__(256) plonk_quotient_kernel(PlonkQuotien
     const size_t row_next = (size_t)((i + (1u << A.qd_bits)) & (size - 1)) << A.step_log;
     PlonkAcc acc;
     acc.nc = A.n_challenges;
-    for (u32 c = 0; c < A.n_challenges; ++c) { acc.g[c] = 0; acc.total[c] = 0; acc.pow[c] = A.alpha_pow[c]; }
+    acc.g[0] = acc.g[1] = 0; acc.total[0] = acc.total[1] = 0;
+    acc.pow[0] = A.alpha_pow[0]; acc.pow[1] = A.alpha_pow[A.n_challenges > 1 ? 1 : 0];
     const u64 *sig = A.cs + (size_t)A.num_constants * A.cs_stride;
     u32 term = 0;
     // vanishing_z_1_terms: L_0(x) (Z(x) - 1)
@@ -478,7 +490,8 @@ static __global__ void __launch_bounds__(256) plonk_quotient_kernel(PlonkQuotien
         acc.end_gate(filt);
     }
     u64 *out = sl ? A.out2 : A.out;
-    for (u32 c = 0; c < A.n_challenges; ++c) out[(size_t)c * A.out_stride + i] = gl_canon(gl_mul(acc.total[c], inv_zh));
+    out[i] = gl_canon(gl_mul(acc.total[0], inv_zh));
+    if (A.n_challenges > 1) out[A.out_stride + i] = gl_canon(gl_mul(acc.total[1], inv_zh));
 }
 
 static __global__ void plonk_add_slices_kernel(u64 *out, const u64 *out2, size_t count) {
