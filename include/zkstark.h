@@ -42,7 +42,7 @@ typedef enum { ZK_HASH_POSEIDON = 0, ZK_HASH_KECCAK25 = 1 } zk_hasher;
  * TEST_STARK_CONFIG at evm_arithmetization/src/testing_utils.rs:41-51). */
 typedef struct {
     uint32_t rate_bits;          /* LDE blow-up = 2^rate_bits (1 in production) */
-    uint32_t cap_height;         /* Merkle cap has 2^cap_height digests (4) */
+    uint32_t cap_height;         /* Merkle cap has 2^cap_height digests (4); any value up to the tree height */
     uint32_t hasher;             /* zk_hasher */
     uint32_t num_challenges;     /* 2 */
     uint32_t proof_of_work_bits; /* 16 */

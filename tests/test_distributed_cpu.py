@@ -233,3 +233,48 @@ def test_split_columns_and_residue_classes():
         for t in range(1 << (log_n - log_w)):
             s = (q << (log_n - log_w)) | t
             assert _bitrev(s, log_n) == _bitrev(t, log_n - log_w) * (1 << log_w) + _bitrev(q, log_w)
+
+
+# ---- bench.py's process groups: the safety net the scaling line runs on -------------------------------------------------------
+def _rungroup_worker(rank, world, port, q, backend):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import argparse
+    import bench
+    a = argparse.Namespace(dist_backend=backend, dist_timeout_s=20.0)
+    rg = bench.RunGroup(a, rank, world, 0, True)
+    rg.barrier()
+    mx = rg.max_over_ranks(10.0 + rank)
+    per = rg.per_rank(100.0 + rank)
+    st = bench.dist_selftest(rank, world, rg.backend, rg.group())
+    q.put((rank, dict(rg.info), rg.backend, mx, per, st))
+    rg.dist.barrier(group=rg.gloo)          # (not rg.close(): after a fallback that ends the process before the queue flushes)
+    rg.dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_bench_rungroup_falls_back_to_gloo_and_never_fails(backend):
+    """bench.py --gpus N must print its line whatever RCCL does (r03 verdict, next-round item 1).  There is no GPU here, so
+    the `nccl` group cannot come up: both ranks must agree on the gloo fallback, record why, and still get their barrier,
+    the MAX over ranks, the per-rank times and the product collectives."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rungroup_worker, args=(r, 2, port, q, backend)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r = q.get(timeout=180)
+        res[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        info, used, mx, per, st = res[r]
+        assert used == "gloo" and mx == 11.0 and per == [100.0, 101.0]
+        assert st["ok"], st
+        if backend == "nccl":
+            assert info["ok"] is False and info["fallback"] == "gloo" and info["tried"] == "nccl" and info["error"]
+        else:
+            assert info["ok"] is True and "fallback" not in info

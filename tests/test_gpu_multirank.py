@@ -277,3 +277,93 @@ def test_row_sharded_commit_equals_single_gpu_cap(shape, world, hasher):
         assert np.array_equal(res[r][0], want), r
         assert res[r][1]["rows"] == (2 << log_n) // world
     full.free()
+
+
+# ---- BASELINE configs[3] at shape level: one block's segments through the multi-segment entries --------------------------------
+BLOCK_SEGMENTS, BLOCK_MAX_LOG = 8, 13
+
+
+def _block_direct_words():
+    import torch
+    import zk_evm_amd
+    import zk_evm_amd.segment as sg
+    from tools.benchlib import block_jobs, block_segment_shapes
+    from zk_evm_amd.all_stark import AllStark
+    st, cfg = AllStark((1, 2, 3, 4)), zk_evm_amd.StarkConfig()
+    shapes = block_segment_shapes(BLOCK_SEGMENTS, max_log=BLOCK_MAX_LOG)
+    assert any(not all(u) for _, u in shapes) and len({tuple(l) for l, _ in shapes}) > 1      # absent tables, several shapes
+    jobs = block_jobs(shapes)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    return st, cfg, jobs, [sg.all_proof_to_words(sg.prove_with_traces(st, cfg, j.load(dev), j.table_in_use, j.public_values))
+                           for j in jobs]
+
+
+def test_block_job_list_through_scheduler_three_in_flight():
+    """A block = a list of differently shaped segments (heights inside the witness_b19807080 ranges,
+    scripts/prove_stdio.rs:89-101, clipped for test time; optional tables absent in some): `SegmentScheduler(in_flight=3)`
+    returns, in job order, exactly the proofs of the direct `zk_prove_segment` calls (standard_fast_config)."""
+    import torch
+    import zk_evm_amd.segment as sg
+    from zk_evm_amd.scheduler import SegmentScheduler
+    st, cfg, jobs, direct = _block_direct_words()
+    with SegmentScheduler(st, cfg, devices=[torch.cuda.current_device()], in_flight=3) as sch:
+        got = sch.map(jobs)
+        assert sum(s.segments for s in sch.stats) == len(jobs) and not any(s.errors for s in sch.stats)
+    for d, g in zip(direct, got):
+        assert np.array_equal(d, sg.all_proof_to_words(g))
+
+
+def _block_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import zk_evm_amd
+    import zk_evm_amd.segment as sg
+    from tools.benchlib import block_jobs, block_segment_shapes
+    from zk_evm_amd.all_stark import AllStark
+    from zk_evm_amd.scheduler import run_distributed
+    jobs = block_jobs(block_segment_shapes(BLOCK_SEGMENTS, max_log=BLOCK_MAX_LOG))
+    outs = run_distributed(AllStark((1, 2, 3, 4)), zk_evm_amd.StarkConfig(), jobs, device=0, in_flight=2)
+    q.put((rank, None if outs is None else [sg.all_proof_to_words(o) for o in outs]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_block_job_list_through_run_distributed_two_ranks():
+    """The same block through `scheduler.run_distributed` as two ranks (gloo, both on this GPU; the reference maps a block's
+    segments onto workers, zero/src/prover.rs:219-228): jobs dealt round-robin, two in flight per rank, proofs gathered on
+    rank 0 as words -- every one equal to the direct proof."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_block_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[1] is None and len(res[0]) == BLOCK_SEGMENTS
+    _, _, _, direct = _block_direct_words()
+    for d, g in zip(direct, res[0]):
+        assert np.array_equal(d, g)
+
+
+def test_bench_line_survives_a_broken_rccl():
+    """r03 verdict, next-round item 1: `bench.py --gpus 2 --dist-backend nccl` must print its line when RCCL cannot come up.
+    Two ranks on ONE device is something RCCL refuses (and the bootstrap interface named here does not exist): the probe
+    fails, both ranks agree on gloo, the line carries `dist: {ok: false, fallback: gloo, error}` and every rank's time."""
+    out = _bench("--gpus", "2", "--devices", "0,0", "--dist-backend", "nccl", "--dist-timeout-s", "60", *SMALL,
+                 env_extra={"NCCL_SOCKET_IFNAME": "nonexistent0"})
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    d = out["dist"]
+    assert d["ok"] is False and d["fallback"] == "gloo" and d["tried"] == "nccl" and d["error"], d
+    assert len(out["per_rank_ms_per_step"]) == 2 and all(x > 0 for x in out["per_rank_ms_per_step"])

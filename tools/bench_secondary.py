@@ -1,0 +1,855 @@
+#!/usr/bin/env python3
+"""The secondary objects of the bench line, each in ITS OWN PROCESS: `python tools/bench_secondary.py --name <secondary>`
+prints one JSON object on its last stdout line.  bench.py starts one child per secondary after its timed region, with a
+time limit per child and an overall budget, so a secondary that hangs costs its own limit and nothing else (r03 verdict,
+weak 11: they used to run inside the driver's entry point).  None of these is `value`."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from tools.benchlib import (HBM_PEAK_GBS, REALISTIC_LOG_NS, block_jobs, block_segment_shapes, commit_report,  # noqa: E402,F401
+                            measure_commit, segment_committed_cells, synthetic_segment_traces)
+
+
+def cpu_baseline(cols, log_n, sample_log_n, hasher, max_reps=5):
+    """Time the oracle's from_values on a bounded sample (cols x 2^sample_log_n) and extrapolate
+    linearly in rows to the full workload (slightly optimistic for the CPU: NTT is n log n)."""
+    import ctypes
+    import math
+    import numpy as np
+    from tests.oracle_lib import load_oracle, splitmix64
+    o = load_oracle()
+    # threads actually available to this process: affinity mask and cgroup CPU quota, not just the core count OpenMP
+    # sees (running 128 threads inside a smaller quota makes the baseline look worse than the hardware is)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else int(o.lib.orc_num_threads())
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cores = min(cores, int(o.lib.orc_num_threads()))
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
+    n = 1 << sample_log_n
+    vals = np.stack([splitmix64(0x6FEB51B7EC230F25 + c, n) for c in range(cols)])
+    o.commit_values(vals[:, : 1 << 10].copy(), want_leaves=False, hasher=hasher)  # warm
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        o.commit_values(vals, rate_bits=1, cap_height=4, hasher=hasher, want_leaves=False)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > 10.0 or reps >= max_reps:
+            break
+    per_sample = el / reps
+    scale = float(1 << (log_n - sample_log_n))
+    return {
+        "value": 1.0 / (per_sample * scale),
+        "unit": "commits/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"oracle from_values on {cols} x 2^{sample_log_n} rows ({reps} reps, "
+                  f"{per_sample:.3f} s each), scaled x{int(scale)} rows to 2^{log_n}",
+        "seconds_per_full_commit_est": per_sample * scale,
+    }
+
+
+def arithmetic_table_trace(dev, log_n):
+    """ArithmeticStark-shaped table for the table-proof comparison: one-hot operation flags, 16-bit limbs, the real
+    range-counter and frequency columns (arithmetic_stark.rs:130-156), so the table's own logUp argument and its CTL
+    (looked side of CTL 0, all_stark.rs:176-181) are exactly the reference's."""
+    import torch
+    n = 1 << log_n
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    trace = torch.zeros((116, n), dtype=torch.int64, device=dev)
+    which = torch.randint(0, 18, (n,), device=dev, generator=g)
+    for i in range(17):
+        trace[i] = (which == i).to(torch.int64)
+    trace[17] = torch.randint(0, 256, (n,), dtype=torch.int64, device=dev, generator=g)        # opcode
+    trace[18:114] = torch.randint(0, 1 << 16, (96, n), dtype=torch.int64, device=dev, generator=g)
+    trace[114] = torch.clamp(torch.arange(n, device=dev), max=65535)
+    trace[115, : 1 << 16] = torch.bincount(trace[18:114].reshape(-1), minlength=1 << 16)
+    return trace
+
+
+def gpu_table_proof(ctx, trace, all_stark, cfg, reps):
+    """One ArithmeticStark table proof on the GPU: from_values + transcript + CTL data + prove_single_table
+    (= the reference's keccak_benchmark shape, keccak_stark.rs:692-760: `from_values` and `prove_single_table` timed
+    together).  -> (seconds per proof, stage seconds, last proof)."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.prover as zp
+    from zk_evm_amd.all_stark import Table
+    from zk_evm_amd.stark import ctl_partial_sums
+    looked = all_stark.cross_table_lookups[0].looked_table
+    assert looked.table == Table.Arithmetic
+    entry = [(looked.columns, looked.filter)]
+    times, stages, pr = [], {}, None
+    for it in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tb = zk.PolynomialBatch.from_values(trace, 1, False, 4, ctx=ctx)
+        ch = zk.Challenger(0)
+        ch.observe_cap(tb.merkle_tree.cap)
+        chal = [(ch.get_challenge(), ch.get_challenge()) for _ in range(cfg.num_challenges)]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        zd = [zp.CtlZData(b, gm, entry, ctl_partial_sums(trace, entry, b, gm, 3, ctx=ctx)) for b, gm in chal]
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        pr = zp.prove_single_table(zp.AIR_ARITHMETIC, cfg, trace, tb, all_stark.lookups[Table.Arithmetic], zd, chal, ch)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        tb.free()
+        if it:  # first iteration is warm-up
+            times.append(t3 - t0)
+            for k, v in (("trace commitment", t1 - t0), ("ctl columns", t2 - t1), ("prove_with_commitment", t3 - t2)):
+                stages[k] = stages.get(k, 0.0) + v / reps
+    return sum(times) / len(times), stages, pr
+
+
+def cpu_table_proof_baseline(ctx, dev, log_n, gpu_reps=3):
+    """`cpu_baseline`: ONE whole ArithmeticStark table proof MEASURED on the host -- trace commitment, logUp helper
+    columns, CTL columns, auxiliary commitment, quotient (the complete Arithmetic AIR, 707 constraints, + lookup + CTL
+    checks), quotient commitment, openings, FRI with standard_fast_config -- by the CPU oracle (C + OpenMP over columns /
+    leaves / rows, the axes rayon uses in the reference), next to the same proof of the same trace on the GPU, and the
+    two proofs compared word for word."""
+    import ctypes as C
+    import math
+    import platform
+    import numpy as np
+    import zk_evm_amd as zk
+    import tests.oracle_lib as ol
+    from oracle import airs as oairs
+    from oracle import all_stark as oas
+    from oracle import fast_stark as FS
+    from oracle import stark as OS
+    from zk_evm_amd.all_stark import AllStark
+    o = ol.load_oracle()
+    ol.setup_fri_api(o)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else int(o.lib.orc_num_threads())
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cores = min(cores, int(o.lib.orc_num_threads()))
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
+    model = platform.processor() or "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    trace = arithmetic_table_trace(dev, log_n)
+    cfg = zk.StarkConfig.standard_fast_config()
+    gpu_s, gpu_stages, gp = gpu_table_proof(ctx, trace, AllStark((1, 2, 3, 4)), cfg, gpu_reps)
+    host = trace.cpu().numpy().view(np.uint64)
+    del trace
+    # ---- the CPU proof, measured once ----
+    reg = oas.Registry(False)
+    ocfg = ol.make_cfg()
+    stages = {}
+    t0 = time.perf_counter()
+    commit = o.commit_values(host, rate_bits=1, cap_height=4, hasher=0)
+    och = ol.new_challenger(o, 0)
+    o.lib.orc_challenger_observe_cap(C.byref(och), commit["cap"], 16)
+    chal = [OS.GrandProductChallenge(o.lib.orc_challenger_get(C.byref(och)), o.lib.orc_challenger_get(C.byref(och)))
+            for _ in range(ocfg.num_challenges)]
+    stages["trace commitment"] = time.perf_counter() - t0
+    looked = reg.ctls[0].looked_table
+    zds = [OS.CtlZData(ch, [(looked.columns, looked.filter)], 0) for ch in chal]
+    init = np.zeros(12, dtype=np.uint64)
+    o.lib.orc_challenger_compact(C.byref(och), init)
+    cp = FS.prove_with_commitment(o, ol, ocfg, oairs.AIRS[5][0], host, commit, reg.lookups[0], zds,
+                                  [(c.beta, c.gamma) for c in chal], och, timing=stages)
+    cpu_s = time.perf_counter() - t0
+    same = (np.array_equal(gp.trace_cap, commit["cap"]) and np.array_equal(gp.auxiliary_polys_cap, cp["aux_cap"])
+            and np.array_equal(gp.quotient_polys_cap, cp["quotient_cap"])
+            and np.array_equal(gp.openings.reshape(-1), cp["openings"]) and np.array_equal(gp.opening_proof, cp["fri"]))
+    return {
+        "value": 1.0 / cpu_s, "unit": "ArithmeticStark table proofs/s (116 columns x 2^%d rows)" % log_n, "cores": cores,
+        "kind": "port", "cpu_model": model, "omp_num_threads": cores,
+        "sample": "ONE whole ArithmeticStark table proof, 116 x 2^%d rows, standard_fast_config (2 challenges, 84 queries, "
+                  "16 PoW bits), measured end to end, not scaled: from_values + logUp (96 columns) + CTL + auxiliary "
+                  "commitment + quotient (707 AIR constraints + lookup / CTL checks) + quotient commitment + openings + "
+                  "FRI; oracle = C/OpenMP restatement (NTT, Poseidon, Merkle, FRI) with the constraint program traced from "
+                  "the Python restatement and interpreted per row" % log_n,
+        "seconds": cpu_s, "stages_s": {k: round(v, 3) for k, v in stages.items()},
+        "gpu_same_proof": {"seconds": gpu_s, "proofs_per_s": 1.0 / gpu_s, "stages_s": {k: round(v, 4) for k, v in gpu_stages.items()},
+                           "ratio_to_this_oracle": cpu_s / gpu_s,
+                           "ratio_note": "against THIS repository's oracle (textbook C/OpenMP NTT + Poseidon and a tape interpreter "
+                                         "for the constraints), not against plonky2's AVX2 / rayon prover: a statement that the two "
+                                         "proofs are the same work, not a speed claim"},
+        "proofs_identical": bool(same),
+    }
+
+
+def segments_in_flight(ctx, workers, per_worker, arena_peak, all_stark, cfg, traces, in_use, cdk_erigon):
+    """W segments in flight on this GPU through the product scheduler (zk_evm_amd/scheduler.py: one worker thread +
+    Context + HIP stream per slot, one shared job queue); every job proves the resident traces."""
+    import torch
+    import zk_evm_amd.segment as sg
+    from zk_evm_amd.scheduler import SegmentJob, SegmentScheduler
+    ctx.mem_trim()                                    # the main ctx hands its idle slabs back; every worker grows its own
+    free, total = torch.cuda.mem_get_info()
+    need = workers * arena_peak
+    if need > 0.9 * free:
+        return {"skipped": f"{workers} arenas of {arena_peak / 1e9:.0f} GB do not fit in the {free / 1e9:.0f} GB free"}
+
+    def job():
+        return SegmentJob(lambda dev: traces, in_use, sg.PublicValues(burn_addr=1 if cdk_erigon else None))
+    el = 0.0
+    with SegmentScheduler(all_stark, cfg, [ctx.device], workers) as sch:
+        for n in (2, per_worker):                      # warm-up (arena growth), then the timed round
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sch.map([job() for _ in range(workers * n)])
+            el = time.perf_counter() - t0
+        errors = [e for st in sch.stats for e in st.errors]
+    if errors:
+        return {"error": errors[0]}
+    return {"workers_per_gpu": workers, "proofs": workers * per_worker, "value": workers * per_worker / el,
+            "unit": "segment proofs/s", "note": "SegmentScheduler: one Context + stream + worker thread per in-flight "
+                                                "segment, one job queue, shared resident inputs"}
+
+
+def realistic_profile(ctx, dev, a, all_stark, cfg, steps=4, in_flight=3):
+    """Secondary object: the `north_star` shape -- per-table heights at the upper ends of the reference's own ranges
+    (scripts/prove_stdio.rs:89-101: Arithmetic 2^17, BytePacking 2^14, Cpu 2^19, Keccak 2^17, KeccakSponge 2^13, Logic
+    2^16, Memory 2^21, MemBefore / MemAfter 2^19) -- one segment at a time, and `in_flight` segments per GPU through the
+    product scheduler."""
+    import torch
+    import zk_evm_amd.segment as sg
+    from zk_evm_amd.scheduler import SegmentJob, SegmentScheduler
+    n_tab = all_stark.num_tables
+    log_ns = REALISTIC_LOG_NS + [14] * (n_tab - 9)
+    traces = synthetic_segment_traces(log_ns, dev, seed=11, cdk_erigon=a.cdk_erigon)
+    in_use = [True] * n_tab
+
+    def pv():
+        return sg.PublicValues(burn_addr=1 if a.cdk_erigon else None)
+    sg.prove_with_traces(all_stark, cfg, traces, in_use, pv(), ctx=ctx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sg.prove_with_traces(all_stark, cfg, traces, in_use, pv(), ctx=ctx)
+    torch.cuda.synchronize()
+    single = (time.perf_counter() - t0) / steps
+    peak = ctx.mem_stats()["peak_in_use"]
+    out = {"log_ns": log_ns, "steps": steps, "single": {"value": 1.0 / single, "unit": "segment proofs/s", "ms_per_proof": 1e3 * single},
+           "trace_GB": 8.0 * sum(c << l for c, l in zip(all_stark.table_columns, log_ns)) / 1e9}
+    try:
+        with SegmentScheduler(all_stark, cfg, [ctx.device], in_flight) as sch:
+            mk = lambda: SegmentJob(lambda d: traces, in_use, pv())
+            sch.map([mk() for _ in range(2 * in_flight)])                # warm-up: every worker grows its arena
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sch.map([mk() for _ in range(steps * in_flight)])
+            el = time.perf_counter() - t0
+        out["in_flight"] = {"workers_per_gpu": in_flight, "value": steps * in_flight / el, "unit": "segment proofs/s"}
+    except Exception as e:
+        out["in_flight"] = {"error": repr(e)}
+    # ---- one segment carried through its recursion layer (fixed_recursive_verifier.rs:2053-2160, 3167-3179) -----------------
+    # prove_segment = the STARK, then per table a StarkWrapperCircuit proof and its shrink() chain down to 2^13 rows, then the
+    # root circuit.  Modelled as 35 PLONK proofs: per table one wrapper proof at 2^14 rows and two shrinking proofs at 2^13
+    # (27), the root at 2^14 and seven more 2^13 steps for the larger tables.  The chains of different tables are
+    # independent, a chain's own steps are serial: step k of all nine tables is ONE zk_plonk_prove_batch call (synthetic
+    # circuits carrying all fourteen gate kinds; witness generation is the Rust side's and is not in this number).
+    try:
+        import zk_evm_amd
+        import zk_evm_amd.plonk as zp
+        g = torch.Generator(device=dev)
+        g.manual_seed(123)
+        circ = {}
+        ctx2 = zk_evm_amd.Context(ctx.device)                              # the recursion layer's own context and stream
+        st2 = torch.cuda.Stream(device=dev)
+        for lb in (13, 14):
+            cs, wires = plonk_synthetic_circuit(dev, lb, g)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(st2):
+                circ[lb] = (zp.CircuitData(zp.CircuitConfig(), lb, PLONK_RECURSION_GATES, 4, cs, PLONK_K_IS, [1, 2, 3, 4], 123, ctx=ctx2), wires)
+        plan = [(14, 9), (13, 9), (13, 9), (13, 7), (14, 1)]               # (circuit rows, proofs in the batch), in chain order
+
+        def recursion():
+            n = 0
+            with torch.cuda.stream(st2):                                   # (thread-local: whichever thread runs this)
+                for lb, k in plan:
+                    cd, wires = circ[lb]
+                    cd.prove_batch([wires] * k, [[5, 6, 7]] * k, in_flight=min(k, 6))
+                    n += k
+            return n
+
+        def stark():
+            sg.prove_with_traces(all_stark, cfg, traces, in_use, pv(), ctx=ctx)
+        stark(); n_rec = recursion()                                         # noqa: E702  (warm: worker contexts, arenas)
+        torch.cuda.synchronize()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            stark()
+        t_stark = (time.perf_counter() - t0) / reps
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            recursion()
+        t_rec = (time.perf_counter() - t0) / reps
+        # pipelined: the STARK of segment k + 1 (this thread, ctx) beside the recursion of segment k (a second thread)
+        import threading
+        t0 = time.perf_counter()
+        th = None
+        for _ in range(reps + 1):
+            stark()
+            if th is not None:
+                th.join()
+            th = threading.Thread(target=recursion)
+            th.start()
+        th.join()
+        t_pipe = (time.perf_counter() - t0) / (reps + 1)
+        out["segment_with_recursion"] = {
+            "plonk_proofs_per_segment": n_rec, "stark_ms": 1e3 * t_stark, "recursion_ms": 1e3 * t_rec,
+            "serial": {"value": 1.0 / (t_stark + t_rec), "unit": "segments/s"},
+            "pipelined": {"value": 1.0 / t_pipe, "unit": "segments/s",
+                          "note": "the next segment's STARK runs beside this segment's recursion proofs (two host threads)"},
+            "note": "realistic table heights; 35 synthetic-circuit PLONK proofs per segment in five zk_plonk_prove_batch calls "
+                    "(chain order); circuit witness generation (Rust) not included"}
+        for cd, _ in circ.values():
+            cd.free()
+        ctx2.close()
+    except Exception as e:
+        out["segment_with_recursion"] = {"error": repr(e)}
+    del traces
+    torch.cuda.empty_cache()
+    return out
+
+
+def h2d_profile(dev, trace_bytes, step_s, step_fn=None):
+    """Secondary object: host->device bandwidth measured here (1 GiB, pageable and pinned) and what uploading the step's
+    traces costs -- `value` itself starts with the traces resident in HBM (bench contract).  With `step_fn`, the overlapped
+    case is MEASURED: a second stream uploads one segment's worth of trace bytes from pinned host memory into a second
+    device buffer while `step_fn` proves the resident segment."""
+    import torch
+    n = 1 << 27                                             # 1 GiB of int64
+    dst = torch.empty(n, dtype=torch.int64, device=dev)
+    res = {}
+    pinned = None
+    for kind in ("pageable", "pinned"):
+        try:
+            src = torch.ones(n, dtype=torch.int64)
+            if kind == "pinned":
+                src = src.pin_memory()
+                pinned = src
+            dst.copy_(src)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            res[kind + "_GBs"] = 3 * 8.0 * n / (time.perf_counter() - t0) / 1e9
+            del src
+        except Exception as e:
+            res[kind + "_error"] = repr(e)
+    del dst
+    bw = max([v for k, v in res.items() if k.endswith("_GBs")] or [0.0])
+    if bw > 0:
+        up = trace_bytes / 1e9 / bw
+        res.update(trace_GB=trace_bytes / 1e9, upload_s=up,
+                   serial_upload_then_prove={"value": 1.0 / (step_s + up), "unit": "segment proofs/s"},
+                   overlapped_upload_modelled={"value": 1.0 / max(step_s, up), "unit": "segment proofs/s",
+                                               "note": "arithmetic only: 1 / max(proof time, upload time)"},
+                   note="the eight non-Cpu tables can be generated on the device from operation logs (zk_*_generate_trace), "
+                        "which leaves only the Cpu rows and the logs on PCIe")
+    if step_fn is not None and pinned is not None:
+        try:
+            total = int(trace_bytes) // 8
+            second = torch.empty(total, dtype=torch.int64, device=dev)          # where segment k+1's traces land
+            upl = torch.cuda.Stream(device=dev)
+
+            def upload():
+                with torch.cuda.stream(upl):
+                    for off in range(0, total, n):
+                        m = min(n, total - off)
+                        second[off: off + m].copy_(pinned[:m], non_blocking=True)
+            reps = 3
+            upload(); step_fn(); upl.synchronize(); torch.cuda.synchronize()  # noqa: E702  (warm)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                upload()
+                step_fn()
+                upl.synchronize()
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / reps
+            res["overlapped_upload"] = {
+                "value": 1.0 / el, "unit": "segment proofs/s", "s_per_segment": el, "measured": True,
+                "note": "measured: %.1f GB from pinned host memory on a second stream into a second device buffer while the "
+                        "resident segment is proven (%d repetitions); proof alone %.3f s, upload alone %.3f s"
+                        % (trace_bytes / 1e9, reps, step_s, trace_bytes / 1e9 / bw)}
+            del second
+        except Exception as e:
+            res["overlapped_upload"] = {"error": repr(e)}
+    return res
+
+
+def from_logs_profile(ctx, dev, all_stark, cfg, reps=3):
+    """Secondary object: operation logs -> witness tables ON THE DEVICE -> segment proof, i.e. the
+    path that replaces the 3.9 GB trace upload of `realistic` by the upload of the interpreter's compact logs
+    (`witness/traces.rs:135-262` `Traces::into_tables`).  Synthetic logs in the C ABI's packed record layouts, sized so
+    the tables come out at the `prove_stdio.rs` heights (Arithmetic 2^17, BytePacking 2^14, Cpu 2^19, Keccak 2^17,
+    KeccakSponge 2^13, Logic 2^16, Memory 2^21, MemBefore 2^19); the Cpu rows are the interpreter's own output and are
+    uploaded as they are.  Logs are random, not an execution: the generators' and the prover's work does not depend on it."""
+    import numpy as np
+    import torch
+    import zk_evm_amd.segment as sg
+    import zk_evm_amd.tracegen as tg
+    rng = np.random.default_rng(7)
+    u64 = lambda *shape: rng.integers(0, 1 << 64, size=shape, dtype=np.uint64)
+    tr = tg.Traces()
+    n_ar = 120000                                           # one-row kinds only: 120 000 rows -> 2^17
+    ar = np.zeros((n_ar, 18), dtype=np.uint64)
+    ar[:, 0] = rng.choice([tg.ARITH_ADD, tg.ARITH_MUL, tg.ARITH_SUB, tg.ARITH_LT, tg.ARITH_GT], size=n_ar)
+    ar[:, 2:10] = u64(n_ar, 8)
+    tr.arithmetic_ops = ar
+    n_bp = 15000
+    bp = np.zeros((n_bp, 10), dtype=np.uint64)
+    bp[:, 0] = rng.integers(0, 2, size=n_bp)
+    bp[:, 2], bp[:, 3], bp[:, 4], bp[:, 5] = 1, rng.integers(0, 1 << 16, size=n_bp), np.arange(2, 2 + n_bp), 32
+    bp[:, 6:10] = u64(n_bp, 4)
+    tr.byte_packing_ops = bp
+    n_cpu_cols = all_stark.table_columns[2]
+    cpu = u64(1 << 19, n_cpu_cols) >> np.uint64(1)
+    pick = rng.integers(0, 19, size=1 << 19)                # CTL filter columns binary, as in synthetic_segment_traces
+    for i, k in enumerate(range(6, 24)):
+        cpu[:, k] = pick == i
+    for k in list(range(24, 33)) + [41, 54, 67, 80]:
+        cpu[:, k] = rng.integers(0, 2, size=1 << 19)
+    tr.cpu = torch.from_numpy(cpu.view(np.int64))
+    n_k = 5400                                              # 24 rows per permutation -> 2^17
+    tr.keccak_inputs = (u64(n_k, 25), np.arange(2, 2 + n_k, dtype=np.uint64))
+    tr.keccak_sponge_ops = [((0, 2, int(a)), 2 + i, rng.bytes(int(l))) for i, (a, l) in
+                            enumerate(zip(rng.integers(0, 1 << 16, size=3500), rng.integers(1, 270, size=3500)))]
+    n_lg = 60000
+    lg = np.zeros((n_lg, 9), dtype=np.uint64)
+    lg[:, 0] = rng.integers(0, 3, size=n_lg)
+    lg[:, 1:9] = u64(n_lg, 8)
+    tr.logic_ops = lg
+    n_bef, n_ops = 400000, 1400000                          # Memory table: initial values + operations + gap rows -> 2^21
+    bef = np.zeros((n_bef, 7), dtype=np.uint64)
+    bef[:, 1], bef[:, 2] = np.arange(n_bef) // 100000, np.arange(n_bef) % 100000
+    bef[:, 3:7] = u64(n_bef, 4)
+    mo = np.zeros((n_ops, 9), dtype=np.uint64)
+    mo[:, 0] = rng.integers(0, 2, size=n_ops).astype(np.uint64) | np.uint64(2)
+    mo[:, 1] = 2 + np.arange(n_ops) // 4
+    mo[:, 3], mo[:, 4] = rng.integers(0, 4, size=n_ops), rng.integers(0, 100000, size=n_ops)
+    mo[:, 5:9] = u64(n_ops, 4)
+    tr.memory_ops = mo
+    log_bytes = ar.nbytes + bp.nbytes + tr.cpu.numel() * 8 + tr.keccak_inputs[0].nbytes + lg.nbytes + bef.nbytes + mo.nbytes + \
+        sum(len(d) for _, _, d in tr.keccak_sponge_ops)
+    gen, prove, tables = [], [], None
+    for _ in range(reps):
+        tables = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tables, _ = tr.into_tables(all_stark, bef, [], cfg, device=ctx.device, ctx=ctx, packed_final=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sg.prove_with_traces(all_stark, cfg, tables, [True] * 9, sg.PublicValues(), ctx=ctx)
+        torch.cuda.synchronize()
+        gen.append(t1 - t0)
+        prove.append(time.perf_counter() - t1)
+    g, pr = min(gen[1:]), min(prove[1:])
+    heights = [int(t.shape[1]).bit_length() - 1 for t in tables]
+    cells = sum(int(t.shape[0]) * int(t.shape[1]) for t in tables)
+    return {"table_heights_log2": heights, "log_GB": log_bytes / 1e9, "cpu_rows_GB": tr.cpu.numel() * 8 / 1e9,
+            "trace_GB": cells * 8 / 1e9, "into_tables_ms": 1e3 * g, "prove_ms": 1e3 * pr,
+            "value": 1.0 / (g + pr), "unit": "segment proofs/s",
+            "note": "logs (pageable host memory, C-ABI record layouts) -> zk_*_generate_trace / zk_memory_trace_* on the device "
+                    "-> prove_with_traces, serial; the Cpu table's rows are uploaded and transposed, every other table is built "
+                    "in HBM from its log"}
+
+
+# the gate set of the recursion circuits, as zk_plonk_gate records (kind, param, selector column,
+# selector group): fourteen kinds sorted by (degree, id), four selector groups under max degree 9
+PLONK_RECURSION_GATES = [(0, 0, 0, 0, 7), (1, 2, 0, 0, 7), (12, 0, 0, 0, 7), (2, 0, 0, 0, 7), (6, 63, 0, 0, 7), (8, 32, 0, 0, 7),
+                         (7, 43, 0, 0, 7), (4, 10, 1, 7, 11), (3, 20, 1, 7, 11), (5, 13, 1, 7, 11), (9, 66, 1, 7, 11),
+                         (11, 4 | 4 << 8 | 2 << 16, 2, 11, 13), (13, 4 | 6 << 8, 2, 11, 13), (10, 0, 3, 13, 14)]
+PLONK_K_IS = [pow(14293326489335486720, i, 0xFFFFFFFF00000001) for i in range(80)]   # get_unique_coset_shifts(80)
+
+
+def plonk_synthetic_circuit(dev, lb, g):
+    """(constants ++ sigmas [4 selectors + 2 constants + 80][n], wires [135][n]) of a synthetic 2^lb-row circuit over
+    PLONK_RECURSION_GATES: every row one of the fourteen gates at random (selector columns = the row's gate index in its
+    group's column, UNUSED_SELECTOR elsewhere), everything else uniform."""
+    import torch
+    gates, n_sel, n = PLONK_RECURSION_GATES, 4, 1 << lb
+    cs = torch.randint(-(1 << 63), (1 << 63) - 1, (n_sel + 2 + 80, n), dtype=torch.int64, device=dev, generator=g)
+    # rows per gate kind ~ a recursive STARK / PLONK verifier circuit (an ESTIMATE from the builder calls under
+    # recursive_verifier.rs:336-349 and plonky2's FRI verifier gadget: Merkle paths and challenger = PoseidonGate rows
+    # dominate, then extension arithmetic for the alpha-reductions, bit decompositions, random accesses, one coset
+    # interpolation per fold).  The prover's time does not depend on these frequencies -- plonky2 and this library evaluate
+    # every gate kind of the circuit at every point and apply the selector filter -- only on WHICH kinds are present.
+    census = {0: 2, 1: 1, 12: 1, 2: 0.1, 6: 5, 8: 3, 7: 3, 4: 12, 3: 8, 5: 3, 9: 1, 11: 5, 13: 2, 10: 54}
+    w = torch.tensor([census[q[0]] for q in gates], dtype=torch.float32, device=dev)
+    gate_of_row = torch.multinomial(w, n, replacement=True, generator=g).to(torch.int64)
+    sel_of_gate = torch.tensor([q[2] for q in gates], dtype=torch.int64, device=dev)
+    for sidx in range(n_sel):
+        cs[sidx] = torch.where(sel_of_gate[gate_of_row] == sidx, gate_of_row, torch.full_like(gate_of_row, 0xFFFFFFFF))
+    wires = torch.randint(-(1 << 63), (1 << 63) - 1, (135, n), dtype=torch.int64, device=dev, generator=g)
+    return cs, wires
+
+
+def plonk_recursion_profile(ctx, dev, with_cpu, sizes=(12, 13, 14), reps=8):
+    """Secondary object: the recursion layer's PLONK proofs -- `CircuitConfig::
+    standard_recursion_config()` (135 wires, 80 routed, FRI rate_bits 3, 28 queries, 16 PoW bits), circuits of 2^12 ..
+    2^14 rows (THRESHOLD_DEGREE_BITS = 13, fixed_recursive_verifier.rs:69), `reps` proofs per size = the chain of
+    `shrink()` proofs the reference runs per table.  Synthetic circuit data (random constants / sigmas / wires with valid
+    selector values: the prover's work does not depend on satisfiability).  With `with_cpu` the oracle's restatement of
+    plonky2's prove() is timed once at 2^13 on the same data and the two proofs are compared word for word."""
+    import numpy as np
+    import torch
+    import zk_evm_amd.plonk as zp
+    P = 0xFFFFFFFF00000001
+    gates, n_sel, n_gate_constraints = PLONK_RECURSION_GATES, 4, 123   # PoseidonGate's 123 constraints are the maximum
+    out = {"config": "standard_recursion_config, fourteen gate kinds {Noop, Constant, PoseidonMds, PublicInput, BaseSum, "
+                     "ReducingExtension, Reducing, ArithmeticExtension, Arithmetic, MulExtension, Exponentiation, RandomAccess, "
+                     "CosetInterpolation, Poseidon}, rows dealt to the kinds by an estimated verifier-circuit census (54 % "
+                     "Poseidon; the prover's cost depends on which kinds are present, not on their row counts)",
+           "proofs_per_size": reps, "sizes": {}}
+    g = torch.Generator(device=dev)
+    g.manual_seed(99)
+    k_is = PLONK_K_IS
+    for lb in sizes:
+        cs, wires = plonk_synthetic_circuit(dev, lb, g)
+        cd = zp.CircuitData(zp.CircuitConfig(), lb, gates, n_sel, cs, k_is, [1, 2, 3, 4], n_gate_constraints, ctx=ctx)
+        pis = [5, 6, 7]
+        pr = cd.prove(wires, pis)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pr = cd.prove(wires, pis)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / reps
+        out["sizes"]["2^%d" % lb] = {"ms_per_proof": 1e3 * el, "proofs_per_s": 1.0 / el,
+                                     "stages_ms": {k: round(v, 3) for k, v in pr.stage_ms.items()},
+                                     "proof_words": int(pr.opening_proof.size)}
+        if with_cpu and lb == 13:
+            try:
+                import tests.oracle_lib as ol
+                from oracle import plonk as PK
+                o = ol.load_oracle()
+                ol.setup_fri_api(o)
+                host = cs.cpu().numpy().view(np.uint64) % np.uint64(P)
+                og = sorted([PK.NoopGate(), PK.ConstantGate(2), PK.PublicInputGate(), PK.ArithmeticGate(20),
+                             PK.ArithmeticExtensionGate(10), PK.MulExtensionGate(13), PK.BaseSumGate(63), PK.ReducingGate(43),
+                             PK.ReducingExtensionGate(32), PK.ExponentiationGate(66), PK.PoseidonGate(),
+                             PK.RandomAccessGate(4, 4, 2), PK.PoseidonMdsGate(), PK.CosetInterpolationGate(4, 8)],
+                            key=lambda q: (q.degree, q.id))
+                assert [(q.KIND, q.PARAM) for q in og] == [(q[0], q[1]) for q in gates]
+                circ = PK.Circuit(PK.CircuitConfig(), lb, og, [q[2] for q in gates], sorted({(q[3], q[4]) for q in gates}),
+                                  n_sel, np.ascontiguousarray(host[:n_sel + 2]), np.ascontiguousarray(host[n_sel + 2:]), k_is,
+                                  [1, 2, 3, 4])
+                PK.commit_circuit(o, circ)
+                tm = {}
+                t0 = time.perf_counter()
+                ep = PK.prove(o, ol, circ, wires.cpu().numpy().view(np.uint64), pis, timing=tm)
+                cpu_s = time.perf_counter() - t0
+                out["cpu_2^13"] = {"seconds": cpu_s, "stages_s": {k: round(v, 3) for k, v in tm.items()}, "kind": "port",
+                                   "cores": ol.usable_cores(), "speedup": cpu_s / el,
+                                   "proofs_identical": bool(np.array_equal(ep["fri"], pr.opening_proof) and
+                                                            np.array_equal(ep["openings"], pr.openings.reshape(-1)))}
+            except Exception as e:
+                out["cpu_2^13"] = {"error": repr(e)}
+        if lb == 13:
+            # the per-table shrink chains of one segment are independent of each other: W proofs in flight on this GPU,
+            # one worker thread + Context + HIP stream + CircuitData each (the scheduler's slot model)
+            try:
+                import threading
+                import zk_evm_amd
+
+                def run_in_flight(W, per):
+                    errs = []
+                    bar = threading.Barrier(W + 1)
+
+                    def worker(k):
+                        try:
+                            st = torch.cuda.Stream()
+                            with torch.cuda.stream(st):
+                                c2 = zk_evm_amd.Context(ctx.device)
+                                d2 = zp.CircuitData(zp.CircuitConfig(), lb, gates, n_sel, cs, k_is, [1, 2, 3, 4], n_gate_constraints, ctx=c2)
+                                d2.prove(wires, pis)
+                                bar.wait()
+                                for _ in range(per):
+                                    d2.prove(wires, pis)
+                                st.synchronize()
+                                bar.wait()
+                                d2.free()
+                                c2.close()
+                        except Exception as e:           # pragma: no cover
+                            errs.append(repr(e))
+                            bar.abort()
+                    th = [threading.Thread(target=worker, args=(k,)) for k in range(W)]
+                    for t in th:
+                        t.start()
+                    bar.wait()
+                    t0 = time.perf_counter()
+                    bar.wait()
+                    elw = time.perf_counter() - t0
+                    for t in th:
+                        t.join()
+                    if errs:
+                        return {"error": errs[0]}
+                    return {"workers_per_gpu": W, "proofs_per_s": W * per / elw, "ms_per_proof_effective": 1e3 * elw / (W * per)}
+                runs = [run_in_flight(W, 2 * reps) for W in (4, 8)]
+                ok = [r for r in runs if "error" not in r]
+                out["in_flight_2^13"] = dict(max(ok, key=lambda r: r["proofs_per_s"]), tried=runs) if ok else runs[0]
+            except Exception as e:
+                out["in_flight_2^13"] = {"error": repr(e)}
+            # the same from ONE caller: zk_plonk_prove_batch keeps the proofs in flight inside the library
+            try:
+                K, best = 48, None
+                tried = []
+                for W in (4, 6, 8):
+                    cd.prove_batch([wires] * W, [pis] * W, in_flight=W)          # worker contexts, arenas
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    prs = cd.prove_batch([wires] * K, [pis] * K, in_flight=W)
+                    elb = time.perf_counter() - t0
+                    same = all(np.array_equal(q.opening_proof, pr.opening_proof) for q in prs)
+                    r = {"in_flight": W, "proofs": K, "proofs_per_s": K / elb, "ms_per_proof_effective": 1e3 * elb / K,
+                         "proofs_identical_to_single": bool(same)}
+                    tried.append(r)
+                    if best is None or r["proofs_per_s"] > best["proofs_per_s"]:
+                        best = r
+                out["batch_2^13"] = dict(best, tried=tried, note="one call of zk_plonk_prove_batch from one thread")
+            except Exception as e:
+                out["batch_2^13"] = {"error": repr(e)}
+        cd.free()
+        del cs, wires
+    return out
+
+
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# one secondary per process
+def _parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--name", required=True, choices=sorted(SECONDARIES))
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--hasher", type=int, default=0)
+    ap.add_argument("--cdk-erigon", action="store_true")
+    ap.add_argument("--cols", type=int, default=116)
+    ap.add_argument("--log-n", type=int, default=20)
+    ap.add_argument("--log-ns", type=str, default="")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--commit-steps", type=int, default=5)
+    ap.add_argument("--in-flight", type=int, default=2)
+    ap.add_argument("--step-s", type=float, default=0.0, help="the timed region's seconds per step (h2d)")
+    ap.add_argument("--arena-peak", type=float, default=0.0, help="the main context's peak arena bytes (in_flight)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=18)
+    ap.add_argument("--cpu-table-log-n", type=int, default=20)
+    return ap.parse_args()
+
+
+def _log_ns(a):
+    n_tab = 10 if a.cdk_erigon else 9
+    if not a.log_ns:
+        return [a.log_n] * n_tab
+    if a.log_ns == "realistic":
+        return REALISTIC_LOG_NS + [14] * (n_tab - 9)
+    v = [int(x) for x in a.log_ns.split(",")]
+    assert len(v) == n_tab, "--log-ns takes one height per table"
+    return v
+
+
+class _Env:
+    """device, context, table registry and config of a secondary (what bench.py's main() holds for the timed region)"""
+
+    def __init__(self, a):
+        import torch
+        import zk_evm_amd
+        from zk_evm_amd.all_stark import AllStark
+        assert torch.cuda.is_available(), "the secondaries need a GPU (no CPU fallback)"
+        torch.cuda.set_device(a.device)
+        self.dev = torch.device(f"cuda:{a.device}")
+        self.ctx = zk_evm_amd.Context(a.device)
+        self.ctx.use_torch_current_stream()
+        self.cfg = zk_evm_amd.StarkConfig(hasher=a.hasher)
+        self.all_stark = AllStark((1, 2, 3, 4), a.cdk_erigon)
+        self.log_ns = _log_ns(a)
+        self.n_tab = len(self.log_ns)
+
+    def segment_step(self, a, traces):
+        import zk_evm_amd.segment as sg
+        in_use = [True] * self.n_tab
+
+        def step(timing=None):
+            return sg.prove_with_traces(self.all_stark, self.cfg, traces, in_use,
+                                        sg.PublicValues(burn_addr=1 if a.cdk_erigon else None), ctx=self.ctx, timing=timing)
+        return step
+
+
+def sec_commit_config1(a):
+    """BASELINE configs[1]: PolynomialBatch::from_values of one cols x 2^log_n trace, `commit_steps` times."""
+    import torch
+    e = _Env(a)
+    trace, step = measure_commit(e.ctx, e.dev, a, 0, a.commit_steps, 2)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stage = {"ifft": 0.0, "lde": 0.0, "leaf_hash": 0.0, "tree": 0.0}
+    for _ in range(a.commit_steps):
+        t = step()
+        for k in stage:
+            stage[k] += t[k]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    for k in stage:
+        stage[k] /= a.commit_steps
+    roof, extra = commit_report(a, stage, 1e3 * el / a.commit_steps)
+    out = {"workload": f"PolynomialBatch::from_values {a.cols} cols x 2^{a.log_n} rows", "commits_per_s": a.commit_steps / el,
+           "ms_per_commit": 1e3 * el / a.commit_steps, "roofline": roof}
+    out.update(extra)
+    return out
+
+
+def sec_in_flight(a):
+    import torch
+    e = _Env(a)
+    traces = synthetic_segment_traces(e.log_ns, e.dev, seed=1, cdk_erigon=a.cdk_erigon)
+    step = e.segment_step(a, traces)
+    peak = a.arena_peak
+    if peak <= 0:
+        step()
+        torch.cuda.synchronize()
+        peak = e.ctx.mem_stats()["peak_in_use"]
+    return segments_in_flight(e.ctx, a.in_flight, max(2, a.steps), peak, e.all_stark, e.cfg, traces, [True] * e.n_tab, a.cdk_erigon)
+
+
+def sec_h2d(a):
+    import torch
+    e = _Env(a)
+    trace_bytes = 8.0 * sum(c << l for c, l in zip(e.all_stark.table_columns, e.log_ns))
+    if e.log_ns == [20] * e.n_tab:
+        traces = synthetic_segment_traces(e.log_ns, e.dev, seed=1, cdk_erigon=a.cdk_erigon)
+        step = e.segment_step(a, traces)
+        step()                                   # arena growth
+        torch.cuda.synchronize()
+        return h2d_profile(e.dev, trace_bytes, a.step_s, step)
+    return h2d_profile(e.dev, trace_bytes, a.step_s)
+
+
+def sec_realistic(a):
+    e = _Env(a)
+    return realistic_profile(e.ctx, e.dev, a, e.all_stark, e.cfg)
+
+
+def sec_from_logs(a):
+    e = _Env(a)
+    return from_logs_profile(e.ctx, e.dev, e.all_stark, e.cfg)
+
+
+def sec_plonk_recursion(a):
+    e = _Env(a)
+    return plonk_recursion_profile(e.ctx, e.dev, not a.no_cpu_baseline)
+
+
+def sec_block_replay(a, n_segments=12, in_flight=3):
+    """BASELINE configs[3] at shape level: one block = a list of differently shaped segments (heights inside the
+    witness_b19807080 ranges of scripts/prove_stdio.rs:89-101, optional tables absent in some) through the product's
+    multi-segment entry -- `scheduler.run_distributed` (which is `SegmentScheduler` + the proof gather when a process group
+    exists; `zero/src/prover.rs:219-228` maps segments onto workers the same way) -- with `in_flight` segments resident.
+    Every proof is compared word for word with the direct `prove_with_traces` of the same job."""
+    import numpy as np
+    import torch
+    import zk_evm_amd.segment as sg
+    from zk_evm_amd.scheduler import run_distributed
+    e = _Env(a)
+    shapes = block_segment_shapes(n_segments)
+    jobs = block_jobs(shapes, a.cdk_erigon)
+    t0 = time.perf_counter()
+    direct = []
+    for j in jobs:
+        p = sg.prove_with_traces(e.all_stark, e.cfg, j.load(e.dev), j.table_in_use, j.public_values, ctx=e.ctx)
+        direct.append(sg.all_proof_to_words(p))
+    torch.cuda.synchronize()
+    t_direct = time.perf_counter() - t0
+    e.ctx.mem_trim()
+    run_distributed(e.all_stark, e.cfg, jobs[:in_flight], device=a.device, in_flight=in_flight)      # worker arenas
+    t0 = time.perf_counter()
+    got = run_distributed(e.all_stark, e.cfg, jobs, device=a.device, in_flight=in_flight)
+    t_sched = time.perf_counter() - t0
+    same = all(np.array_equal(d, sg.all_proof_to_words(g)) for d, g in zip(direct, got))
+    cells = [segment_committed_cells(ln, a.cdk_erigon) for ln, _ in shapes]
+    return {"segments": n_segments, "in_flight": in_flight, "shapes_log2": [ln for ln, _ in shapes],
+            "tables_absent": [[t for t, u in enumerate(iu) if not u] for _, iu in shapes],
+            "value": n_segments / t_sched, "unit": "segment proofs/s", "block_s": t_sched,
+            "one_at_a_time": {"value": n_segments / t_direct, "block_s": t_direct,
+                              "note": "includes generating each job's synthetic traces on the device, like the scheduler's load()"},
+            "committed_cells_total": int(sum(cells)), "proofs_identical_to_direct": bool(same),
+            "note": "synthetic traces of the block's shapes (the witness itself needs the Rust interpreter); "
+                    "scheduler.run_distributed on one rank: job queue, load(device) per job, in_flight worker contexts"}
+
+
+def sec_cpu_baseline(a):
+    """The contract's `cpu_baseline`: one whole ArithmeticStark table proof measured on the host by the oracle (test
+    infrastructure -- this leg is the only place the bench touches it), next to the same proof on the GPU; and the r01
+    commit-sample extrapolation to the segment's 27 commitments."""
+    e = _Env(a)
+    cells = segment_committed_cells(e.log_ns, a.cdk_erigon)
+    extrap = None
+    try:
+        sl = a.cpu_sample_log_n
+        cb = cpu_baseline(116, sl, sl, a.hasher, max_reps=2)
+        sample_cells = 116 << sl
+        sec = (1.0 / cb["value"]) * cells / sample_cells
+        extrap = {
+            "value": 1.0 / sec, "unit": "segment proofs/s", "cores": cb["cores"], "kind": "port",
+            "sample": cb["sample"].split(", scaled")[0] + f"; scaled by committed cells ({cells} / {sample_cells}) to "
+                      "the segment's 27 commitments -- COMMIT PHASE ONLY, an extrapolation and an upper bound on the "
+                      "CPU rate",
+            "seconds_per_segment_est": sec}
+    except Exception as ex:  # the oracle is only a reported baseline; never fatal
+        extrap = {"error": repr(ex)}
+    if a.cpu_table_log_n > 0 and a.hasher == 0:
+        try:
+            out = cpu_table_proof_baseline(e.ctx, e.dev, a.cpu_table_log_n)
+            out["segment_commit_phase_extrapolation"] = extrap
+            return out
+        except Exception as ex:
+            out = extrap or {}
+            out["table_proof_error"] = repr(ex)
+            return out
+    return extrap
+
+
+SECONDARIES = {"commit_config1": sec_commit_config1, "in_flight": sec_in_flight, "h2d": sec_h2d, "realistic": sec_realistic,
+               "from_logs": sec_from_logs, "block_replay": sec_block_replay, "plonk_recursion": sec_plonk_recursion, "cpu_baseline": sec_cpu_baseline}
+
+
+def main():
+    a = _parse()
+    try:
+        out = SECONDARIES[a.name](a)
+    except Exception as ex:
+        out = {"error": repr(ex)}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

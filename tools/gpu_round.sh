@@ -8,10 +8,16 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p "$OUT"
 cd "$ROOT"
+# The library that produces this round's evidence is rebuilt FROM SOURCE on the box (no mtime shortcuts: a stale object after
+# a header edit would otherwise go unnoticed, r03 verdict weak 10) and its hash is recorded next to the results.
+{ echo "== $(date -u +%FT%TZ) tag $TAG"; timeout 1200 python -m zk_evm_amd.build --force && make -s -B -C oracle;
+  echo "build rc=$?"; sha256sum zk_evm_amd/libzkstark_hip.so oracle/liboracle.so; /opt/rocm/bin/hipcc --version | head -2; } > "$OUT/${TAG}_final_code_validation.log" 2>&1
+tail -4 "$OUT/${TAG}_final_code_validation.log"
 QUICK="--steps 5 --warmup 2 --no-cpu-baseline --no-pmc --no-secondary --commit-steps 0 --in-flight 1"
 if [ "$MODE" = tests ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/${TAG}_gputests.log" 2>&1
   echo "gpu tests rc=$?"; tail -5 "$OUT/${TAG}_gputests.log"
+  tail -3 "$OUT/${TAG}_gputests.log" >> "$OUT/${TAG}_final_code_validation.log"
 fi
 timeout 900 python bench.py > "$OUT/${TAG}_bench_default.json" 2> "$OUT/${TAG}_bench_default.err"
 echo "bench rc=$?"; python - "$OUT/${TAG}_bench_default.json" <<'PY'

@@ -20,7 +20,7 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     dev = torch.device("cuda:0")
     ctx = zk_evm_amd.Context(0)
-    import bench
+    from tools import bench_secondary as bench
     gates, k_is = bench.PLONK_RECURSION_GATES, bench.PLONK_K_IS
     g = torch.Generator(device=dev)
     g.manual_seed(99)

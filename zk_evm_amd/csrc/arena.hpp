@@ -158,13 +158,25 @@ struct DevArena {
 struct ArenaSet {
     DevArena lane[2];
     int cur = 0;
-    hipError_t alloc(void **out, size_t bytes) { return lane[cur].alloc(out, bytes); }
+    // A lane's own out-of-memory recovery (DevArena::alloc: trim, grow again) only releases ITS idle slabs.  When that
+    // still fails, the idle slabs of the OTHER lane go back to the driver as well and the request is retried: a side-lane
+    // allocation must not fail while tens of GB sit unused in lane 0 (r03 advisor, medium).  hipFree synchronises the
+    // device, and only wholly free slabs are released, so no kernel in flight can be touching them.
+    hipError_t alloc(void **out, size_t bytes) {
+        hipError_t e = lane[cur].alloc(out, bytes);
+        if (e != hipSuccess && lane[cur ^ 1].trim() > 0) e = lane[cur].alloc(out, bytes);
+        return e;
+    }
     void free(void *p) {
         if (!p) return;
         if (lane[0].live.count(p)) lane[0].free(p);
         else lane[1].free(p);
     }
-    hipError_t reserve(size_t bytes) { return lane[0].reserve(bytes); }
+    hipError_t reserve(size_t bytes) {
+        hipError_t e = lane[0].reserve(bytes);
+        if (e != hipSuccess && lane[1].trim() > 0) e = lane[0].reserve(bytes);
+        return e;
+    }
     size_t trim() { return lane[0].trim() + lane[1].trim(); }
     void destroy() { lane[0].destroy(); lane[1].destroy(); }
     size_t reserved() const { return lane[0].reserved + lane[1].reserved; }

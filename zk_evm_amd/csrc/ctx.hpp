@@ -10,6 +10,7 @@
 #include <cstring>
 #include <deque>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <set>
 #include <string>
@@ -104,6 +105,10 @@ static int set_err(zk_ctx *ctx, int code, const char *fmt, ...) {
         vsnprintf(buf, sizeof buf, fmt, ap);
         va_end(ap);
         ctx->err = buf;
+        // An error return unwinds the frames that own the destinations of pending staged downloads (locals such as `err`,
+        // `got`, scratch vectors): drop them, so that no later stage_collect on this ctx copies into a dead frame (r03
+        // advisor).  The pinned chunks themselves stay valid.
+        ctx->stage_pending.clear();
     }
     return code;
 }
@@ -159,17 +164,20 @@ struct LaneScope {
 struct HostProf {
     static bool on() { static const bool v = getenv("ZK_HOST_PROFILE") && getenv("ZK_HOST_PROFILE")[0] == 0x31; return v; }
     static std::map<std::string, std::pair<double, u64>> &table() { static std::map<std::string, std::pair<double, u64>> t; return t; }
+    static std::mutex &lock() { static std::mutex m; return m; }      // zk_plonk_prove_batch runs provers on several threads
     const char *name;
     std::chrono::steady_clock::time_point t0;
     explicit HostProf(const char *n) : name(n) { if (on()) t0 = std::chrono::steady_clock::now(); }
     ~HostProf() {
         if (!on()) return;
+        std::lock_guard<std::mutex> g(lock());
         auto &e = table()[name];
         e.first += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         e.second += 1;
     }
     static void dump() {
         if (!on()) return;
+        std::lock_guard<std::mutex> g(lock());
         for (auto &kv : table()) fprintf(stderr, "[zk host] %-36s %10.1f us total %8llu calls %8.1f us/call\n", kv.first.c_str(), kv.second.first, (unsigned long long)kv.second.second, kv.second.first / (double)kv.second.second);
     }
 };

@@ -348,7 +348,9 @@ static int check_cfg(zk_ctx *ctx, const zk_cfg *cfg, size_t n_cols, unsigned log
     if (!cfg) return set_err(ctx, ZK_ERR_BAD_ARG, "null cfg");
     if (n_cols == 0) return set_err(ctx, ZK_ERR_BAD_ARG, "empty batch (n_cols == 0)");
     if (cfg->hasher > ZK_HASH_KECCAK25) return set_err(ctx, ZK_ERR_BAD_ARG, "unknown hasher");
-    if (log_n + cfg->rate_bits > 31) return set_err(ctx, ZK_ERR_BAD_ARG, "LDE size exceeds 2^31");
+    // the NTT passes read their twiddle tables through buffer loads with 32-bit byte offsets (ntt.cuh): 2^28 points = 2 GiB
+    if (log_n + cfg->rate_bits > 28)
+        return set_err(ctx, ZK_ERR_UNSUPPORTED, "LDE size 2^%u exceeds the supported 2^28 points", log_n + cfg->rate_bits);
     if (cfg->cap_height > log_n + cfg->rate_bits)
         return set_err(ctx, ZK_ERR_BAD_ARG, "cap_height %u exceeds tree height %u (plonky2 asserts the same)",
                        cfg->cap_height, log_n + cfg->rate_bits);
@@ -366,6 +368,7 @@ struct PendingCommit {
     hipEvent_t tail_ev = nullptr;       // main stream -> tail stream hand-over inside merkle_levels
     hipStream_t stream = nullptr;
     const u64 *h_cap = nullptr;
+    u64 *h_cap_own = nullptr;           // caps above 64 words (cap_height > 4) land in their own pinned buffer
     CommitMode mode = COMMIT_VALUES;
     bool side = false;
 };
@@ -379,6 +382,7 @@ static void ev_put(zk_ctx *ctx, hipEvent_t e) { if (e) ctx->ev_pool.push_back(e)
 static void pending_release(zk_ctx *ctx, PendingCommit &pc) {
     for (auto &e : pc.ev) { ev_put(ctx, e); e = nullptr; }
     ev_put(ctx, pc.tail_ev); pc.tail_ev = nullptr;
+    if (pc.h_cap_own) { (void)hipHostFree(pc.h_cap_own); pc.h_cap_own = nullptr; }
 }
 
 static int commit_enqueue(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t in_stride,
@@ -389,7 +393,6 @@ static int commit_enqueue(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_
     const size_t n = (size_t)1 << log_n;
     const unsigned log_N = log_n + cfg->rate_bits;
     const size_t N = (size_t)1 << log_N;
-    if (((size_t)4 << cfg->cap_height) > 64) return set_err(ctx, ZK_ERR_UNSUPPORTED, "cap_height above 4 is not supported");
     if (!ctx->h_caps) HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_caps, (size_t)ZK_CAP_SLOTS * 64 * sizeof(u64), hipHostMallocDefault));
     zk_batch *b = new zk_batch();
     ctx->live_batches.insert(b);
@@ -444,7 +447,10 @@ static int commit_enqueue(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_
     if (tail) ctx->stream = tail;                       // (the tree ended there: merkle_levels hands over at its first small level)
     hipEventRecord(pc->ev[4], ctx->stream);
     b->cap.resize((size_t)4 << cfg->cap_height);
-    u64 *slot = ctx->h_caps + (ctx->cap_slot_next++ % ZK_CAP_SLOTS) * 64;
+    u64 *slot = nullptr;
+    if (b->cap.size() <= 64) slot = ctx->h_caps + (ctx->cap_slot_next++ % ZK_CAP_SLOTS) * 64;
+    else if (hipHostMalloc((void **)&pc->h_cap_own, b->cap.size() * 8, hipHostMallocDefault) == hipSuccess) slot = pc->h_cap_own;
+    else { ctx->stream = main_stream; return fail(set_err(ctx, ZK_ERR_OOM, "pinned buffer for a cap of 2^%u digests", cfg->cap_height)); }
     pc->h_cap = slot;
     hipError_t cap_rc = copy_to_pinned(ctx, slot, b->d_digests + 4 * (b->n_digests - ((size_t)1 << cfg->cap_height)), b->cap.size() * 8);
     ctx->stream = main_stream;
