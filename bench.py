@@ -193,7 +193,7 @@ class RunGroup:
             os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             sk.close()
         try:
-            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=1200))
             self.gloo = dist.group.WORLD
             self.info.update(backend="gloo", ok=True)
         except Exception as e:
@@ -201,11 +201,22 @@ class RunGroup:
             return
         if a.dist_backend != "nccl":
             return
-        # RCCL beside it.  Blocking waits turn a collective that never completes into an exception after the group's
-        # time limit instead of a watchdog abort of the process.
+        # RCCL beside it -- but first PROBED IN A CHILD PROCESS per rank.  A communicator that cannot come up does not
+        # always raise: `ncclCommInitRank` can block inside the library for as long as a peer is alive (seen on the gpurun
+        # box with two ranks on one device: the process-group timeout never fired, the gloo agreement below waited its full
+        # 600 s and the run died).  A child that hangs is killed by its pid after --dist-timeout-s; this process never
+        # enters RCCL unless every rank's child got an all-reduce through.
+        err, grp = self._probe_in_child(local_dev, a.dist_timeout_s), None
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.gloo)
+        if int(flag.item()) != 0:
+            self.info.update(backend="gloo", ok=False, fallback="gloo", tried="nccl",
+                             error=err or "the RCCL probe failed on another rank")
+            return
+        # Blocking waits turn a collective that never completes into an exception after the group's time limit instead of a
+        # watchdog abort of the process.
         os.environ["TORCH_NCCL_BLOCKING_WAIT"] = "1"
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
-        err, grp = None, None
         try:
             torch.cuda.set_device(local_dev)
             to = datetime.timedelta(seconds=a.dist_timeout_s)
@@ -225,10 +236,55 @@ class RunGroup:
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.gloo)
         if int(flag.item()) == 0:
             self.nccl = grp
-            self.info.update(backend="nccl", ok=True, probe="all_reduce SUM of device tensors over %d rank(s)" % world)
+            self.info.update(backend="nccl", ok=True, probe="all_reduce SUM of device tensors over %d rank(s), first in a child "
+                                                            "process per rank, then in this one" % world)
         else:
             self.info.update(backend="gloo", ok=False, fallback="gloo", tried="nccl",
                              error=err or "the RCCL probe failed on another rank")
+
+    PROBE = ("import os, sys, datetime, torch, torch.distributed as dist\n"
+             "d = int(sys.argv[1]); torch.cuda.set_device(d)\n"
+             "dist.init_process_group('nccl', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']),\n"
+             "                        timeout=datetime.timedelta(seconds=float(sys.argv[2])), device_id=torch.device('cuda', d))\n"
+             "t = torch.ones(1, dtype=torch.float64, device='cuda')\n"
+             "dist.all_reduce(t); torch.cuda.synchronize()\n"
+             "assert int(t.item()) == int(os.environ['WORLD_SIZE']), t\n"
+             "print('RCCL_PROBE_OK', flush=True)\n"
+             "os._exit(0)\n")
+
+    def _probe_in_child(self, local_dev, limit_s):
+        """None if a child of this rank brought up an RCCL group with the other ranks' children (their own rendezvous port,
+        agreed over gloo) and got one all-reduce through; otherwise what went wrong.  Never blocks longer than limit_s."""
+        import signal
+        import socket
+        import subprocess
+        torch, dist = self.torch, self.dist
+        port = torch.zeros(1, dtype=torch.int64)
+        if self.rank == 0:
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port[0] = sk.getsockname()[1]
+            sk.close()
+        dist.broadcast(port, src=0, group=self.gloo)
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(int(port.item())), RANK=str(self.rank),
+                   WORLD_SIZE=str(self.world), LOCAL_RANK=str(self.rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        try:
+            p = subprocess.Popen([sys.executable, "-c", self.PROBE, str(local_dev), str(limit_s)], env=env,
+                                 stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        except OSError as e:
+            return "cannot start the probe: %r" % e
+        try:
+            so, se = p.communicate(timeout=limit_s)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except OSError:
+                pass
+            p.communicate()
+            return "the RCCL probe process did not finish within %.0f s (killed)" % limit_s
+        if p.returncode == 0 and "RCCL_PROBE_OK" in so:
+            return None
+        return "the RCCL probe process failed (exit code %s): %s" % (p.returncode, (se or so).strip()[-300:])
 
     @property
     def backend(self):

@@ -573,6 +573,56 @@ int zk_memory_gen_mem_after_trace(zk_ctx *ctx, const zk_memory_gen *gen, unsigne
                                   size_t col_stride);
 void zk_memory_gen_free(zk_memory_gen *gen);
 
+/* ---- sharding INSIDE one table (SURVEY 8(e) level 3; orchestration: zk_evm_amd/sharding.py over torch.distributed) -------
+ * The reference commits and proves a table on one machine (`prover.rs:90-111`, `prove_single_table` `prover.rs:301-341`); these
+ * entry points are the per-rank pieces when ONE table's commitment and proof are spread over W = 2^shard_log_w GPUs:
+ * columns sharded for the NTTs, an all-to-all to ROW shards (rank q = the leaves [q N/W, (q+1) N/W) of the Merkle tree, i.e.
+ * the natural rows j with j mod W = bitrev_W(q), in leaf order), leaf hashing + one subtree group per rank, all-gather of the
+ * sub-roots = the cap; quotient values, FRI batch combination and the initial-tree query openings on the row shards; the
+ * (two-column) FRI layers and the (four-column) quotient chunks replicated after an all-gather.
+ *
+ * zk_shard_pack_leaf_rows: d_lde = this rank's LDE columns [n_cols][2^log_lde] (natural order) -> d_out [W][n_cols][Nl],
+ *   block q = the rows of rank q in leaf order: the send buffers of the all-to-all, written in one pass.
+ * zk_batch_from_parts: a zk_batch VIEW over caller-owned device memory (zk_batch_free releases the handle only):
+ *   column shard: d_coeffs = [n_cols][n] bit-reversed coefficients of this rank's columns (zk_fri_openings on them);
+ *   row shard (shard_log_w > 0): d_rows = [n_cols][Nl] leaf-ordered rows, d_digests = the levels of this rank's subtrees
+ *   (zk_hash_rows + zk_merkle_build with cap_height - shard_log_w), cap = the whole tree's cap (host, 2^cap_height x 4).
+ * zk_gl_add_scalar_columns: column c += add[c]: the carry of a running sum (CTL Z column) computed per row block. */
+int zk_shard_pack_leaf_rows(zk_ctx *ctx, const uint64_t *d_lde, size_t col_stride, size_t n_cols, unsigned log_lde,
+                            unsigned shard_log_w, uint64_t *d_out);
+int zk_batch_from_parts(zk_ctx *ctx, const zk_cfg *cfg, size_t n_cols, unsigned log_n, const uint64_t *d_coeffs,
+                        const uint64_t *d_rows, const uint64_t *d_digests, const uint64_t *cap, unsigned shard_log_w,
+                        unsigned shard_rank, zk_batch **out);
+int zk_gl_add_scalar_columns(zk_ctx *ctx, uint64_t *d_cols, size_t col_stride, size_t n_cols, size_t n_rows,
+                             const uint64_t *add);
+/* The quotient VALUES at this rank's rows (zk_quotient_polys, first half): d_*_rows = the row shards of the trace / auxiliary
+ * LDE, d_*_next = the shard of the rank that holds the NEXT rows (natural row + 2: one rank for the whole shard; the same
+ * pointers when W <= 2).  d_out: [num_challenges][Nl].  zk_quotient_commit_values = the second half on the all-gathered
+ * values (d_values: [num_challenges][2n], NATURAL order): coset iNTT, chunk split, `from_coeffs` commitment. */
+int zk_quotient_values_sharded(zk_ctx *ctx, const zk_cfg *cfg, uint32_t air_id, const uint64_t *air_consts,
+                               size_t n_air_consts, const uint64_t *d_trace_rows, const uint64_t *d_trace_next,
+                               size_t n_trace_cols, const uint64_t *d_aux_rows, const uint64_t *d_aux_next,
+                               size_t n_aux_cols, unsigned log_n, unsigned shard_log_w, unsigned shard_rank,
+                               const uint64_t *alphas, const uint64_t *lookup_program, size_t lookup_words,
+                               const uint64_t *lookup_challenges, size_t n_lookup_challenges,
+                               const uint64_t *ctl_program, size_t ctl_words, unsigned constraint_degree,
+                               uint64_t *d_out);
+int zk_quotient_commit_values(zk_ctx *ctx, const zk_cfg *cfg, const uint64_t *d_values, unsigned log_n,
+                              unsigned constraint_degree, zk_batch **quotient_out);
+/* `prove_openings` in two steps.  zk_fri_combine_sharded: the batch combination sum_b alpha^.. (G_b(x) - y_b) / (x - z_b) at
+ * this rank's rows (every oracle a row-shard view of the same sharding), alpha drawn by the caller from the replicated
+ * transcript; d_out [2][Nl] (extension components), leaf order.  zk_fri_prove_from_values: everything after it from the
+ * all-gathered values (d_vals: [2][N], NATURAL order, overwritten) -- commit-phase trees, final polynomial, proof of work,
+ * query rounds -- on every rank alike; the challenger must be in the state right after alpha.  The initial-tree opening of
+ * query x is written for whole oracles and for a row shard that owns leaf x, and left zero otherwise: the caller takes those
+ * words from the owner's proof.  xs_out (optional): the num_query_rounds query indices. */
+int zk_fri_combine_sharded(zk_ctx *ctx, const zk_cfg *cfg, const zk_batch *const *oracles, size_t n_oracles,
+                           const zk_fri_batch *batches, size_t n_batches, const uint64_t *openings,
+                           const uint64_t alpha[2], uint64_t *d_out);
+int zk_fri_prove_from_values(zk_ctx *ctx, const zk_cfg *cfg, const zk_batch *const *oracles, size_t n_oracles,
+                             const zk_fri_batch *batches, size_t n_batches, uint64_t *d_vals, zk_challenger *chal,
+                             uint64_t *proof, uint64_t *xs_out);
+
 /* library / device info */
 const char *zk_version(void);
 int zk_device_info(int device, char *name_out, size_t name_len, int *cu_count, size_t *hbm_bytes);

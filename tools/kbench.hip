@@ -70,6 +70,7 @@ int main(int argc, char **argv) {
     ctx->stream = ctx->own_stream;
     hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     u64 *vals, *coeffs, *lde, *dig;
     const size_t nd = zk_merkle_num_digests(log_N, cap_height);
     hipMalloc(&vals, cols * n * 8); hipMalloc(&coeffs, cols * n * 8); hipMalloc(&lde, cols * N * 8); hipMalloc(&dig, nd * 32);
@@ -81,9 +82,8 @@ int main(int argc, char **argv) {
     double tot[4] = {0, 0, 0, 0};
     for (int it = 0; it < reps + 1; ++it) {
         hipEventRecord(ev[0], ctx->stream);
-        int rc = ntt_values_to_coeffs(ctx, vals, n, coeffs, n, cols, log_n, nullptr);
-        hipEventRecord(ev[1], ctx->stream);
-        if (rc == ZK_OK) rc = ntt_coeffs_to_values(ctx, coeffs, n, lde, N, cols, log_n, rate_bits, coset);
+        // the commitment's own plan (ZK_NTT_FUSE=0: the two separate transforms); ev[1] = after the fused pass
+        int rc = ntt_values_to_coeffs_to_lde(ctx, vals, n, coeffs, n, lde, N, cols, log_n, rate_bits, coset, ev[1]);
         hipEventRecord(ev[2], ctx->stream);
         if (rc == ZK_OK) rc = hash_rows(ctx, ZK_HASH_POSEIDON, lde, N, cols, N, log_N, 1, dig);
         hipEventRecord(ev[3], ctx->stream);

@@ -96,6 +96,14 @@ SIGNATURES = {
                                           ui, C.c_int, vp, vp, C.POINTER(vp)]),
     "zk_table_aux_commit": (C.c_int, [vp, C.POINTER(ZkCfg), u64p, sz, sz, ui, u64p, sz, u64p, sz, u64p, sz, u64p, ui,
                                       C.POINTER(vp)]),
+    "zk_shard_pack_leaf_rows": (C.c_int, [vp, u64p, sz, sz, ui, ui, u64p]),
+    "zk_batch_from_parts": (C.c_int, [vp, C.POINTER(ZkCfg), sz, ui, u64p, u64p, u64p, u64p, ui, ui, C.POINTER(vp)]),
+    "zk_gl_add_scalar_columns": (C.c_int, [vp, u64p, sz, sz, sz, u64p]),
+    "zk_quotient_values_sharded": (C.c_int, [vp, C.POINTER(ZkCfg), u32, u64p, sz, u64p, u64p, sz, u64p, u64p, sz, ui, ui, ui,
+                                             u64p, u64p, sz, u64p, sz, u64p, sz, ui, u64p]),
+    "zk_quotient_commit_values": (C.c_int, [vp, C.POINTER(ZkCfg), u64p, ui, ui, C.POINTER(vp)]),
+    "zk_fri_combine_sharded": (C.c_int, [vp, C.POINTER(ZkCfg), vp, sz, vp, sz, u64p, u64p, u64p]),
+    "zk_fri_prove_from_values": (C.c_int, [vp, C.POINTER(ZkCfg), vp, sz, vp, sz, u64p, vp, u64p, u64p]),
     "zk_table_proof_get": (C.c_int, [vp, vp]),
     "zk_table_proof_free": (None, [vp]),
     "zk_ctx_set_check_ctls": (C.c_int, [vp, C.c_int]),

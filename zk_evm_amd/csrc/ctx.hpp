@@ -95,6 +95,13 @@ struct zk_batch {
     u64 *d_digests = nullptr;  // level-concatenated 32-byte slots
     size_t n_digests = 0;
     std::vector<u64> cap;      // host copy
+    // Views assembled by the caller from its own device memory (zk_batch_from_parts; SURVEY 8(e) level 3, sharding.py): the
+    // blocks are not the arena's.  A COLUMN shard keeps d_coeffs of its columns only (openings); a ROW shard (shard_lw > 0)
+    // keeps in d_lde the rows of ONE subtree group -- [n_cols][N >> shard_lw], row t = leaf shard_rank * (N >> shard_lw) + t,
+    // i.e. LEAF order -- and in d_digests the levels of that subtree down to its 2^(cap_height - shard_lw) roots; `cap` is
+    // the whole tree's cap (all-gathered by the caller).
+    bool borrowed = false;
+    unsigned shard_lw = 0, shard_rank = 0;
 };
 
 static int set_err(zk_ctx *ctx, int code, const char *fmt, ...) {

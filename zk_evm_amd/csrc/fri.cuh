@@ -282,6 +282,9 @@ struct FriCombineArgs {
     u64 *out_a, *out_b;                         // [N] each
     u64 *g;                                     // MODE 1 out / MODE 2 in: component (b, c) at g + (2 b + c) * g_stride
     size_t g_stride;
+    // MODE 0 over ONE ROW SHARD (SURVEY 8(e) level 3): the columns hold the shard's rows in leaf order, thread j = leaf
+    // shard_rank * n_rows + j, whose point is the natural index bitrev(that); shard_lw = 0: the whole domain, natural order
+    u32 shard_lw, shard_rank;
 };
 
 // The column pointers come out of a device array, so the compiler knows nothing about their address space and would emit
@@ -296,7 +299,7 @@ __device__ __forceinline__ u64 fri_col_load(const u64 *col, u32 j) {
 template <int NB, int MODE>
 __global__ void __launch_bounds__(256) fri_combine_kernel(FriCombineArgs A) {
     u32 j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >> A.log_N) return;
+    if (j >> (A.log_N - (MODE == 0 ? A.shard_lw : 0))) return;
     gl2 sums[NB];
     if (MODE == 2) {
 #pragma unroll
@@ -343,8 +346,9 @@ __global__ void __launch_bounds__(256) fri_combine_kernel(FriCombineArgs A) {
         }
     }
     const u32 half = 1u << (A.log_N - 1);
-    u64 w = A.tw[j & (half - 1)];
-    if (j & half) w = gl_neg(w);
+    const u32 jx = (MODE == 0 && A.shard_lw) ? bitrev32((A.shard_rank << (A.log_N - A.shard_lw)) + j, A.log_N) : j;
+    u64 w = A.tw[jx & (half - 1)];
+    if (jx & half) w = gl_neg(w);
     const u64 x = gl_mul(w, A.coset_shift);
     // 1 / (x - z_b) for all batches from ONE extension-field inversion (prefix products, Montgomery's trick): an inversion is
     // ~100 multiplies, the three of a STARK table's opening were a third of this kernel's pointwise part

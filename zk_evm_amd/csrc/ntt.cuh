@@ -225,6 +225,76 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
     }
 }
 
+// The LAST values -> coefficients pass and the FIRST coefficients -> values pass of a commitment work on the same tiles: the
+// contiguous pass of the inverse transform leaves coefficients [k 2^c, (k + 1) 2^c) of a column (bit-reversed order) in tile k,
+// and the contiguous pass of the low-degree extension reads exactly those to produce values [k 2^(c + rate), (k + 1) 2^(c + rate))
+// of the 2^rate times longer transform.  Fused, the coefficients are written once (they are kept for the openings) and never
+// read back: 80 instead of 88 bytes per trace element of `from_values` cross HBM, one launch and one load phase fewer.
+//   pd: the inverse transform's contiguous pass (log_d = 0, r = c; dst = the coefficient array, out_const = 1 / n)
+//   pt: the extension's contiguous pass (log_d = 0, r = c + rate, first_stage = log_rep = rate; in_scale = coset powers in
+//       coefficient order; dst = the LDE array; last_pass when no strided pass follows)
+// Same arithmetic in the same order as the two separate passes: bit-identical coefficients and values.
+#define ZK_NTT_FUSED_MAX_PER_THREAD 8
+template <bool DIT, bool PAD>
+__device__ __forceinline__ void ntt_tile_stages(u64 *tile, const NttPass &p, u32 base, u32 elems, u32 tid, u32 nthr) {
+    int done = p.first_stage;
+    const int r = p.r;
+    while (done < r) {
+        const int k = r - done < 3 ? r - done : 3;
+        const int log_q = DIT ? done : (r - done - k);
+        if (k == 3) ntt_step<DIT, 3, PAD>(tile, p, log_q, base, elems, tid, nthr);
+        else if (k == 2) ntt_step<DIT, 2, PAD>(tile, p, log_q, base, elems, tid, nthr);
+        else ntt_step<DIT, 1, PAD>(tile, p, log_q, base, elems, tid, nthr);
+        __syncthreads();
+        done += k;
+    }
+}
+
+static __global__ void __launch_bounds__(1024) ntt_fused_kernel(NttPass pd, NttPass pt) {
+    extern __shared__ __attribute__((aligned(16))) u64 tile[];
+    const u32 tid = threadIdx.x, nthr = blockDim.x;
+    const u32 tile_id = pd.cols_fastest ? blockIdx.y : blockIdx.x;
+    const u32 col_id = pd.cols_fastest ? blockIdx.x : blockIdx.y;
+    const int c = pd.r, rate = pt.log_rep;
+    const u32 elems_c = 1u << c, elems_v = elems_c << rate;
+    const u32 base_c = tile_id << c, base_v = base_c << rate;
+    const u64 *src = pd.src + (size_t)col_id * pd.src_stride;
+    u64 *coeffs = pd.dst + (size_t)col_id * pd.dst_stride;
+    u64 *dst = pt.dst + (size_t)col_id * pt.dst_stride;
+
+    for (u32 e = tid; e < elems_c; e += nthr) tile[e] = src[base_c + e];
+    __syncthreads();
+    ntt_tile_stages<false, false>(tile, pd, base_c, elems_c, tid, nthr);      // values -> coefficients, stages c-1 .. 0
+
+    // coefficients leave (canonical, scaled by 1 / n); their coset-scaled copies stay in registers until every lane has read
+    // its own, then go back into the tile as the 2^rate replicas the skipped stages would have produced
+    u64 keep[ZK_NTT_FUSED_MAX_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < ZK_NTT_FUSED_MAX_PER_THREAD; ++k) {
+        const u32 e = tid + (u32)k * nthr;
+        if (e < elems_c) {
+            const u64 cf = gl_mul_canon(tile[e], pd.out_const);
+            coeffs[base_c + e] = cf;
+            keep[k] = pt.in_scale ? gl_mul(cf, pt.in_scale[base_c + e]) : cf;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ZK_NTT_FUSED_MAX_PER_THREAD; ++k) {
+        const u32 e = tid + (u32)k * nthr;
+        if (e < elems_c)
+            for (u32 j = 0; j < (1u << rate); ++j) tile[(e << rate) + j] = keep[k];
+    }
+    __syncthreads();
+    ntt_tile_stages<true, false>(tile, pt, base_v, elems_v, tid, nthr);      // coefficients -> values, stages rate .. c+rate-1
+
+    for (u32 e = tid; e < elems_v; e += nthr) {
+        u64 v = tile[e];
+        if (pt.last_pass) v = gl_canon(v);
+        dst[base_v + e] = v;
+    }
+}
+
 // In-place bit-reversal permutation of each column (only used by the natural<->natural API
 // entry points; the commit path never calls it).
 static __global__ void bitrev_permute_kernel(u64 *data, size_t stride, int log_n) {

@@ -235,7 +235,31 @@ struct QuotientArgs {
     u32 n_air_constraints;   // K_air (quotient_count_kernel<Air>); the checks kernel starts at this position
     u32 *count_out;       // quotient_count_kernel: receives K
     int *err_flag;        // set to 3 when the number of constraints met differs from n_constraints
+    // Row shard (SURVEY 8(e) level 3, sharding.py): this launch covers n_points = size >> shard_lw points, thread t = the row
+    // of LEAF index (shard_rank << log(size >> shard_lw)) + t, i.e. natural point bitrev(that).  `trace` / `aux` hold those
+    // rows (stride = rows of the shard); the NEXT rows (natural + 2^qd_bits) all belong to ONE other rank, whose shard the
+    // caller has fetched into trace_next / aux_next (the same pointers when that rank is this one).  shard_lw = 0: the whole
+    // coset, natural order, n_points = size.
+    u32 n_points;
+    u32 shard_lw, shard_rank;
+    const u64 *trace_next, *aux_next;
 };
+// thread -> (point index on the coset, row in the local matrices, row of the next point in the *_next matrices)
+struct QuotientRows { u32 point, row, row_next; };
+__device__ __forceinline__ QuotientRows quotient_rows(const QuotientArgs &A, u32 t, u32 size) {
+    QuotientRows r;
+    if (A.shard_lw == 0) {
+        r.point = t;
+        r.row = t << A.step_log;
+        r.row_next = ((t + (1u << A.qd_bits)) & (size - 1)) << A.step_log;
+    } else {                                                   // (step_log == 0: the caller checks)
+        const u32 size_log = A.log_n + A.qd_bits, local_log = size_log - A.shard_lw;
+        r.point = bitrev32((A.shard_rank << local_log) + t, size_log);
+        r.row = t;
+        r.row_next = bitrev32((r.point + (1u << A.qd_bits)) & (size - 1), size_log) & ((1u << local_log) - 1);
+    }
+    return r;
+}
 
 // The constraints of the table at coset point i, in starky's order: AIR, lookups, CTLs -- evaluated by TWO kernels.  The
 // weighted sum over constraints is additive, so the table's own AIR (`air_constraints`, one kernel per AIR type, compiled
@@ -243,18 +267,17 @@ struct QuotientArgs {
 // every table) each walk their share of the alpha powers -- positions [0, K_air) and [K_air, K) -- and the second adds the
 // first's partial sums before dividing by Z_H.  Each kernel gets the registers and the occupancy its own code needs.
 template <class Air, class CONS>
-__device__ __forceinline__ void air_constraints(const QuotientArgs &A, u32 i, u32 size, CONS &cons) {
-    const u32 row = i << A.step_log;
-    const u32 row_next = ((i + (1u << A.qd_bits)) & (size - 1)) << A.step_log;
-    RowView lv{A.trace, A.trace_stride, row}, nv{A.trace, A.trace_stride, row_next};
+__device__ __forceinline__ void air_constraints(const QuotientArgs &A, u32 t, u32 size, CONS &cons) {
+    const QuotientRows q = quotient_rows(A, t, size);
+    RowView lv{A.trace, A.trace_stride, q.row}, nv{A.shard_lw ? A.trace_next : A.trace, A.trace_stride, q.row_next};
     Air::eval(lv, nv, cons, A.air_consts);
 }
 template <class CONS>
-__device__ __forceinline__ void check_constraints(const QuotientArgs &A, u32 i, u32 size, CONS &cons) {
-    const u32 row = i << A.step_log;
-    const u32 row_next = ((i + (1u << A.qd_bits)) & (size - 1)) << A.step_log;
-    RowView lv{A.trace, A.trace_stride, row}, nv{A.trace, A.trace_stride, row_next};
-    RowView alv{A.aux, A.aux_stride, row}, anv{A.aux, A.aux_stride, row_next};
+__device__ __forceinline__ void check_constraints(const QuotientArgs &A, u32 t, u32 size, CONS &cons) {
+    const QuotientRows q = quotient_rows(A, t, size);
+    const u32 row = q.row, row_next = q.row_next;
+    RowView lv{A.trace, A.trace_stride, row}, nv{A.shard_lw ? A.trace_next : A.trace, A.trace_stride, row_next};
+    RowView alv{A.aux, A.aux_stride, row}, anv{A.shard_lw ? A.aux_next : A.aux, A.aux_stride, row_next};
     const u32 chunk = A.constraint_degree - 1;
     auto ld = [&](u32 col, u32 next, u64 &v) { v = (next ? nv : lv)[col].v; return true; };   // `eval_with_next`
     // ---- starky eval_packed_lookups_generic ----
@@ -431,10 +454,10 @@ __device__ __forceinline__ void point_setup(const QuotientArgs &A, u32 i, u32 fi
 template <class Air>
 __device__ __forceinline__ void quotient_air_body(const QuotientArgs &A) {
     const u32 size_log = A.log_n + A.qd_bits;
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >> size_log) return;
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;          // thread = local row; its coset point: quotient_rows
+    if (i >= A.n_points) return;
     PointSetup P;
-    point_setup(A, i, 0, P);
+    point_setup(A, quotient_rows(A, i, 1u << size_log).point, 0, P);
     air_constraints<Air>(A, i, 1u << size_log, P.cons);
     if (P.cons.ap0 != A.alpha_pow[0] + (A.n_constraints - A.n_air_constraints) && i == 0) atomicExch(A.err_flag, 3);
     u64 r0 = dot_acc_reduce(P.cons.d0), r1 = dot_acc_reduce(P.cons.d1);
@@ -470,9 +493,9 @@ __global__ void quotient_count_kernel(QuotientArgs A) {
 static __global__ void __launch_bounds__(256, ZK_CHECKS_WAVES) quotient_checks_kernel(QuotientArgs A) {
     const u32 size_log = A.log_n + A.qd_bits;
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >> size_log) return;
+    if (i >= A.n_points) return;
     PointSetup P;
-    point_setup(A, i, A.n_air_constraints, P);
+    point_setup(A, quotient_rows(A, i, 1u << size_log).point, A.n_air_constraints, P);
     check_constraints(A, i, 1u << size_log, P.cons);
     if (P.cons.ap0 != A.alpha_pow[0] && i == 0) atomicExch(A.err_flag, 3);   // met fewer / more constraints than K
     const u64 r0 = gl_add(A.out[i], dot_acc_reduce(P.cons.d0));

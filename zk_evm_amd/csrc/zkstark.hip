@@ -73,6 +73,7 @@ extern "C" int zk_ctx_create(int device, zk_ctx **out) {
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true, true>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     *out = ctx;
     return ZK_OK;
 }
@@ -337,9 +338,11 @@ extern "C" void zk_batch_free(zk_batch *b) {
     hipSetDevice(b->ctx->device);
     b->ctx->live_batches.erase(b);
     zk_ctx *ctx = b->ctx;   // blocks return to the ctx arena (reused in stream order)
-    ctx->arena.free(b->d_coeffs);
-    ctx->arena.free(b->d_lde);
-    ctx->arena.free(b->d_digests);
+    if (!b->borrowed) {
+        ctx->arena.free(b->d_coeffs);
+        ctx->arena.free(b->d_lde);
+        ctx->arena.free(b->d_digests);
+    }
     delete b;
 }
 
@@ -420,17 +423,21 @@ static int commit_enqueue(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_
     // make sure table construction is not billed to a stage
     hipEventRecord(pc->ev[0], ctx->stream);
     if (mode == COMMIT_VALUES) {
-        rc = ntt_values_to_coeffs(ctx, d_in, in_stride, b->d_coeffs, n, n_cols, log_n, nullptr);
+        // inverse transform and extension as one plan (the last pass of the one and the first of the other fused on their
+        // common tiles, ntt_host.inc); ev[1] is recorded after the fused pass
+        rc = ntt_values_to_coeffs_to_lde(ctx, d_in, in_stride, b->d_coeffs, n, b->d_lde, N, n_cols, log_n, cfg->rate_bits,
+                                         coset, pc->ev[1]);
+        if (rc != ZK_OK) return fail(rc);
     } else {
         B_HIP(hipMemcpy2DAsync(b->d_coeffs, n * 8, d_in, in_stride * 8, n * 8, n_cols,
                                hipMemcpyDeviceToDevice, ctx->stream));
         if (mode == COMMIT_COEFFS) rc = bitrev_columns(ctx, b->d_coeffs, n, n_cols, log_n);
+        if (rc != ZK_OK) return fail(rc);
+        hipEventRecord(pc->ev[1], ctx->stream);
+        if ((rc = check_abort(ctx)) != ZK_OK) return fail(rc);
+        rc = ntt_coeffs_to_values(ctx, b->d_coeffs, n, b->d_lde, N, n_cols, log_n, cfg->rate_bits, coset);
+        if (rc != ZK_OK) return fail(rc);
     }
-    if (rc != ZK_OK) return fail(rc);
-    hipEventRecord(pc->ev[1], ctx->stream);
-    if ((rc = check_abort(ctx)) != ZK_OK) return fail(rc);
-    rc = ntt_coeffs_to_values(ctx, b->d_coeffs, n, b->d_lde, N, n_cols, log_n, cfg->rate_bits, coset);
-    if (rc != ZK_OK) return fail(rc);
     hipEventRecord(pc->ev[2], ctx->stream);
     if ((rc = check_abort(ctx)) != ZK_OK) return fail(rc);
     rc = hash_rows(ctx, cfg->hasher, b->d_lde, N, n_cols, N, (int)log_N, 1, b->d_digests);
@@ -615,6 +622,7 @@ extern "C" int zk_batch_merkle_path(const zk_batch *b, size_t leaf_index, uint64
 #include "stark_host.inc"
 #include "quotient_host.inc"
 #include "segment_host.inc"
+#include "shard_host.inc"
 
 // ---- the cross-TU interface (internal.hpp) ----------------------------------------------------------------------
 int zki_commit(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t in_stride, size_t n_cols, unsigned log_n,

@@ -1,0 +1,433 @@
+"""`prove_single_table` with ONE table spread over the ranks of a process group -- SURVEY 8(e) level 3, the `north_star`'s
+"RCCL all-gather over xGMI for FRI folding and Merkle-cap reduction".  Reference seam: the per-table commit loop
+`evm_arithmetization/src/prover.rs:90-111` and `prove_single_table` `prover.rs:301-341` (starky `prove_with_commitment`).
+
+What is sharded, and how (W = 2^k ranks, one per GPU; N = 2n LDE points):
+
+  input        rank q holds the contiguous ROW BLOCK q of the trace, all C columns (witness generation is row-parallel:
+               `zk_keccak_generate_trace` & co. write row blocks);
+  aux columns  CTL helper / Z columns are row-wise sums over the block (`zk_ctl_partial_sums` on the block); a Z column is a
+               reverse running sum, so block q adds the totals of the blocks after it: ONE all-gather of a word per column;
+  commitment   all-to-all #1 row blocks -> COLUMN shards (NTTs are per column): iNTT + coset LDE; the coefficients stay on
+               the column owner (openings).  all-to-all #2 column shards -> ROW shards: `zk_shard_pack_leaf_rows` writes the
+               send buffers in LEAF order in one pass, so the receive buffers ARE the row shard: rank q = the leaves
+               [q N/W, (q+1) N/W) = the natural rows j with j mod W = bitrev_W(q).  Leaf hashing + the local subtrees;
+               all-gather of the 2^cap_height / W sub-roots per rank = the cap ("Merkle-cap reduction");
+  quotient     needs rows j and j + 2: the next rows of a whole shard live on ONE other rank (residue + 2 mod W) -- a
+               point-to-point exchange of the trace + auxiliary shards when W > 2, nothing when W <= 2.  Values on the local
+               rows (`zk_quotient_values_sharded`), all-gather (16 B per point), then the 4-column chunk batch is committed
+               on every rank alike (`zk_quotient_commit_values`): replicated, it is 4 columns wide;
+  openings     each column owner evaluates its coefficient columns at zeta, g zeta (and 1 for the CTL Z columns); all-gather;
+  FRI          batch combination on the local rows (`zk_fri_combine_sharded`: the pass that reads every LDE column),
+               all-gather of the combined polynomial (2 columns: 16 B per point), then the commit-phase trees, folds, final
+               polynomial and proof of work on every rank alike (`zk_fri_prove_from_values`): the FRI layers are two
+               columns wide, sharding them would trade < 1 ms of kernels for a collective per round.  The initial-tree
+               opening of query x comes from the rank that owns leaf x (its row + the path inside its subtree).
+
+The proof equals the single-GPU `zk_prove_table` proof word for word (tests/test_gpu_multirank.py).  Tables with logUp
+lookups or next-row CTL columns are rejected here (no candidate for this mode has them: Keccak, Logic); the Python side is
+orchestration only -- every kernel is the library's."""
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from ._lib import ZkStarkError
+from .sharding import _bitrev, split_columns
+
+P = 0xFFFFFFFF00000001
+
+
+# ---- collectives on lists of device tensors (RCCL under nccl; host round trips under gloo) ------------------------------
+def _dist(group):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_world_size(group), dist.get_rank(group)
+    return None, 1, 0
+
+
+def all_to_all(send: List, recv: List, group=None) -> None:
+    """recv[p] <- what rank p holds in its send[this rank].  `dist.all_to_all` on device tensors under nccl (RCCL: every
+    pair of GPUs on its own xGMI link); W scatters of host copies under gloo (the CPU-side tests)."""
+    dist, world, rank = _dist(group)
+    if dist is None:
+        recv[0].copy_(send[0])
+        return
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all(recv, send, group=group)
+        return
+    for p in range(world):
+        out = recv[p].cpu()
+        src = dist.get_global_rank(group, p) if group is not None else p
+        dist.scatter(out, [s.cpu().contiguous() for s in send] if p == rank else None, src=src, group=group)
+        recv[p].copy_(out)
+
+
+def all_gather_tensor(t, group=None) -> List:
+    """every rank's `t` (same shape everywhere), in rank order"""
+    import torch
+    dist, world, rank = _dist(group)
+    if dist is None:
+        return [t]
+    if dist.get_backend(group) == "nccl":
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t.contiguous(), group=group)
+        return parts
+    host = t.cpu().contiguous()
+    parts = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(parts, host, group=group)
+    return [p.to(t.device) for p in parts]
+
+
+def exchange(send, dst: int, src: int, group=None):
+    """point to point: this rank's `send` goes to group rank `dst`, the result comes from group rank `src`"""
+    import torch
+    dist, world, rank = _dist(group)
+    if dist is None or (dst == rank and src == rank):
+        return send
+    nccl = dist.get_backend(group) == "nccl"
+    out = torch.empty_like(send) if nccl else torch.empty(send.shape, dtype=send.dtype)
+    buf = send.contiguous() if nccl else send.cpu().contiguous()
+    g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    ops = [dist.P2POp(dist.isend, buf, g(dst), group), dist.P2POp(dist.irecv, out, g(src), group)]
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
+    return out if nccl else out.to(send.device)
+
+
+# ---- one sharded oracle -------------------------------------------------------------------------------------------------
+class ShardedOracle:
+    """What a rank keeps of one committed matrix: the coefficient columns of its COLUMN shard, the leaf-ordered rows of
+    its ROW shard with the local subtrees, and the whole cap.  `col_batch` / `row_batch` are library views over this
+    object's tensors (zk_batch_from_parts)."""
+
+    def __init__(self, ctx, cfg, n_cols, log_n, cols, coeffs, rows, digests, cap, lw, rank):
+        import torch  # noqa: F401
+        self.ctx, self.n_cols, self.log_n, self.cols = ctx, n_cols, log_n, cols
+        self.coeffs, self.rows, self.digests, self.cap = coeffs, rows, digests, cap
+        lib = ctx.lib
+        capw = np.ascontiguousarray(cap, dtype=np.uint64).reshape(-1)
+        self.col_batch = None
+        if coeffs is not None and coeffs.shape[0]:
+            h = C.c_void_p()
+            ctx.check(lib.zk_batch_from_parts(ctx.handle, C.byref(cfg), coeffs.shape[0], log_n, C.c_void_p(coeffs.data_ptr()),
+                                              None, None, capw.ctypes.data, 0, 0, C.byref(h)))
+            self.col_batch = h
+        h = C.c_void_p()
+        ctx.check(lib.zk_batch_from_parts(ctx.handle, C.byref(cfg), n_cols, log_n, None, C.c_void_p(rows.data_ptr()),
+                                          C.c_void_p(digests.data_ptr()) if digests is not None else None, capw.ctypes.data,
+                                          lw, rank, C.byref(h)))
+        self.row_batch = h
+
+    def free(self):
+        for h in (self.col_batch, self.row_batch):
+            if h and getattr(self.ctx, "handle", None):
+                self.ctx.lib.zk_batch_free(h)
+        self.col_batch = self.row_batch = None
+
+
+def commit_rows_sharded(block, config, ctx, group=None, timing=None) -> ShardedOracle:
+    """`PolynomialBatch::from_values` of the matrix whose row block `rank` is `block` (K, n / W): steps "commitment" of the
+    module docstring.  Returns this rank's ShardedOracle; its `cap` equals the single-GPU commitment's."""
+    import time
+
+    import torch
+
+    from .collectives import all_gather_words
+    dist, world, rank = _dist(group)
+    fri = config.fri_config
+    lw = world.bit_length() - 1
+    if world != 1 << lw or lw > fri.cap_height:
+        raise ValueError("the number of ranks must be a power of two and at most 2^cap_height")
+    K, nb = int(block.shape[0]), int(block.shape[1])
+    n = nb * world
+    log_n = n.bit_length() - 1
+    if n != 1 << log_n or block.stride(1) != 1:
+        raise ValueError("row blocks must be contiguous and a power-of-two fraction of the table")
+    log_N = log_n + fri.rate_bits
+    N, Nl = 1 << log_N, (1 << log_N) >> lw
+    if Nl < 1 << (fri.cap_height - lw) or Nl < 2:
+        raise ValueError("the table is too small for %d ranks" % world)
+    dev = block.device
+    lib = ctx.lib
+    cfg = config.to_c()
+    cols = split_columns(K, world)
+    k_me = len(cols[rank])
+    t0 = time.perf_counter()
+    # all-to-all #1: row blocks -> column shards (the send pieces are contiguous slices of the column-major block)
+    block = block.contiguous()
+    send = [block[cols[p].start: cols[p].stop] for p in range(world)]
+    recv = [torch.empty((k_me, nb), dtype=torch.int64, device=dev) for _ in range(world)]
+    all_to_all(send, recv, group)
+    coeffs = torch.stack(recv, dim=1).reshape(k_me, n).contiguous()          # column c = its W row blocks in order
+    del recv
+    packed = torch.empty((world, k_me, Nl), dtype=torch.int64, device=dev)
+    if k_me:
+        lde = torch.empty((k_me, N), dtype=torch.int64, device=dev)
+        ctx.check(lib.zk_ifft(ctx.handle, C.c_void_p(coeffs.data_ptr()), n, k_me, log_n))
+        ctx.check(lib.zk_lde(ctx.handle, C.c_void_p(coeffs.data_ptr()), n, C.c_void_p(lde.data_ptr()), N, k_me, log_n, fri.rate_bits))
+        # all-to-all #2, send side: every destination's rows in leaf order, one pass over the LDE
+        ctx.check(lib.zk_shard_pack_leaf_rows(ctx.handle, C.c_void_p(lde.data_ptr()), N, k_me, log_N, lw, C.c_void_p(packed.data_ptr())))
+        torch.cuda.synchronize(dev)
+        del lde
+    t1 = time.perf_counter()
+    rows = torch.empty((K, Nl), dtype=torch.int64, device=dev)
+    all_to_all([packed[q] for q in range(world)], [rows[cols[p].start: cols[p].stop] for p in range(world)], group)
+    del packed
+    t2 = time.perf_counter()
+    # leaf hashing + local subtrees; the sub-roots of all ranks, in rank order, are the cap
+    cap_local_h = fri.cap_height - lw
+    log_leaves = log_N - lw
+    n_dig = int(lib.zk_merkle_num_digests(log_leaves, cap_local_h))
+    dig = torch.zeros((n_dig, 4), dtype=torch.int64, device=dev)
+    ctx.check(lib.zk_hash_rows(ctx.handle, config.hasher, C.c_void_p(rows.data_ptr()), Nl, K, Nl, C.c_void_p(dig.data_ptr())))
+    ctx.check(lib.zk_merkle_build(ctx.handle, config.hasher, C.c_void_p(dig.data_ptr()), log_leaves, cap_local_h))
+    sub = dig[n_dig - (1 << cap_local_h):].cpu().numpy().view(np.uint64).reshape(-1)
+    cap = np.concatenate(all_gather_words(sub, sub.size, group)).reshape(1 << fri.cap_height, 4)
+    if timing is not None:
+        timing["column shards: all-to-all #1 + iNTT + LDE + pack"] = timing.get("column shards: all-to-all #1 + iNTT + LDE + pack", 0.0) + t1 - t0
+        timing["all-to-all #2 to row shards"] = timing.get("all-to-all #2 to row shards", 0.0) + t2 - t1
+        timing["row shards: leaf hashing + subtrees + cap all-gather"] = timing.get("row shards: leaf hashing + subtrees + cap all-gather", 0.0) + time.perf_counter() - t2
+    return ShardedOracle(ctx, cfg, K, log_n, cols, coeffs, rows, dig, cap, lw, rank)
+
+
+# ---- helpers -------------------------------------------------------------------------------------------------------------
+def _entries_use_next_row(columns_filters) -> bool:
+    def col_next(c):
+        return bool(getattr(c, "next_row_linear_combination", None))
+    for cols, filt in columns_filters:
+        if any(col_next(c) for c in cols):
+            return True
+        if filt is not None:
+            for a, b in getattr(filt, "products", []):
+                if col_next(a) or col_next(b):
+                    return True
+            if any(col_next(c) for c in getattr(filt, "constants", [])):
+                return True
+    return False
+
+
+def _ext_mul(a, b):
+    return ((a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
+
+
+def _leaf_to_natural(t, log_N: int):
+    """columns given in leaf (bit-reversed) order -> natural order"""
+    import torch
+    idx = torch.tensor([_bitrev(j, log_N) for j in range(1 << log_N)], dtype=torch.int64, device=t.device)
+    return t.index_select(1, idx).contiguous()
+
+
+def table_ctl_specs(all_stark, table: int, ctl_challenges) -> List[Tuple[int, int, list]]:
+    """The z-data of `table` in starky's order (`cross_table_lookup_data`): per CTL, per challenge, the run of this table's
+    looking entries, then the looked entry -> [(beta, gamma, [(columns, filter)])]"""
+    from itertools import groupby
+    out = []
+    for ctl in all_stark.cross_table_lookups:
+        for beta, gamma in ctl_challenges:
+            for t, grp in groupby(ctl.looking_tables, key=lambda x: x.table):
+                if t == table:
+                    out.append((beta, gamma, [(x.columns, x.filter) for x in grp]))
+            if ctl.looked_table.table == table:
+                out.append((beta, gamma, [(ctl.looked_table.columns, ctl.looked_table.filter)]))
+    return out
+
+
+def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tuple[int, int, list]], ctl_challenges, challenger,
+                            constraint_degree: int = 3, air_consts: Sequence[int] = (), lookups=(), requires_ctls: bool = True,
+                            group=None, ctx=None, timing: Optional[dict] = None):
+    """`prove_single_table` (prover.rs:301-341) of ONE table over the ranks of `group` (module docstring).
+    block: CUDA int64 (C, n / W), this rank's contiguous row block of the trace; `challenger`: the transcript, replicated,
+    in the state the single-GPU call would receive it in (it is advanced identically on every rank).  Returns the
+    `StarkProof` on group rank 0, None elsewhere."""
+    import time
+
+    import torch
+
+    from .collectives import all_gather_words, gather_varlen_words
+    from .context import default_context
+    from .fri import FriBatchInfo, FriInstanceInfo, stark_fri_instance
+    from .polynomial_batch import PolynomialBatch
+    from .prover import StarkProof, encode_ctl_set, CtlZData
+    from .stark import ctl_partial_sums
+    if lookups:
+        raise NotImplementedError("row-sharded proving of a table with logUp lookups is not built (no level-3 candidate has them)")
+    dist, world, rank = _dist(group)
+    dev = block.device
+    ctx = ctx or default_context(dev.index or 0)
+    ctx.use_torch_current_stream()
+    lib = ctx.lib
+    fri = config.fri_config
+    nchal = config.num_challenges
+    lw = world.bit_length() - 1
+    C_tr, nb = int(block.shape[0]), int(block.shape[1])
+    n = nb * world
+    log_n = n.bit_length() - 1
+    log_N = log_n + fri.rate_bits
+    N, Nl = 1 << log_N, (1 << log_N) >> lw
+    cfg = config.to_c()
+    t_start = time.perf_counter()
+    # ---- trace commitment ----------------------------------------------------------------------------------------------------
+    trace = commit_rows_sharded(block, config, ctx, group, timing)
+    init_state = challenger.compact()                                  # "Clear buffered outputs." (prover.rs:320)
+    # ---- auxiliary polynomials: CTL helper / Z columns on the row block, carries across blocks ------------------------------
+    aux = None
+    n_helpers_of, zdatas = [], []
+    if ctl_specs:
+        helpers, zs = [], []
+        for beta, gamma, entries in ctl_specs:
+            if _entries_use_next_row(entries):
+                raise NotImplementedError("row-sharded proving with next-row CTL columns is not built")
+            cols = ctl_partial_sums(block, entries, beta, gamma, constraint_degree, ctx=ctx)      # helpers (if any), then Z
+            n_helpers_of.append(int(cols.shape[0]) - 1)
+            helpers.append(cols[:-1])
+            zs.append(cols[-1:])
+            zdatas.append(CtlZData(beta, gamma, entries, cols))
+        zmat = torch.cat(zs, dim=0).contiguous()                       # (n_z, nb): reverse running sums WITHIN the block
+        tot = zmat[:, 0].cpu().numpy().view(np.uint64)                 # block totals
+        parts = all_gather_words(tot, tot.size, group)
+        carry = np.zeros(tot.size, dtype=np.uint64)
+        for z in range(tot.size):                                      # the blocks after this one
+            carry[z] = sum(int(parts[q][z]) % P for q in range(rank + 1, world)) % P
+        if carry.any():
+            ctx.check(lib.zk_gl_add_scalar_columns(ctx.handle, C.c_void_p(zmat.data_ptr()), nb, zmat.shape[0], nb, carry.ctypes.data))
+        # starky's order of the auxiliary polynomials: lookup columns (none here), all helper columns, all Z columns
+        aux_block = torch.cat([h for h in helpers if h.shape[0]] + [zmat], dim=0).contiguous()
+        aux = commit_rows_sharded(aux_block, config, ctx, group, timing)
+        challenger.observe_cap(aux.cap)
+    n_aux = aux.n_cols if aux is not None else 0
+    n_z = len(ctl_specs)
+    t_commit = time.perf_counter()
+    # ---- quotient -------------------------------------------------------------------------------------------------------------
+    alphas = np.array(challenger.get_n_challenges(nchal), dtype=np.uint64)
+    qd_bits = 1 if constraint_degree - 1 >= 2 else 0
+    if fri.rate_bits != qd_bits:
+        raise NotImplementedError("row-sharded quotient needs rate_bits == quotient_degree_bits")
+    res = _bitrev(rank, lw)                                            # this rank's rows: natural j = i W + res
+    nxt = _bitrev((res + (1 << qd_bits)) % world, lw) if world > 1 else 0     # the rank that holds rows j + 2^qd_bits
+    prv = _bitrev((res - (1 << qd_bits)) % world, lw) if world > 1 else 0     # ... and the rank whose next rows are ours
+    trace_next = exchange(trace.rows, prv, nxt, group) if nxt != rank else trace.rows
+    aux_next = (exchange(aux.rows, prv, nxt, group) if nxt != rank else aux.rows) if aux is not None else None
+    qloc = torch.empty((nchal, Nl), dtype=torch.int64, device=dev)
+    ac = np.array(list(air_consts), dtype=np.uint64)
+    # the ctl program carries the per-z-data helper counts; the column tensors themselves are not read (aux rows are)
+    cp = encode_ctl_set(zdatas) if zdatas else None
+    ctx.check(lib.zk_quotient_values_sharded(
+        ctx.handle, C.byref(cfg), air_id, ac.ctypes.data if ac.size else None, ac.size,
+        C.c_void_p(trace.rows.data_ptr()), C.c_void_p(trace_next.data_ptr()), C_tr,
+        C.c_void_p(aux.rows.data_ptr()) if aux is not None else None, C.c_void_p(aux_next.data_ptr()) if aux is not None else None,
+        n_aux, log_n, lw, rank, alphas.ctypes.data, None, 0, None, 0,
+        cp.ctypes.data if cp is not None else None, cp.size if cp is not None else 0, constraint_degree, C.c_void_p(qloc.data_ptr())))
+    torch.cuda.synchronize(dev)
+    del trace_next, aux_next
+    q_leaf = torch.cat(all_gather_tensor(qloc, group), dim=1)          # (nchal, N), leaf order (rank q = leaves [q Nl, (q+1) Nl))
+    q_nat = _leaf_to_natural(q_leaf, log_N)
+    h = C.c_void_p()
+    ctx.check(lib.zk_quotient_commit_values(ctx.handle, C.byref(cfg), C.c_void_p(q_nat.data_ptr()), log_n, constraint_degree, C.byref(h)))
+    quotient = PolynomialBatch(ctx, h, fri.rate_bits, fri.cap_height, config.hasher)
+    n_quot = quotient.num_polys
+    quotient_cap = quotient.merkle_tree.cap.elements.copy()
+    challenger.observe_cap(quotient_cap)
+    t_quot = time.perf_counter()
+    # ---- openings -------------------------------------------------------------------------------------------------------------
+    zeta = challenger.get_extension_challenge()
+    zp = (zeta[0] % P, zeta[1] % P)
+    for _ in range(log_n):
+        zp = _ext_mul(zp, zp)
+    if zp == (1, 0):
+        raise ZkStarkError(-1, "Opening point is in the subgroup.")
+    g = pow(7277203076849721926, 1 << (32 - log_n), P)                 # primitive_root_of_unity(degree_bits)
+    g_zeta = (zeta[0] % P * g % P, zeta[1] % P * g % P)
+    ctl_batch = requires_ctls and n_z > 0
+    instance = stark_fri_instance(zeta, g_zeta, C_tr, n_aux, n_quot, (n_aux - n_z, n_aux) if ctl_batch else None)
+
+    def local_openings(oracle, points):
+        """this rank's columns of `oracle` at `points` -> (len(points), K_me, 2) on every rank, gathered to (len(points), K, 2)"""
+        k_me = len(oracle.cols[rank])
+        kmax = max(len(c) for c in oracle.cols)
+        mine = np.zeros((len(points), kmax, 2), dtype=np.uint64)
+        if k_me:
+            inst = FriInstanceInfo([FriBatchInfo(pt, [(0, i) for i in range(k_me)]) for pt in points])
+            arr, keep = inst.to_c()
+            out = np.zeros((len(points) * k_me, 2), dtype=np.uint64)
+            ctx.check(lib.zk_fri_openings(ctx.handle, (C.c_void_p * 1)(oracle.col_batch), 1, arr, len(points), out.ctypes.data))
+            mine[:, :k_me] = out.reshape(len(points), k_me, 2)
+        parts = all_gather_words(mine.reshape(-1), mine.size, group)
+        full = np.zeros((len(points), oracle.n_cols, 2), dtype=np.uint64)
+        for p, part in enumerate(parts):
+            cr = oracle.cols[p]
+            full[:, cr.start: cr.stop] = part.reshape(len(points), kmax, 2)[:, : len(cr)]
+        return full
+    tr_op = local_openings(trace, [zeta, g_zeta])
+    ax_op = local_openings(aux, [zeta, g_zeta, (1, 0)]) if aux is not None else None
+    qinst = FriInstanceInfo([FriBatchInfo(zeta, [(0, i) for i in range(n_quot)])])
+    arr, keep = qinst.to_c()
+    q_op = np.zeros((n_quot, 2), dtype=np.uint64)
+    ctx.check(lib.zk_fri_openings(ctx.handle, (C.c_void_p * 1)(quotient.handle), 1, arr, 1, q_op.ctypes.data))
+    pieces = [tr_op[0]] + ([ax_op[0]] if aux is not None else []) + [q_op, tr_op[1]] + ([ax_op[1]] if aux is not None else [])
+    if ctl_batch:
+        pieces.append(ax_op[2][n_aux - n_z:])
+    openings = np.concatenate(pieces, axis=0)
+    assert openings.shape[0] == instance.n_openings
+    challenger.observe_elements(openings.reshape(-1))                  # observe_openings
+    t_open = time.perf_counter()
+    # ---- FRI --------------------------------------------------------------------------------------------------------------------
+    alpha = np.array(challenger.get_extension_challenge(), dtype=np.uint64)
+    # the quotient's rows of this shard (leaf order) out of the replicated batch
+    qpack = torch.empty((world, n_quot, Nl), dtype=torch.int64, device=dev)
+    ctx.check(lib.zk_shard_pack_leaf_rows(ctx.handle, C.c_void_p(quotient.lde_device_ptr()), N, n_quot, log_N, lw, C.c_void_p(qpack.data_ptr())))
+    q_rows = qpack[rank].contiguous()
+    hq = C.c_void_p()
+    ctx.check(lib.zk_batch_from_parts(ctx.handle, C.byref(cfg), n_quot, log_n, None, C.c_void_p(q_rows.data_ptr()), None,
+                                      np.ascontiguousarray(quotient_cap, dtype=np.uint64).ctypes.data, lw, rank, C.byref(hq)))
+    arr, keep = instance.to_c()
+    shard_oracles = [trace.row_batch] + ([aux.row_batch] if aux is not None else []) + [hq]
+    comb = torch.empty((2, Nl), dtype=torch.int64, device=dev)
+    opn = np.ascontiguousarray(openings, dtype=np.uint64)
+    ctx.check(lib.zk_fri_combine_sharded(ctx.handle, C.byref(cfg), (C.c_void_p * len(shard_oracles))(*shard_oracles), len(shard_oracles),
+                                         arr, len(instance.batches), opn.ctypes.data, alpha.ctypes.data, C.c_void_p(comb.data_ptr())))
+    lib.zk_batch_free(hq)
+    vals = _leaf_to_natural(torch.cat(all_gather_tensor(comb, group), dim=1), log_N)     # (2, N), natural order
+    layout_oracles = [trace.row_batch] + ([aux.row_batch] if aux is not None else []) + [quotient.handle]
+    ocols = np.array([C_tr] + ([n_aux] if aux is not None else []) + [n_quot], dtype=np.uint64)
+    nw = int(lib.zk_fri_proof_words(C.byref(cfg), log_n, ocols.ctypes.data, len(ocols)))
+    if nw == 0:
+        raise ZkStarkError(-1, "unsupported FRI configuration")
+    proof = np.zeros(nw, dtype=np.uint64)
+    xs = np.zeros(fri.num_query_rounds, dtype=np.uint64)
+    ctx.check(lib.zk_fri_prove_from_values(ctx.handle, C.byref(cfg), (C.c_void_p * len(layout_oracles))(*layout_oracles), len(layout_oracles),
+                                           arr, len(instance.batches), C.c_void_p(vals.data_ptr()), challenger.handle,
+                                           proof.ctypes.data, xs.ctypes.data))
+    # ---- the initial-tree openings of every query from the rank that owns its leaf ---------------------------------------------
+    R, cap_len, Q, K, F = (int(x) for x in proof[:5])
+    off_queries = 6 + R + K + R * cap_len * 4 + 2 * F + 1
+    query_words = (nw - off_queries) // Q if Q else 0
+    n_shard = len(ocols) - 1                                           # trace (+ aux): the quotient is whole on every rank
+    per_oracle = [int(c) + 4 * (log_N - fri.cap_height) for c in ocols]
+    mine = []
+    for q in range(Q):
+        if int(xs[q]) >> (log_N - lw) == rank:
+            base = off_queries + q * query_words
+            mine.append(np.concatenate([np.array([q], dtype=np.uint64), proof[base: base + sum(per_oracle[:n_shard])]]))
+    payload = np.concatenate(mine) if mine else np.zeros(0, dtype=np.uint64)
+    parts = gather_varlen_words(payload, dst=0, group=group)
+    trace_cap, aux_cap = trace.cap, (aux.cap if aux is not None else None)
+    trace.free()
+    if aux is not None:
+        aux.free()
+    quotient.free()
+    if timing is not None:
+        t_end = time.perf_counter()
+        timing.update({"commitments (trace + auxiliary)": t_commit - t_start, "quotient": t_quot - t_commit,
+                       "openings": t_open - t_quot, "FRI": t_end - t_open, "ranks": world, "rows per rank": Nl})
+    if rank != 0:
+        return None
+    rec = 1 + sum(per_oracle[:n_shard])
+    for part in parts:
+        for k in range(0, part.size, rec):
+            q = int(part[k])
+            base = off_queries + q * query_words
+            proof[base: base + rec - 1] = part[k + 1: k + rec]
+    return StarkProof(trace_cap=np.asarray(trace_cap, dtype=np.uint64), auxiliary_polys_cap=None if aux_cap is None else np.asarray(aux_cap, dtype=np.uint64),
+                      quotient_polys_cap=np.asarray(quotient_cap, dtype=np.uint64), openings=openings, opening_proof=proof,
+                      init_challenger_state=init_state, num_ctl_zs=n_z, degree_bits=log_n)
