@@ -90,7 +90,8 @@ def parse():
 # ------------------------------------------------------------------------------------------------------------------------
 # secondaries: one child process each (tools/bench_secondary.py), a limit each, one budget for all of them
 SECONDARY_LIMITS_S = {"commit_config1": 120, "in_flight": 240, "h2d": 240, "realistic": 300, "block_replay": 300,
-                      "from_logs": 180, "plonk_recursion": 300, "cpu_baseline": 420}
+                      "from_logs": 180, "plonk_recursion": 300, "cpu_baseline": 420, "cpu_segment": 1500}
+EXPLICIT_ONLY = {"cpu_segment"}          # minutes of CPU time: only when named in --secondary
 
 
 def run_secondary(name, a, device, deadline, extra=()):
@@ -399,7 +400,7 @@ def main():
     ctx = zk_evm_amd.Context(local)
     ctx.use_torch_current_stream()
     hname = "poseidon" if a.hasher == 0 else "keccak25"
-    wanted = set(SECONDARY_LIMITS_S) if a.secondary == "all" else {s for s in a.secondary.split(",") if s}
+    wanted = (set(SECONDARY_LIMITS_S) - EXPLICIT_ONLY) if a.secondary == "all" else {s for s in a.secondary.split(",") if s}
     unknown = wanted - set(SECONDARY_LIMITS_S)
     assert not unknown, "unknown secondaries: %s" % sorted(unknown)
 
@@ -624,6 +625,8 @@ def main():
                                       traffic_source="FETCH_SIZE x2 + WRITE_SIZE of every NTT kernel launch of one segment, "
                                                      "this run; the time is the un-profiled timed region's")
                     out["ntt"]["frac_of_hbm_peak_on_traffic"] = out["ntt"]["achieved_GBs_on_traffic"] / HBM_PEAK_GBS
+        if rank == 0 and world == 1 and "cpu_segment" in wanted and a.secondary != "all":
+            secondaries.append(("cpu_segment", []))
         if rank == 0 and not a.no_cpu_baseline and world == 1:
             secondaries.insert(0, ("cpu_baseline", []))      # the contract's field first: it must never lose its time to the others
     # ---- every rank's own time (a straggler shows), the process-group record, the product collectives' self-test ----------

@@ -27,6 +27,10 @@ void orc_gl2_inv(const uint64_t a[2], uint64_t out[2]);
 
 /* hashes */
 void orc_poseidon_permute(uint64_t st[12]);
+/* the same permutation, blocked schedule + lazy arithmetic (poseidon_fast.c); orc_poseidon_use_fast: which one the hashes use */
+void orc_poseidon_permute_fast(uint64_t st[12]);
+void orc_poseidon_use_fast(int on);
+double orc_poseidon_perms_per_second(int fast, size_t n);
 void orc_poseidon_hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4]);
 void orc_poseidon_hash_or_noop(const uint64_t *in, size_t n, uint64_t out[4]);
 void orc_poseidon_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t out[4]);

@@ -16,6 +16,7 @@
 #include "goldilocks.h"
 #include "../include/poseidon_constants.h"
 #include "oracle.h"
+#include <stdlib.h>
 #include <string.h>
 
 static const uint64_t RC[ZK_POSEIDON_ROUNDS * ZK_POSEIDON_WIDTH] = ZK_POSEIDON_RC_INIT;
@@ -64,13 +65,24 @@ void orc_poseidon_permute(uint64_t st[12]) {
     }
 }
 
+/* Which evaluation of the permutation the sponge / compression functions below use: the blocked one of
+ * poseidon_fast.c (default; it checks itself against `orc_poseidon_permute` at first use) or the plain one above
+ * (ORACLE_PLAIN_POSEIDON=1 in the environment, or orc_poseidon_use_fast(0)).  Same outputs either way. */
+static int use_fast = -1;
+void orc_poseidon_use_fast(int on) { use_fast = on ? 1 : 0; }
+static inline void permute(uint64_t st[12]) {
+    if (use_fast < 0) { const char *e = getenv("ORACLE_PLAIN_POSEIDON"); use_fast = !(e && e[0] == '1'); }
+    if (use_fast) orc_poseidon_permute_fast(st);
+    else orc_poseidon_permute(st);
+}
+
 /* [EXT] hashing.rs `hash_n_to_m_no_pad` with m = 4. */
 void orc_poseidon_hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4]) {
     uint64_t st[12] = {0};
     for (size_t off = 0; off < n; off += 8) {
         size_t len = n - off < 8 ? n - off : 8;
         for (size_t i = 0; i < len; ++i) st[i] = gl_canon(in[off + i]);
-        orc_poseidon_permute(st);
+        permute(st);
     }
     /* n == 0: no permutation at all, output = zeros (matches upstream loop structure). */
     memcpy(out, st, 4 * sizeof(uint64_t));
@@ -90,6 +102,6 @@ void orc_poseidon_two_to_one(const uint64_t l[4], const uint64_t r[4], uint64_t 
     uint64_t st[12] = {0};
     memcpy(st, l, 32);
     memcpy(st + 4, r, 32);
-    orc_poseidon_permute(st);
+    permute(st);
     memcpy(out, st, 32);
 }

@@ -31,6 +31,10 @@ class Oracle:
         L.orc_gl2_mul.argtypes = [u64p, u64p, u64p]
         L.orc_gl2_inv.argtypes = [u64p, u64p]
         L.orc_poseidon_permute.argtypes = [u64p]
+        L.orc_poseidon_permute_fast.argtypes = [u64p]
+        L.orc_poseidon_use_fast.argtypes = [C.c_int]
+        L.orc_poseidon_perms_per_second.restype = C.c_double
+        L.orc_poseidon_perms_per_second.argtypes = [C.c_int, C.c_size_t]
         L.orc_poseidon_hash_no_pad.argtypes = [u64p, C.c_size_t, u64p]
         L.orc_poseidon_hash_or_noop.argtypes = [u64p, C.c_size_t, u64p]
         L.orc_poseidon_two_to_one.argtypes = [u64p, u64p, u64p]

@@ -74,3 +74,25 @@ def test_shim_abort_and_public_values_use_what_exists():
     # hunk header of the new file matches its body
     m = re.search(r"\+\+\+ b/evm_arithmetization/src/hip\.rs.*?\n@@ -0,0 \+1,(\d+) @@\n((?:\+.*\n)+)", p)
     assert int(m.group(1)) == len(m.group(2).splitlines())
+
+
+def test_patch_uses_only_upstream_items_of_the_table():
+    """rust/upstream_api.json (tools/rust_api_table.py) lists every plonky2 / starky item the
+    reference-side patch relies on with the in-tree use that corroborates it.  An import or a TimingTree method the table does
+    not know is how `pop_with_duration_ms` and a wrong module path got into r03: fail here instead."""
+    import json
+    rows = json.load(open(os.path.join(ROOT, "rust", "upstream_api.json")))
+    known = {r["item"] for r in rows}
+    p = open(os.path.join(ROOT, "rust", "evm_arithmetization_hip.patch")).read()
+    for ln in p.splitlines():
+        m = re.match(r"\+use ((?:plonky2|starky)(?:::\w+)*)::(\{[^}]*\}|\w+);", ln.strip())
+        if m:
+            items = m.group(2).strip("{}").split(",") if m.group(2).startswith("{") else [m.group(2)]
+            for it in items:
+                assert "%s::%s" % (m.group(1), it.strip()) in known, ln
+    methods = set(re.findall(r"\btiming\.(\w+)\(", "\n".join(ln for ln in p.splitlines() if ln.startswith("+"))))
+    assert methods <= {"push", "pop"}, methods
+    assert {"TimingTree::push", "TimingTree::pop"} <= known
+    # every row says where it was corroborated, or admits that it was not
+    assert all(r["status"] in ("corroborated", "recalled") and (r["in_tree"] or r["status"] == "recalled") for r in rows)
+    assert "plonky2::hash::hashing::PlonkyPermutation" in known and not any("plonk_common::PlonkyPermutation" in k for k in known)
