@@ -588,6 +588,10 @@ void zk_memory_gen_free(zk_memory_gen *gen);
  *   row shard (shard_log_w > 0): d_rows = [n_cols][Nl] leaf-ordered rows, d_digests = the levels of this rank's subtrees
  *   (zk_hash_rows + zk_merkle_build with cap_height - shard_log_w), cap = the whole tree's cap (host, 2^cap_height x 4).
  * zk_gl_add_scalar_columns: column c += add[c]: the carry of a running sum (CTL Z column) computed per row block. */
+/* zk_shard_values_to_lde: the NTT half of `from_values` on this rank's columns: d_values [n_cols][n] -> d_coeffs [n_cols][n]
+ *   (bit-reversed coefficient order, as every zk_batch keeps them) and d_lde [n_cols][n << rate_bits] (natural order). */
+int zk_shard_values_to_lde(zk_ctx *ctx, const uint64_t *d_values, size_t n_cols, unsigned log_n, unsigned rate_bits,
+                           uint64_t *d_coeffs, uint64_t *d_lde);
 int zk_shard_pack_leaf_rows(zk_ctx *ctx, const uint64_t *d_lde, size_t col_stride, size_t n_cols, unsigned log_lde,
                             unsigned shard_log_w, uint64_t *d_out);
 int zk_batch_from_parts(zk_ctx *ctx, const zk_cfg *cfg, size_t n_cols, unsigned log_n, const uint64_t *d_coeffs,

@@ -258,17 +258,21 @@ def realistic_profile(ctx, dev, a, all_stark, cfg, steps=4, in_flight=3):
     peak = ctx.mem_stats()["peak_in_use"]
     out = {"log_ns": log_ns, "steps": steps, "single": {"value": 1.0 / single, "unit": "segment proofs/s", "ms_per_proof": 1e3 * single},
            "trace_GB": 8.0 * sum(c << l for c, l in zip(all_stark.table_columns, log_ns)) / 1e9}
-    try:
-        with SegmentScheduler(all_stark, cfg, [ctx.device], in_flight) as sch:
-            mk = lambda: SegmentJob(lambda d: traces, in_use, pv())
-            sch.map([mk() for _ in range(2 * in_flight)])                # warm-up: every worker grows its arena
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            sch.map([mk() for _ in range(steps * in_flight)])
-            el = time.perf_counter() - t0
-        out["in_flight"] = {"workers_per_gpu": in_flight, "value": steps * in_flight / el, "unit": "segment proofs/s"}
-    except Exception as e:
-        out["in_flight"] = {"error": repr(e)}
+    tried = []
+    for w in (in_flight, in_flight + 2):              # the chain of a realistic-height proof is latency-bound: more resident segments fill it
+        try:
+            with SegmentScheduler(all_stark, cfg, [ctx.device], w) as sch:
+                mk = lambda: SegmentJob(lambda d: traces, in_use, pv())
+                sch.map([mk() for _ in range(2 * w)])                # warm-up: every worker grows its arena
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                sch.map([mk() for _ in range(steps * w)])
+                el = time.perf_counter() - t0
+            tried.append({"workers_per_gpu": w, "value": steps * w / el, "unit": "segment proofs/s"})
+        except Exception as e:
+            tried.append({"workers_per_gpu": w, "error": repr(e)})
+    ok = [t for t in tried if "value" in t]
+    out["in_flight"] = dict(max(ok, key=lambda t: t["value"]), tried=tried) if ok else tried[0]
     # ---- one segment carried through its recursion layer (fixed_recursive_verifier.rs:2053-2160, 3167-3179) -----------------
     # prove_segment = the STARK, then per table a StarkWrapperCircuit proof and its shrink() chain down to 2^13 rows, then the
     # root circuit.  Modelled as 35 PLONK proofs: per table one wrapper proof at 2^14 rows and two shrinking proofs at 2^13

@@ -96,6 +96,7 @@ SIGNATURES = {
                                           ui, C.c_int, vp, vp, C.POINTER(vp)]),
     "zk_table_aux_commit": (C.c_int, [vp, C.POINTER(ZkCfg), u64p, sz, sz, ui, u64p, sz, u64p, sz, u64p, sz, u64p, ui,
                                       C.POINTER(vp)]),
+    "zk_shard_values_to_lde": (C.c_int, [vp, u64p, sz, ui, ui, u64p, u64p]),
     "zk_shard_pack_leaf_rows": (C.c_int, [vp, u64p, sz, sz, ui, ui, u64p]),
     "zk_batch_from_parts": (C.c_int, [vp, C.POINTER(ZkCfg), sz, ui, u64p, u64p, u64p, u64p, ui, ui, C.POINTER(vp)]),
     "zk_gl_add_scalar_columns": (C.c_int, [vp, u64p, sz, sz, sz, u64p]),

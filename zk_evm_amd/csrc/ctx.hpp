@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -76,6 +77,9 @@ struct zk_ctx {
     std::vector<StageReadback> stage_pending;   // stage_download results not yet copied to their destinations
     char *h_big = nullptr;                      // pinned landing buffer for the large downloads (FRI query words)
     size_t h_big_bytes = 0;
+    int *h_flags = nullptr;                     // pinned: the quotient kernels' deferred error flag (quotient_host.inc)
+    volatile uint64_t *h_seq = nullptr;         // coherent pinned word the GPU bumps at a read-back point (zk_stream_wait)
+    uint64_t seq_next = 0;
     std::map<std::pair<u64, u64>, std::shared_ptr<void>> entry_shapes;
     // device-resident copies of per-table-definition constants (programs, compiled shapes, AIR constants): const_upload
     struct DevConst { std::vector<u64> words; u64 *d = nullptr; };
@@ -101,6 +105,7 @@ struct zk_batch {
     // i.e. LEAF order -- and in d_digests the levels of that subtree down to its 2^(cap_height - shard_lw) roots; `cap` is
     // the whole tree's cap (all-gathered by the caller).
     bool borrowed = false;
+    bool row_shard = false;             // d_lde holds leaf-ordered rows of one shard (also with ONE rank: shard_lw = 0)
     unsigned shard_lw = 0, shard_rank = 0;
 };
 
@@ -279,6 +284,39 @@ static hipError_t stage_download(zk_ctx *ctx, void *h_dst, const void *d_src, si
     if (!h) return e;
     ctx->stage_pending.push_back({h, h_dst, bytes});
     return copy_to_pinned(ctx, h, d_src, bytes);
+}
+// Wait for everything enqueued on `st` so far -- the Fiat-Shamir read-backs (a cap, an opening set, a PoW answer: ~100 per
+// realistic-height segment).  hipStreamSynchronize costs the calling thread 20-40 us on this runtime beyond the GPU's own
+// time; instead a one-lane kernel behind the copies writes the next sequence number into a coherent pinned word and the
+// host spins on it (stream order: it runs after the copy kernels, whose stores went to the same kind of memory).  Falls back
+// to hipStreamSynchronize when the word cannot be allocated, when ZK_SYNC_POLL=0, or after ~2 s without progress (then the
+// synchronisation reports whatever went wrong).
+static __global__ void zk_signal_kernel(volatile uint64_t *seq, uint64_t value) {
+    __threadfence_system();
+    *seq = value;
+}
+static const bool kSyncPoll = !(getenv("ZK_SYNC_POLL") && getenv("ZK_SYNC_POLL")[0] == 0x30);
+static hipError_t zk_stream_wait(zk_ctx *ctx, hipStream_t st) {
+    if (!kSyncPoll) return hipStreamSynchronize(st);
+    if (!ctx->h_seq) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocCoherent) != hipSuccess) { (void)hipGetLastError(); return hipStreamSynchronize(st); }
+        ctx->h_seq = (volatile uint64_t *)p;
+        *ctx->h_seq = 0;
+    }
+    const uint64_t want = ++ctx->seq_next;
+    zk_signal_kernel<<<1, 1, 0, st>>>(ctx->h_seq, want);
+    if (hipGetLastError() != hipSuccess) return hipStreamSynchronize(st);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0; *ctx->h_seq < want; ++spins) {
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+        if ((spins & 0xFFFF) == 0xFFFF && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2))
+            return hipStreamSynchronize(st);              // a fault or a very long kernel: let the runtime say which
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return hipSuccess;
 }
 static inline void stage_collect(zk_ctx *ctx) {
     for (auto &r : ctx->stage_pending) memcpy(r.h_dst, r.h_pinned, r.bytes);

@@ -284,7 +284,7 @@ struct FriCombineArgs {
     size_t g_stride;
     // MODE 0 over ONE ROW SHARD (SURVEY 8(e) level 3): the columns hold the shard's rows in leaf order, thread j = leaf
     // shard_rank * n_rows + j, whose point is the natural index bitrev(that); shard_lw = 0: the whole domain, natural order
-    u32 shard_lw, shard_rank;
+    u32 sharded, shard_lw, shard_rank;
 };
 
 // The column pointers come out of a device array, so the compiler knows nothing about their address space and would emit
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(256) fri_combine_kernel(FriCombineArgs A) {
         }
     }
     const u32 half = 1u << (A.log_N - 1);
-    const u32 jx = (MODE == 0 && A.shard_lw) ? bitrev32((A.shard_rank << (A.log_N - A.shard_lw)) + j, A.log_N) : j;
+    const u32 jx = (MODE == 0 && A.sharded) ? bitrev32((A.shard_rank << (A.log_N - A.shard_lw)) + j, A.log_N) : j;
     u64 w = A.tw[jx & (half - 1)];
     if (jx & half) w = gl_neg(w);
     const u64 x = gl_mul(w, A.coset_shift);

@@ -47,6 +47,11 @@ struct NttPass {
     int last_pass;       // the values leave the transform: store canonical representatives
     int nt;              // stream the tile data with non-temporal loads / stores (the twiddle levels keep the L2)
     int cols_fastest;    // grid = (columns, tiles): consecutive workgroups run the SAME tile of different columns (ntt_host.inc)
+    // Phase stagger (ntt_host.inc kNttStagger*): the workgroups that share a CU start together and would stay in lock step --
+    // all loading, then all in their butterflies, then all storing -- so the memory phases (HBM at 5 TB/s, VALU idle) and the
+    // compute phases (HBM idle) never overlap.  The first-resident workgroups selected by stagger_mode wait stagger_ticks
+    // (100 MHz wall clock) before their load; every later workgroup inherits the phase of the slot it takes over.
+    u32 stagger_ticks, stagger_mode, stagger_blocks;
 };
 
 // One radix-2 butterfly (a, b) -> (a + w b, a - w b).  BOTH directions use this Cooley-Tukey form: the canonical product
@@ -70,6 +75,14 @@ __device__ __forceinline__ void ntt_bfly(u64 &a, u64 &b, u64 w) {
 // consecutive lanes (64-byte stride: eight lanes per bank pair), q = 8 two lanes per bank pair; with one pad word per
 // eight the same steps touch every bank once per quarter wave.  (PMC r03n: 48 % of the LDS-active cycles were bank conflicts,
 // and since the shorter field multiply the kernel no longer hides them under VALU issue.)
+#ifdef ZK_NTT_DEBUG          // tools/kbench only (WRONG results): time the phases of a pass in isolation
+#define ZK_NTT_DBG(bit) (p.nt & (bit))
+#else
+#define ZK_NTT_DBG(bit) 0
+#endif
+#ifndef ZK_NTT_LOADS_IN_FLIGHT
+#define ZK_NTT_LOADS_IN_FLIGHT 8      // = tile elements per lane with the default plan (ntt_host.inc kThreadsShift = 3)
+#endif
 template <bool PAD>
 __device__ __forceinline__ u32 ntt_ph(u32 i) { return PAD ? i + (i >> 3) : i; }
 
@@ -161,6 +174,18 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
     }
 }
 
+__device__ __forceinline__ void ntt_stagger(const NttPass &p) {
+    if (p.stagger_ticks == 0) return;
+    const u32 lin = blockIdx.x + gridDim.x * blockIdx.y;
+    if (lin >= p.stagger_blocks) return;
+    // mode 1: every other workgroup of the first wave; mode 2: its second half (which of the two shares CUs depends on how the
+    // dispatcher fills them: measured, ntt_host.inc)
+    const bool late = p.stagger_mode == 1 ? (lin & 1) : lin >= (p.stagger_blocks >> 1);
+    if (!late) return;
+    const u64 t0 = wall_clock64();
+    while (wall_clock64() - t0 < p.stagger_ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 // DIT = false: stages from the largest distance down (values, natural -> coefficients, bit-reversed).
 // DIT = true : stages from the smallest distance up (coefficients, bit-reversed -> values, natural).
 template <bool DIT, bool PAD = false>
@@ -178,30 +203,61 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
     const u64 *src = p.src + (size_t)col_id * p.src_stride;
     u64 *dst = p.dst + (size_t)col_id * p.dst_stride;
     const u32 elems = 1u << (r + log_t);
+    ntt_stagger(p);
 
     // ---- load (global index x = base + t*d + u  ->  lds[t*T + u]) ----
-    if (p.log_rep) {
+    // ZK_NTT_LOADS_IN_FLIGHT loads per lane are issued before the first is consumed.  (Until r04 this was a rolled loop --
+    // address, global_load, s_waitcnt vmcnt(0), ds_write, next -- i.e. elems / threads = 8 SERIAL HBM round trips per tile and
+    // lane: the "load phase" cost more wall time than the butterflies, and only the other resident workgroup hid part of it:
+    // PMC r03x had the kernel at 0.75 of the VALU issue rate and 5.3 cycles per instruction.)
+    if (ZK_NTT_DBG(8)) {
+    } else if (p.log_rep) {
         // lde's first pass (always the contiguous one, log_d = 0): every coefficient is read and scaled ONCE and written
         // to its 2^log_rep replicas in the tile (the stages that would have produced them are skipped)
-        const u32 sbase = base >> p.log_rep, rep = 1u << p.log_rep;
-        for (u32 se = tid; se < (elems >> p.log_rep); se += nthr) {
-            u64 v = p.nt ? __builtin_nontemporal_load(src + sbase + se) : src[sbase + se];
-            if (p.in_scale) v = gl_mul(v, p.in_scale[sbase + se]);
-            for (u32 k = 0; k < rep; ++k) tile[ntt_ph<PAD>((se << p.log_rep) + k)] = v;
+        const u32 sbase = base >> p.log_rep, rep = 1u << p.log_rep, n_src = elems >> p.log_rep;
+        for (u32 s0 = tid; s0 < n_src; s0 += nthr * ZK_NTT_LOADS_IN_FLIGHT) {
+            u64 v[ZK_NTT_LOADS_IN_FLIGHT], sc[ZK_NTT_LOADS_IN_FLIGHT];
+#pragma unroll
+            for (int k = 0; k < ZK_NTT_LOADS_IN_FLIGHT; ++k) {
+                const u32 se = s0 + (u32)k * nthr;
+                if (se < n_src) {
+                    v[k] = (p.nt & 1) ? __builtin_nontemporal_load(src + sbase + se) : src[sbase + se];
+                    if (p.in_scale) sc[k] = p.in_scale[sbase + se];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < ZK_NTT_LOADS_IN_FLIGHT; ++k) {
+                const u32 se = s0 + (u32)k * nthr;
+                if (se < n_src) {
+                    const u64 w = p.in_scale ? gl_mul(v[k], sc[k]) : v[k];
+                    for (u32 j = 0; j < rep; ++j) tile[ntt_ph<PAD>((se << p.log_rep) + j)] = w;
+                }
+            }
         }
     } else {
-        for (u32 e = tid; e < elems; e += nthr) {
-            u32 t = e >> log_t, u = e & (T - 1);
-            u32 x = base + (t << p.log_d) + u;
-            u64 v = p.nt ? __builtin_nontemporal_load(src + x) : src[x];
-            if (p.in_scale) v = gl_mul(v, p.in_scale[x]);
-            tile[ntt_ph<PAD>(e)] = v;
+        for (u32 e0 = tid; e0 < elems; e0 += nthr * ZK_NTT_LOADS_IN_FLIGHT) {
+            u64 v[ZK_NTT_LOADS_IN_FLIGHT], sc[ZK_NTT_LOADS_IN_FLIGHT];
+#pragma unroll
+            for (int k = 0; k < ZK_NTT_LOADS_IN_FLIGHT; ++k) {
+                const u32 e = e0 + (u32)k * nthr;
+                if (e < elems) {
+                    const u32 t = e >> log_t, u = e & (T - 1);
+                    const u32 x = base + (t << p.log_d) + u;
+                    v[k] = (p.nt & 1) ? __builtin_nontemporal_load(src + x) : src[x];
+                    if (p.in_scale) sc[k] = p.in_scale[x];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < ZK_NTT_LOADS_IN_FLIGHT; ++k) {
+                const u32 e = e0 + (u32)k * nthr;
+                if (e < elems) tile[ntt_ph<PAD>(e)] = p.in_scale ? gl_mul(v[k], sc[k]) : v[k];
+            }
         }
     }
     __syncthreads();
 
     // ---- stages first_stage .. r-1 in radix-2^k register steps ----
-    int done = p.first_stage;
+    int done = ZK_NTT_DBG(2) ? r : p.first_stage;       // (kbench -DZK_NTT_DEBUG, nt & 2: no butterflies -- the memory phases alone)
     while (done < r) {
         const int k = r - done < 3 ? r - done : 3;
         const int log_q = DIT ? done : (r - done - k);
@@ -212,16 +268,32 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
         done += k;
     }
 
-    // ---- store ----
-    for (u32 e = tid; e < elems; e += nthr) {
-        u32 t = e >> log_t, u = e & (T - 1);
-        u32 x = base + (t << p.log_d) + u;
-        u64 v = tile[ntt_ph<PAD>(e)];
-        if (p.out_scale) v = gl_mul_canon(v, p.out_scale[x]);
-        else if (p.apply_out_const) v = gl_mul_canon(v, p.out_const);
-        else if (p.last_pass) v = gl_canon(v);          // between passes any u64 representative will do
-        if (p.nt) __builtin_nontemporal_store(v, dst + x);
-        else dst[x] = v;
+    if (ZK_NTT_DBG(4)) return;                          // (nt & 4: no stores; nt & 8: no loads -- the butterflies alone)
+    // ---- store ---- (the LDS reads of ZK_NTT_LOADS_IN_FLIGHT elements issued together; stores do not wait)
+    for (u32 e0 = tid; e0 < elems; e0 += nthr * ZK_NTT_LOADS_IN_FLIGHT) {
+        u64 v[ZK_NTT_LOADS_IN_FLIGHT], sc[ZK_NTT_LOADS_IN_FLIGHT];
+#pragma unroll
+        for (int k = 0; k < ZK_NTT_LOADS_IN_FLIGHT; ++k) {
+            const u32 e = e0 + (u32)k * nthr;
+            if (e < elems) {
+                v[k] = tile[ntt_ph<PAD>(e)];
+                if (p.out_scale) { const u32 t = e >> log_t, u = e & (T - 1); sc[k] = p.out_scale[base + (t << p.log_d) + u]; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ZK_NTT_LOADS_IN_FLIGHT; ++k) {
+            const u32 e = e0 + (u32)k * nthr;
+            if (e < elems) {
+                const u32 t = e >> log_t, u = e & (T - 1);
+                const u32 x = base + (t << p.log_d) + u;
+                u64 w = v[k];
+                if (p.out_scale) w = gl_mul_canon(w, sc[k]);
+                else if (p.apply_out_const) w = gl_mul_canon(w, p.out_const);
+                else if (p.last_pass) w = gl_canon(w);          // between passes any u64 representative will do
+                if (p.nt & 1) __builtin_nontemporal_store(w, dst + x);
+                else dst[x] = w;
+            }
+        }
     }
 }
 
@@ -262,7 +334,13 @@ static __global__ void __launch_bounds__(1024) ntt_fused_kernel(NttPass pd, NttP
     u64 *coeffs = pd.dst + (size_t)col_id * pd.dst_stride;
     u64 *dst = pt.dst + (size_t)col_id * pt.dst_stride;
 
-    for (u32 e = tid; e < elems_c; e += nthr) tile[e] = src[base_c + e];
+    for (u32 e0 = tid; e0 < elems_c; e0 += nthr * ZK_NTT_LOADS_IN_FLIGHT) {        // all of a lane's loads in flight at once
+        u64 v[ZK_NTT_LOADS_IN_FLIGHT];
+#pragma unroll
+        for (int k = 0; k < ZK_NTT_LOADS_IN_FLIGHT; ++k) { const u32 e = e0 + (u32)k * nthr; if (e < elems_c) v[k] = src[base_c + e]; }
+#pragma unroll
+        for (int k = 0; k < ZK_NTT_LOADS_IN_FLIGHT; ++k) { const u32 e = e0 + (u32)k * nthr; if (e < elems_c) tile[e] = v[k]; }
+    }
     __syncthreads();
     ntt_tile_stages<false, false>(tile, pd, base_c, elems_c, tid, nthr);      // values -> coefficients, stages c-1 .. 0
 
@@ -272,10 +350,15 @@ static __global__ void __launch_bounds__(1024) ntt_fused_kernel(NttPass pd, NttP
 #pragma unroll
     for (int k = 0; k < ZK_NTT_FUSED_MAX_PER_THREAD; ++k) {
         const u32 e = tid + (u32)k * nthr;
+        if (e < elems_c) keep[k] = pt.in_scale ? pt.in_scale[base_c + e] : 1;      // the coset factors: loads in flight first
+    }
+#pragma unroll
+    for (int k = 0; k < ZK_NTT_FUSED_MAX_PER_THREAD; ++k) {
+        const u32 e = tid + (u32)k * nthr;
         if (e < elems_c) {
             const u64 cf = gl_mul_canon(tile[e], pd.out_const);
             coeffs[base_c + e] = cf;
-            keep[k] = pt.in_scale ? gl_mul(cf, pt.in_scale[base_c + e]) : cf;
+            keep[k] = pt.in_scale ? gl_mul(cf, keep[k]) : cf;
         }
     }
     __syncthreads();
@@ -288,10 +371,15 @@ static __global__ void __launch_bounds__(1024) ntt_fused_kernel(NttPass pd, NttP
     __syncthreads();
     ntt_tile_stages<true, false>(tile, pt, base_v, elems_v, tid, nthr);      // coefficients -> values, stages rate .. c+rate-1
 
-    for (u32 e = tid; e < elems_v; e += nthr) {
-        u64 v = tile[e];
-        if (pt.last_pass) v = gl_canon(v);
-        dst[base_v + e] = v;
+    for (u32 e0 = tid; e0 < elems_v; e0 += nthr * ZK_NTT_LOADS_IN_FLIGHT) {
+        u64 v[ZK_NTT_LOADS_IN_FLIGHT];
+#pragma unroll
+        for (int k = 0; k < ZK_NTT_LOADS_IN_FLIGHT; ++k) { const u32 e = e0 + (u32)k * nthr; if (e < elems_v) v[k] = tile[e]; }
+#pragma unroll
+        for (int k = 0; k < ZK_NTT_LOADS_IN_FLIGHT; ++k) {
+            const u32 e = e0 + (u32)k * nthr;
+            if (e < elems_v) dst[base_v + e] = pt.last_pass ? gl_canon(v[k]) : v[k];
+        }
     }
 }
 

@@ -241,6 +241,7 @@ struct QuotientArgs {
     // caller has fetched into trace_next / aux_next (the same pointers when that rank is this one).  shard_lw = 0: the whole
     // coset, natural order, n_points = size.
     u32 n_points;
+    u32 sharded;          // 1: the row-shard maps below (also with ONE rank, shard_lw = 0: leaf order, next rows in trace_next = trace)
     u32 shard_lw, shard_rank;
     const u64 *trace_next, *aux_next;
 };
@@ -248,7 +249,7 @@ struct QuotientArgs {
 struct QuotientRows { u32 point, row, row_next; };
 __device__ __forceinline__ QuotientRows quotient_rows(const QuotientArgs &A, u32 t, u32 size) {
     QuotientRows r;
-    if (A.shard_lw == 0) {
+    if (!A.sharded) {
         r.point = t;
         r.row = t << A.step_log;
         r.row_next = ((t + (1u << A.qd_bits)) & (size - 1)) << A.step_log;
@@ -269,15 +270,15 @@ __device__ __forceinline__ QuotientRows quotient_rows(const QuotientArgs &A, u32
 template <class Air, class CONS>
 __device__ __forceinline__ void air_constraints(const QuotientArgs &A, u32 t, u32 size, CONS &cons) {
     const QuotientRows q = quotient_rows(A, t, size);
-    RowView lv{A.trace, A.trace_stride, q.row}, nv{A.shard_lw ? A.trace_next : A.trace, A.trace_stride, q.row_next};
+    RowView lv{A.trace, A.trace_stride, q.row}, nv{A.sharded ? A.trace_next : A.trace, A.trace_stride, q.row_next};
     Air::eval(lv, nv, cons, A.air_consts);
 }
 template <class CONS>
 __device__ __forceinline__ void check_constraints(const QuotientArgs &A, u32 t, u32 size, CONS &cons) {
     const QuotientRows q = quotient_rows(A, t, size);
     const u32 row = q.row, row_next = q.row_next;
-    RowView lv{A.trace, A.trace_stride, row}, nv{A.shard_lw ? A.trace_next : A.trace, A.trace_stride, row_next};
-    RowView alv{A.aux, A.aux_stride, row}, anv{A.shard_lw ? A.aux_next : A.aux, A.aux_stride, row_next};
+    RowView lv{A.trace, A.trace_stride, row}, nv{A.sharded ? A.trace_next : A.trace, A.trace_stride, row_next};
+    RowView alv{A.aux, A.aux_stride, row}, anv{A.sharded ? A.aux_next : A.aux, A.aux_stride, row_next};
     const u32 chunk = A.constraint_degree - 1;
     auto ld = [&](u32 col, u32 next, u64 &v) { v = (next ? nv : lv)[col].v; return true; };   // `eval_with_next`
     // ---- starky eval_packed_lookups_generic ----

@@ -13,7 +13,7 @@ int zki_quotient_airs_a(zk_ctx *ctx, uint32_t air_id, const QuotientArgs &A, u32
         case ZK_AIR_ARITHMETIC: {
             if (n_trace_cols != AirArithmetic::COLUMNS)
                 return set_err(ctx, ZK_ERR_BAD_ARG, "AIR %u expects %u trace columns, got %zu", air_id, (unsigned)AirArithmetic::COLUMNS, n_trace_cols);
-            if (count || !kArithTiled || A.shard_lw)   // the constraint count, ZK_ARITH_TILED=0, or a row shard (its rows are not
+            if (count || !kArithTiled || A.sharded)   // the constraint count, ZK_ARITH_TILED=0, or a row shard (its rows are not
                                                       // consecutive points): the one-lane-per-point form
                 return launch_quotient_air<AirArithmetic, true>(ctx, A, size, scratch, count);
             static bool attr_set = false;     // (idempotent; a race only repeats the call)

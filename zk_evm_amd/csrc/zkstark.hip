@@ -97,6 +97,8 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     for (auto &e : ctx->ev_pool) if (e) hipEventDestroy(e);
     if (ctx->h_caps) hipHostFree(ctx->h_caps);
     if (ctx->h_big) hipHostFree(ctx->h_big);
+    if (ctx->h_seq) hipHostFree((void *)ctx->h_seq);
+    if (ctx->h_flags) hipHostFree(ctx->h_flags);
     for (auto &kv : ctx->dev_consts) if (kv.second.d) hipFree(kv.second.d);
     for (char *c : ctx->stage_chunks) hipHostFree(c);
     if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
@@ -496,7 +498,7 @@ static int commit_impl(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t i
                        size_t n_cols, unsigned log_n, CommitMode mode, zk_batch **out) {
     PendingCommit pc;
     ZK_TRY(commit_enqueue(ctx, cfg, d_in, in_stride, n_cols, log_n, mode, &pc));
-    hipError_t e = hipStreamSynchronize(pc.stream);
+    hipError_t e = zk_stream_wait(ctx, pc.stream);
     if (e != hipSuccess) {
         pending_release(ctx, pc);
         zk_batch_free(pc.b);

@@ -47,8 +47,10 @@ def _dist(group):
 
 
 def all_to_all(send: List, recv: List, group=None) -> None:
-    """recv[p] <- what rank p holds in its send[this rank].  `dist.all_to_all` on device tensors under nccl (RCCL: every
-    pair of GPUs on its own xGMI link); W scatters of host copies under gloo (the CPU-side tests)."""
+    """recv[p] <- what rank p holds in its send[this rank] (the pieces may differ in size: column counts that W does not
+    divide).  `dist.all_to_all` on device tensors under nccl (RCCL: every pair of GPUs on its own xGMI link); pairwise
+    sends of host copies under gloo (the CPU-side tests)."""
+    import torch
     dist, world, rank = _dist(group)
     if dist is None:
         recv[0].copy_(send[0])
@@ -56,11 +58,16 @@ def all_to_all(send: List, recv: List, group=None) -> None:
     if dist.get_backend(group) == "nccl":
         dist.all_to_all(recv, send, group=group)
         return
-    for p in range(world):
-        out = recv[p].cpu()
-        src = dist.get_global_rank(group, p) if group is not None else p
-        dist.scatter(out, [s.cpu().contiguous() for s in send] if p == rank else None, src=src, group=group)
-        recv[p].copy_(out)
+    g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    recv[rank].copy_(send[rank])
+    host_out = {p: torch.empty(recv[p].shape, dtype=recv[p].dtype) for p in range(world) if p != rank and recv[p].numel()}
+    ops = [dist.P2POp(dist.isend, send[p].cpu().contiguous(), g(p), group) for p in range(world) if p != rank and send[p].numel()]
+    ops += [dist.P2POp(dist.irecv, host_out[p], g(p), group) for p in host_out]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    for p, t in host_out.items():
+        recv[p].copy_(t)
 
 
 def all_gather_tensor(t, group=None) -> List:
@@ -159,17 +166,19 @@ def commit_rows_sharded(block, config, ctx, group=None, timing=None) -> ShardedO
     send = [block[cols[p].start: cols[p].stop] for p in range(world)]
     recv = [torch.empty((k_me, nb), dtype=torch.int64, device=dev) for _ in range(world)]
     all_to_all(send, recv, group)
-    coeffs = torch.stack(recv, dim=1).reshape(k_me, n).contiguous()          # column c = its W row blocks in order
+    values = torch.stack(recv, dim=1).reshape(k_me, n).contiguous()          # column c = its W row blocks in order
     del recv
+    coeffs = torch.empty((k_me, n), dtype=torch.int64, device=dev)            # bit-reversed coefficient order (zk_batch layout)
     packed = torch.empty((world, k_me, Nl), dtype=torch.int64, device=dev)
     if k_me:
         lde = torch.empty((k_me, N), dtype=torch.int64, device=dev)
-        ctx.check(lib.zk_ifft(ctx.handle, C.c_void_p(coeffs.data_ptr()), n, k_me, log_n))
-        ctx.check(lib.zk_lde(ctx.handle, C.c_void_p(coeffs.data_ptr()), n, C.c_void_p(lde.data_ptr()), N, k_me, log_n, fri.rate_bits))
+        ctx.check(lib.zk_shard_values_to_lde(ctx.handle, C.c_void_p(values.data_ptr()), k_me, log_n, fri.rate_bits,
+                                             C.c_void_p(coeffs.data_ptr()), C.c_void_p(lde.data_ptr())))
         # all-to-all #2, send side: every destination's rows in leaf order, one pass over the LDE
         ctx.check(lib.zk_shard_pack_leaf_rows(ctx.handle, C.c_void_p(lde.data_ptr()), N, k_me, log_N, lw, C.c_void_p(packed.data_ptr())))
         torch.cuda.synchronize(dev)
         del lde
+    del values
     t1 = time.perf_counter()
     rows = torch.empty((K, Nl), dtype=torch.int64, device=dev)
     all_to_all([packed[q] for q in range(world)], [rows[cols[p].start: cols[p].stop] for p in range(world)], group)
