@@ -87,7 +87,7 @@ def test_scheduler_two_in_flight_reproduces_direct_proofs(oracle):
         assert np.array_equal(d, words(g))
 
 
-def _tp_worker(rank, world, port, q, backend="gloo"):
+def _tp_worker(rank, world, port, q, backend="gloo", wide=()):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -109,10 +109,16 @@ def _tp_worker(rank, world, port, q, backend="gloo"):
     pv = to_public_values(make_pv(np.random.default_rng(78)))
     in_use = [True, True, True, True, True, True, True, True, False]
     shapes = [(t.shape[0], l) for t, l in zip(host, log_ns)]
-    mine = assign_tables(shapes, world)[rank]
+    solo = [t for t in range(len(host)) if t not in wide]                       # (the library's own assignment: row-sharded tables aside)
+    mine = [solo[k] for k in assign_tables([shapes[t] for t in solo], world)[rank]]
     traces = [to_dev(t) if i in mine else None for i, t in enumerate(host)]     # a rank only holds the tables it owns
     timing = {}
-    proof = prove_segment_table_parallel(st, cfg, traces, in_use, pv, timing=timing)
+    row_sharded = {}
+    for t in wide:                                    # level 3 inside level 2: this table's ROW BLOCK on every rank
+        nb = host[t].shape[1] // world
+        row_sharded[t] = to_dev(np.ascontiguousarray(host[t][:, rank * nb: (rank + 1) * nb]))
+        traces[t] = None
+    proof = prove_segment_table_parallel(st, cfg, traces, in_use, pv, timing=timing, row_sharded=row_sharded)
     extra = None
     if backend == "nccl":
         # the throughput path through the same process group: two segments dealt over the ranks, proofs gathered as words
@@ -169,6 +175,42 @@ def test_table_parallel_segment_equals_single_gpu_proof():
         assert p.exitcode == 0
     assert sorted(res[0][0] + res[1][0]) == list(range(9)) and res[0][0] and res[1][0]
     assert res[1][1] is None and res[0][2] == res[0][0]
+    log_ns = [9, 8, 10, 7, 8, 8, 11, 8, 8]
+    host = make_traces(np.random.default_rng(77), log_ns)
+    pv = to_public_values(make_pv(np.random.default_rng(78)))
+    cfg = zk_evm_amd.StarkConfig(fri_config=zk_evm_amd.FriConfig(num_query_rounds=5, proof_of_work_bits=4))
+    in_use = [True, True, True, True, True, True, True, True, False]
+    direct = sg.prove_with_traces(AllStark((1, 2, 3, 4)), cfg, [to_dev(t) for t in host], in_use, pv)
+    assert np.array_equal(_proof_words(direct), res[0][1])
+
+
+def test_table_parallel_segment_with_row_sharded_keccak_and_logic():
+    """Level 3 inside level 2: the Keccak and Logic tables of the segment are committed AND proven by both ranks together
+    (row shards), the other seven live on one rank each -- rank 0's AllProof still equals zk_prove_segment's word for word."""
+    import socket
+    import torch.multiprocessing as mp
+    import zk_evm_amd
+    import zk_evm_amd.segment as sg
+    from tests.gpu_util import to_dev
+    from tests.test_gpu_segment import make_pv, make_traces, to_public_values
+    from zk_evm_amd.all_stark import AllStark
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tp_worker, args=(r, 2, port, q, "gloo", (3, 5))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in procs:
+        r, mine, words, owned, _ = q.get(timeout=600)
+        res[r] = (mine, words, owned)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[1][1] is None
     log_ns = [9, 8, 10, 7, 8, 8, 11, 8, 8]
     host = make_traces(np.random.default_rng(77), log_ns)
     pv = to_public_values(make_pv(np.random.default_rng(78)))

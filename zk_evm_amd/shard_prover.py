@@ -244,11 +244,12 @@ def table_ctl_specs(all_stark, table: int, ctl_challenges) -> List[Tuple[int, in
 
 def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tuple[int, int, list]], ctl_challenges, challenger,
                             constraint_degree: int = 3, air_consts: Sequence[int] = (), lookups=(), requires_ctls: bool = True,
-                            group=None, ctx=None, timing: Optional[dict] = None):
+                            group=None, ctx=None, timing: Optional[dict] = None, trace_oracle: "Optional[ShardedOracle]" = None):
     """`prove_single_table` (prover.rs:301-341) of ONE table over the ranks of `group` (module docstring).
     block: CUDA int64 (C, n / W), this rank's contiguous row block of the trace; `challenger`: the transcript, replicated,
-    in the state the single-GPU call would receive it in (it is advanced identically on every rank).  Returns the
-    `StarkProof` on group rank 0, None elsewhere."""
+    in the state the single-GPU call would receive it in (it is advanced identically on every rank).  `trace_oracle`: the
+    trace commitment when the caller made it earlier (`commit_rows_sharded(block, ...)`: a segment commits every trace before
+    the transcript starts, prover.rs:90-127); it is consumed here.  Returns the `StarkProof` on group rank 0, None elsewhere."""
     import time
 
     import torch
@@ -277,7 +278,7 @@ def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tupl
     cfg = config.to_c()
     t_start = time.perf_counter()
     # ---- trace commitment ----------------------------------------------------------------------------------------------------
-    trace = commit_rows_sharded(block, config, ctx, group, timing)
+    trace = trace_oracle if trace_oracle is not None else commit_rows_sharded(block, config, ctx, group, timing)
     init_state = challenger.compact()                                  # "Clear buffered outputs." (prover.rs:320)
     # ---- auxiliary polynomials: CTL helper / Z columns on the row block, carries across blocks ------------------------------
     aux = None

@@ -70,7 +70,7 @@ def gather_caps(local_caps: Dict[int, np.ndarray], n_tables: int, cap_len: int =
 
 # ---- table-parallel proof of ONE segment (latency mode, SURVEY 8(e) level 2) ------------------------------------------
 def prove_segment_table_parallel(all_stark, config, trace_poly_values, table_in_use, public_values, group=None, ctx=None,
-                                 timing=None):
+                                 timing=None, row_sharded=None):
     """`prove_with_traces` (prover.rs:72-194) with the tables of ONE segment spread over the ranks of `group`.
 
     What shards (prover.rs:90-111): every table's trace commitment is independent of the transcript, and a table's CTL /
@@ -86,6 +86,11 @@ def prove_segment_table_parallel(all_stark, config, trace_poly_values, table_in_
     Everything that crosses ranks is a fixed-shape int64 tensor (collectives.py): table shapes, a status word after every
     local step (a failing rank never strands the others in a collective: all of them raise), caps, challenger states,
     and at the end the flat proof words gathered on rank 0.
+
+    row_sharded: {table: this rank's contiguous ROW BLOCK of that table's trace, CUDA (C, n / W)} -- tables whose commitment
+    and proof are spread over ALL ranks (level 3, shard_prover.py: the 2431-column Keccak table is what bounds this mode
+    otherwise); every rank passes its block, trace_poly_values[t] is ignored for them.  Their steps of the chain run on every
+    rank at once on the replicated transcript, so no state is broadcast after them.
 
     trace_poly_values[t] is only read on the owner of t (others may pass None).  Returns the `AllProof` on rank 0 of the
     group (None elsewhere); bit-identical to the single-GPU `prove_with_traces`.  Latency, not throughput: the chain is
@@ -120,10 +125,14 @@ def prove_segment_table_parallel(all_stark, config, trace_poly_values, table_in_
             err = e
         co.agree(err, what, group)
         return val
+    row_sharded = dict(row_sharded or {})
     # every rank needs the shapes to compute the same assignment: (cols, log_n) of the tables it was given, (0, 0) = absent
     mine_shapes = np.zeros((n_tab, 2), dtype=np.uint64)
     for t, tr in enumerate(trace_poly_values):
-        if tr is not None:
+        if t in row_sharded:
+            blk = row_sharded[t]
+            mine_shapes[t] = (int(blk.shape[0]), (int(blk.shape[1]) * world).bit_length() - 1)
+        elif tr is not None:
             c, n, ln, _ = _trace_args(tr)
             mine_shapes[t] = (c, ln)
     shapes = [None] * n_tab
@@ -136,16 +145,17 @@ def prove_segment_table_parallel(all_stark, config, trace_poly_values, table_in_
         if any(s is None for s in shapes):
             raise ValueError("every table's trace must be present on at least one rank")
         owner = [0] * n_tab
-        for r, ts in enumerate(assign_tables(shapes, world)):
-            for t in ts:
-                owner[t] = r
-        mine = [t for t in range(n_tab) if owner[t] == rank]
+        solo = [t for t in range(n_tab) if t not in row_sharded]
+        for r, ts in enumerate(assign_tables([shapes[t] for t in solo], world)):
+            for k in ts:
+                owner[solo[k]] = r
+        mine = [t for t in solo if owner[t] == rank]
         missing = [t for t in mine if trace_poly_values[t] is None]
         if missing:
             raise ValueError("rank %d owns tables %s but was not given their traces" % (rank, missing))
         return owner, mine
     owner, mine = step("the table assignment", plan)
-    dev0 = trace_poly_values[mine[0]].device if mine else None
+    dev0 = trace_poly_values[mine[0]].device if mine else (next(iter(row_sharded.values())).device if row_sharded else None)
     ctx = ctx or default_context((dev0.index or 0) if dev0 is not None else torch.cuda.current_device())
     t0 = time.perf_counter()
     # ---- phase 1: trace commitments of the owned tables, one all-gather of caps -----------------------------------
@@ -153,8 +163,16 @@ def prove_segment_table_parallel(all_stark, config, trace_poly_values, table_in_
         t: PolynomialBatch.from_values(trace_poly_values[t], fri.rate_bits, False, fri.cap_height, hasher=hasher, ctx=ctx)
         for t in mine})
     aux = {}
+    wide = {}
     try:
-        caps = gather_caps({t: batches[t].merkle_tree.cap.elements for t in mine}, n_tab, 1 << fri.cap_height, group)
+        # the row-sharded tables: every rank takes part in each commitment (column-sharded NTT, all-to-all, sub-root all-gather)
+        from .shard_prover import commit_rows_sharded, prove_table_row_sharded, table_ctl_specs
+        for t in sorted(row_sharded):
+            wide[t] = step("a row-sharded trace commitment", lambda t=t: commit_rows_sharded(row_sharded[t], config, ctx, group))
+        local = {t: batches[t].merkle_tree.cap.elements for t in mine}
+        if rank == 0:                                  # (every rank holds a row-sharded table's cap; one of them reports it)
+            local.update({t: wide[t].cap for t in wide})
+        caps = gather_caps(local, n_tab, 1 << fri.cap_height, group)
         t1 = time.perf_counter()
         # ---- transcript seed, replicated (prover.rs:114-144) ---------------------------------------------------------------
         ch = Challenger(hasher)
@@ -192,6 +210,14 @@ def prove_segment_table_parallel(all_stark, config, trace_poly_values, table_in_
         for t in range(n_tab):
             if not table_in_use[t]:
                 continue
+            if t in wide:                              # all ranks together, on the replicated transcript
+                pr = step("the row-sharded proof of table %d" % t, lambda t=t: prove_table_row_sharded(
+                    all_stark.table_air[t], config, row_sharded[t], table_ctl_specs(all_stark, t, ctl_challenges), ctl_challenges, ch,
+                    constraint_degree=deg, air_consts=all_stark.air_consts[t], lookups=all_stark.lookups[t], group=group, ctx=ctx,
+                    trace_oracle=wide.pop(t)))
+                if pr is not None:
+                    proofs[t] = sg.StarkProofWithMetadata(pr, pr.init_challenger_state)
+                continue
             state, err = np.zeros(32, dtype=np.uint64), None
             if owner[t] == rank:
                 try:
@@ -219,6 +245,8 @@ def prove_segment_table_parallel(all_stark, config, trace_poly_values, table_in_
         for b in list(batches.values()) + [a for a in aux.values() if a is not None]:
             if b.handle:
                 b.free()
+        for o in wide.values():
+            o.free()
     if timing is not None:
         timing.update({"compute owned trace commitments + cap all-gather": t1 - t0,
                        "CTL data + auxiliary commitments (owned tables, parallel over ranks)": t2 - t1,
