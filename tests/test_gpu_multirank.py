@@ -459,11 +459,12 @@ def _l3_prover_worker(rank, world, port, q, shape):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shape,world", [((2431, 14, 3), 2), ((2431, 12, 3), 4), ((523, 10, 5), 4), ((523, 11, 5), 8)])
+@pytest.mark.parametrize("shape,world", [((2431, 14, 3), 2), ((2431, 12, 3), 4), ((523, 10, 5), 4), ((523, 11, 5), 8), ((12, 12, 7), 4)])
 def test_row_sharded_table_proof_equals_single_gpu_proof(shape, world):
     """`prove_single_table` of ONE table over 2 / 4 / 8 ranks (gloo, the ranks share this GPU; under gloo every exchange is a
     host copy over loopback TCP, which is what bounds the sizes here): KeccakStark's 2431 columns x 2^14 rows over two ranks,
-    x 2^12 over four, and the Logic table over four and eight -- column-sharded NTTs, all-to-all to row shards in leaf order, sub-root all-gather, CTL Z
+    x 2^12 over four, the Logic table over four and eight, and MemBefore (a LOOKING table of the memory CTL and the looked
+    table of its own: the order of its z-data is starky's) over four -- column-sharded NTTs, all-to-all to row shards in leaf order, sub-root all-gather, CTL Z
     carries across row blocks, the quotient on row shards with the next rows fetched from the neighbour rank (W > 2), openings
     from the column owners, FRI batch combination on the local rows, query openings from the leaf owners -- equals the
     single-GPU `zk_prove_table` proof WORD FOR WORD (caps, openings, FRI proof, init_challenger_state), and leaves the
@@ -554,3 +555,76 @@ def _l3_nccl_worker(port, q):
     q.put((bool(np.array_equal(got.to_words(), want.to_words())), dist.get_backend()))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _l3_custom_spec(chal):
+    """a CTL shape with HELPER columns (three looking entries in one run -> two helper columns + Z per challenge) and a
+    single-entry one, on a constraint-free AIR: what no real level-3 candidate exercises (Keccak / Logic are looked-only)"""
+    from zk_evm_amd.stark import Column, Filter
+    f0, f1 = Filter.new_simple(Column.single(0)), Filter.new_simple(Column.single(1))
+    run = [(Column.singles([2, 3, 4]), f0), (Column.singles([5, 6, 7]), f1),
+           ([Column.linear_combination_with_constant([(8, 3), (9, 5)], 7), Column.single(2), Column.constant_col(11)], f0)]
+    single = [(Column.singles([3, 9]), f1)]
+    return [(b, g, e) for e in (run, single) for b, g in chal]
+
+
+def _l3_custom_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zk_evm_amd.shard_prover import prove_table_row_sharded
+    st, cfg, ch, chal = _l3_setup(0)
+    tr = _l3_custom_trace()
+    nb = tr.shape[1] // world
+    proof = prove_table_row_sharded(0, cfg, tr[:, rank * nb: (rank + 1) * nb].contiguous(), _l3_custom_spec(chal), chal, ch)
+    q.put((rank, None if proof is None else proof.to_words(), ch.export_state()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _l3_custom_trace():
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    tr = torch.randint(-(1 << 63), (1 << 63) - 1, (10, 1 << 11), dtype=torch.int64, device="cuda", generator=g)
+    tr[0] = torch.randint(0, 2, (1 << 11,), dtype=torch.int64, device="cuda", generator=g)
+    tr[1] = torch.randint(0, 2, (1 << 11,), dtype=torch.int64, device="cuda", generator=g)
+    return tr
+
+
+def test_row_sharded_proof_with_ctl_helper_columns():
+    """The auxiliary-column half of the level-3 prover on a shape with HELPER columns and several z-data per challenge: the
+    per-block `zk_ctl_partial_sums`, the Z carries across the four row blocks and starky's ordering of the auxiliary
+    polynomials (all helper columns, then all Z) -- proof equal to the single-GPU one (constraint-free AIR, ten columns)."""
+    import socket
+    import torch.multiprocessing as mp
+    import zk_evm_amd
+    import zk_evm_amd.prover as zp
+    from zk_evm_amd.stark import ctl_partial_sums
+    world = 4
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_l3_custom_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict((r[0], r[1:]) for r in (q.get(timeout=600) for _ in procs))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    st, cfg, ch, chal = _l3_setup(0)
+    tr = _l3_custom_trace()
+    tb = zk_evm_amd.PolynomialBatch.from_values(tr, cfg.fri_config.rate_bits, False, cfg.fri_config.cap_height, hasher=cfg.hasher)
+    zd = [zp.CtlZData(b, gm, e, ctl_partial_sums(tr, e, b, gm, 3)) for b, gm, e in _l3_custom_spec(chal)]
+    assert sorted(z.n_helpers for z in zd) == [0, 0, 2, 2]
+    want = zp.prove_single_table(0, cfg, tr, tb, [], zd, chal, ch, constraint_degree=3)
+    assert np.array_equal(res[0][0], want.to_words())
+    for r in range(world):
+        assert np.array_equal(res[r][1], ch.export_state())
+    tb.free()

@@ -804,7 +804,29 @@ def sec_block_replay(a, n_segments=12, in_flight=3):
     t_sched = time.perf_counter() - t0
     same = all(np.array_equal(d, sg.all_proof_to_words(g)) for d, g in zip(direct, got))
     cells = [segment_committed_cells(ln, a.cdk_erigon) for ln, _ in shapes]
-    return {"segments": n_segments, "in_flight": in_flight, "shapes_log2": [ln for ln, _ in shapes],
+    # BASELINE configs[4] at shape level: 20 blocks proven back to back (witness_b1000_b1019 is absent from the reference mount and
+    # would need the Rust interpreter anyway) -- 20 x 6 differently shaped segments through the same entry, aggregated rate; every
+    # tenth proof is compared with the direct call
+    cont = None
+    try:
+        n_blocks, per_block = 20, 6
+        cshapes = [s for bk in range(n_blocks) for s in block_segment_shapes(per_block, seed=1000 + bk)]
+        cjobs = block_jobs(cshapes, a.cdk_erigon, seed0=9000)
+        t0 = time.perf_counter()
+        cgot = run_distributed(e.all_stark, e.cfg, cjobs, device=a.device, in_flight=in_flight)
+        t_cont = time.perf_counter() - t0
+        ok = True
+        for i in range(0, len(cjobs), 10):
+            j = cjobs[i]
+            d = sg.all_proof_to_words(sg.prove_with_traces(e.all_stark, e.cfg, j.load(e.dev), j.table_in_use, j.public_values, ctx=e.ctx))
+            ok = ok and np.array_equal(d, sg.all_proof_to_words(cgot[i]))
+        cont = {"blocks": n_blocks, "segments": len(cjobs), "value": len(cjobs) / t_cont, "unit": "segment proofs/s",
+                "blocks_per_s": n_blocks / t_cont, "seconds": t_cont, "sampled_proofs_identical_to_direct": bool(ok),
+                "note": "BASELINE configs[4] at shape level: 20 blocks x 6 segments of the b19807080 height ranges, one GPU, "
+                        "%d segments resident" % in_flight}
+    except Exception as ex:
+        cont = {"error": repr(ex)}
+    return {"segments": n_segments, "in_flight": in_flight, "continuous_20_blocks": cont, "shapes_log2": [ln for ln, _ in shapes],
             "tables_absent": [[t for t, u in enumerate(iu) if not u] for _, iu in shapes],
             "value": n_segments / t_sched, "unit": "segment proofs/s", "block_s": t_sched,
             "one_at_a_time": {"value": n_segments / t_direct, "block_s": t_direct,
