@@ -273,7 +273,10 @@ __device__ __forceinline__ void air_constraints(const QuotientArgs &A, u32 t, u3
     RowView lv{A.trace, A.trace_stride, q.row}, nv{A.sharded ? A.trace_next : A.trace, A.trace_stride, q.row_next};
     Air::eval(lv, nv, cons, A.air_consts);
 }
-template <class CONS>
+// DUAL = false: the two-challenges-in-one-walk paths (dual lookups, twin z-data) are compiled OUT -- the host launches that
+// variant when it compiled every blob with one coefficient slot (ZK_CTL_TWINS=0 ZK_LOOKUP_DUAL=0): one challenge per walk,
+// half the live accumulators (r03 verdict, next-round item 5; measured in DESIGN section 9.2).
+template <bool DUAL, class CONS>
 __device__ __forceinline__ void check_constraints(const QuotientArgs &A, u32 t, u32 size, CONS &cons) {
     const QuotientRows q = quotient_rows(A, t, size);
     const u32 row = q.row, row_next = q.row_next;
@@ -291,7 +294,7 @@ __device__ __forceinline__ void check_constraints(const QuotientArgs &A, u32 t, 
             const u32 ne = (u32)lp[sub];
             const u32 n_help = (ne + chunk - 1) / chunk + 1;
             const CBlob LB(A.cblob + A.cblob[l]);
-            if (A.lookup_dual) {                     // challenges 0 and 1 in one walk over the looked columns
+            if (DUAL && A.lookup_dual) {             // challenges 0 and 1 in one walk over the looked columns
                 const u32 per = n_help + 1;          // n_help - 1 helper checks, Z on the first row, the transition
                 const u32 h0[2] = {start, start + n_help};
                 Fe hs[2];
@@ -342,7 +345,7 @@ __device__ __forceinline__ void check_constraints(const QuotientArgs &A, u32 t, 
             const u32 ne = (u32)cp[sub];
             const u32 h0 = A.num_lookup_columns + start_index;
             const CBlob ZB(A.cblob + A.cblob[n_lookups_total + zi]);
-            if (zi + 1 < n_z && A.cblob[n_lookups_total + zi + 1] == ZK_CBLOB_TWIN) {
+            if (DUAL && zi + 1 < n_z && A.cblob[n_lookups_total + zi + 1] == ZK_CBLOB_TWIN) {
                 // this z-data and the next are the two challenges of one looking run: one walk (quotient_host.inc "TWINS")
                 const u32 per = n_help + 2;
                 const u32 hh[2] = {h0, h0 + n_help};
@@ -491,13 +494,14 @@ __global__ void quotient_count_kernel(QuotientArgs A) {
 #ifndef ZK_CHECKS_WAVES
 #define ZK_CHECKS_WAVES 1
 #endif
+template <bool DUAL>
 static __global__ void __launch_bounds__(256, ZK_CHECKS_WAVES) quotient_checks_kernel(QuotientArgs A) {
     const u32 size_log = A.log_n + A.qd_bits;
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n_points) return;
     PointSetup P;
     point_setup(A, quotient_rows(A, i, 1u << size_log).point, A.n_air_constraints, P);
-    check_constraints(A, i, 1u << size_log, P.cons);
+    check_constraints<DUAL>(A, i, 1u << size_log, P.cons);
     if (P.cons.ap0 != A.alpha_pow[0] && i == 0) atomicExch(A.err_flag, 3);   // met fewer / more constraints than K
     const u64 r0 = gl_add(A.out[i], dot_acc_reduce(P.cons.d0));
     A.out[i] = gl_canon(gl_mul(r0, P.inv_zh.v));
@@ -511,7 +515,7 @@ static __global__ void quotient_checks_count_kernel(QuotientArgs A) {
     if (threadIdx.x || blockIdx.x) return;
     CountConsumer cons;
     cons.count = 0;
-    check_constraints(A, 0, 1u << (A.log_n + A.qd_bits), cons);
+    check_constraints<true>(A, 0, 1u << (A.log_n + A.qd_bits), cons);
     *A.count_out = cons.count;
 }
 // out[k * cap + j] = alpha_k^j
