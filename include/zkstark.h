@@ -627,6 +627,24 @@ int zk_fri_prove_from_values(zk_ctx *ctx, const zk_cfg *cfg, const zk_batch *con
                              const zk_fri_batch *batches, size_t n_batches, uint64_t *d_vals, zk_challenger *chal,
                              uint64_t *proof, uint64_t *xs_out);
 
+/* The FRI commit phase itself over row shards -- every layer stays on the rank that owns its leaves, one sub-root all-gather per
+ * round -- as an alternative to zk_fri_prove_from_values (which replicates the two-column layers after ONE all-gather); same proof.
+ *   zk_fri_commit_round_sharded : this rank's part of a layer (d_vals [2][len_local], LEAF order) -> its leaves (2^arity_bits
+ *                                 consecutive values), local subtrees down to 2^(cap_height - shard_log_w) roots in d_digests
+ *   zk_fri_fold_values_sharded  : the fold on values: f'(x^arity) = sum_j (beta / x)^j u_j with u = the leaf's inverse DFT;
+ *                                 `shift` = the coset shift of THIS layer; d_out [2][len_local >> arity_bits], leaf order
+ *   zk_fri_proof_of_work        : the grind on the caller's transcript (smallest witness; observed; response checked)
+ *   zk_fri_initial_openings     : leaf rows + Merkle paths of the queries xs in the given oracles (zeros where another rank owns
+ *                                 the leaf); out [n_queries][sum_k (n_cols_k + 4 (log_lde - cap_height))] */
+int zk_fri_commit_round_sharded(zk_ctx *ctx, const zk_cfg *cfg, const uint64_t *d_vals, unsigned log_layer,
+                                unsigned shard_log_w, uint64_t *d_digests);
+int zk_fri_fold_values_sharded(zk_ctx *ctx, const zk_cfg *cfg, const uint64_t *d_vals, unsigned log_layer,
+                               unsigned shard_log_w, unsigned shard_rank, uint64_t shift, const uint64_t beta[2],
+                               uint64_t *d_out);
+int zk_fri_proof_of_work(zk_ctx *ctx, const zk_cfg *cfg, zk_challenger *chal, uint64_t *witness_out);
+int zk_fri_initial_openings(zk_ctx *ctx, const zk_cfg *cfg, const zk_batch *const *oracles, size_t n_oracles,
+                            const uint64_t *xs, size_t n_queries, uint64_t *out);
+
 /* library / device info */
 const char *zk_version(void);
 int zk_device_info(int device, char *name_out, size_t name_len, int *cu_count, size_t *hbm_bytes);

@@ -436,7 +436,7 @@ def _l3_setup(table):
     return st, cfg, ch, chal
 
 
-def _l3_prover_worker(rank, world, port, q, shape):
+def _l3_prover_worker(rank, world, port, q, shape, fri="replicated"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch
@@ -453,14 +453,17 @@ def _l3_prover_worker(rank, world, port, q, shape):
     timing = {}
     proof = prove_table_row_sharded(st.table_air[table], cfg, block, table_ctl_specs(st, table, chal), chal, ch,
                                     constraint_degree=st.constraint_degree, air_consts=st.air_consts[table],
-                                    lookups=st.lookups[table], timing=timing)
+                                    lookups=st.lookups[table], timing=timing, fri=fri)
     q.put((rank, None if proof is None else proof.to_words(), ch.export_state(), {k: v for k, v in timing.items() if isinstance(v, (int, float))}))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shape,world", [((2431, 14, 3), 2), ((2431, 12, 3), 4), ((523, 10, 5), 4), ((523, 11, 5), 8), ((12, 12, 7), 4)])
-def test_row_sharded_table_proof_equals_single_gpu_proof(shape, world):
+@pytest.mark.parametrize("shape,world,fri", [((2431, 14, 3), 2, "replicated"), ((2431, 12, 3), 4, "replicated"), ((523, 10, 5), 4, "replicated"),
+                                             ((523, 11, 5), 8, "replicated"), ((12, 12, 7), 4, "replicated"),
+                                             ((2431, 14, 3), 2, "sharded"), ((2431, 12, 3), 4, "sharded"), ((523, 11, 5), 8, "sharded"),
+                                             ((12, 12, 7), 4, "sharded")])
+def test_row_sharded_table_proof_equals_single_gpu_proof(shape, world, fri):
     """`prove_single_table` of ONE table over 2 / 4 / 8 ranks (gloo, the ranks share this GPU; under gloo every exchange is a
     host copy over loopback TCP, which is what bounds the sizes here): KeccakStark's 2431 columns x 2^14 rows over two ranks,
     x 2^12 over four, the Logic table over four and eight, and MemBefore (a LOOKING table of the memory CTL and the looked
@@ -468,7 +471,10 @@ def test_row_sharded_table_proof_equals_single_gpu_proof(shape, world):
     carries across row blocks, the quotient on row shards with the next rows fetched from the neighbour rank (W > 2), openings
     from the column owners, FRI batch combination on the local rows, query openings from the leaf owners -- equals the
     single-GPU `zk_prove_table` proof WORD FOR WORD (caps, openings, FRI proof, init_challenger_state), and leaves the
-    transcript in the same state (r03 verdict, missing 1 / next-round item 2; reference seam prover.rs:90-111, 301-341)."""
+    transcript in the same state (r03 verdict, missing 1 / next-round item 2; reference seam prover.rs:90-111, 301-341).
+    fri = "sharded": the FRI commit phase itself stays on the shards -- local leaves and subtrees per round, one sub-root
+    all-gather per round, folds on the local VALUES, final polynomial from the all-gathered last layer, every query answered by
+    the rank that owns its leaf -- against "replicated" (one all-gather, then the two-column layers on every rank)."""
     import socket
     import torch.multiprocessing as mp
     import zk_evm_amd
@@ -481,7 +487,7 @@ def test_row_sharded_table_proof_equals_single_gpu_proof(shape, world):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_l3_prover_worker, args=(r, world, port, q, shape)) for r in range(world)]
+    procs = [ctx.Process(target=_l3_prover_worker, args=(r, world, port, q, shape, fri)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}

@@ -105,6 +105,10 @@ SIGNATURES = {
     "zk_quotient_commit_values": (C.c_int, [vp, C.POINTER(ZkCfg), u64p, ui, ui, C.POINTER(vp)]),
     "zk_fri_combine_sharded": (C.c_int, [vp, C.POINTER(ZkCfg), vp, sz, vp, sz, u64p, u64p, u64p]),
     "zk_fri_prove_from_values": (C.c_int, [vp, C.POINTER(ZkCfg), vp, sz, vp, sz, u64p, vp, u64p, u64p]),
+    "zk_fri_commit_round_sharded": (C.c_int, [vp, C.POINTER(ZkCfg), u64p, ui, ui, u64p]),
+    "zk_fri_fold_values_sharded": (C.c_int, [vp, C.POINTER(ZkCfg), u64p, ui, ui, ui, C.c_uint64, u64p, u64p]),
+    "zk_fri_proof_of_work": (C.c_int, [vp, C.POINTER(ZkCfg), vp, u64p]),
+    "zk_fri_initial_openings": (C.c_int, [vp, C.POINTER(ZkCfg), vp, sz, u64p, sz, u64p]),
     "zk_table_proof_get": (C.c_int, [vp, vp]),
     "zk_table_proof_free": (None, [vp]),
     "zk_ctx_set_check_ctls": (C.c_int, [vp, C.c_int]),

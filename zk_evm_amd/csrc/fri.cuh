@@ -392,6 +392,56 @@ static __global__ void fri_fold_kernel(const u64 *ca, const u64 *cb, u64 *oa, u6
     ob[k] = gl_canon(acc.b);
 }
 
+// ---- the same fold on VALUES, for a layer kept in LEAF (bit-reversed) order -- the form that is local to a row shard ----------
+// A commit-phase leaf is 2^ab consecutive leaf-ordered values v_i = f(x zeta^bitrev(i)), zeta = the primitive 2^ab-th root, x = the
+// coset point shift * w^l' of the leaf (l' = bitrev of its index).  With f(X) = sum_j X^j f_j(X^(2^ab)) the folded polynomial is
+// f' = sum_j beta^j f_j and  f'(x^(2^ab)) = sum_j (beta / x)^j u_j,  u_j = 2^-ab sum_p zeta^(-p j) f(x zeta^p)  -- a size-2^ab
+// inverse DFT and a Horner step per leaf.  Exact field arithmetic: the same values as the coefficient fold above followed by its
+// NTT, and they land in leaf order of the next layer (leaf s of this layer = point bitrev(s) of the next).
+struct FriFoldValArgs {
+    const u64 *va, *vb;     // [len_local] each: this shard's values, leaf order
+    u64 *oa, *ob;           // [len_local >> ab]
+    u32 n_out;              // len_local >> ab
+    int ab;                 // arity bits
+    u32 log_leaves;         // log2 of the GLOBAL number of leaves of this layer (layer bits - ab)
+    u32 leaf_base;          // global index of this shard's first leaf
+    u64 shift_inv;          // (coset shift of this layer)^-1
+    u64 w_inv;              // (primitive root of order 2^(log_leaves + ab))^-1
+    u64 zeta_inv_pow[16];   // zeta^-k, k < 2^ab
+    u64 inv_arity;          // 2^-ab
+    u64 beta[2];
+};
+static __global__ void fri_fold_values_kernel(FriFoldValArgs A) {
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= A.n_out) return;
+    const int arity = 1 << A.ab;
+    gl2 v[16];
+    for (int i = 0; i < arity; ++i) {                       // v[p] = f(x zeta^p): stored position i holds p = bitrev(i)
+        const u32 p = bitrev32((u32)i, A.ab);
+        v[p] = gl2_make(A.va[(size_t)s * arity + i], A.vb[(size_t)s * arity + i]);
+    }
+    const u32 lp = bitrev32(A.leaf_base + s, A.log_leaves); // the leaf's point index l'
+    const u64 x_inv = gl_mul(A.shift_inv, gl_pow(A.w_inv, lp));
+    const gl2 t = gl2_mul_base(gl2_make(A.beta[0], A.beta[1]), x_inv);
+    gl2 acc = gl2_make(0, 0);
+    for (int j = arity - 1; j >= 0; --j) {                  // Horner in t over u_j (the 2^-ab factor once at the end)
+        gl2 u = gl2_make(0, 0);
+        for (int p = 0; p < arity; ++p) u = gl2_add(u, gl2_mul_base(v[p], A.zeta_inv_pow[(p * j) & (arity - 1)]));
+        acc = gl2_add(gl2_mul(acc, t), u);
+    }
+    acc = gl2_mul_base(acc, A.inv_arity);
+    A.oa[s] = gl_canon(acc.a);
+    A.ob[s] = gl_canon(acc.b);
+}
+// the rows hash_rows wants for a leaf-ordered layer: column 2 i + c of leaf s = component c of value s * arity + i
+static __global__ void fri_leaf_rows_kernel(const u64 *va, const u64 *vb, u64 *out, u32 n_leaves, int ab) {
+    const u32 e = blockIdx.x * blockDim.x + threadIdx.x;     // e = s * arity + i
+    if ((e >> ab) >= n_leaves) return;
+    const u32 s = e >> ab, i = e & ((1u << ab) - 1);
+    out[(size_t)(2 * i) * n_leaves + s] = va[e];
+    out[(size_t)(2 * i + 1) * n_leaves + s] = vb[e];
+}
+
 // ---- proof of work -----------------------------------------------------------------------------
 // candidate w = base + tid: state = inter with w at `pos`; Poseidon; accept if state[7] has
 // >= bits leading zeros.  atomicMin keeps the smallest accepted candidate of the launch.

@@ -19,10 +19,11 @@ What is sharded, and how (W = 2^k ranks, one per GPU; N = 2n LDE points):
                on every rank alike (`zk_quotient_commit_values`): replicated, it is 4 columns wide;
   openings     each column owner evaluates its coefficient columns at zeta, g zeta (and 1 for the CTL Z columns); all-gather;
   FRI          batch combination on the local rows (`zk_fri_combine_sharded`: the pass that reads every LDE column),
-               all-gather of the combined polynomial (2 columns: 16 B per point), then the commit-phase trees, folds, final
-               polynomial and proof of work on every rank alike (`zk_fri_prove_from_values`): the FRI layers are two
-               columns wide, sharding them would trade < 1 ms of kernels for a collective per round.  The initial-tree
-               opening of query x comes from the rank that owns leaf x (its row + the path inside its subtree).
+               then either (fri="replicated") ONE all-gather of the combined polynomial (2 columns: 16 B per point) and the
+               commit-phase trees, folds, final polynomial and proof of work on every rank alike (`zk_fri_prove_from_values`)
+               or (fri="sharded") every layer on the rank that owns its leaves: local subtrees and one sub-root all-gather per
+               round, folds on the local values (`_fri_sharded`).  The initial-tree opening of query x comes from the rank
+               that owns leaf x (its row + the path inside its subtree); in the sharded form so do the round openings.
 
 The proof equals the single-GPU `zk_prove_table` proof word for word (tests/test_gpu_multirank.py).  Tables with logUp
 lookups or next-row CTL columns are rejected here (no candidate for this mode has them: Keccak, Logic); the Python side is
@@ -242,14 +243,121 @@ def table_ctl_specs(all_stark, table: int, ctl_challenges) -> List[Tuple[int, in
     return out
 
 
+def _fri_sharded(ctx, cfg, config, comb, log_n: int, lw: int, rank: int, world: int, group, challenger, oracles, ocols, nw: int):
+    """`fri_proof` ([EXT] fri/prover.rs: committed trees, final polynomial, proof of work, query rounds) with every layer kept on
+    the rank that owns its leaves.  comb: (2, N / W) -- the batch combination at this rank's leaves (zk_fri_combine_sharded).
+    Per round: the leaves are 2^arity_bits consecutive local values, the local subtrees are hashed here, ONE all-gather of their
+    roots gives the round's cap ("Merkle-cap reduction"), beta comes from the replicated transcript, and the fold runs on the
+    local VALUES (zk_fri_fold_values_sharded) -- leaf s of a layer is point bitrev(s) of the next, so the next layer is again
+    this rank's contiguous run of leaves.  The last layer (2^5 .. 2^8 values) is all-gathered and interpolated for the final
+    polynomial.  A query is answered entirely by the rank that owns its leaf: the same top bits select the rank in every layer.
+    Returns the flat FriProof (layout: include/zkstark.h) on rank 0, None elsewhere; the transcript advances on every rank."""
+    import torch
+
+    from .collectives import all_gather_words, gather_varlen_words
+    lib = ctx.lib
+    fc = config.fri_config
+    ab = int(cfg.arity_bits)
+    arity = 1 << ab
+    log_N = log_n + fc.rate_bits
+    N = 1 << log_N
+    ar = (C.c_uint32 * 32)()
+    R = int(lib.zk_fri_reduction_arity_bits(C.byref(cfg), log_n, ar, 32))
+    if R < 0 or R > 32:
+        raise ZkStarkError(-1, "unsupported FRI configuration")
+    dev = comb.device
+    cur, lg, shift = comb.contiguous(), log_N, 14293326489335486720            # coset_shift()
+    caps, rounds = [], []
+    for r in range(R):
+        if lg - lw < ab or lg - ab < fc.cap_height:
+            raise ValueError("FRI layer %d (2^%d values) is too small to stay sharded over %d ranks: use fri='replicated'" % (r, lg, world))
+        leaf_log = lg - ab - lw
+        n_dig = int(lib.zk_merkle_num_digests(leaf_log, fc.cap_height - lw))
+        dig = torch.zeros((n_dig, 4), dtype=torch.int64, device=dev)
+        ctx.check(lib.zk_fri_commit_round_sharded(ctx.handle, C.byref(cfg), C.c_void_p(cur.data_ptr()), lg, lw, C.c_void_p(dig.data_ptr())))
+        sub = dig[n_dig - (1 << (fc.cap_height - lw)):].cpu().numpy().view(np.uint64).reshape(-1)
+        cap = np.concatenate(all_gather_words(sub, sub.size, group)).reshape(1 << fc.cap_height, 4)     # sub-roots in rank order
+        challenger.observe_cap(cap)
+        beta = np.array(challenger.get_extension_challenge(), dtype=np.uint64)
+        nxt = torch.empty((2, cur.shape[1] >> ab), dtype=torch.int64, device=dev)
+        ctx.check(lib.zk_fri_fold_values_sharded(ctx.handle, C.byref(cfg), C.c_void_p(cur.data_ptr()), lg, lw, rank, C.c_uint64(shift),
+                                                 beta.ctypes.data, C.c_void_p(nxt.data_ptr())))
+        caps.append(cap)
+        rounds.append((cur.cpu().numpy().view(np.uint64), dig.cpu().numpy().view(np.uint64), lg))
+        cur, lg = nxt, lg - ab
+        shift = pow(shift, arity, P)
+    # final polynomial: the last layer in full, natural order, coset iNTT -> natural coefficients; the first len >> rate_bits
+    torch.cuda.synchronize(dev)
+    last = _leaf_to_natural(torch.cat(all_gather_tensor(cur, group), dim=1), lg).contiguous()
+    ctx.check(lib.zk_coset_ifft(ctx.handle, C.c_void_p(last.data_ptr()), 1 << lg, 2, lg, C.c_uint64(shift)))
+    co = last.cpu().numpy().view(np.uint64) % np.uint64(P)
+    flen = (1 << lg) >> fc.rate_bits
+    final = np.stack([co[0, :flen], co[1, :flen]], axis=1).reshape(-1)
+    challenger.observe_elements(final)
+    wit = np.zeros(1, dtype=np.uint64)
+    ctx.check(lib.zk_fri_proof_of_work(ctx.handle, C.byref(cfg), challenger.handle, wit.ctypes.data))
+    Q = fc.num_query_rounds
+    xs = np.array([challenger.get_challenge() % N for _ in range(Q)], dtype=np.uint64)
+    # ---- query rounds: the owner of leaf x answers the whole round --------------------------------------------------------------
+    per_init = sum(int(c) + 4 * (log_N - fc.cap_height) for c in ocols)
+    init = np.zeros(Q * per_init, dtype=np.uint64)
+    ctx.check(lib.zk_fri_initial_openings(ctx.handle, C.byref(cfg), (C.c_void_p * len(oracles))(*oracles), len(oracles),
+                                          xs.ctypes.data, Q, init.ctypes.data))
+    mine = []
+    for q in range(Q):
+        x = int(xs[q])
+        if x >> (log_N - lw) != rank:
+            continue
+        rec = [np.array([q], dtype=np.uint64), init[q * per_init: (q + 1) * per_init]]
+        for vals, dig, lgr in rounds:
+            x >>= ab                                                   # the leaf of this round
+            leaf_log = lgr - ab - lw
+            slot = x & ((1 << leaf_log) - 1)
+            ev = np.stack([vals[0, slot * arity: (slot + 1) * arity], vals[1, slot * arity: (slot + 1) * arity]], axis=1).reshape(-1)
+            rec.append(ev)
+            off, idx = 0, slot
+            for lvl in range(leaf_log, fc.cap_height - lw, -1):        # siblings inside this rank's subtrees
+                rec.append(dig[off + (idx ^ 1)])
+                off += 1 << lvl
+                idx >>= 1
+        mine.append(np.concatenate([np.asarray(a, dtype=np.uint64).reshape(-1) for a in rec]))
+    payload = np.concatenate(mine) if mine else np.zeros(0, dtype=np.uint64)
+    parts = gather_varlen_words(payload, dst=0, group=group)
+    if rank != 0:
+        return None
+    proof = np.zeros(nw, dtype=np.uint64)
+    K = len(ocols)
+    proof[:6] = [R, 1 << fc.cap_height, Q, K, flen, log_N]
+    proof[6: 6 + R] = [ab] * R
+    proof[6 + R: 6 + R + K] = ocols
+    pos = 6 + R + K
+    for cap in caps:
+        proof[pos: pos + cap.size] = cap.reshape(-1)
+        pos += cap.size
+    proof[pos: pos + final.size] = final
+    pos += final.size
+    proof[pos] = wit[0]
+    pos += 1
+    query_words = (nw - pos) // Q if Q else 0
+    for part in parts:
+        for k in range(0, part.size, 1 + query_words):
+            q = int(part[k])
+            proof[pos + q * query_words: pos + (q + 1) * query_words] = part[k + 1: k + 1 + query_words]
+    return proof
+
+
 def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tuple[int, int, list]], ctl_challenges, challenger,
                             constraint_degree: int = 3, air_consts: Sequence[int] = (), lookups=(), requires_ctls: bool = True,
-                            group=None, ctx=None, timing: Optional[dict] = None, trace_oracle: "Optional[ShardedOracle]" = None):
+                            group=None, ctx=None, timing: Optional[dict] = None, trace_oracle: "Optional[ShardedOracle]" = None,
+                            fri: str = "replicated"):
     """`prove_single_table` (prover.rs:301-341) of ONE table over the ranks of `group` (module docstring).
     block: CUDA int64 (C, n / W), this rank's contiguous row block of the trace; `challenger`: the transcript, replicated,
     in the state the single-GPU call would receive it in (it is advanced identically on every rank).  `trace_oracle`: the
     trace commitment when the caller made it earlier (`commit_rows_sharded(block, ...)`: a segment commits every trace before
-    the transcript starts, prover.rs:90-127); it is consumed here.  Returns the `StarkProof` on group rank 0, None elsewhere."""
+    the transcript starts, prover.rs:90-127); it is consumed here.  `fri`: "replicated" -- the combined polynomial is
+    all-gathered once and every rank runs the (two-column) commit phase -- or "sharded" -- every FRI layer stays on the rank that
+    owns its leaves: local trees, one sub-root all-gather per round, folds on values (`_fri_sharded`); the same proof either way.
+    Returns the `StarkProof` on group rank 0, None elsewhere."""
     import time
 
     import torch
@@ -267,13 +375,13 @@ def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tupl
     ctx = ctx or default_context(dev.index or 0)
     ctx.use_torch_current_stream()
     lib = ctx.lib
-    fri = config.fri_config
+    fri_cfg = config.fri_config
     nchal = config.num_challenges
     lw = world.bit_length() - 1
     C_tr, nb = int(block.shape[0]), int(block.shape[1])
     n = nb * world
     log_n = n.bit_length() - 1
-    log_N = log_n + fri.rate_bits
+    log_N = log_n + fri_cfg.rate_bits
     N, Nl = 1 << log_N, (1 << log_N) >> lw
     cfg = config.to_c()
     t_start = time.perf_counter()
@@ -311,7 +419,7 @@ def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tupl
     # ---- quotient -------------------------------------------------------------------------------------------------------------
     alphas = np.array(challenger.get_n_challenges(nchal), dtype=np.uint64)
     qd_bits = 1 if constraint_degree - 1 >= 2 else 0
-    if fri.rate_bits != qd_bits:
+    if fri_cfg.rate_bits != qd_bits:
         raise NotImplementedError("row-sharded quotient needs rate_bits == quotient_degree_bits")
     res = _bitrev(rank, lw)                                            # this rank's rows: natural j = i W + res
     nxt = _bitrev((res + (1 << qd_bits)) % world, lw) if world > 1 else 0     # the rank that holds rows j + 2^qd_bits
@@ -334,7 +442,7 @@ def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tupl
     q_nat = _leaf_to_natural(q_leaf, log_N)
     h = C.c_void_p()
     ctx.check(lib.zk_quotient_commit_values(ctx.handle, C.byref(cfg), C.c_void_p(q_nat.data_ptr()), log_n, constraint_degree, C.byref(h)))
-    quotient = PolynomialBatch(ctx, h, fri.rate_bits, fri.cap_height, config.hasher)
+    quotient = PolynomialBatch(ctx, h, fri_cfg.rate_bits, fri_cfg.cap_height, config.hasher)
     n_quot = quotient.num_polys
     quotient_cap = quotient.merkle_tree.cap.elements.copy()
     challenger.observe_cap(quotient_cap)
@@ -397,30 +505,42 @@ def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tupl
     ctx.check(lib.zk_fri_combine_sharded(ctx.handle, C.byref(cfg), (C.c_void_p * len(shard_oracles))(*shard_oracles), len(shard_oracles),
                                          arr, len(instance.batches), opn.ctypes.data, alpha.ctypes.data, C.c_void_p(comb.data_ptr())))
     lib.zk_batch_free(hq)
-    vals = _leaf_to_natural(torch.cat(all_gather_tensor(comb, group), dim=1), log_N)     # (2, N), natural order
     layout_oracles = [trace.row_batch] + ([aux.row_batch] if aux is not None else []) + [quotient.handle]
     ocols = np.array([C_tr] + ([n_aux] if aux is not None else []) + [n_quot], dtype=np.uint64)
     nw = int(lib.zk_fri_proof_words(C.byref(cfg), log_n, ocols.ctypes.data, len(ocols)))
     if nw == 0:
         raise ZkStarkError(-1, "unsupported FRI configuration")
-    proof = np.zeros(nw, dtype=np.uint64)
-    xs = np.zeros(fri.num_query_rounds, dtype=np.uint64)
-    ctx.check(lib.zk_fri_prove_from_values(ctx.handle, C.byref(cfg), (C.c_void_p * len(layout_oracles))(*layout_oracles), len(layout_oracles),
-                                           arr, len(instance.batches), C.c_void_p(vals.data_ptr()), challenger.handle,
-                                           proof.ctypes.data, xs.ctypes.data))
-    # ---- the initial-tree openings of every query from the rank that owns its leaf ---------------------------------------------
-    R, cap_len, Q, K, F = (int(x) for x in proof[:5])
-    off_queries = 6 + R + K + R * cap_len * 4 + 2 * F + 1
-    query_words = (nw - off_queries) // Q if Q else 0
-    n_shard = len(ocols) - 1                                           # trace (+ aux): the quotient is whole on every rank
-    per_oracle = [int(c) + 4 * (log_N - fri.cap_height) for c in ocols]
-    mine = []
-    for q in range(Q):
-        if int(xs[q]) >> (log_N - lw) == rank:
-            base = off_queries + q * query_words
-            mine.append(np.concatenate([np.array([q], dtype=np.uint64), proof[base: base + sum(per_oracle[:n_shard])]]))
-    payload = np.concatenate(mine) if mine else np.zeros(0, dtype=np.uint64)
-    parts = gather_varlen_words(payload, dst=0, group=group)
+    if fri == "sharded":
+        proof = _fri_sharded(ctx, cfg, config, comb, log_n, lw, rank, world, group, challenger, layout_oracles, ocols, nw)
+    elif fri != "replicated":
+        raise ValueError("fri must be 'replicated' or 'sharded'")
+    else:
+        vals = _leaf_to_natural(torch.cat(all_gather_tensor(comb, group), dim=1), log_N)     # (2, N), natural order
+        proof = np.zeros(nw, dtype=np.uint64)
+        xs = np.zeros(fri_cfg.num_query_rounds, dtype=np.uint64)
+        ctx.check(lib.zk_fri_prove_from_values(ctx.handle, C.byref(cfg), (C.c_void_p * len(layout_oracles))(*layout_oracles), len(layout_oracles),
+                                               arr, len(instance.batches), C.c_void_p(vals.data_ptr()), challenger.handle,
+                                               proof.ctypes.data, xs.ctypes.data))
+        # ---- the initial-tree openings of every query from the rank that owns its leaf -------------------------------------------
+        R, cap_len, Q, K, F = (int(x) for x in proof[:5])
+        off_queries = 6 + R + K + R * cap_len * 4 + 2 * F + 1
+        query_words = (nw - off_queries) // Q if Q else 0
+        n_shard = len(ocols) - 1                                       # trace (+ aux): the quotient is whole on every rank
+        per_oracle = [int(c) + 4 * (log_N - fri_cfg.cap_height) for c in ocols]
+        mine = []
+        for q in range(Q):
+            if int(xs[q]) >> (log_N - lw) == rank:
+                base = off_queries + q * query_words
+                mine.append(np.concatenate([np.array([q], dtype=np.uint64), proof[base: base + sum(per_oracle[:n_shard])]]))
+        payload = np.concatenate(mine) if mine else np.zeros(0, dtype=np.uint64)
+        parts = gather_varlen_words(payload, dst=0, group=group)
+        if rank == 0:
+            rec = 1 + sum(per_oracle[:n_shard])
+            for part in parts:
+                for k in range(0, part.size, rec):
+                    q = int(part[k])
+                    base = off_queries + q * query_words
+                    proof[base: base + rec - 1] = part[k + 1: k + rec]
     trace_cap, aux_cap = trace.cap, (aux.cap if aux is not None else None)
     trace.free()
     if aux is not None:
@@ -432,12 +552,6 @@ def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tupl
                        "openings": t_open - t_quot, "FRI": t_end - t_open, "ranks": world, "rows per rank": Nl})
     if rank != 0:
         return None
-    rec = 1 + sum(per_oracle[:n_shard])
-    for part in parts:
-        for k in range(0, part.size, rec):
-            q = int(part[k])
-            base = off_queries + q * query_words
-            proof[base: base + rec - 1] = part[k + 1: k + rec]
     return StarkProof(trace_cap=np.asarray(trace_cap, dtype=np.uint64), auxiliary_polys_cap=None if aux_cap is None else np.asarray(aux_cap, dtype=np.uint64),
                       quotient_polys_cap=np.asarray(quotient_cap, dtype=np.uint64), openings=openings, opening_proof=proof,
                       init_challenger_state=init_state, num_ctl_zs=n_z, degree_bits=log_n)
