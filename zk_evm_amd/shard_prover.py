@@ -26,8 +26,9 @@ What is sharded, and how (W = 2^k ranks, one per GPU; N = 2n LDE points):
                that owns leaf x (its row + the path inside its subtree); in the sharded form so do the round openings.
 
 The proof equals the single-GPU `zk_prove_table` proof word for word (tests/test_gpu_multirank.py).  Tables with logUp
-lookups or next-row CTL columns are rejected here (no candidate for this mode has them: Keccak, Logic); the Python side is
-orchestration only -- every kernel is the library's."""
+next-row columns in a lookup or a CTL entry are rejected here (a block's last row would need its neighbour's first: Cpu, Memory);
+logUp lookups are handled (forward running sums with carries from the blocks before).  The Python side is orchestration only --
+every kernel is the library's."""
 import ctypes as C
 from typing import List, Optional, Sequence, Tuple
 
@@ -366,10 +367,9 @@ def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tupl
     from .context import default_context
     from .fri import FriBatchInfo, FriInstanceInfo, stark_fri_instance
     from .polynomial_batch import PolynomialBatch
-    from .prover import StarkProof, encode_ctl_set, CtlZData
-    from .stark import ctl_partial_sums
-    if lookups:
-        raise NotImplementedError("row-sharded proving of a table with logUp lookups is not built (no level-3 candidate has them)")
+    from .prover import StarkProof, encode_ctl_set, encode_lookup_set, CtlZData
+    from .stark import ctl_partial_sums, lookup_helper_columns
+    lookups = list(lookups or [])
     dist, world, rank = _dist(group)
     dev = block.device
     ctx = ctx or default_context(dev.index or 0)
@@ -391,7 +391,41 @@ def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tupl
     # ---- auxiliary polynomials: CTL helper / Z columns on the row block, carries across blocks ------------------------------
     aux = None
     n_helpers_of, zdatas = [], []
-    if ctl_specs:
+    # logUp lookups (`lookup_helper_columns`; the lookup challenges are the CTL betas, prover.rs:328): the helper columns are
+    # row-wise; a lookup's Z is a FORWARD running sum from 0 (z[i + 1] = z[i] + sum_h h[i] - freq[i] / (table[i] + alpha)), so a
+    # block adds the totals of the blocks BEFORE it -- its own total needs the increment of its last row, evaluated here from
+    # that row's values.  Order of the auxiliary polynomials: per lookup, per challenge, the helpers then Z; then the CTL columns.
+    lookup_cols = []
+    lookup_challenges = [b for b, _ in ctl_challenges] if lookups else []
+    if lookups:
+        def col_at_last(c):
+            if getattr(c, "next_row_linear_combination", None):
+                raise NotImplementedError("row-sharded proving with next-row lookup columns is not built")
+            acc = int(c.constant) % P
+            for k, f in c.linear_combination:
+                acc = (acc + (int(last_row[int(k)]) % P) * (int(f) % P)) % P
+            return acc
+        last_row = block[:, nb - 1].cpu().numpy().view(np.uint64)
+        lz, lz_tot = [], []
+        for lk in lookups:
+            for c in list(lk.columns) + [lk.table_column, lk.frequencies_column]:
+                if getattr(c, "next_row_linear_combination", None):
+                    raise NotImplementedError("row-sharded proving with next-row lookup columns is not built")
+            for alpha in lookup_challenges:
+                cols = lookup_helper_columns(lk, block, alpha, constraint_degree, ctx=ctx)        # helpers ..., Z (from 0 in this block)
+                hl = cols[:-1, nb - 1].cpu().numpy().view(np.uint64)
+                inc = (sum(int(x) % P for x in hl) - col_at_last(lk.frequencies_column) *
+                       pow((col_at_last(lk.table_column) + alpha) % P, P - 2, P)) % P
+                lz.append(cols)
+                lz_tot.append((int(cols[-1, nb - 1].cpu().numpy().view(np.uint64)) % P + inc) % P)
+        tots = all_gather_words(np.array(lz_tot, dtype=np.uint64), len(lz_tot), group)
+        for k, cols in enumerate(lz):
+            carry = sum(int(tots[q][k]) for q in range(rank)) % P          # the blocks before this one
+            if carry:
+                z = cols[-1:]
+                ctx.check(lib.zk_gl_add_scalar_columns(ctx.handle, C.c_void_p(z.data_ptr()), nb, 1, nb, np.array([carry], dtype=np.uint64).ctypes.data))
+            lookup_cols.append(cols)
+    if ctl_specs or lookup_cols:
         helpers, zs = [], []
         for beta, gamma, entries in ctl_specs:
             if _entries_use_next_row(entries):
@@ -401,16 +435,19 @@ def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tupl
             helpers.append(cols[:-1])
             zs.append(cols[-1:])
             zdatas.append(CtlZData(beta, gamma, entries, cols))
-        zmat = torch.cat(zs, dim=0).contiguous()                       # (n_z, nb): reverse running sums WITHIN the block
-        tot = zmat[:, 0].cpu().numpy().view(np.uint64)                 # block totals
-        parts = all_gather_words(tot, tot.size, group)
-        carry = np.zeros(tot.size, dtype=np.uint64)
-        for z in range(tot.size):                                      # the blocks after this one
-            carry[z] = sum(int(parts[q][z]) % P for q in range(rank + 1, world)) % P
-        if carry.any():
-            ctx.check(lib.zk_gl_add_scalar_columns(ctx.handle, C.c_void_p(zmat.data_ptr()), nb, zmat.shape[0], nb, carry.ctypes.data))
-        # starky's order of the auxiliary polynomials: lookup columns (none here), all helper columns, all Z columns
-        aux_block = torch.cat([h for h in helpers if h.shape[0]] + [zmat], dim=0).contiguous()
+        pieces = list(lookup_cols)
+        if zs:
+            zmat = torch.cat(zs, dim=0).contiguous()                   # (n_z, nb): reverse running sums WITHIN the block
+            tot = zmat[:, 0].cpu().numpy().view(np.uint64)             # block totals
+            parts = all_gather_words(tot, tot.size, group)
+            carry = np.zeros(tot.size, dtype=np.uint64)
+            for z in range(tot.size):                                  # the blocks after this one
+                carry[z] = sum(int(parts[q][z]) % P for q in range(rank + 1, world)) % P
+            if carry.any():
+                ctx.check(lib.zk_gl_add_scalar_columns(ctx.handle, C.c_void_p(zmat.data_ptr()), nb, zmat.shape[0], nb, carry.ctypes.data))
+            pieces += [h for h in helpers if h.shape[0]] + [zmat]
+        # starky's order of the auxiliary polynomials: lookup columns, all CTL helper columns, all CTL Z columns
+        aux_block = torch.cat(pieces, dim=0).contiguous()
         aux = commit_rows_sharded(aux_block, config, ctx, group, timing)
         challenger.observe_cap(aux.cap)
     n_aux = aux.n_cols if aux is not None else 0
@@ -430,11 +467,14 @@ def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tupl
     ac = np.array(list(air_consts), dtype=np.uint64)
     # the ctl program carries the per-z-data helper counts; the column tensors themselves are not read (aux rows are)
     cp = encode_ctl_set(zdatas) if zdatas else None
+    lp = encode_lookup_set(lookups) if lookups else None
+    lch = np.array([a % (1 << 64) for a in lookup_challenges], dtype=np.uint64)
     ctx.check(lib.zk_quotient_values_sharded(
         ctx.handle, C.byref(cfg), air_id, ac.ctypes.data if ac.size else None, ac.size,
         C.c_void_p(trace.rows.data_ptr()), C.c_void_p(trace_next.data_ptr()), C_tr,
         C.c_void_p(aux.rows.data_ptr()) if aux is not None else None, C.c_void_p(aux_next.data_ptr()) if aux is not None else None,
-        n_aux, log_n, lw, rank, alphas.ctypes.data, None, 0, None, 0,
+        n_aux, log_n, lw, rank, alphas.ctypes.data, lp.ctypes.data if lp is not None else None, lp.size if lp is not None else 0,
+        lch.ctypes.data if lch.size else None, lch.size,
         cp.ctypes.data if cp is not None else None, cp.size if cp is not None else 0, constraint_degree, C.c_void_p(qloc.data_ptr())))
     torch.cuda.synchronize(dev)
     del trace_next, aux_next
