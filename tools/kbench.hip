@@ -97,5 +97,16 @@ int main(int argc, char **argv) {
            tot[0], tot[1], tot[2], tot[3], 40.0 * cols * n / ((tot[0] + tot[1]) * 1e-3) / 1e9);
     printf("fnv coeffs %016llx lde %016llx digests %016llx\n", (unsigned long long)checksum(ctx, coeffs, cols * n),
            (unsigned long long)checksum(ctx, lde, cols * N), (unsigned long long)checksum(ctx, dig, nd * 4));
+#ifdef ZK_NTT_DEBUG
+    if (getenv("ZK_NTT_NT") && (atoi(getenv("ZK_NTT_NT")) & 64)) {
+        u64 tr[16];
+        hipMemcpyFromSymbol(tr, HIP_SYMBOL(zk_ntt_trace), sizeof tr);
+        const char *nm[8] = {"top (copy, index)", "step 1 + waits (tile, t1)", "issue T, N", "exchange 1", "step 2 + wait (t2; prev N)", "exchange 2", "step 3 (+ wait t3)", "issue A, S"};
+        double tot = 0;
+        for (int k = 0; k < 8; ++k) tot += (double)tr[k];
+        printf("persistent strided pass (last launched), one wave, %llu bodies, %.2f us per body:\n", (unsigned long long)tr[9], tot / tr[9] / 100.0);
+        for (int k = 0; k < 8; ++k) printf("    %-30s %7.2f us\n", nm[k], (double)tr[k] / tr[9] / 100.0);
+    }
+#endif
     return 0;
 }

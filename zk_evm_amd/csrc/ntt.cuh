@@ -297,6 +297,221 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
     }
 }
 
+// ---- the strided pass as a PERSISTENT, software-pipelined kernel (r04q) -------------------------------------------------
+// ntt_pass_kernel is load -> barrier -> butterflies -> barrier -> store, and the two workgroups that share a CU run those phases
+// in lock step: HBM moves the tiles at ~5 TB/s with the vector units idle, then the butterflies run with HBM idle -- the two
+// ADD (DESIGN section 4 "r04": 2.02 + 2.30 = 3.94 ms).  A wave's loads return in order, so a prefetch issued inside the
+// butterflies is waited for by the next twiddle load; here the ORDER of issue is arranged so that it never is:
+//   one workgroup per CU walks its tiles (2^9 rows x 16 contiguous elements = one radix-8 sub-problem per lane and step);
+//   per tile a lane issues, in this order: the twiddles of steps 2 and 3, the EIGHT ELEMENTS OF THE NEXT TILE (straight into
+//   registers, in step 1's layout: four 128-byte row segments per wave and instruction, like the tile load of the
+//   generic kernel), then runs step 1 on twiddles fetched during the previous tile, issues the next tile's step-1 twiddles,
+//   and goes on to steps 2 and 3 -- whose `s_waitcnt vmcnt(N)` leaves the younger loads outstanding -- and stores step 3's
+//   results straight from registers (again four 128-byte segments per wave and instruction).  The next tile's elements have
+//   the whole of this tile's butterflies to arrive.  LDS only carries the two exchanges between the steps (two buffers, so
+//   two barriers per tile instead of five, and no LDS round trip at either end).
+// Same butterflies in the same order on the same operands as ntt_pass_kernel: bit-identical output.
+// Geometry is fixed: r = 9, log_t = 4, 1024 threads; no load / store factors (a strided pass never has any: they belong
+// to the contiguous pass at the coefficient end).  Everything else takes ntt_pass_kernel (ntt_host.inc launch_pass).
+template <bool DIT>
+__device__ __forceinline__ void ntt_tw7(__amdgpu_buffer_rsrc_t twr, const NttPass &p, int log_q, u32 x0, u64 (&tw)[7]) {
+    const int log_D0 = p.log_d + log_q;
+    if (ZK_NTT_DBG(16)) {                                // (kbench -DZK_NTT_DEBUG: no twiddle loads)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) tw[i] = x0 + i;
+        return;
+    }
+    if (DIT) {
+        const u32 g8 = (x0 & ((1u << log_D0) - 1)) * 8;
+#pragma unroll
+        for (int lm = 0; lm < 3; ++lm)
+#pragma unroll
+            for (int mm = 0; mm < (1 << lm); ++mm)
+                tw[(1 << lm) - 1 + mm] = ntt_tw_load(twr, g8, ((1u << (log_D0 + lm)) - 1) + ((u32)mm << log_D0));
+    } else {
+#pragma unroll
+        for (int lm = 2; lm >= 0; --lm) {
+            const int log_D = log_D0 + lm;
+            const u32 lvl = (1u << (p.log_n - 1 - log_D)) - 1;
+            const u32 blk8 = (x0 >> (log_D + 1)) * 8;
+#pragma unroll
+            for (int hg = 0; hg < (1 << (2 - lm)); ++hg) tw[(1 << (2 - lm)) - 1 + hg] = ntt_tw_load(twr, blk8, lvl + hg);
+        }
+    }
+}
+template <bool DIT>
+__device__ __forceinline__ void ntt_radix8(u64 (&v)[8], const u64 (&tw)[7]) {
+    if (DIT) {
+#pragma unroll
+        for (int lm = 0; lm < 3; ++lm) {
+            const int hm = 1 << lm;
+#pragma unroll
+            for (int mm = 0; mm < hm; ++mm)
+#pragma unroll
+                for (int m = mm; m < 8; m += 2 * hm) ntt_bfly(v[m], v[m + hm], tw[hm - 1 + mm]);
+        }
+    } else {
+#pragma unroll
+        for (int lm = 2; lm >= 0; --lm) {
+            const int hm = 1 << lm;
+#pragma unroll
+            for (int hg = 0; hg < (1 << (2 - lm)); ++hg)
+#pragma unroll
+                for (int mm = 0; mm < hm; ++mm) ntt_bfly(v[hg * 2 * hm + mm], v[hg * 2 * hm + mm + hm], tw[(1 << (2 - lm)) - 1 + hg]);
+        }
+    }
+}
+
+#ifdef ZK_NTT_DEBUG
+__device__ u64 zk_ntt_trace[16];                       // tools/kbench_dbg: time per body section of one wave (10 ns ticks), + bodies
+__device__ __forceinline__ u64 ntt_dbg_now() { u64 t; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+#define ZK_NTT_MARK(k) do { if (p.nt & 64) { const u64 n_ = ntt_dbg_now(); tr[k] += n_ - tlast; tlast = n_; } } while (0)
+#else
+#define ZK_NTT_MARK(k) do { } while (0)
+#endif
+#define ZK_NTT_PERSIST_R 9
+#define ZK_NTT_PERSIST_LOG_T 4
+template <bool DIT>
+__global__ void __launch_bounds__(1024) ntt_strided_persist_kernel(NttPass p, u32 n_cols, u32 n_items) {
+    extern __shared__ __attribute__((aligned(16))) u64 tile[];
+    u64 *const buf_a = tile, *const buf_b = tile + (1u << (ZK_NTT_PERSIST_R + ZK_NTT_PERSIST_LOG_T));
+    const u32 tid = threadIdx.x, u = tid & 15, w = tid >> 4;
+    const int log_d = p.log_d;
+    const int log_lo_tiles = log_d - ZK_NTT_PERSIST_LOG_T;
+    const __amdgpu_buffer_rsrc_t twr = ntt_tw_rsrc(p.tw);
+    // the three register steps: rows t0 + m * 2^lq, m < 8 (ntt_step with K = 3 and one sub-problem per lane)
+    constexpr int lq1 = DIT ? 0 : 6, lq2 = 3, lq3 = DIT ? 6 : 0;
+    const u32 r1 = ((w >> lq1) << (lq1 + 3)) + (w & ((1u << lq1) - 1));
+    const u32 r2 = ((w >> lq2) << (lq2 + 3)) + (w & ((1u << lq2) - 1));
+    const u32 r3 = ((w >> lq3) << (lq3 + 3)) + (w & ((1u << lq3) - 1));
+    const u32 l1 = (r1 << 4) + u, l2 = (r2 << 4) + u, l3 = (r3 << 4) + u;             // LDS index of element 0 of each step
+    const u32 g1 = (r1 << log_d) + u, g3 = (r3 << log_d) + u, g2 = (r2 << log_d) + u;  // the same, relative to the tile base
+    const u32 G = gridDim.x;
+
+    // item -> (column, tile base); the items of a workgroup are it, it + G, it + 2 G, ... (columns fastest: the workgroups that
+    // run side by side work on the same tile index of different columns and share its twiddles in the L2).  Items past the end
+    // are clamped to the workgroup's first one: their loads are issued (one path through the loop) and never used.
+    auto item_base = [&](u32 item, u32 &c) {
+        if (item >= n_items) item = blockIdx.x;
+        c = item % n_cols;
+        const u32 tl = item / n_cols;
+        return ((tl >> log_lo_tiles) << (log_d + ZK_NTT_PERSIST_R)) + ((tl & ((1u << log_lo_tiles) - 1)) << ZK_NTT_PERSIST_LOG_T);
+    };
+    auto fetch = [&](u64 (&dst)[8], u32 c, u32 b) {
+        const char *s = reinterpret_cast<const char *>(p.src + (size_t)c * p.src_stride);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) dst[m] = ZK_NTT_DBG(8) ? (u64)(b + m) : *reinterpret_cast<const u64 *>(s + ((b + g1 + ((u32)m << (lq1 + log_d))) << 3));
+    };
+    auto exchange = [&](u64 (&v)[8], u64 *buf, u32 lw, int lqw, u32 lr, int lqr) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) buf[lw + ((u32)m << (lqw + 4))] = v[m];
+        if (!ZK_NTT_DBG(32)) __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = buf[lr + ((u32)m << (lqr + 4))];
+    };
+    auto store = [&](const u64 (&v)[8], u32 c, u32 b) {
+        char *const d = reinterpret_cast<char *>(p.dst + (size_t)c * p.dst_stride);
+        if (!ZK_NTT_DBG(4)) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                *reinterpret_cast<u64 *>(d + ((b + g3 + ((u32)m << (lq3 + log_d))) << 3)) = p.last_pass ? gl_canon(v[m]) : v[m];
+        } else if (v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7] == 0x123456789abcdefull) *reinterpret_cast<u64 *>(d) = 1;
+    };
+
+    u32 it = blockIdx.x;
+    if (it >= n_items) return;
+    u32 col0, base0, col1, base1, col2, base2;             // the tile being transformed, the next one, the one after
+    u64 nxa[8], nxb[8];                                    // tile data in flight: consumed alternately, reloaded two tiles ahead
+    u64 t1a[7], t2a[7], t3a[7], t1b[7], t2b[7], t3b[7];    // twiddles of the tile body a / body b works on
+
+    // The pipelined bodies come as  a (b a)*  -- an odd number: with an even count the first tile is done here, unpipelined.
+    if (!((((n_items - it) + G - 1) / G) & 1)) {
+        base0 = item_base(it, col0);
+        fetch(nxa, col0, base0);
+        ntt_tw7<DIT>(twr, p, lq1, base0 + g1, t1a);
+        ntt_tw7<DIT>(twr, p, lq2, base0 + g2, t2a);
+        ntt_tw7<DIT>(twr, p, lq3, base0 + g3, t3a);
+        ntt_radix8<DIT>(nxa, t1a);
+        exchange(nxa, buf_a, l1, lq1, l2, lq2);
+        ntt_radix8<DIT>(nxa, t2a);
+        exchange(nxa, buf_b, l2, lq2, l3, lq3);
+        ntt_radix8<DIT>(nxa, t3a);
+        store(nxa, col0, base0);
+        it += G;
+        __syncthreads();                                   // (buf_a / buf_b are free again)
+    }
+    base0 = item_base(it, col0);
+    base1 = item_base(it + G, col1);
+    fetch(nxa, col0, base0);
+    fetch(nxb, col1, base1);
+    ntt_tw7<DIT>(twr, p, lq1, base0 + g1, t1a);
+    ntt_tw7<DIT>(twr, p, lq2, base0 + g2, t2a);
+    ntt_tw7<DIT>(twr, p, lq3, base0 + g3, t3a);
+
+    // One tile.  A wave's vector-memory operations complete IN ORDER (one counter, loads and stores alike), so whatever is
+    // needed soon must not have been issued behind something slow.  Order of issue per body, and when each is needed:
+    //     step 1                                   (its twiddles: issued after step 1 of the previous body)
+    //     T: step-1 twiddles of the next tile           -> step 1 of the next body ... fast (L2), and ahead of:
+    //     N: the tile two ahead, into the buffer just consumed -> top of the body after the next ... slow (HBM)
+    //     steps 2, 3                               (their twiddles: issued at the end of the previous body, ahead of N)
+    //     A: step-2 / step-3 twiddles of the NEXT tile  -> steps 2, 3 of the next body ... fast, and ahead of:
+    //     S: this tile's stores                    -> nothing waits for them before T of the next body is needed, a body later
+#ifdef ZK_NTT_DEBUG
+    u64 tr[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = ntt_dbg_now();
+#endif
+    auto body = [&](u64 (&nx)[8], u64 (&t1)[7], u64 (&t2)[7], u64 (&t3)[7], u64 (&t1n)[7], u64 (&t2n)[7], u64 (&t3n)[7], auto tag) {
+        // (the copies of the body must not be merged back into one with the buffers rotated by register copies -- copying a
+        // register with a load in flight waits for it: distinct asm comments keep them apart)
+        if (decltype(tag)::value == 0) asm volatile("; persist body a"); else if (decltype(tag)::value == 1) asm volatile("; persist body b"); else asm volatile("; persist body a'");
+        u64 v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = nx[m];
+        base2 = item_base(it + 2 * G, col2);
+        ZK_NTT_MARK(0);
+        if (!ZK_NTT_DBG(2)) ntt_radix8<DIT>(v, t1);
+        __builtin_amdgcn_sched_barrier(0);
+        ZK_NTT_MARK(1);                                    // step 1 and its waits (the tile, its twiddles)
+        ntt_tw7<DIT>(twr, p, lq1, base1 + g1, t1n);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(nx, col2, base2);
+        __builtin_amdgcn_sched_barrier(0);
+        ZK_NTT_MARK(2);                                    // issue of T and N
+        exchange(v, buf_a, l1, lq1, l2, lq2);
+        ZK_NTT_MARK(3);                                    // first exchange (write, barrier, read)
+        if (!ZK_NTT_DBG(2)) ntt_radix8<DIT>(v, t2);
+        else v[0] += t2[0] + t2[1] + t2[2] + t2[3] + t2[4] + t2[5] + t2[6] + t1[0] + t1[1] + t1[2] + t1[3] + t1[4] + t1[5] + t1[6];
+        __builtin_amdgcn_sched_barrier(0);
+        ZK_NTT_MARK(4);                                    // step 2 and its wait (twiddles; behind them in order: the previous N)
+        exchange(v, buf_b, l2, lq2, l3, lq3);
+        ZK_NTT_MARK(5);
+        if (!ZK_NTT_DBG(2)) ntt_radix8<DIT>(v, t3);
+        else v[0] += t3[0] + t3[1] + t3[2] + t3[3] + t3[4] + t3[5] + t3[6];
+        __builtin_amdgcn_sched_barrier(0);
+        ZK_NTT_MARK(6);                                    // step 3
+        ntt_tw7<DIT>(twr, p, lq2, base1 + g2, t2n);
+        ntt_tw7<DIT>(twr, p, lq3, base1 + g3, t3n);
+        __builtin_amdgcn_sched_barrier(0);
+        store(v, col0, base0);
+        __builtin_amdgcn_sched_barrier(0);
+        ZK_NTT_MARK(7);                                    // issue of A and S
+#ifdef ZK_NTT_DEBUG
+        tr[9] += 1;
+#endif
+        col0 = col1; base0 = base1; col1 = col2; base1 = base2;
+        it += G;
+    };
+    // a (b a)*: the loop header joins two copies of body a, whose pending memory operations are the same -- a header joining
+    // the prologue and a body takes the worst case of both wait counts and waits for the prefetch
+    body(nxa, t1a, t2a, t3a, t1b, t2b, t3b, std::integral_constant<int, 2>());
+    while (it < n_items) {
+        body(nxb, t1b, t2b, t3b, t1a, t2a, t3a, std::integral_constant<int, 1>());
+        body(nxa, t1a, t2a, t3a, t1b, t2b, t3b, std::integral_constant<int, 0>());
+    }
+#ifdef ZK_NTT_DEBUG
+    if ((p.nt & 64) && blockIdx.x == 37 && tid == 64 * 5) for (int k = 0; k < 10; ++k) zk_ntt_trace[k] = tr[k];
+#endif
+}
+
 // The LAST values -> coefficients pass and the FIRST coefficients -> values pass of a commitment work on the same tiles: the
 // contiguous pass of the inverse transform leaves coefficients [k 2^c, (k + 1) 2^c) of a column (bit-reversed order) in tile k,
 // and the contiguous pass of the low-degree extension reads exactly those to produce values [k 2^(c + rate), (k + 1) 2^(c + rate))
