@@ -25,10 +25,11 @@ What is sharded, and how (W = 2^k ranks, one per GPU; N = 2n LDE points):
                round, folds on the local values (`_fri_sharded`).  The initial-tree opening of query x comes from the rank
                that owns leaf x (its row + the path inside its subtree); in the sharded form so do the round openings.
 
-The proof equals the single-GPU `zk_prove_table` proof word for word (tests/test_gpu_multirank.py).  Tables with logUp
-next-row columns in a lookup or a CTL entry are rejected here (a block's last row would need its neighbour's first: Cpu, Memory);
-logUp lookups are handled (forward running sums with carries from the blocks before).  The Python side is orchestration only --
-every kernel is the library's."""
+The proof equals the single-GPU `zk_prove_table` proof word for word (tests/test_gpu_multirank.py), for every table of the
+AllStark: logUp lookups (forward running sums with carries from the blocks before), CTL looking runs with helper columns, and
+columns that read the next row across a block boundary (Memory's range-check lookup, the Cpu table's CTL entries: the block's
+last row is redone on a "seam" trace holding the next block's first row).  The Python side is orchestration only -- every
+kernel is the library's."""
 import ctypes as C
 from typing import List, Optional, Sequence, Tuple
 
@@ -397,27 +398,34 @@ def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tupl
     # that row's values.  Order of the auxiliary polynomials: per lookup, per challenge, the helpers then Z; then the CTL columns.
     lookup_cols = []
     lookup_challenges = [b for b, _ in ctl_challenges] if lookups else []
+    # Columns that read the NEXT row (Memory's range-check lookup, the Cpu table's CTL entries): the last row of a block needs
+    # the first row of the block after it (the last block: row 0).  The builders run on the block and wrap around inside it, so
+    # their values AT the block's last row are redone -- by the same kernels, on a 16-row "seam" trace whose row 0 is the
+    # block's last row and whose other rows are the next block's first row (an all-gather of one row per rank).
+    MINI = 16
+    firsts = all_gather_words(block[:, 0].cpu().numpy().view(np.uint64), int(block.shape[0]), group)
+    seam = torch.from_numpy(np.ascontiguousarray(firsts[(rank + 1) % world]).view(np.int64)).to(dev).reshape(-1, 1).repeat(1, MINI).contiguous()
+    seam[:, 0] = block[:, nb - 1]
+    # ... except in the LAST block: starky's `Column::eval_table` takes the next row's values to be 0 at the last row of the
+    # trace ("If the lookups are correctly written, the filter should be 0 in that case anyway") -- which is what the builders
+    # do at the last row of whatever they are given, so the last block is right as it stands
+    use_seam = rank + 1 < world
+
+    def word(x):
+        return int(x.cpu().numpy().reshape(-1).view(np.uint64)[0]) % P
+
     if lookups:
-        def col_at_last(c):
-            if getattr(c, "next_row_linear_combination", None):
-                raise NotImplementedError("row-sharded proving with next-row lookup columns is not built")
-            acc = int(c.constant) % P
-            for k, f in c.linear_combination:
-                acc = (acc + (int(last_row[int(k)]) % P) * (int(f) % P)) % P
-            return acc
-        last_row = block[:, nb - 1].cpu().numpy().view(np.uint64)
         lz, lz_tot = [], []
         for lk in lookups:
-            for c in list(lk.columns) + [lk.table_column, lk.frequencies_column]:
-                if getattr(c, "next_row_linear_combination", None):
-                    raise NotImplementedError("row-sharded proving with next-row lookup columns is not built")
             for alpha in lookup_challenges:
                 cols = lookup_helper_columns(lk, block, alpha, constraint_degree, ctx=ctx)        # helpers ..., Z (from 0 in this block)
-                hl = cols[:-1, nb - 1].cpu().numpy().view(np.uint64)
-                inc = (sum(int(x) % P for x in hl) - col_at_last(lk.frequencies_column) *
-                       pow((col_at_last(lk.table_column) + alpha) % P, P - 2, P)) % P
+                mini = lookup_helper_columns(lk, seam, alpha, constraint_degree, ctx=ctx)
+                if use_seam:
+                    cols[:-1, nb - 1] = mini[:-1, 0]                   # the last row's helpers with the true next row
+                # Z[i + 1] = Z[i] + (sum of the helpers - freq / (table + alpha))[i]: the seam's Z[1] is the last row's increment
+                # (the last block's total is not used by anybody)
                 lz.append(cols)
-                lz_tot.append((int(cols[-1, nb - 1].cpu().numpy().view(np.uint64)) % P + inc) % P)
+                lz_tot.append((word(cols[-1, nb - 1]) + word(mini[-1, 1])) % P)
         tots = all_gather_words(np.array(lz_tot, dtype=np.uint64), len(lz_tot), group)
         for k, cols in enumerate(lz):
             carry = sum(int(tots[q][k]) for q in range(rank)) % P          # the blocks before this one
@@ -428,9 +436,16 @@ def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tupl
     if ctl_specs or lookup_cols:
         helpers, zs = [], []
         for beta, gamma, entries in ctl_specs:
-            if _entries_use_next_row(entries):
-                raise NotImplementedError("row-sharded proving with next-row CTL columns is not built")
             cols = ctl_partial_sums(block, entries, beta, gamma, constraint_degree, ctx=ctx)      # helpers (if any), then Z
+            if use_seam and _entries_use_next_row(entries):
+                # Z[i] = Z[i + 1] + term(i), Z[last] = term(last): the block's Z all contain its last row's term, computed
+                # with the wrong next row -- replace it by the seam's (Z[0] - Z[1] there is term(row 0))
+                mini = ctl_partial_sums(seam, entries, beta, gamma, constraint_degree, ctx=ctx)
+                cols[:-1, nb - 1] = mini[:-1, 0]
+                delta = (word(mini[-1, 0]) - word(mini[-1, 1]) - word(cols[-1, nb - 1])) % P
+                if delta:
+                    z = cols[-1:]
+                    ctx.check(lib.zk_gl_add_scalar_columns(ctx.handle, C.c_void_p(z.data_ptr()), nb, 1, nb, np.array([delta], dtype=np.uint64).ctypes.data))
             n_helpers_of.append(int(cols.shape[0]) - 1)
             helpers.append(cols[:-1])
             zs.append(cols[-1:])
