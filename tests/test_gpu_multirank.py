@@ -17,6 +17,26 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _qget(q, procs, timeout):
+    """`q.get` that notices a dead worker: a rank that raised leaves its peers inside a collective, and the test would otherwise
+    sit out the whole timeout (r04: fifteen GPU-minutes) -- the survivors are killed and the exit code reported (the
+    traceback is on the captured stderr)."""
+    import queue
+    import time
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            return q.get(timeout=5)
+        except queue.Empty:
+            dead = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode not in (None, 0)]
+            if dead or time.monotonic() > deadline:
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()
+                raise AssertionError("worker (index, exit code) %s died / timed out" % dead)
+
+
+
 def _bench(*args, env_extra=None, timeout=900):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env.update(env_extra or {})
@@ -168,7 +188,7 @@ def test_table_parallel_segment_equals_single_gpu_proof():
         p.start()
     res = {}
     for _ in procs:
-        r, mine, words, owned, _ = q.get(timeout=600)
+        r, mine, words, owned, _ = _qget(q, procs, 600)
         res[r] = (mine, words, owned)
     for p in procs:
         p.join(timeout=120)
@@ -205,7 +225,7 @@ def test_table_parallel_segment_with_row_sharded_keccak_and_logic():
         p.start()
     res = {}
     for _ in procs:
-        r, mine, words, owned, _ = q.get(timeout=600)
+        r, mine, words, owned, _ = _qget(q, procs, 600)
         res[r] = (mine, words, owned)
     for p in procs:
         p.join(timeout=120)
@@ -250,7 +270,7 @@ def test_table_parallel_and_scheduler_over_nccl_world1():
     q = ctx.Queue()
     p = ctx.Process(target=_tp_worker, args=(0, 1, port, q, "nccl"))
     p.start()
-    r, mine, words, owned, extra = q.get(timeout=600)
+    r, mine, words, owned, extra = _qget(q, [p], 600)
     p.join(timeout=120)
     assert p.exitcode == 0 and mine == list(range(9))
     log_ns = [9, 8, 10, 7, 8, 8, 11, 8, 8]
@@ -306,7 +326,7 @@ def test_row_sharded_commit_equals_single_gpu_cap(shape, world, hasher):
         p.start()
     res = {}
     for _ in procs:
-        r, cap, timing = q.get(timeout=600)
+        r, cap, timing = _qget(q, procs, 600)
         res[r] = (cap, timing)
     for p in procs:
         p.join(timeout=120)
@@ -389,7 +409,7 @@ def test_block_job_list_through_run_distributed_two_ranks():
     procs = [ctx.Process(target=_block_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=900) for _ in procs)
+    res = dict(_qget(q, procs, 900) for _ in procs)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -508,7 +528,7 @@ def test_row_sharded_table_proof_equals_single_gpu_proof(shape, world, fri):
     res = {}
     try:
         for _ in procs:
-            r, words, state, timing = q.get(timeout=300)
+            r, words, state, timing = _qget(q, procs, 600)
             assert not isinstance(words, str), "rank %d failed:\n%s" % (r, state)
             res[r] = (words, state, timing)
     except BaseException:
@@ -553,7 +573,7 @@ def test_all_to_all_and_sharded_prover_over_rccl_world1():
     q = ctx.Queue()
     p = ctx.Process(target=_l3_nccl_worker, args=(port, q))
     p.start()
-    same, backend = q.get(timeout=600)
+    same, backend = _qget(q, [p], 600)
     p.join(timeout=120)
     assert p.exitcode == 0 and backend == "nccl" and same
 
@@ -642,7 +662,7 @@ def test_row_sharded_proof_with_ctl_helper_columns():
     procs = [ctx.Process(target=_l3_custom_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict((r[0], r[1:]) for r in (q.get(timeout=600) for _ in procs))
+    res = dict((r[0], r[1:]) for r in (_qget(q, procs, 600) for _ in procs))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
