@@ -57,6 +57,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["segment", "commit"], default="segment")
+    ap.add_argument("--mode", choices=["segments", "table_parallel", "table_parallel_keccak_rows"], default="segments",
+                    help="how N ranks share the work: `segments` (default; SURVEY 8(e) level 1: one independent segment per GPU "
+                         "and step, weak scaling, no data-path collective) or the LATENCY modes -- ONE segment per step proven by "
+                         "all ranks together, strong scaling: `table_parallel` (level 2: a table per rank, caps all-gathered, the "
+                         "challenger state broadcast along the chain) and `table_parallel_keccak_rows` (level 2 with the "
+                         "2431-column Keccak table row-sharded over all ranks, level 3: all-to-all, sub-root all-gather, sharded "
+                         "quotient / openings / FRI combination)")
     ap.add_argument("--commit-steps", type=int, default=5, help="configs[1] commits timed as a secondary object")
     ap.add_argument("--cols", type=int, default=116)
     ap.add_argument("--log-n", type=int, default=20)
@@ -464,9 +471,31 @@ def main():
         in_use = [True] * n_tab
         TABLE_COLUMNS = all_stark.table_columns
 
+        latency_mode = a.mode != "segments"
+        if latency_mode:
+            # every rank generates the SAME segment (seed 1) and keeps what it owns: its tables (the library's own assignment)
+            # and, for the row-sharded table, its row block
+            from zk_evm_amd.sharding import assign_tables, prove_segment_table_parallel
+            KECCAK = 3
+            if rank != 0 or world > 1:
+                del traces
+                traces = synthetic_segment_traces(log_ns, dev, seed=1, cdk_erigon=a.cdk_erigon)
+            wide = {}
+            if a.mode == "table_parallel_keccak_rows" and world > 1:
+                nb = traces[KECCAK].shape[1] // world
+                wide = {KECCAK: traces[KECCAK][:, rank * nb:(rank + 1) * nb].contiguous()}
+            solo = [t for t in range(n_tab) if t not in wide]
+            mine = [solo[k] for k in assign_tables([(TABLE_COLUMNS[t], log_ns[t]) for t in solo], world)[rank]]
+            traces = [tr if t in mine else None for t, tr in enumerate(traces)]
+            torch.cuda.empty_cache()
+            grp = rg.group() if world > 1 else None
+
         def step(timing=None):
-            return sg.prove_with_traces(all_stark, cfg, traces, in_use, sg.PublicValues(burn_addr=1 if a.cdk_erigon else None),
-                                        ctx=ctx, timing=timing)
+            pv = sg.PublicValues(burn_addr=1 if a.cdk_erigon else None)
+            if latency_mode:
+                return prove_segment_table_parallel(all_stark, cfg, traces, in_use, pv, group=grp, ctx=ctx, timing=timing,
+                                                    row_sharded=wide or None)
+            return sg.prove_with_traces(all_stark, cfg, traces, in_use, pv, ctx=ctx, timing=timing)
         if a.pmc_child:                       # one segment under rocprofv3 --pmc (collect_kernel_counters), nothing printed
             step()
             torch.cuda.synchronize()
@@ -485,14 +514,17 @@ def main():
         tot = ctx.commit_totals(reset=True)
         side = ctx.side_commit_totals(reset=True)
         mem = ctx.mem_stats()
+        timing = {}
+        if latency_mode:
+            step(timing)                     # (the stage breakdown's extra proof: every rank is part of it in these modes)
         if rank == 0:
             ms_per_step = 1e3 * elapsed / a.steps
             leaf_ms = tot["leaf_hash"]
             achieved = tot["leaf_hash_bytes"] / (leaf_ms * 1e-3) / 1e9
             ntt_ms = tot["ifft"] + tot["lde"]
             proof_words = sum(int(p.proof.opening_proof.size) for p in proof.multi_proof.stark_proofs if p is not None)
-            timing = {}
-            step(timing)                     # one extra, synchronised, untimed proof for the stage breakdown
+            if not latency_mode:
+                step(timing)                 # one extra, synchronised, untimed proof for the stage breakdown
             trace_bytes = 8.0 * sum(c << l for c, l in zip(TABLE_COLUMNS, log_ns))
             # HBM bytes per leaf-hash launch (mean over the 27 launches of a segment) from the rocprofv3 --pmc passes
             # on this same workload, summarised in profiles/pmc_latest.json["segment"]; only valid for the default shape
@@ -516,13 +548,15 @@ def main():
             out = {
                 "metric": "segment STARK proofs/sec (2^20-row traces, all nine AllStark tables)" if log_ns == [20] * 9 else
                           "segment STARK proofs/sec (table heights 2^%s%s)" % (",".join(map(str, log_ns)), ", cdk_erigon" if a.cdk_erigon else ""),
-                "value": world * a.steps / elapsed, "unit": "segment proofs/s", "n_gpus": world, "steps": a.steps,
-                "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+                "value": (1 if latency_mode else world) * a.steps / elapsed, "unit": "segment proofs/s", "n_gpus": world, "steps": a.steps,
+                "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if latency_mode else "weak",
                 "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                 "config": {"workload": f"prove_with_traces: full AllStark segment proof (BASELINE configs[2]), 9 tables x "
                                        f"2^{log_ns[0] if uniform else log_ns} rows ({sum(TABLE_COLUMNS)} trace columns, {trace_bytes / 1e9:.1f} GB), "
                                        f"10 CTLs + lookups, standard_fast_config, hasher {hname}",
-                           "parallelism": f"{world} independent segments (one per GPU), no collective",
+                           "parallelism": (f"{world} independent segments (one per GPU), no collective" if not latency_mode else
+                                           f"ONE segment per step over {world} ranks, mode {a.mode}: tables {mine} on rank 0"
+                                           + (", Keccak's rows over all ranks" if wide else "")),
                            "committed_cells": cells, "proof_words": proof_words},
                 "roofline": {"bound": "hbm", "limiting_resource": "integer VALU issue (the `valu` object), not HBM: `frac` is the "
                                                                     "contract's HBM fraction, `valu.frac` says how good the kernel is",

@@ -65,6 +65,18 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert abs(two["value"] - 2 * two["steps"] / (two["ms_per_step"] * two["steps"] / 1e3)) < 1e-6 * two["value"]
 
 
+@pytest.mark.parametrize("mode", ["table_parallel", "table_parallel_keccak_rows"])
+def test_bench_latency_modes_two_ranks_on_one_gpu(mode):
+    """`bench.py --mode ...`: ONE segment per step proven by all ranks together (SURVEY 8(e) levels 2 and 2 + 3) through the
+    same launch path as the scaling line -- strong scaling, value = segments / time (not x ranks), every rank inside the
+    collectives of every step including the stage-breakdown proof."""
+    b = _bench("--gpus", "2", "--devices", "0,0", "--dist-backend", "gloo", "--mode", mode, *SMALL)
+    assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["unit"] == "segment proofs/s"
+    assert abs(b["value"] - 1e3 / b["ms_per_step"]) < 1e-6 * b["value"]
+    assert mode in b["config"]["parallelism"] and ("Keccak's rows" in b["config"]["parallelism"]) == mode.endswith("rows")
+    assert "per-table proofs (serial chain over owners)" in b["segment_timing_s"] and len(b["per_rank_ms_per_step"]) == 2
+
+
 def test_bench_joins_an_external_launcher():
     """the driver's form: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
