@@ -590,6 +590,50 @@ def test_all_to_all_and_sharded_prover_over_rccl_world1():
     assert p.exitcode == 0 and backend == "nccl" and same
 
 
+def _l3_big_pieces_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    import zk_evm_amd
+    from zk_evm_amd.shard_prover import NCCL_PIECE_BYTES, commit_rows_sharded
+    cfg = zk_evm_amd.StarkConfig()
+    ctx = zk_evm_amd.context.default_context(0)
+    ctx.use_torch_current_stream()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(7)
+    tr = torch.randint(0, 2 ** 62, (2431, 1 << 16), dtype=torch.int64, device="cuda", generator=g)       # 1.27 GB; the LDE twice that
+    assert tr.numel() * 8 > (1 << 30) > NCCL_PIECE_BYTES
+    tb = zk_evm_amd.PolynomialBatch.from_values(tr, 1, False, 4, hasher=cfg.hasher)
+    want = np.asarray(tb.merkle_tree.cap.elements).reshape(-1).copy()
+    got = np.asarray(commit_rows_sharded(tr, cfg, ctx, None, {}).cap).reshape(-1)
+    q.put(bool(np.array_equal(got, want)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_exchanges_above_one_gib_are_cut_into_pieces():
+    """RCCL on this image silently CORRUPTS a send / recv of more than 2^30 bytes (found in r04 with one rank: a wrong cap for
+    KeccakStark's 2431 columns at 2^15 rows and up, while every library kernel was right).  `shard_prover.all_to_all` / `exchange`
+    hand RCCL at most 256 MiB at a time: the level-3 commitment of 2431 x 2^16 (pieces of 1.27 and 2.5 GB) equals
+    `PolynomialBatch::from_values`."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_l3_big_pieces_worker, args=(port, q))
+    p.start()
+    same = _qget(q, [p], 600)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and same
+
+
 def _l3_nccl_worker(port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -39,6 +39,7 @@ from ._lib import ZkStarkError
 from .sharding import _bitrev, split_columns
 
 P = 0xFFFFFFFF00000001
+NCCL_PIECE_BYTES = 256 << 20      # the largest piece handed to one RCCL send / recv (see all_to_all)
 
 
 # ---- collectives on lists of device tensors (RCCL under nccl; host round trips under gloo) ------------------------------
@@ -59,7 +60,32 @@ def all_to_all(send: List, recv: List, group=None) -> None:
         recv[0].copy_(send[0])
         return
     if dist.get_backend(group) == "nccl":
-        dist.all_to_all(recv, send, group=group)
+        # In pieces of at most NCCL_PIECE_BYTES: RCCL (2.26, this image) returned CORRUPTED data, silently, for a send / recv of
+        # more than 2^30 bytes (measured with one rank: 1.07 GB intact, 1.27 GB not -- tools/l3_one_rank_overhead.py found it
+        # as a wrong cap), and the pieces of a wide table over few ranks are larger than that.  Pieces are cut along dim 0
+        # (columns); a piece's sender and receiver see the same shape, so they cut alike; the number of rounds is agreed.
+        def rows_per_round(x):
+            per_row = max(1, x.numel() // int(x.shape[0])) * x.element_size() if x.numel() else 1
+            return max(1, NCCL_PIECE_BYTES // per_row)
+        rounds = 1
+        for x in list(send) + list(recv):
+            if x.numel():
+                rounds = max(rounds, -(-int(x.shape[0]) // rows_per_round(x)))
+        if world > 1:
+            r_t = torch.tensor([rounds], dtype=torch.int64, device=send[0].device)
+            dist.all_reduce(r_t, op=dist.ReduceOp.MAX, group=group)
+            rounds = int(r_t.item())
+        if rounds == 1:
+            dist.all_to_all(recv, send, group=group)
+            return
+
+        def cut(x, i):
+            if not x.numel():
+                return x
+            step = rows_per_round(x)
+            return x[i * step: (i + 1) * step]
+        for i in range(rounds):
+            dist.all_to_all([cut(x, i) for x in recv], [cut(x, i) for x in send], group=group)
         return
     g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     recv[rank].copy_(send[rank])
@@ -99,9 +125,14 @@ def exchange(send, dst: int, src: int, group=None):
     out = torch.empty_like(send) if nccl else torch.empty(send.shape, dtype=send.dtype)
     buf = send.contiguous() if nccl else send.cpu().contiguous()
     g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
-    ops = [dist.P2POp(dist.isend, buf, g(dst), group), dist.P2POp(dist.irecv, out, g(src), group)]
-    for w in dist.batch_isend_irecv(ops):
-        w.wait()
+    # (under nccl in pieces of at most NCCL_PIECE_BYTES, cut along dim 0: see all_to_all; the shards have one shape everywhere)
+    step = int(buf.shape[0]) if not (nccl and buf.dim() and buf.numel()) else \
+        max(1, NCCL_PIECE_BYTES // max(1, (buf.numel() // buf.shape[0]) * buf.element_size()))
+    for lo in range(0, max(1, int(buf.shape[0]) if buf.dim() else 1), max(1, step)):
+        sl = slice(lo, lo + step) if buf.dim() else Ellipsis
+        ops = [dist.P2POp(dist.isend, buf[sl], g(dst), group), dist.P2POp(dist.irecv, out[sl], g(src), group)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
     return out if nccl else out.to(send.device)
 
 
@@ -223,10 +254,24 @@ def _ext_mul(a, b):
     return ((a[0] * b[0] + 7 * a[1] * b[1]) % P, (a[0] * b[1] + a[1] * b[0]) % P)
 
 
+_BITREV_IDX = {}
+
+
 def _leaf_to_natural(t, log_N: int):
     """columns given in leaf (bit-reversed) order -> natural order"""
     import torch
-    idx = torch.tensor([_bitrev(j, log_N) for j in range(1 << log_N)], dtype=torch.int64, device=t.device)
+    key = (log_N, str(t.device))
+    idx = _BITREV_IDX.get(key)
+    if idx is None:
+        # on the device, one pass per bit (a host-built table took seconds at 2^21 points -- measured on one rank, where
+        # nothing else hides it: tools/l3_one_rank_overhead.py)
+        j = torch.arange(1 << log_N, dtype=torch.int64, device=t.device)
+        idx = torch.zeros_like(j)
+        for b in range(log_N):
+            idx |= ((j >> b) & 1) << (log_N - 1 - b)
+        if len(_BITREV_IDX) > 64:
+            _BITREV_IDX.clear()
+        _BITREV_IDX[key] = idx
     return t.index_select(1, idx).contiguous()
 
 
