@@ -481,14 +481,14 @@ def main():
                 del traces
                 traces = synthetic_segment_traces(log_ns, dev, seed=1, cdk_erigon=a.cdk_erigon)
             wide = {}
-            if a.mode == "table_parallel_keccak_rows" and world > 1:
+            if a.mode == "table_parallel_keccak_rows":               # (one rank: the whole table as its only block)
                 nb = traces[KECCAK].shape[1] // world
                 wide = {KECCAK: traces[KECCAK][:, rank * nb:(rank + 1) * nb].contiguous()}
             solo = [t for t in range(n_tab) if t not in wide]
             mine = [solo[k] for k in assign_tables([(TABLE_COLUMNS[t], log_ns[t]) for t in solo], world)[rank]]
             traces = [tr if t in mine else None for t, tr in enumerate(traces)]
             torch.cuda.empty_cache()
-            grp = rg.group() if world > 1 else None
+            grp = rg.group() if rg.dist is not None and rg.gloo is not None else None
 
         def step(timing=None):
             pv = sg.PublicValues(burn_addr=1 if a.cdk_erigon else None)
