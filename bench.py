@@ -692,6 +692,15 @@ def main():
             ran[name] = res.get("wall_s") if isinstance(res, dict) else None
             out[name] = res
         out["secondary_wall_s"] = ran
+    # RCCL leaves its version banner in the C runtime's stdout buffer until exit -- on every rank, and a launcher merges the
+    # ranks' stdout: out with it now, everywhere, so that rank 0's JSON line is the LAST line
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    rg.barrier()
     if rank == 0:
         print(json.dumps(out), flush=True)
     rg.close()
