@@ -19,7 +19,8 @@ class ZkStarkError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, _LIB_NAME)
+    # ZK_STARK_LIB: a diagnostic build of the same sources (tools/asan_build.sh: AddressSanitizer + UBSan on the host side)
+    return os.environ.get("ZK_STARK_LIB") or os.path.join(_HERE, _LIB_NAME)
 
 
 _lib = None
