@@ -9,4 +9,8 @@ if nm -D "$ZK_STARK_LIB" | grep -q __asan_init; then
   export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:detect_odr_violation=0
   export LD_PRELOAD=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 fi
+if nm -D "$ZK_STARK_LIB" | grep -q __tsan_init; then
+  export TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0:log_path=$ROOT/gpurun_out/ubsan/tsan
+  export LD_PRELOAD=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.tsan-x86_64.so | head -1)
+fi
 python -m pytest "$@"
