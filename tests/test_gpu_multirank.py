@@ -609,7 +609,13 @@ def _l3_big_pieces_worker(port, q):
     tb = zk_evm_amd.PolynomialBatch.from_values(tr, 1, False, 4, hasher=cfg.hasher)
     want = np.asarray(tb.merkle_tree.cap.elements).reshape(-1).copy()
     got = np.asarray(commit_rows_sharded(tr, cfg, ctx, None, {}).cap).reshape(-1)
-    q.put(bool(np.array_equal(got, want)))
+    # the neighbour-shard exchange of the quotient (W > 2) takes the same precaution; with one rank it returns early, so its
+    # piece loop is driven directly: this rank to itself through RCCL's send / recv
+    from zk_evm_amd.shard_prover import _p2p_in_pieces
+    back = torch.zeros_like(tr)
+    _p2p_in_pieces(dist, tr, back, 0, 0, None, NCCL_PIECE_BYTES)
+    torch.cuda.synchronize()
+    q.put(bool(np.array_equal(got, want)) and bool(torch.equal(tr, back)))
     dist.barrier()
     dist.destroy_process_group()
 

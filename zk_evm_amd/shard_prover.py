@@ -115,6 +115,18 @@ def all_gather_tensor(t, group=None) -> List:
     return [p.to(t.device) for p in parts]
 
 
+def _p2p_in_pieces(dist, buf, out, dst_global: int, src_global: int, group, piece_bytes: int) -> None:
+    """buf -> rank dst, out <- rank src, at most `piece_bytes` per send / recv (cut along dim 0; both ends hold one shape)"""
+    rows = int(buf.shape[0]) if buf.dim() else 1
+    per_row = max(1, buf.numel() // max(1, rows)) * buf.element_size()
+    step = rows if not (buf.dim() and buf.numel()) else max(1, piece_bytes // per_row)
+    for lo in range(0, max(1, rows), max(1, step)):
+        sl = slice(lo, lo + step) if buf.dim() else Ellipsis
+        ops = [dist.P2POp(dist.isend, buf[sl], dst_global, group), dist.P2POp(dist.irecv, out[sl], src_global, group)]
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
 def exchange(send, dst: int, src: int, group=None):
     """point to point: this rank's `send` goes to group rank `dst`, the result comes from group rank `src`"""
     import torch
@@ -125,14 +137,8 @@ def exchange(send, dst: int, src: int, group=None):
     out = torch.empty_like(send) if nccl else torch.empty(send.shape, dtype=send.dtype)
     buf = send.contiguous() if nccl else send.cpu().contiguous()
     g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
-    # (under nccl in pieces of at most NCCL_PIECE_BYTES, cut along dim 0: see all_to_all; the shards have one shape everywhere)
-    step = int(buf.shape[0]) if not (nccl and buf.dim() and buf.numel()) else \
-        max(1, NCCL_PIECE_BYTES // max(1, (buf.numel() // buf.shape[0]) * buf.element_size()))
-    for lo in range(0, max(1, int(buf.shape[0]) if buf.dim() else 1), max(1, step)):
-        sl = slice(lo, lo + step) if buf.dim() else Ellipsis
-        ops = [dist.P2POp(dist.isend, buf[sl], g(dst), group), dist.P2POp(dist.irecv, out[sl], g(src), group)]
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+    # (under nccl in pieces of at most NCCL_PIECE_BYTES: see all_to_all)
+    _p2p_in_pieces(dist, buf, out, g(dst), g(src), group, NCCL_PIECE_BYTES if nccl else 1 << 62)
     return out if nccl else out.to(send.device)
 
 
