@@ -340,21 +340,16 @@ def commit_columns_row_sharded(values_shard, n_cols_total: int, config, ctx=None
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     # 2. rows of residue class bitrev_W(q), in leaf-slot order, to rank q
-    perm = torch.tensor([_bitrev(i, log_N - log_w) for i in range(rows_local)], dtype=torch.int64, device=dev)
+    from .shard_prover import _BITREV_IDX, _leaf_to_natural, all_to_all   # (device-side bit reversal; RCCL transfers in pieces)
+    _leaf_to_natural(lde[:1, :rows_local], log_N - log_w)                    # fills the index cache
+    perm = _BITREV_IDX[(log_N - log_w, str(dev))]
     send = [lde[:, _bitrev(q, log_w)::world].index_select(1, perm).contiguous() for q in range(world)]
     del lde
     if not multi:
         recv = send
-    elif dist.get_backend(group) == "nccl":
+    else:
         recv = [torch.empty((len(cols[p]), rows_local), dtype=torch.int64, device=dev) for p in range(world)]
-        dist.all_to_all(recv, send, group=group)
-    else:                                          # gloo has no all-to-all: W scatters of host tensors
-        recv = []
-        for p in range(world):
-            out = torch.empty((len(cols[p]), rows_local), dtype=torch.int64)
-            src = dist.get_global_rank(group, p) if group is not None else p
-            dist.scatter(out, [s.cpu() for s in send] if p == rank else None, src=src, group=group)
-            recv.append(out.to(dev))
+        all_to_all(send, recv, group)
     local = torch.cat(recv, dim=0).contiguous()                    # [C][N / W], row = leaf slot within this rank's subtree
     del send, recv
     torch.cuda.synchronize(dev)
