@@ -129,9 +129,15 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
         u64 v[1 << K];
         // element m lives at ((t0 + m q) << log_t) + u = a0 + m (q << log_t): one add per address
         const u32 a0 = (t0 << log_t) + u;
+        // PAD (log_t = 0): element t0 + m q lives at ph(t0 + m q) = ph(t0) + ph(m q) -- no carry between the two parts: q is a
+        // power of two, t0 mod q < q and t0's bits above are a multiple of 8 q / 8 ... (m q mod 8 is a multiple of q, t0 mod 8 <
+        // q when q < 8, and m q mod 8 = 0 when q >= 8) -- so the pad costs ONE shift-add per sub-problem; the per-m parts are
+        // wave-uniform.  (r03's form re-derived ph() for every access and lost more in index arithmetic than the conflicts cost.)
+        const u32 pa0 = PAD ? t0 + (t0 >> 3) : 0;
 #pragma unroll
         for (int m = 0; m < (1 << K); ++m)
-            v[m] = PAD ? tile[ntt_ph<PAD>(((t0 + m * q) << log_t) + u)] : *reinterpret_cast<u64 *>(tile_b + (a0 * 8 + m * stride8));
+            v[m] = PAD ? *reinterpret_cast<u64 *>(tile_b + (pa0 * 8 + ntt_ph<true>((u32)m << log_q) * 8))
+                       : *reinterpret_cast<u64 *>(tile_b + (a0 * 8 + m * stride8));
         const u32 x0 = base + (t0 << p.log_d) + u;      // global index of v[0]; bits [log_D0, log_D0 + K) are zero
         if (DIT) {
             // pair (x, x + D), D = D0 << lm: twiddle T_D[x mod D]; x_m mod D = g + (m mod hm) * D0
@@ -168,7 +174,7 @@ __device__ __forceinline__ void ntt_step(u64 *tile, const NttPass &p, int log_q,
         }
 #pragma unroll
         for (int m = 0; m < (1 << K); ++m) {
-            if (PAD) tile[ntt_ph<PAD>(((t0 + m * q) << log_t) + u)] = v[m];
+            if (PAD) *reinterpret_cast<u64 *>(tile_b + (pa0 * 8 + ntt_ph<true>((u32)m << log_q) * 8)) = v[m];
             else *reinterpret_cast<u64 *>(tile_b + (a0 * 8 + m * stride8)) = v[m];
         }
     }
@@ -250,7 +256,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
 #pragma unroll
             for (int k = 0; k < ZK_NTT_LOADS_IN_FLIGHT; ++k) {
                 const u32 e = e0 + (u32)k * nthr;
-                if (e < elems) tile[ntt_ph<PAD>(e)] = p.in_scale ? gl_mul(v[k], sc[k]) : v[k];
+                if (e < elems) tile[PAD ? ntt_ph<true>(e0) + (u32)k * (nthr + (nthr >> 3)) : e] = p.in_scale ? gl_mul(v[k], sc[k]) : v[k];   // (nthr is a multiple of 8)
             }
         }
     }
@@ -276,7 +282,7 @@ __global__ void __launch_bounds__(1024) ntt_pass_kernel(NttPass p) {
         for (int k = 0; k < ZK_NTT_LOADS_IN_FLIGHT; ++k) {
             const u32 e = e0 + (u32)k * nthr;
             if (e < elems) {
-                v[k] = tile[ntt_ph<PAD>(e)];
+                v[k] = tile[PAD ? ntt_ph<true>(e0) + (u32)k * (nthr + (nthr >> 3)) : e];
                 if (p.out_scale) { const u32 t = e >> log_t, u = e & (T - 1); sc[k] = p.out_scale[base + (t << p.log_d) + u]; }
             }
         }
