@@ -62,15 +62,13 @@ def all_to_all(send: List, recv: List, group=None) -> None:
     if dist.get_backend(group) == "nccl":
         # In pieces of at most NCCL_PIECE_BYTES: RCCL (2.26, this image) returned CORRUPTED data, silently, for a send / recv of
         # more than 2^30 bytes (measured with one rank: 1.07 GB intact, 1.27 GB not -- tools/l3_one_rank_overhead.py found it
-        # as a wrong cap), and the pieces of a wide table over few ranks are larger than that.  Pieces are cut along dim 0
-        # (columns); a piece's sender and receiver see the same shape, so they cut alike; the number of rounds is agreed.
-        def rows_per_round(x):
-            per_row = max(1, x.numel() // int(x.shape[0])) * x.element_size() if x.numel() else 1
-            return max(1, NCCL_PIECE_BYTES // per_row)
+        # as a wrong cap), and the pieces of a wide table over few ranks are larger than that.  Every piece is cut along dim 0
+        # (columns) into the SAME number of nearly equal parts -- agreed by one all-reduce -- so that no round has an empty
+        # part unless a piece has fewer columns than there are rounds; sender and receiver of a piece see the same shape.
         rounds = 1
         for x in list(send) + list(recv):
             if x.numel():
-                rounds = max(rounds, -(-int(x.shape[0]) // rows_per_round(x)))
+                rounds = max(rounds, -(-(x.numel() * x.element_size()) // NCCL_PIECE_BYTES))
         if world > 1:
             r_t = torch.tensor([rounds], dtype=torch.int64, device=send[0].device)
             dist.all_reduce(r_t, op=dist.ReduceOp.MAX, group=group)
@@ -79,11 +77,9 @@ def all_to_all(send: List, recv: List, group=None) -> None:
             dist.all_to_all(recv, send, group=group)
             return
 
-        def cut(x, i):
-            if not x.numel():
-                return x
-            step = rows_per_round(x)
-            return x[i * step: (i + 1) * step]
+        def cut(x, i):                         # part i of `rounds` nearly equal parts along dim 0: the same cut at both ends of a piece
+            n = int(x.shape[0])
+            return x[i * n // rounds: (i + 1) * n // rounds]
         for i in range(rounds):
             dist.all_to_all([cut(x, i) for x in recv], [cut(x, i) for x in send], group=group)
         return
