@@ -162,6 +162,23 @@ def dist_selftest(rank, world, backend, group=None):
             assert [p.size for p in parts] == [10 + r for r in range(world)] and all(int(p[-1]) == (9 + r) * (r + 1) for r, p in enumerate(parts))
         res["ok"] = True
         res["collectives"] = ["all_gather (caps)", "all_reduce MAX (status)", "broadcast (challenger state)", "gather (proof words)"]
+        if backend == "nccl" and world == 1:
+          try:
+            # what the level-3 exchanges rely on (shard_prover.all_to_all): RCCL 2.26 of this image returned corrupted data for a
+            # send / recv above 2^30 bytes, and pieces are therefore cut to 256 MiB; reported so that a fixed RCCL shows up
+            import torch
+            import torch.distributed as dist
+            from zk_evm_amd.shard_prover import all_to_all
+            a = torch.arange(160 << 20, dtype=torch.int64, device=co.device_for(group))          # 1.25 GiB
+            b, c = torch.zeros_like(a), torch.zeros_like(a)
+            dist.all_to_all([b], [a], group=group)
+            all_to_all([a.view(64, -1)], [c.view(64, -1)], group)
+            torch.cuda.synchronize()
+            res["rccl_single_piece_above_1GiB_intact"] = bool(torch.equal(a, b))
+            res["pieces_of_256MiB_intact"] = bool(torch.equal(a, c))
+            del a, b, c
+          except Exception as e:                   # (a report, not part of the self-test's verdict)
+            res["large_piece_check_error"] = repr(e)
     except Exception as e:
         res["ok"] = False
         res["error"] = repr(e)
