@@ -4,7 +4,6 @@ per-kernel-class counters of one segment.  Nothing here is timed by the driver: 
 import json
 import os
 import sys
-import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
