@@ -37,7 +37,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 from tools.benchlib import (HBM_PEAK_GBS, REALISTIC_LOG_NS, collect_kernel_counters, commit_report,  # noqa: E402,F401
-                            kernel_counter_report, measure_commit, segment_committed_cells, synthetic_segment_traces)
+                            contract_line, kernel_counter_report, measure_commit, segment_committed_cells,
+                            synthetic_segment_traces, write_extra)
 
 
 def parse():
@@ -85,6 +86,9 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not collect the dominant kernel's HBM-traffic / VALU counters with rocprofv3 --pmc child passes "
                          "(the committed profiles/pmc_latest.json is quoted instead, marked as such)")
+    ap.add_argument("--extra-name", type=str, default="bench_extra.json",
+                    help="file name (next to bench.py and under gpurun_out/) of the FULL result: stage tables, kernel counters, "
+                         "every secondary object -- stdout carries only the small contract line")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-sample-log-n", type=int, default=18)
     ap.add_argument("--cpu-table-log-n", type=int, default=20,
@@ -719,7 +723,14 @@ def main():
     sys.stdout.flush()
     rg.barrier()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        # the full result goes to bench_extra.json (and gpurun_out/); stdout gets the small contract line, on a line of its
+        # own, last (tools/benchlib.contract_line; tests/test_bench_helpers.py pins its size and strict-JSON round trip)
+        try:
+            write_extra(out, name=os.path.basename(a.extra_name))
+        except Exception as e:
+            sys.stderr.write("bench_extra.json not written: %r\n" % (e,))
+        sys.stdout.write("\n" + contract_line(out, os.path.basename(a.extra_name)) + "\n")
+        sys.stdout.flush()
     rg.close()
 
 

@@ -41,7 +41,10 @@ typedef enum { ZK_HASH_POSEIDON = 0, ZK_HASH_KECCAK25 = 1 } zk_hasher;
  * (reference: StarkConfig::standard_fast_config() at zero/src/prover_state/mod.rs:283,
  * TEST_STARK_CONFIG at evm_arithmetization/src/testing_utils.rs:41-51). */
 typedef struct {
-    uint32_t rate_bits;          /* LDE blow-up = 2^rate_bits (1 in production) */
+    uint32_t rate_bits;          /* LDE blow-up = 2^rate_bits (1 in production).  degree_bits + rate_bits <= 28 in every commit /
+                                  * quotient / shard entry point (ZK_ERR_UNSUPPORTED above: the NTT passes address their twiddle
+                                  * tables through 32-bit buffer offsets); the reference's own ceiling is the field's
+                                  * two-adicity, 32 -- its largest table, Memory, is capped at 2^22 + 1 (prove_stdio.rs:89-101) */
     uint32_t cap_height;         /* Merkle cap has 2^cap_height digests (4); any value up to the tree height */
     uint32_t hasher;             /* zk_hasher */
     uint32_t num_challenges;     /* 2 */

@@ -49,18 +49,18 @@ static inline uint64_t sub_l(uint64_t a, uint64_t b) {
 /* root^k, k < n/2, per (log_n, direction): built once, shared by every column and thread */
 static uint64_t *tw_cache[2][33];
 static const uint64_t *twiddles(unsigned log_n, int inverse, uint64_t root) {
-    uint64_t *t = tw_cache[inverse][log_n];
+    uint64_t *t = __atomic_load_n(&tw_cache[inverse][log_n], __ATOMIC_ACQUIRE);      /* (published with a release store below) */
     if (t) return t;
 #pragma omp critical(orc_ntt_twiddles)
     {
-        t = tw_cache[inverse][log_n];
+        t = __atomic_load_n(&tw_cache[inverse][log_n], __ATOMIC_ACQUIRE);
         if (!t) {
             size_t half = (size_t)1 << (log_n - 1);
             uint64_t *n = (uint64_t *)malloc(sizeof(uint64_t) * half);
             n[0] = 1;
             for (size_t k = 1; k < half; ++k) n[k] = gl_mul(n[k - 1], root);
-#pragma omp flush
-            tw_cache[inverse][log_n] = t = n;
+            __atomic_store_n(&tw_cache[inverse][log_n], n, __ATOMIC_RELEASE);
+            t = n;
         }
     }
     return t;

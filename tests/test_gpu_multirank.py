@@ -45,7 +45,14 @@ def _bench(*args, env_extra=None, timeout=900):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert lines[0] == r.stdout.rstrip("\n").splitlines()[-1] and len(lines[0]) < 4000      # the contract line: small, and LAST
     return json.loads(lines[0])
+
+
+def _bench_extra():
+    """the full result of the last bench.py run (stage tables etc.): bench_extra.json next to bench.py"""
+    with open(os.path.join(ROOT, "bench_extra.json")) as f:
+        return json.load(f)
 
 
 SMALL = ["--log-n", "12", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--in-flight", "1",
@@ -74,7 +81,7 @@ def test_bench_latency_modes_two_ranks_on_one_gpu(mode):
     assert b["n_gpus"] == 2 and b["scaling"] == "strong" and b["unit"] == "segment proofs/s"
     assert abs(b["value"] - 1e3 / b["ms_per_step"]) < 1e-6 * b["value"]
     assert mode in b["config"]["parallelism"] and ("Keccak's rows" in b["config"]["parallelism"]) == mode.endswith("rows")
-    assert "per-table proofs (serial chain over owners)" in b["segment_timing_s"] and len(b["per_rank_ms_per_step"]) == 2
+    assert "per-table proofs (serial chain over owners)" in _bench_extra()["segment_timing_s"] and len(b["per_rank_ms_per_step"]) == 2
 
 
 def test_bench_joins_an_external_launcher():

@@ -352,3 +352,122 @@ def block_jobs(shapes, cdk_erigon=False, seed0=4000):
         return lambda dev: synthetic_segment_traces(log_ns, dev, seed=seed0 + i, cdk_erigon=cdk_erigon)
     return [SegmentJob(loader(i, log_ns), in_use, sg.PublicValues(burn_addr=1 if cdk_erigon else None), tag=i)
             for i, (log_ns, in_use) in enumerate(shapes)]
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the contract line: small, boring, ASCII, one line -- everything else goes to bench_extra.json (r04 verdict, item 1: the
+# 22 KB line of r04 did not parse on the driver's side)
+CONTRACT_LINE_LIMIT = 4000
+
+
+def _num(x, digits=6):
+    """a finite float rounded to `digits` significant figures, an int as it is, anything else (NaN, inf, None, text) -> None"""
+    import math
+    if isinstance(x, bool):
+        return x
+    if isinstance(x, int):
+        return x
+    if isinstance(x, float) and math.isfinite(x):
+        return float("%.*g" % (digits, x))
+    return None
+
+
+def _pick(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def contract_line(out, extra_path="bench_extra.json"):
+    """The ONE line bench.py prints: the contract's fields, the `roofline` and `cpu_baseline` objects, and a handful of scalars
+    lifted out of the secondaries -- every value a finite number, a short string, a bool or null.  `out` is the full result
+    dict (which goes to `extra_path` unchanged).  Raises if the line would not round-trip through a strict JSON parser."""
+    r = out.get("roofline") or {}
+    roof = {"bound": r.get("bound", "hbm"), "kernel": r.get("kernel"), "achieved": _num(r.get("achieved")),
+            "peak": _num(r.get("peak")), "unit": r.get("unit", "GB/s"), "frac": _num(r.get("frac")),
+            "traffic": _num(r.get("traffic"), 10), "algorithmic_bytes": _num(r.get("algorithmic_bytes"), 10),
+            "ms_per_launch": _num(r.get("ms_per_launch")), "launches": _num(r.get("launches")),
+            "share_of_step": _num(r.get("share_of_step")),
+            "limited_by": "integer VALU issue" if _pick(r, "valu") is not None or r.get("limiting_resource") else None,
+            "valu_cycles_per_wave_instruction": _num(_pick(r, "valu", "cycles_per_wave_instruction")),
+            "valu_frac": _num(_pick(r, "valu", "frac")),
+            "counters_measured_in_this_run": _pick(r, "valu", "measured_in_this_run")}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    for k in ("value", "ms_per_step"):
+        line[k] = _num(line[k], 9)
+    cfg = out.get("config") or {}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:260], "parallelism": str(cfg.get("parallelism", ""))[:160]}
+    line["roofline"] = roof
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        if "error" in cb and "value" not in cb:
+            line["cpu_baseline"] = {"error": str(cb["error"])[:160]}
+        else:
+            line["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": _num(cb.get("cores")),
+                                    "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:400]}
+            for k in ("seconds", "proofs_identical", "shape", "gpu_same_sample_s"):
+                if k in cb:
+                    line["cpu_baseline"][k] = _num(cb[k]) if not isinstance(cb[k], (str, bool, list)) else cb[k]
+    n = out.get("ntt") or {}
+    if n:
+        line["ntt"] = {"achieved_GBs": _num(n.get("achieved_GBs")), "frac": _num(n.get("frac_of_hbm_peak")),
+                       "traffic_over_algorithmic": _num(n.get("traffic_over_algorithmic"))}
+    d = out.get("dist") or {}
+    if d:
+        line["dist"] = {k: d.get(k) for k in ("backend", "world", "ok", "selftest_ok", "fallback", "tried", "payload_device",
+                                               "rccl_single_piece_above_1GiB_intact", "pieces_of_256MiB_intact",
+                                               "comm_c_api_ok") if k in d}
+        if d.get("error"):
+            line["dist"]["error"] = str(d["error"])[:200]
+    if out.get("per_rank_ms_per_step") is not None:
+        line["per_rank_ms_per_step"] = [_num(x) for x in out["per_rank_ms_per_step"]][:16]
+    sc = {"realistic_ms_per_proof": _pick(out, "realistic", "single", "ms_per_proof"),
+          "realistic_proofs_per_s": _pick(out, "realistic", "single", "value"),
+          "realistic_in_flight_proofs_per_s": _pick(out, "realistic", "in_flight", "value"),
+          "in_flight_proofs_per_s": _pick(out, "in_flight", "value"),
+          "commit_config1_per_s": _pick(out, "commit_config1", "commits_per_s"),
+          "commit_config1_ntt_GBs": _pick(out, "commit_config1", "ntt", "achieved_GBs"),
+          "block_replay_segments_per_s": _pick(out, "block_replay", "value"),
+          "from_logs_proofs_per_s": _pick(out, "from_logs", "value"),
+          "plonk_2p13_batch_proofs_per_s": _pick(out, "plonk_recursion", "batch_2^13", "proofs_per_s"),
+          "quotient_ms_total": _pick(out, "kernel_counters", "quotient_ms_total"),
+          "ntt_coeffs_to_values_cycles_per_instruction": _pick(out, "kernel_counters", "ntt_coeffs_to_values", "cycles_per_wave_instruction"),
+          "h2d_pinned_GBs": _pick(out, "h2d", "pinned_GBs"),
+          "overlapped_upload_proofs_per_s": _pick(out, "h2d", "overlapped_upload", "value")}
+    line["secondary"] = {k: _num(v) for k, v in sc.items() if _num(v) is not None}
+    failed = sorted(k for k, v in out.items() if isinstance(v, dict) and "error" in v and "value" not in v and k != "cpu_baseline")
+    if failed:
+        line["secondary_failed"] = failed[:12]
+    line["extra"] = extra_path
+    s = json.dumps(line, allow_nan=False, ensure_ascii=True, separators=(", ", ": "))
+    assert "\n" not in s and len(s) < CONTRACT_LINE_LIMIT, "contract line too long: %d bytes" % len(s)
+    json.loads(s)
+    return s
+
+
+def write_extra(out, root=ROOT, name="bench_extra.json"):
+    """the full result (stage tables, kernel counters, every secondary) next to bench.py and, when the scratch directory
+    exists or can be made, under gpurun_out/ so that it travels back from the GPU box"""
+    def clean(x):
+        import math
+        if isinstance(x, dict):
+            return {str(k): clean(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [clean(v) for v in x]
+        if isinstance(x, float) and not math.isfinite(x):
+            return None
+        return x
+    txt = json.dumps(clean(out), allow_nan=False, indent=1)
+    written = []
+    for d in (root, os.path.join(root, "gpurun_out")):
+        try:
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, name), "w") as f:
+                f.write(txt + "\n")
+            written.append(os.path.join(d, name))
+        except OSError:
+            pass
+    return written

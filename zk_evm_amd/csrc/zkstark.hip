@@ -567,6 +567,7 @@ extern "C" int zk_batch_coeffs(const zk_batch *b, size_t col, uint64_t *out) {
     if (!b || !out) return ZK_ERR_BAD_ARG;
     zk_ctx *ctx = b->ctx;
     if (col >= b->n_cols) return set_err(ctx, ZK_ERR_BAD_ARG, "column %zu out of range", col);
+    if (!b->d_coeffs) return set_err(ctx, ZK_ERR_BAD_ARG, "this batch view holds no coefficients (zk_batch_from_parts row shard)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     size_t n = (size_t)1 << b->log_n;
     std::vector<u64> tmp(n);
@@ -578,6 +579,9 @@ extern "C" int zk_batch_coeffs(const zk_batch *b, size_t col, uint64_t *out) {
 
 static int gather_row(const zk_batch *b, size_t natural_row, uint64_t *out) {
     zk_ctx *ctx = b->ctx;
+    // a view made by zk_batch_from_parts may hold one shard's leaf-ordered rows, or no values at all: not indexable as a
+    // whole natural-order batch of stride N
+    if (b->row_shard || !b->d_lde) return set_err(ctx, ZK_ERR_BAD_ARG, "this batch view holds no whole natural-order LDE (row shard / column-only view)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     size_t N = (size_t)1 << (b->log_n + b->rate_bits);
     HIP_TRY(ctx, hipMemcpy2DAsync(out, 8, b->d_lde + natural_row, N * 8, 8, b->n_cols,
@@ -607,6 +611,7 @@ extern "C" int zk_batch_merkle_path(const zk_batch *b, size_t leaf_index, uint64
     zk_ctx *ctx = b->ctx;
     unsigned log_N = b->log_n + b->rate_bits;
     if (leaf_index >> log_N) return set_err(ctx, ZK_ERR_BAD_ARG, "leaf index out of range");
+    if (b->row_shard || !b->d_digests) return set_err(ctx, ZK_ERR_BAD_ARG, "this batch view holds no whole Merkle tree (row shard / column-only view)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const u64 *lvl = b->d_digests;
     size_t idx = leaf_index;

@@ -178,6 +178,7 @@ def commit_rows_sharded(block, config, ctx, group=None, timing=None) -> ShardedO
 
     from .collectives import all_gather_words
     dist, world, rank = _dist(group)
+    ctx.use_torch_current_stream()         # the torch ops around the library calls (all_to_all, stack) must be ordered with them
     fri = config.fri_config
     lw = world.bit_length() - 1
     if world != 1 << lw or lw > fri.cap_height:
@@ -478,7 +479,8 @@ def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tupl
             carry = sum(int(tots[q][k]) for q in range(rank)) % P          # the blocks before this one
             if carry:
                 z = cols[-1:]
-                ctx.check(lib.zk_gl_add_scalar_columns(ctx.handle, C.c_void_p(z.data_ptr()), nb, 1, nb, np.array([carry], dtype=np.uint64).ctypes.data))
+                add = np.array([carry], dtype=np.uint64)          # (bound to a name: `.ctypes.data` of a temporary dangles)
+                ctx.check(lib.zk_gl_add_scalar_columns(ctx.handle, C.c_void_p(z.data_ptr()), nb, 1, nb, add.ctypes.data))
             lookup_cols.append(cols)
     if ctl_specs or lookup_cols:
         helpers, zs = [], []
@@ -492,7 +494,8 @@ def prove_table_row_sharded(air_id: int, config, block, ctl_specs: Sequence[Tupl
                 delta = (word(mini[-1, 0]) - word(mini[-1, 1]) - word(cols[-1, nb - 1])) % P
                 if delta:
                     z = cols[-1:]
-                    ctx.check(lib.zk_gl_add_scalar_columns(ctx.handle, C.c_void_p(z.data_ptr()), nb, 1, nb, np.array([delta], dtype=np.uint64).ctypes.data))
+                    add = np.array([delta], dtype=np.uint64)
+                    ctx.check(lib.zk_gl_add_scalar_columns(ctx.handle, C.c_void_p(z.data_ptr()), nb, 1, nb, add.ctypes.data))
             n_helpers_of.append(int(cols.shape[0]) - 1)
             helpers.append(cols[:-1])
             zs.append(cols[-1:])
