@@ -33,6 +33,7 @@ typedef enum {
     ZK_ERR_HIP = -3,
     ZK_ERR_ABORTED = -4,
     ZK_ERR_UNSUPPORTED = -5,
+    ZK_ERR_COMM = -6,            /* a collective failed, timed out, or another rank of the job reported an error */
 } zk_status;
 
 typedef enum { ZK_HASH_POSEIDON = 0, ZK_HASH_KECCAK25 = 1 } zk_hasher;
@@ -647,6 +648,90 @@ int zk_fri_fold_values_sharded(zk_ctx *ctx, const zk_cfg *cfg, const uint64_t *d
 int zk_fri_proof_of_work(zk_ctx *ctx, const zk_cfg *cfg, zk_challenger *chal, uint64_t *witness_out);
 int zk_fri_initial_openings(zk_ctx *ctx, const zk_cfg *cfg, const zk_batch *const *oracles, size_t n_oracles,
                             const uint64_t *xs, size_t n_queries, uint64_t *out);
+
+/* ---- the multi-GPU provers behind this ABI (SURVEY 8(e) levels 2 and 3; csrc/comm_host.inc, shard_prove_host.inc) ------------
+ * A zk_comm is the set of ranks of one job -- one process (or thread) per GPU, one zk_ctx each.  The reference runs ONE prover
+ * per machine (`zero/src/ops.rs:24-67` -> `prove`, `evm_arithmetization/src/prover.rs:72-194`); these calls replace that seam
+ * when a segment's tables (level 2) or one table's rows (level 3) are spread over the GPUs of a node.
+ *   zk_comm_unique_id + zk_comm_create : RCCL (the C API of <rccl/rccl.h>, loaded at run time; one rank per GPU, xGMI).  Rank 0
+ *       makes the id and hands it to the others by whatever the caller has (a pipe, MPI, a file); every rank then calls
+ *       zk_comm_create -- collectively, like ncclCommInitRank.  Sends / receives are cut into pieces of at most 256 MiB
+ *       (ZK_COMM_PIECE_MB; RCCL 2.26 corrupted larger ones: tools/rccl_repro.py).
+ *   zk_comm_create_host : host-staged transport over POSIX shared memory `name` (unique per job; no '/'): ranks may share a GPU
+ *       (tests on a one-GPU box; a fallback where RCCL cannot come up).  slot_bytes = outbox per rank (0 = 32 MiB,
+ *       ZK_COMM_SLOT_MB overrides); ctx may be NULL for a communicator that only moves host payloads (zk_comm_*_host).
+ *       A rank that waits ZK_COMM_TIMEOUT_S (300) for a peer gives up with ZK_ERR_COMM -- and so do all the others.
+ * After ZK_ERR_COMM the communicator is dead: free it on every rank.  world must be a power of two. */
+#define ZK_COMM_ID_BYTES 128
+typedef struct zk_comm zk_comm;
+int zk_comm_unique_id(uint8_t out[ZK_COMM_ID_BYTES]);
+int zk_comm_create(zk_ctx *ctx, const uint8_t id[ZK_COMM_ID_BYTES], unsigned rank, unsigned world, zk_comm **out);
+int zk_comm_create_host(zk_ctx *ctx, const char *name, unsigned rank, unsigned world, size_t slot_bytes, zk_comm **out);
+void zk_comm_free(zk_comm *comm);
+unsigned zk_comm_rank(const zk_comm *comm);
+unsigned zk_comm_world(const zk_comm *comm);
+const char *zk_comm_transport(const zk_comm *comm);      /* "rccl" | "host" */
+const char *zk_comm_last_error(const zk_comm *comm);
+/* out[0] bytes sent to other ranks, [1] bytes received from them, [2] collectives issued -- since creation */
+int zk_comm_stats(const zk_comm *comm, uint64_t out[3]);
+int zk_comm_barrier(zk_comm *comm);
+/* The collectives the provers are built from, for callers that move their own data through the job's communicator (and for the
+ * tests): all-gather / broadcast of host bytes (either transport), all-to-all with per-pair byte counts of host buffers (host
+ * transport) and of device buffers (either; on ctx's stream; RCCL: whole 8-byte words), all-gather of device buffers. */
+int zk_comm_all_gather_host(zk_comm *comm, const void *send, size_t bytes, void *recv);
+int zk_comm_broadcast_host(zk_comm *comm, void *buf, size_t bytes, unsigned root);
+int zk_comm_all_to_all_host(zk_comm *comm, const void *const *send, const size_t *send_bytes, void *const *recv,
+                            const size_t *recv_bytes);
+int zk_comm_all_to_all_device(zk_comm *comm, const void *const *d_send, const size_t *send_bytes, void *const *d_recv,
+                              const size_t *recv_bytes);
+int zk_comm_all_gather_device(zk_comm *comm, const void *d_send, size_t bytes, void *d_recv);
+/* host wall clock per stage of the sharded calls, accumulated: [0] all-to-all #1 + iNTT + LDE + pack, [1] all-to-all #2,
+ * [2] leaf hashing + subtrees + cap all-gather, [3] auxiliary columns + carries, [4] quotient, [5] openings, [6] FRI;
+ * returns the number of stages */
+size_t zk_comm_last_timing(zk_comm *comm, double *out_ms, size_t max, int reset);
+
+/* Level 3: ONE table over all ranks of `comm` (W = 2^k <= 2^cap_height GPUs).  Rank q passes the contiguous ROW BLOCK q of the
+ * trace (d_row_block: column c at + c * col_stride, 2^log_n / W rows; log_n = the WHOLE table's).  Collective: every rank calls
+ * with the same table description and a transcript in the same state; the proof -- equal to zk_prove_table's on one GPU, word
+ * for word -- and the advanced transcript come back on EVERY rank.
+ *   zk_commit_rows_sharded : `PolynomialBatch::from_values` (prover.rs:90-111): column-sharded NTTs between two all-to-alls, leaf
+ *       hashing on row shards, the sub-roots all-gathered into the cap (zk_sharded_batch_cap; the same on every rank).
+ *   zk_prove_table_sharded : `prove_single_table` (prover.rs:301-341).  lookup_program / ctl_zdata / ctl_challenges /
+ *       requires_ctls as for zk_prove_table -- but the CTL helper / Z columns are built HERE, on the row blocks, with the
+ *       cross-block carries (no d_ctl_cols).  trace_commitment: the table's zk_commit_rows_sharded result when the caller made it
+ *       earlier (a segment commits every trace before the transcript starts), else NULL; the caller still frees it.
+ *       fri_mode 0: the two-column FRI layers replicated after ONE all-gather; 1: every layer on the rank that owns its leaves,
+ *       one sub-root all-gather per round.  Same proof either way. */
+typedef struct zk_sharded_batch zk_sharded_batch;
+int zk_commit_rows_sharded(zk_ctx *ctx, zk_comm *comm, const zk_cfg *cfg, const uint64_t *d_row_block, size_t col_stride,
+                           size_t n_cols, unsigned log_n, zk_sharded_batch **out);
+int zk_sharded_batch_cap(const zk_sharded_batch *batch, uint64_t *cap_out);
+const zk_batch *zk_sharded_batch_rows(const zk_sharded_batch *batch);       /* the row-shard view (zk_batch_from_parts form) */
+const zk_batch *zk_sharded_batch_columns(const zk_sharded_batch *batch);    /* the column-shard view; NULL if this rank owns none */
+void zk_sharded_batch_free(zk_sharded_batch *batch);
+int zk_prove_table_sharded(zk_ctx *ctx, zk_comm *comm, const zk_cfg *cfg, uint32_t air_id, const uint64_t *air_consts,
+                           size_t n_air_consts, const uint64_t *d_row_block, size_t col_stride, size_t n_trace_cols,
+                           unsigned log_n, zk_sharded_batch *trace_commitment, const uint64_t *lookup_program,
+                           size_t lookup_words, const uint64_t *ctl_zdata, size_t ctl_words, const uint64_t *ctl_challenges,
+                           unsigned constraint_degree, int requires_ctls, unsigned fri_mode, zk_challenger *challenger,
+                           zk_table_proof **out);
+
+/* Level 2: the tables of ONE segment over the ranks of `comm` -- `prove_with_traces` (prover.rs:72-194) as a collective call.
+ * What shards (prover.rs:90-111): every table's trace commitment is independent of the transcript, and a table's CTL / logUp
+ * columns and its whole `prove_single_table` only read that table's own trace -- so table t lives on exactly one rank and no
+ * bulk data moves: ONE all-gather of the caps, then the 31-word challenger state owner -> all after each table of the (serial,
+ * prover.rs:251-259) chain.  zk_assign_tables is the assignment (largest cost first onto the least loaded rank; deterministic):
+ * the caller puts table t's trace on rank owner[t] and passes d_trace = NULL elsewhere.  row_sharded[t] != 0 (NULL = none): table t
+ * is spread over ALL ranks instead (level 3: d_trace = this rank's ROW BLOCK, col_stride its stride, log_n the whole table's).
+ * Every rank passes the same table descriptions (n_cols, log_n, air, programs, in_use, optional), wiring and public values;
+ * EVERY rank gets the whole segment proof, bit-identical to zk_prove_segment's on one GPU.  Latency, not throughput: independent
+ * segments on independent GPUs (one zk_prove_segment per rank, no collective) remain the throughput path. */
+int zk_assign_tables(const size_t *n_cols, const unsigned *log_n, size_t n_tables, unsigned world, const uint8_t *row_sharded,
+                     uint32_t *owner_out);
+int zk_prove_segment_table_parallel(zk_ctx *ctx, zk_comm *comm, const zk_cfg *cfg, const zk_table_in *tables, size_t n_tables,
+                                    const uint8_t *row_sharded, const uint64_t *ctl_wiring, size_t wiring_words,
+                                    const uint64_t *public_value_elements, size_t n_public_values, unsigned constraint_degree,
+                                    int mem_before_table, int mem_after_table, unsigned fri_mode, zk_segment_proof **out);
 
 /* library / device info */
 const char *zk_version(void);

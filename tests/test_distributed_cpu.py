@@ -278,60 +278,3 @@ def test_bench_rungroup_falls_back_to_gloo_and_never_fails(backend):
             assert info["ok"] is False and info["fallback"] == "gloo" and info["tried"] == "nccl" and info["error"]
         else:
             assert info["ok"] is True and "fallback" not in info
-
-
-def _shard_helpers_worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import torch
-    from zk_evm_amd.shard_prover import _bitrev, _leaf_to_natural, all_gather_tensor, all_to_all, exchange
-    from zk_evm_amd.sharding import split_columns
-    ok = True
-    # all-to-all #1 of the level-3 prover: row blocks -> column shards, column counts that the ranks do not divide (11 over 4)
-    K, nb = 11, 8
-    cols = split_columns(K, world)
-    full = torch.arange(K * nb * world, dtype=torch.int64).reshape(K, nb * world) * 3 + 1            # the whole (K, n) matrix
-    block = full[:, rank * nb:(rank + 1) * nb].contiguous()
-    send = [block[cols[p].start: cols[p].stop] for p in range(world)]
-    recv = [torch.empty((len(cols[rank]), nb), dtype=torch.int64) for _ in range(world)]
-    all_to_all(send, recv)
-    values = torch.stack(recv, dim=1).reshape(len(cols[rank]), nb * world)
-    ok &= bool(torch.equal(values, full[cols[rank].start: cols[rank].stop]))
-    # all-to-all #2: column shards -> row shards (every destination gets this rank's columns of ITS rows)
-    send2 = [values[:, q_ * nb:(q_ + 1) * nb].contiguous() for q_ in range(world)]
-    rows = torch.empty((K, nb), dtype=torch.int64)
-    all_to_all(send2, [rows[cols[p].start: cols[p].stop] for p in range(world)])
-    ok &= bool(torch.equal(rows, block))
-    # the quotient's neighbour exchange: residue + 2 (mod W) in bit-reversed rank numbering, a permutation of the ranks
-    lw = world.bit_length() - 1
-    res = _bitrev(rank, lw)
-    nxt, prv = _bitrev((res + 2) % world, lw), _bitrev((res - 2) % world, lw)
-    got = exchange(torch.full((3, 4), rank, dtype=torch.int64), prv, nxt) if nxt != rank else torch.full((3, 4), rank, dtype=torch.int64)
-    ok &= bool((got == nxt).all())
-    parts = all_gather_tensor(torch.full((2, 5), 10 + rank, dtype=torch.int64))
-    ok &= [int(p[0, 0]) for p in parts] == [10 + r for r in range(world)]
-    nat = _leaf_to_natural(torch.arange(16, dtype=torch.int64).reshape(1, 16), 4)
-    ok &= nat[0].tolist() == [_bitrev(j, 4) for j in range(16)]
-    q.put((rank, bool(ok)))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("world", [2, 4])
-def test_level3_exchange_helpers_gloo(world):
-    """The data movement of the row-sharded table prover (zk_evm_amd/shard_prover.py) on CPU tensors over gloo: both
-    all-to-alls with column counts the ranks do not divide, the neighbour-shard exchange of the quotient (a ring shift by two
-    residues in bit-reversed rank numbering), the all-gather and the leaf-order permutation -- the kernels between them need a
-    GPU (tests/test_gpu_multirank.py), the routing does not."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_shard_helpers_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = dict(q.get(timeout=180) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert res == {r: True for r in range(world)}

@@ -311,13 +311,15 @@ def _l3_worker(rank, world, port, q, shape, hasher):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import zk_evm_amd
     from tests.oracle_lib import splitmix64
-    from zk_evm_amd.sharding import commit_columns_row_sharded, split_columns
+    from zk_evm_amd.shard_prover import commit_rows_sharded
     n_cols, log_n = shape
-    mine = split_columns(n_cols, world)[rank]
-    vals = np.stack([splitmix64(0xC0FFEE + c, 1 << log_n) for c in mine])        # this rank's columns only
+    nb = (1 << log_n) // world
+    vals = np.stack([splitmix64(0xC0FFEE + c, 1 << log_n)[rank * nb: (rank + 1) * nb] for c in range(n_cols)])   # this rank's ROW BLOCK only
     dev = torch.from_numpy(vals.view(np.int64)).cuda()
     timing = {}
-    cap = commit_columns_row_sharded(dev, n_cols, zk_evm_amd.StarkConfig(hasher=hasher), timing=timing)
+    o = commit_rows_sharded(dev, zk_evm_amd.StarkConfig(hasher=hasher), zk_evm_amd.context.default_context(0), timing=timing)
+    cap = o.cap.copy()
+    o.free()
     q.put((rank, cap, timing))
     dist.barrier()
     dist.destroy_process_group()
@@ -325,7 +327,8 @@ def _l3_worker(rank, world, port, q, shape, hasher):
 
 @pytest.mark.parametrize("shape,world,hasher", [((2431, 14), 2, 0), ((37, 10), 4, 0), ((116, 12), 2, 1)])
 def test_row_sharded_commit_equals_single_gpu_cap(shape, world, hasher):
-    """SURVEY 8(e) level 3, commit phase: columns sharded for the NTTs, all-to-all to row residue classes, row-sharded leaf
+    """SURVEY 8(e) level 3, commit phase (zk_commit_rows_sharded on the host-staged transport): row blocks in, all-to-all to column
+    shards for the NTTs, all-to-all to row residue classes, row-sharded leaf
     hashing + subtrees, all-gather of the sub-roots -- the cap every rank ends up with is the single-GPU
     `PolynomialBatch::from_values` cap of the whole matrix (KeccakStark's 2431 columns x 2^14 rows over two ranks; four ranks;
     the Keccak hasher).  gloo, the ranks share this GPU."""
@@ -356,7 +359,7 @@ def test_row_sharded_commit_equals_single_gpu_cap(shape, world, hasher):
     want = full.merkle_tree.cap.elements
     for r in range(world):
         assert np.array_equal(res[r][0], want), r
-        assert res[r][1]["rows"] == (2 << log_n) // world
+        assert res[r][1]["row shards: leaf hashing + subtrees + cap all-gather"] > 0
     full.free()
 
 
@@ -565,7 +568,7 @@ def test_row_sharded_table_proof_equals_single_gpu_proof(shape, world, fri):
     zd = [zp.CtlZData(b, gm, e, ctl_partial_sums(tr, e, b, gm, st.constraint_degree)) for b, gm, e in table_ctl_specs(st, table, chal)]
     want = zp.prove_single_table(st.table_air[table], cfg, tr, tb, st.lookups[table], zd, chal, ch,
                                  constraint_degree=st.constraint_degree, air_consts=st.air_consts[table])
-    assert all(res[r][0] is None for r in range(1, world))
+    assert all(np.array_equal(res[r][0], res[0][0]) for r in range(1, world))      # the proof comes back on EVERY rank
     got, _ = zp.StarkProof.from_words(res[0][0])
     assert np.array_equal(got.trace_cap, want.trace_cap)
     assert np.array_equal(got.auxiliary_polys_cap, want.auxiliary_polys_cap)
@@ -605,31 +608,37 @@ def _l3_big_pieces_worker(port, q):
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     import zk_evm_amd
-    from zk_evm_amd.shard_prover import NCCL_PIECE_BYTES, commit_rows_sharded
+    from zk_evm_amd.comm import Comm
+    from zk_evm_amd.shard_prover import commit_rows_sharded
     cfg = zk_evm_amd.StarkConfig()
     ctx = zk_evm_amd.context.default_context(0)
     ctx.use_torch_current_stream()
     g = torch.Generator(device="cuda")
     g.manual_seed(7)
     tr = torch.randint(0, 2 ** 62, (2431, 1 << 16), dtype=torch.int64, device="cuda", generator=g)       # 1.27 GB; the LDE twice that
-    assert tr.numel() * 8 > (1 << 30) > NCCL_PIECE_BYTES
+    assert tr.numel() * 8 > (1 << 30)
     tb = zk_evm_amd.PolynomialBatch.from_values(tr, 1, False, 4, hasher=cfg.hasher)
     want = np.asarray(tb.merkle_tree.cap.elements).reshape(-1).copy()
-    got = np.asarray(commit_rows_sharded(tr, cfg, ctx, None, {}).cap).reshape(-1)
-    # the neighbour-shard exchange of the quotient (W > 2) takes the same precaution; with one rank it returns early, so its
-    # piece loop is driven directly: this rank to itself through RCCL's send / recv
-    from zk_evm_amd.shard_prover import _p2p_in_pieces
+    cm = Comm.from_group(ctx)                                       # the RCCL communicator of this (one-rank) group, C API
+    assert cm.transport == "rccl"
+    o = commit_rows_sharded(tr, cfg, ctx, comm=cm)
+    got = np.asarray(o.cap).reshape(-1).copy()
+    o.free()
+    # the library's all-to-all on its own: this rank to itself through ncclSend / ncclRecv, 1.27 GB in pieces of 256 MiB
+    import ctypes as C
     back = torch.zeros_like(tr)
-    _p2p_in_pieces(dist, tr, back, 0, 0, None, NCCL_PIECE_BYTES)
+    nbytes = (C.c_size_t * 1)(tr.numel() * 8)
+    ctx.check(ctx.lib.zk_comm_all_to_all_device(cm.handle, (C.c_void_p * 1)(tr.data_ptr()), nbytes, (C.c_void_p * 1)(back.data_ptr()), nbytes))
     torch.cuda.synchronize()
     q.put(bool(np.array_equal(got, want)) and bool(torch.equal(tr, back)))
+    cm.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_rccl_exchanges_above_one_gib_are_cut_into_pieces():
     """RCCL on this image silently CORRUPTS a send / recv of more than 2^30 bytes (found in r04 with one rank: a wrong cap for
-    KeccakStark's 2431 columns at 2^15 rows and up, while every library kernel was right).  `shard_prover.all_to_all` / `exchange`
+    KeccakStark's 2431 columns at 2^15 rows and up, while every library kernel was right).  The library's exchanges (csrc/comm_host.inc)
     hand RCCL at most 256 MiB at a time: the level-3 commitment of 2431 x 2^16 (pieces of 1.27 and 2.5 GB) equals
     `PolynomialBatch::from_values`."""
     import socket

@@ -146,6 +146,32 @@ SIGNATURES = {
     "zk_initial_memory_merkle_cap": (C.c_int, [vp, C.POINTER(ZkCfg), vp, sz, u64p]),
     "zk_byte_packing_generate_trace": (C.c_int, [vp, u64p, sz, ui, u64p, sz]),
     "zk_keccak_sponge_generate_trace": (C.c_int, [vp, u64p, sz, vp, sz, ui, u64p, sz]),
+    "zk_comm_unique_id": (C.c_int, [vp]),
+    "zk_comm_create": (C.c_int, [vp, vp, ui, ui, C.POINTER(vp)]),
+    "zk_comm_create_host": (C.c_int, [vp, C.c_char_p, ui, ui, sz, C.POINTER(vp)]),
+    "zk_comm_free": (None, [vp]),
+    "zk_comm_rank": (ui, [vp]),
+    "zk_comm_world": (ui, [vp]),
+    "zk_comm_transport": (C.c_char_p, [vp]),
+    "zk_comm_last_error": (C.c_char_p, [vp]),
+    "zk_comm_stats": (C.c_int, [vp, u64p]),
+    "zk_comm_barrier": (C.c_int, [vp]),
+    "zk_comm_all_gather_host": (C.c_int, [vp, vp, sz, vp]),
+    "zk_comm_broadcast_host": (C.c_int, [vp, vp, sz, ui]),
+    "zk_comm_all_to_all_host": (C.c_int, [vp, vp, vp, vp, vp]),
+    "zk_comm_all_to_all_device": (C.c_int, [vp, vp, vp, vp, vp]),
+    "zk_comm_all_gather_device": (C.c_int, [vp, vp, sz, vp]),
+    "zk_comm_last_timing": (sz, [vp, C.POINTER(C.c_double), sz, C.c_int]),
+    "zk_commit_rows_sharded": (C.c_int, [vp, vp, C.POINTER(ZkCfg), u64p, sz, sz, ui, C.POINTER(vp)]),
+    "zk_sharded_batch_cap": (C.c_int, [vp, u64p]),
+    "zk_sharded_batch_rows": (vp, [vp]),
+    "zk_sharded_batch_columns": (vp, [vp]),
+    "zk_sharded_batch_free": (None, [vp]),
+    "zk_prove_table_sharded": (C.c_int, [vp, vp, C.POINTER(ZkCfg), u32, u64p, sz, u64p, sz, sz, ui, vp, u64p, sz, u64p, sz, u64p,
+                                         ui, C.c_int, ui, vp, C.POINTER(vp)]),
+    "zk_assign_tables": (C.c_int, [vp, vp, sz, ui, vp, vp]),
+    "zk_prove_segment_table_parallel": (C.c_int, [vp, vp, C.POINTER(ZkCfg), vp, sz, vp, u64p, sz, u64p, sz, ui, C.c_int, C.c_int, ui,
+                                                  C.POINTER(vp)]),
     "zk_version": (C.c_char_p, []),
     "zk_device_info": (C.c_int, [C.c_int, C.c_char_p, sz, C.POINTER(C.c_int), C.POINTER(sz)]),
 }

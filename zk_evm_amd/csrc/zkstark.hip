@@ -630,6 +630,8 @@ extern "C" int zk_batch_merkle_path(const zk_batch *b, size_t leaf_index, uint64
 #include "quotient_host.inc"
 #include "segment_host.inc"
 #include "shard_host.inc"
+#include "comm_host.inc"
+#include "shard_prove_host.inc"
 
 // ---- the cross-TU interface (internal.hpp) ----------------------------------------------------------------------
 int zki_commit(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_t in_stride, size_t n_cols, unsigned log_n,

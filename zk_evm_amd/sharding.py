@@ -215,7 +215,7 @@ def prove_segment_table_parallel(all_stark, config, trace_poly_values, table_in_
                     all_stark.table_air[t], config, row_sharded[t], table_ctl_specs(all_stark, t, ctl_challenges), ctl_challenges, ch,
                     constraint_degree=deg, air_consts=all_stark.air_consts[t], lookups=all_stark.lookups[t], group=group, ctx=ctx,
                     trace_oracle=wide.pop(t)))
-                if pr is not None:
+                if rank == 0:                          # (the sharded prover returns the proof on every rank)
                     proofs[t] = sg.StarkProofWithMetadata(pr, pr.init_challenger_state)
                 continue
             state, err = np.zeros(32, dtype=np.uint64), None
@@ -289,86 +289,3 @@ def _bitrev(i: int, bits: int) -> int:
         r = (r << 1) | (i & 1)
         i >>= 1
     return r
-
-
-def commit_columns_row_sharded(values_shard, n_cols_total: int, config, ctx=None, group=None, hasher=None, timing=None):
-    """`PolynomialBatch::from_values` of ONE table split over the ranks of `group` -- the Merkle cap only (prototype of SURVEY
-    8(e) level 3, the north_star's "RCCL all-gather ... Merkle-cap reduction"):
-
-      1. COLUMN shard: rank r holds columns split_columns(C, W)[r] of the trace (`values_shard`, CUDA (C_r, n)) and runs the
-         per-column iNTT + coset LDE on them (zk_ifft, zk_lde) -- NTTs are independent per column;
-      2. ALL-TO-ALL to ROW shards: a Poseidon / Keccak sponge over a row is sequential, so leaf hashing wants whole rows.
-         plonky2's leaf order is the bit-reversed row order, hence the W subtrees under the cap are the row RESIDUE classes
-         mod W: rank q receives, from every rank p, the rows j = i W + bitrev_W(q) of p's columns, already permuted into
-         leaf-slot order (local slot bitrev(i)); 16 C n (W - 1) / W^2 bytes per rank, every pair on its own xGMI link;
-      3. row shard: leaf hashing (zk_hash_rows) and the local subtree (zk_merkle_build) down to 2^cap_height / W roots;
-      4. ALL-GATHER of the sub-roots (2^cap_height x 32 B in all) = the cap of the whole table, identical to the single-GPU
-         commitment's.
-    Needs W a power of two <= 2^cap_height.  Returns the (2^cap_height, 4) cap on every rank.  What a full level-3 prover
-    would add -- openings and FRI queries served from row shards -- is not built."""
-    import time
-
-    import torch
-    import torch.distributed as dist
-
-    from .collectives import all_gather_words
-    from .context import default_context
-    from .stark import _trace_args
-    multi = dist.is_available() and dist.is_initialized()
-    world, rank = (dist.get_world_size(group), dist.get_rank(group)) if multi else (1, 0)
-    fri = config.fri_config
-    hasher = config.hasher if hasher is None else hasher
-    log_w = world.bit_length() - 1
-    if world != 1 << log_w or log_w > fri.cap_height:
-        raise ValueError("the number of ranks must be a power of two and at most 2^cap_height")
-    cols = split_columns(n_cols_total, world)
-    c_r, n, log_n, stride = _trace_args(values_shard)
-    if c_r != len(cols[rank]):
-        raise ValueError("rank %d must hold columns %s" % (rank, cols[rank]))
-    log_N = log_n + fri.rate_bits
-    N, rows_local = 1 << log_N, (1 << log_N) >> log_w
-    dev = values_shard.device
-    ctx = ctx or default_context(dev.index or 0)
-    ctx.use_torch_current_stream()
-    lib, C = ctx.lib, __import__("ctypes")
-    t0 = time.perf_counter()
-    # 1. per-column NTTs on the column shard
-    coeffs = values_shard.contiguous().clone()
-    ctx.check(lib.zk_ifft(ctx.handle, C.c_void_p(coeffs.data_ptr()), n, c_r, log_n))
-    lde = torch.empty((c_r, N), dtype=torch.int64, device=dev)
-    ctx.check(lib.zk_lde(ctx.handle, C.c_void_p(coeffs.data_ptr()), n, C.c_void_p(lde.data_ptr()), N, c_r, log_n, fri.rate_bits))
-    torch.cuda.synchronize(dev)
-    t1 = time.perf_counter()
-    # 2. rows of residue class bitrev_W(q), in leaf-slot order, to rank q
-    from .shard_prover import _BITREV_IDX, _leaf_to_natural, all_to_all   # (device-side bit reversal; RCCL transfers in pieces)
-    _leaf_to_natural(lde[:1, :rows_local], log_N - log_w)                    # fills the index cache
-    perm = _BITREV_IDX[(log_N - log_w, str(dev))]
-    send = [lde[:, _bitrev(q, log_w)::world].index_select(1, perm).contiguous() for q in range(world)]
-    del lde
-    if not multi:
-        recv = send
-    else:
-        recv = [torch.empty((len(cols[p]), rows_local), dtype=torch.int64, device=dev) for p in range(world)]
-        all_to_all(send, recv, group)
-    local = torch.cat(recv, dim=0).contiguous()                    # [C][N / W], row = leaf slot within this rank's subtree
-    del send, recv
-    torch.cuda.synchronize(dev)
-    t2 = time.perf_counter()
-    # 3. leaf hashing + local subtree
-    cap_local_h = fri.cap_height - log_w
-    log_leaves = log_N - log_w
-    n_dig = int(lib.zk_merkle_num_digests(log_leaves, cap_local_h))
-    dig = torch.zeros((n_dig, 4), dtype=torch.int64, device=dev)
-    ctx.check(lib.zk_hash_rows(ctx.handle, hasher, C.c_void_p(local.data_ptr()), rows_local, n_cols_total, rows_local,
-                               C.c_void_p(dig.data_ptr())))
-    ctx.check(lib.zk_merkle_build(ctx.handle, hasher, C.c_void_p(dig.data_ptr()), log_leaves, cap_local_h))
-    sub = dig[n_dig - (1 << cap_local_h):].cpu().numpy().view(np.uint64).reshape(-1)
-    t3 = time.perf_counter()
-    # 4. the cap = the sub-roots of all ranks in rank order
-    parts = all_gather_words(sub, sub.size, group)
-    cap = np.concatenate(parts).reshape(1 << fri.cap_height, 4)
-    if timing is not None:
-        timing.update({"column shard: iNTT + LDE": t1 - t0, "all-to-all to row residues": t2 - t1,
-                       "row shard: leaf hashing + subtree": t3 - t2, "sub-root all-gather": time.perf_counter() - t3,
-                       "columns": len(cols[rank]), "rows": rows_local})
-    return cap
