@@ -146,7 +146,7 @@ def run_secondary(name, a, device, deadline, extra=()):
     return out
 
 
-def dist_selftest(rank, world, backend, group=None):
+def dist_selftest(rank, world, backend, group=None, ctx=None):
     """Run the tensor collectives of zk_evm_amd/collectives.py + sharding.gather_caps once through the live process group
     and check what comes back.  Under `nccl` this is RCCL moving device tensors."""
     import numpy as np
@@ -166,23 +166,36 @@ def dist_selftest(rank, world, backend, group=None):
             assert [p.size for p in parts] == [10 + r for r in range(world)] and all(int(p[-1]) == (9 + r) * (r + 1) for r, p in enumerate(parts))
         res["ok"] = True
         res["collectives"] = ["all_gather (caps)", "all_reduce MAX (status)", "broadcast (challenger state)", "gather (proof words)"]
-        if backend == "nccl" and world == 1:
-          try:
-            # what the level-3 exchanges rely on (shard_prover.all_to_all): RCCL 2.26 of this image returned corrupted data for a
-            # send / recv above 2^30 bytes, and pieces are therefore cut to 256 MiB; reported so that a fixed RCCL shows up
+        # the library's own communicator (csrc/comm_host.inc: RCCL's C API under nccl, the host-staged transport otherwise) -- what
+        # zk_prove_table_sharded / zk_prove_segment_table_parallel run on -- made from this group and exercised once
+        try:
+            if ctx is None:
+                raise RuntimeError("no zk_ctx (CPU-side self-test)")
+            import ctypes as C
             import torch
-            import torch.distributed as dist
-            from zk_evm_amd.shard_prover import all_to_all
-            a = torch.arange(160 << 20, dtype=torch.int64, device=co.device_for(group))          # 1.25 GiB
-            b, c = torch.zeros_like(a), torch.zeros_like(a)
-            dist.all_to_all([b], [a], group=group)
-            all_to_all([a.view(64, -1)], [c.view(64, -1)], group)
-            torch.cuda.synchronize()
-            res["rccl_single_piece_above_1GiB_intact"] = bool(torch.equal(a, b))
-            res["pieces_of_256MiB_intact"] = bool(torch.equal(a, c))
-            del a, b, c
-          except Exception as e:                   # (a report, not part of the self-test's verdict)
-            res["large_piece_check_error"] = repr(e)
+            from zk_evm_amd.comm import Comm
+            cm = Comm.from_group(ctx, group)
+            got = cm.all_gather_words(np.arange(4, dtype=np.uint64) + 10 * rank)
+            res["comm_transport"] = cm.transport
+            res["comm_c_api_ok"] = bool(all(int(got[r, 3]) == 3 + 10 * r for r in range(world)))
+            if backend == "nccl" and world == 1:
+                # RCCL 2.26 of this image returned corrupted data for a send / recv above 2^30 bytes (tools/rccl_repro.py), so the
+                # library cuts its exchanges into pieces of 256 MiB; both reported, so that a fixed RCCL shows up
+                import torch.distributed as dist
+                a = torch.arange(160 << 20, dtype=torch.int64, device=co.device_for(group))          # 1.25 GiB
+                b, c = torch.zeros_like(a), torch.zeros_like(a)
+                dist.all_to_all([b], [a], group=group)
+                nbytes = (C.c_size_t * 1)(a.numel() * 8)
+                ctx.use_torch_current_stream()
+                ctx.check(ctx.lib.zk_comm_all_to_all_device(cm.handle, (C.c_void_p * 1)(a.data_ptr()), nbytes, (C.c_void_p * 1)(c.data_ptr()), nbytes))
+                torch.cuda.synchronize()
+                res["rccl_single_piece_above_1GiB_intact"] = bool(torch.equal(a, b))
+                res["pieces_of_256MiB_intact"] = bool(torch.equal(a, c))
+                del a, b, c
+            cm.close()
+        except Exception as e:                   # (a report, not part of the self-test's verdict)
+            res["comm_c_api_ok"] = False
+            res["comm_error"] = repr(e)[:300]
     except Exception as e:
         res["ok"] = False
         res["error"] = repr(e)
@@ -694,7 +707,7 @@ def main():
         # all-reduce, challenger-state broadcast, variable-length gather -- every rank takes part, rank 0 reports.  In a
         # multi-rank run only on request: the scaling line needs nothing but the barrier and the MAX all-reduce above, and
         # must not depend on anything else.
-        selftest = dist_selftest(rank, world, rg.backend, rg.group())
+        selftest = dist_selftest(rank, world, rg.backend, rg.group(), ctx)
         if rank == 0 and out is not None:
             out["dist"].update({k: v for k, v in selftest.items() if k not in ("ok", "error")})
             if not selftest.get("ok"):

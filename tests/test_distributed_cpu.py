@@ -33,6 +33,22 @@ def test_assign_tables_partition_and_balance():
     assert assign_tables(SHAPES, 2) == assign_tables(SHAPES, 2)  # deterministic
 
 
+def test_library_assignment_equals_the_python_one():
+    """zk_assign_tables (what zk_prove_segment_table_parallel uses) == sharding.assign_tables, row-sharded tables aside"""
+    from zk_evm_amd.sharding import table_owners
+    rng = np.random.default_rng(5)
+    for world in (1, 2, 4, 8):
+        for _ in range(20):
+            shapes = [(int(rng.integers(1, 2500)), int(rng.integers(4, 23))) for _ in range(9)]
+            wide = [t for t in range(9) if rng.random() < 0.2]
+            solo = [t for t in range(9) if t not in wide]
+            own = table_owners(shapes, world, wide)
+            want = assign_tables([shapes[t] for t in solo], world)
+            for r, ts in enumerate(want):
+                assert all(own[solo[k]] == r for k in ts)
+            assert all(own[t] == 0 for t in wide)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -103,3 +103,70 @@ def test_c_segment_proof_matches_python_mirror(tmp_path, cdk_erigon):
     mb = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
     ma = np.array(got.public_values.mem_after.mem_cap, dtype=np.uint64)
     assert out[-1] == f"mem_caps fnv {_fnv(0xCBF29CE484222325, mb):016x} {_fnv(0xCBF29CE484222325, ma):016x}"
+
+
+@pytest.mark.parametrize("world,wide,fri_mode", [(2, (3,), 0), (4, (3, 6), 1), (2, (), 0)])
+def test_c_multi_rank_segment_proof_matches_single_gpu(tmp_path, world, wide, fri_mode):
+    """tests/cabi/sharded.c: W processes forked from plain C -- no Python, no torch.distributed in them -- prove ONE segment
+    together through `zk_prove_segment_table_parallel` on the library's communicator (host-staged transport: the ranks share
+    this GPU), Keccak (and Memory: two lookups, one over a next-row column, CTL entries) ROW-SHARDED over all ranks: every
+    rank's segment proof equals the single-GPU zk_prove_segment proof of the Python mirror, word for word (FNV-1a per table)."""
+    import torch
+    import zk_evm_amd as zk
+    import zk_evm_amd.segment as sg
+    from tests.test_gpu_segment import make_pv, make_traces, to_public_values
+    from zk_evm_amd.all_stark import AllStark
+    exe = str(tmp_path / "cabi_sharded")
+    libdir = os.path.join(ROOT, "zk_evm_amd")
+    subprocess.run([shutil.which("gcc") or "gcc", "-std=c11", "-O1", "-Wall", "-Werror",
+                    os.path.join(ROOT, "tests", "cabi", "sharded.c"), "-I", os.path.join(ROOT, "include"),
+                    "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L", libdir, "-lzkstark_hip",
+                    "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+                    "-o", exe], check=True)
+    rng = np.random.default_rng(91)
+    log_ns = [9, 8, 10, 8, 8, 8, 11, 8, 8]
+    traces = make_traces(rng, log_ns)
+    in_use = [True] * 9
+    in_use[8] = False
+    labels = (11, 22, 33, 44)
+    pv = to_public_values(make_pv(rng))
+    scfg = zk.StarkConfig(fri_config=zk.FriConfig(proof_of_work_bits=3, num_query_rounds=4))
+    c = scfg.to_c()
+    words = [0] + [int(getattr(c, name)) for name, _ in c._fields_] + list(labels)
+    elems = sg.public_values_elements(pv)
+    words += [len(elems)] + [int(e) for e in elems]
+    with open(tmp_path / "segment.bin", "wb") as f:
+        f.write(np.array(words, dtype=np.uint64).tobytes())
+        for t, used in zip(traces, in_use):
+            f.write(np.array([int(used), t.shape[1].bit_length() - 1], dtype=np.uint64).tobytes())
+            f.write(np.ascontiguousarray(t).tobytes())
+    name = "zk_cabi_%d_%s" % (os.getpid(), os.urandom(3).hex())
+    r = subprocess.run([exe, str(tmp_path / "segment.bin"), str(world), name, str(tmp_path / "out"), str(fri_mode)] + [str(t) for t in wide],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, ZK_COMM_TIMEOUT_S="120"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    st = AllStark(labels)
+    got = sg.prove_with_traces(st, scfg, [torch.from_numpy(t.view(np.int64)).cuda() for t in traces], in_use, pv)
+    want = ["ctl_challenges " + " ".join(str(x) for bg in got.multi_proof.ctl_challenges for x in bg)]
+    for t in range(st.num_tables):
+        sp = got.multi_proof.stark_proofs[t]
+        if sp is None:
+            want.append(f"table {st.table_names[t]} absent")
+            continue
+        p = sp.proof
+        h = _fnv(0xCBF29CE484222325, sp.init_challenger_state)
+        h = _fnv(h, p.trace_cap)
+        if p.auxiliary_polys_cap is not None:
+            h = _fnv(h, p.auxiliary_polys_cap)
+        h = _fnv(_fnv(_fnv(h, p.quotient_polys_cap), p.openings), p.opening_proof)
+        want.append(f"{h:016x}")
+    mb = np.array(got.public_values.mem_before.mem_cap, dtype=np.uint64)
+    ma = np.array(got.public_values.mem_after.mem_cap, dtype=np.uint64)
+    want.append(f"mem_caps fnv {_fnv(0xCBF29CE484222325, mb):016x} {_fnv(0xCBF29CE484222325, ma):016x}")
+    for rank in range(world):
+        out = open(str(tmp_path / "out") + ".%d" % rank).read().splitlines()
+        assert out[0] == want[0], rank
+        for t in range(st.num_tables):
+            assert out[1 + t].split()[-1] == want[1 + t].split()[-1], (rank, st.table_names[t], out[1 + t])
+        assert out[1 + st.num_tables] == want[-1]
+        comm = out[-1].split()
+        assert comm[:6] == ["comm", "host", "rank", str(rank), "of", str(world)] and int(comm[7]) > 0 and int(comm[9]) > 0

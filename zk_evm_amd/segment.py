@@ -393,6 +393,82 @@ def encode_ctl_wiring(ctls: Sequence[CrossTableLookup]) -> np.ndarray:
     return np.array([len(ctls)] + offs + payload, dtype=np.uint64)
 
 
+def segment_tables(all_stark: AllStark, trace_poly_values: Sequence, table_in_use: Sequence[bool], shapes=None, row_blocks=None):
+    """The `zk_table_in` array of a segment, the encoded CTL wiring, and the arrays that must outlive the call.
+    trace_poly_values[t] may be None for a table this rank does not hold (zk_prove_segment_table_parallel): its height then
+    comes from shapes[t] = log_n.  row_blocks: {table: this rank's ROW BLOCK (C, n / W)} for row-sharded tables (log_n from shapes)."""
+    from .prover import encode_lookup_set
+    from .stark import _trace_args
+    NUM_TABLES, TABLE_NAMES = all_stark.num_tables, all_stark.table_names
+    # the encoded CTL wiring / lookup programs depend only on the table definitions: built once per AllStark
+    cache = all_stark.__dict__.setdefault("_encoded", {})
+    if "wiring" not in cache:
+        cache["wiring"] = encode_ctl_wiring(all_stark.cross_table_lookups)
+        cache["lookups"] = [encode_lookup_set(all_stark.lookups[t]) for t in range(all_stark.num_tables)]
+    tables = (ZkTableIn * NUM_TABLES)()
+    keep = []
+    row_blocks = row_blocks or {}
+    for t in range(NUM_TABLES):
+        ti = tables[t]
+        if t in row_blocks:
+            blk = row_blocks[t]
+            n_cols, stride, log_n = int(blk.shape[0]), (int(blk.stride(0)) if blk.shape[0] > 1 else int(blk.shape[1])), int(shapes[t])
+            ti.d_trace = blk.data_ptr()
+        elif trace_poly_values[t] is None:
+            n_cols, stride, log_n = all_stark.table_columns[t], 0, int(shapes[t])
+            ti.d_trace = None
+        else:
+            tr = trace_poly_values[t]
+            n_cols, n, log_n, stride = _trace_args(tr)
+            ti.d_trace = tr.data_ptr()
+        if n_cols != all_stark.table_columns[t]:
+            raise ZkStarkError(-1, "table %s: expected %d columns, got %d" % (TABLE_NAMES[t], all_stark.table_columns[t], n_cols))
+        lp = cache["lookups"][t]
+        ac = np.array(list(all_stark.air_consts[t]), dtype=np.uint64)
+        keep += [lp, ac]
+        ti.col_stride, ti.n_cols, ti.log_n = stride, n_cols, log_n
+        ti.air_id = all_stark.table_air[t]
+        ti.air_consts, ti.n_air_consts = (ac.ctypes.data if ac.size else None), ac.size
+        ti.lookup_program, ti.lookup_words = (lp.ctypes.data, lp.size) if lp is not None else (None, 0)
+        ti.in_use = 1 if table_in_use[t] else 0
+        ti.optional = 1 if t in all_stark.optional_table_indices else 0
+    return tables, cache["wiring"], keep
+
+
+def segment_proof_from_handle(lib, h, all_stark: AllStark, config: StarkConfig, table_in_use, public_values: PublicValues,
+                              timing: Optional[dict] = None) -> AllProof:
+    """Copy a library-owned zk_segment_proof into an AllProof (the caller still frees the handle)."""
+    from .prover import table_proof_from_handle
+    NUM_TABLES = all_stark.num_tables
+    nchal = config.num_challenges
+    cc = np.zeros(2 * nchal, dtype=np.uint64)
+    lib.zk_segment_proof_ctl_challenges(h, cc.ctypes.data, cc.size)
+    ctl_challenges = [(int(cc[2 * i]), int(cc[2 * i + 1])) for i in range(nchal)]
+    stark_proofs: List[Optional[StarkProofWithMetadata]] = []
+    for t in range(NUM_TABLES):
+        th = lib.zk_segment_proof_table(h, t)
+        if not th:
+            stark_proofs.append(None)
+            continue
+        p = table_proof_from_handle(lib, th)
+        stark_proofs.append(StarkProofWithMetadata(p, p.init_challenger_state))
+    nd = 1 << config.fri_config.cap_height
+    mb, ma = np.zeros(4 * nd, dtype=np.uint64), np.zeros(4 * nd, dtype=np.uint64)
+    lib.zk_segment_proof_mem_caps(h, mb.ctypes.data, ma.ctypes.data, 4 * nd)
+    public_values.mem_before = MemCap.from_elements(mb)
+    public_values.mem_after = MemCap.from_elements(ma)
+    if timing is not None:
+        ms = (C.c_double * (2 + NUM_TABLES))()
+        lib.zk_segment_proof_stage_ms(h, ms, 2 + NUM_TABLES)
+        timing["compute all trace commitments"] = timing.get("compute all trace commitments", 0.0) + ms[0] / 1e3
+        timing["compute CTL data"] = timing.get("compute CTL data", 0.0) + ms[1] / 1e3
+        for t in range(NUM_TABLES):
+            if table_in_use[t]:
+                k = "prove %s STARK" % all_stark.stark_field_names[t]     # prover.rs:232
+                timing[k] = timing.get(k, 0.0) + ms[2 + t] / 1e3
+    return AllProof(MultiProof(stark_proofs, ctl_challenges), public_values, list(table_in_use))
+
+
 def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_values: Sequence,
                       table_in_use: Sequence[bool], public_values: PublicValues, abort_signal=None,
                       hasher: Optional[int] = None, ctx=None, timing: Optional[dict] = None,
@@ -407,10 +483,7 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
     library verifies every cross-table lookup (Memory with the public values' extra looking rows) right after the CTL
     data and raises naming the unbalanced CTL instead of producing a proof the verifier would reject."""
     from .context import default_context
-    from .prover import encode_lookup_set, table_proof_from_handle
-    from .stark import _trace_args
-    NUM_TABLES, TABLE_NAMES = all_stark.num_tables, all_stark.table_names
-    OPTIONAL_TABLE_INDICES = all_stark.optional_table_indices
+    NUM_TABLES = all_stark.num_tables
     if len(trace_poly_values) != NUM_TABLES or len(table_in_use) != NUM_TABLES:
         raise ZkStarkError(-1, "expected one trace and one in-use flag per table")
     if all_stark.cdk_erigon and public_values.burn_addr is None:
@@ -424,29 +497,7 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
     cfg = config.to_c()
     cfg.hasher = hasher
     pv = np.array(public_values_elements(public_values), dtype=np.uint64)      # may raise PublicValuesError
-    # the encoded CTL wiring / lookup programs depend only on the table definitions: built once per AllStark
-    cache = all_stark.__dict__.setdefault("_encoded", {})
-    if "wiring" not in cache:
-        cache["wiring"] = encode_ctl_wiring(all_stark.cross_table_lookups)
-        cache["lookups"] = [encode_lookup_set(all_stark.lookups[t]) for t in range(all_stark.num_tables)]
-    wiring = cache["wiring"]
-    tables = (ZkTableIn * NUM_TABLES)()
-    keep = []
-    for t in range(NUM_TABLES):
-        tr = trace_poly_values[t]
-        n_cols, n, log_n, stride = _trace_args(tr)
-        if n_cols != all_stark.table_columns[t]:
-            raise ZkStarkError(-1, "table %s: expected %d columns, got %d" % (TABLE_NAMES[t], all_stark.table_columns[t], n_cols))
-        lp = cache["lookups"][t]
-        ac = np.array(list(all_stark.air_consts[t]), dtype=np.uint64)
-        keep += [lp, ac]
-        ti = tables[t]
-        ti.d_trace, ti.col_stride, ti.n_cols, ti.log_n = tr.data_ptr(), stride, n_cols, log_n
-        ti.air_id = all_stark.table_air[t]
-        ti.air_consts, ti.n_air_consts = (ac.ctypes.data if ac.size else None), ac.size
-        ti.lookup_program, ti.lookup_words = (lp.ctypes.data, lp.size) if lp is not None else (None, 0)
-        ti.in_use = 1 if table_in_use[t] else 0
-        ti.optional = 1 if t in OPTIONAL_TABLE_INDICES else 0
+    tables, wiring, keep = segment_tables(all_stark, trace_poly_values, table_in_use)
     if check_ctls is not None:
         rows = np.array(get_memory_extra_looking_values(public_values, *check_ctls), dtype=np.uint64)
         ctx.check(ctx.lib.zk_ctx_set_check_ctls(ctx.handle, 1))
@@ -464,34 +515,7 @@ def prove_with_traces(all_stark: AllStark, config: StarkConfig, trace_poly_value
             ctx.set_abort_flag(None)
         if check_ctls is not None:
             ctx.lib.zk_ctx_set_check_ctls(ctx.handle, 0)
-    lib = ctx.lib
     try:
-        nchal = config.num_challenges
-        cc = np.zeros(2 * nchal, dtype=np.uint64)
-        lib.zk_segment_proof_ctl_challenges(h, cc.ctypes.data, cc.size)
-        ctl_challenges = [(int(cc[2 * i]), int(cc[2 * i + 1])) for i in range(nchal)]
-        stark_proofs: List[Optional[StarkProofWithMetadata]] = []
-        for t in range(NUM_TABLES):
-            th = lib.zk_segment_proof_table(h, t)
-            if not th:
-                stark_proofs.append(None)
-                continue
-            p = table_proof_from_handle(lib, th)
-            stark_proofs.append(StarkProofWithMetadata(p, p.init_challenger_state))
-        nd = 1 << config.fri_config.cap_height
-        mb, ma = np.zeros(4 * nd, dtype=np.uint64), np.zeros(4 * nd, dtype=np.uint64)
-        lib.zk_segment_proof_mem_caps(h, mb.ctypes.data, ma.ctypes.data, 4 * nd)
-        public_values.mem_before = MemCap.from_elements(mb)
-        public_values.mem_after = MemCap.from_elements(ma)
-        if timing is not None:
-            ms = (C.c_double * (2 + NUM_TABLES))()
-            lib.zk_segment_proof_stage_ms(h, ms, 2 + NUM_TABLES)
-            timing["compute all trace commitments"] = timing.get("compute all trace commitments", 0.0) + ms[0] / 1e3
-            timing["compute CTL data"] = timing.get("compute CTL data", 0.0) + ms[1] / 1e3
-            for t in range(NUM_TABLES):
-                if table_in_use[t]:
-                    k = "prove %s STARK" % all_stark.stark_field_names[t]     # prover.rs:232
-                    timing[k] = timing.get(k, 0.0) + ms[2 + t] / 1e3
+        return segment_proof_from_handle(ctx.lib, h, all_stark, config, table_in_use, public_values, timing)
     finally:
-        lib.zk_segment_proof_free(h)
-    return AllProof(MultiProof(stark_proofs, ctl_challenges), public_values, list(table_in_use))
+        ctx.lib.zk_segment_proof_free(h)

@@ -69,206 +69,87 @@ def gather_caps(local_caps: Dict[int, np.ndarray], n_tables: int, cap_len: int =
 
 
 # ---- table-parallel proof of ONE segment (latency mode, SURVEY 8(e) level 2) ------------------------------------------
+def table_owners(shapes: Sequence[tuple], world_size: int, row_sharded: Sequence[int] = (), lib=None) -> List[int]:
+    """`zk_assign_tables`: the rank that commits and proves each table (row-sharded tables: every rank; listed as 0)."""
+    import ctypes as C
+    if lib is None:
+        from ._lib import load_library
+        lib = load_library()
+    n = len(shapes)
+    cols = (C.c_size_t * n)(*[int(c) for c, _ in shapes])
+    logs = (C.c_uint * n)(*[int(l) for _, l in shapes])
+    wide = (C.c_uint8 * n)(*[1 if t in set(row_sharded) else 0 for t in range(n)])
+    own = (C.c_uint32 * n)()
+    rc = lib.zk_assign_tables(cols, logs, n, world_size, wide, own)
+    if rc != 0:
+        raise ValueError("zk_assign_tables failed (%d)" % rc)
+    return [int(x) for x in own]
+
+
 def prove_segment_table_parallel(all_stark, config, trace_poly_values, table_in_use, public_values, group=None, ctx=None,
-                                 timing=None, row_sharded=None):
-    """`prove_with_traces` (prover.rs:72-194) with the tables of ONE segment spread over the ranks of `group`.
+                                 timing=None, row_sharded=None, comm=None, fri: str = "replicated"):
+    """`prove_with_traces` (prover.rs:72-194) with the tables of ONE segment spread over the ranks of `group` / `comm` --
+    `zk_prove_segment_table_parallel` (csrc/shard_prove_host.inc; what shards and what does not is described in
+    include/zkstark.h): ONE library call per rank on a `zk_comm`.
 
-    What shards (prover.rs:90-111): every table's trace commitment is independent of the transcript, and a table's CTL /
-    logUp columns and its whole `prove_single_table` only read that table's own trace and LDEs -- so table t lives on
-    exactly one rank (`assign_tables`, largest first) and no bulk data ever moves.  What does not: Fiat-Shamir.
-      phase 1  trace commitments of the owned tables, in parallel; the caps are observed in table order before anything
-               else (prover.rs:118-127) -> ONE all-gather of 2^cap_height x 32 B per table (`gather_caps`); every rank
-               then replays the same transcript (public values, CTL challenges);
-      phase 2  CTL running sums, logUp helper columns and the AUXILIARY COMMITMENT of every owned table, in parallel on all
-               ranks: they depend on the CTL challenges only (prover.rs:134-144; lookup challenges = the CTL betas, :328);
-      phase 3  the per-table proofs in table order on their owners (prover.rs:251-259: serial by construction, the
-               recursive verifier enforces the order), the 31-word challenger state broadcast owner -> all after each.
-    Everything that crosses ranks is a fixed-shape int64 tensor (collectives.py): table shapes, a status word after every
-    local step (a failing rank never strands the others in a collective: all of them raise), caps, challenger states,
-    and at the end the flat proof words gathered on rank 0.
+    trace_poly_values[t] is only read on the owner of t (`table_owners`; others may pass None).
+    row_sharded: {table: this rank's contiguous ROW BLOCK of that table's trace, CUDA (C, n / W)} -- tables whose commitment and
+    proof are spread over ALL ranks (level 3); every rank passes its block, trace_poly_values[t] is ignored for them.
+    Returns the `AllProof` on EVERY rank, bit-identical to the single-GPU `prove_with_traces`.  Latency, not throughput:
+    independent segments on independent GPUs (`scheduler.run_distributed`) remain the throughput path."""
+    import ctypes as C
 
-    row_sharded: {table: this rank's contiguous ROW BLOCK of that table's trace, CUDA (C, n / W)} -- tables whose commitment
-    and proof are spread over ALL ranks (level 3, shard_prover.py: the 2431-column Keccak table is what bounds this mode
-    otherwise); every rank passes its block, trace_poly_values[t] is ignored for them.  Their steps of the chain run on every
-    rank at once on the replicated transcript, so no state is broadcast after them.
-
-    trace_poly_values[t] is only read on the owner of t (others may pass None).  Returns the `AllProof` on rank 0 of the
-    group (None elsewhere); bit-identical to the single-GPU `prove_with_traces`.  Latency, not throughput: the chain is
-    serial, so the gain is bounded by (largest trace commitment + largest phase 2 + sum of the chain steps) / (single-GPU
-    time) -- independent segments on independent GPUs (`scheduler.run_distributed`) remain the throughput path."""
-    import time
-    from itertools import groupby
-
-    import torch
-    import torch.distributed as dist
-
-    from . import collectives as co
     from . import segment as sg
-    from .challenger import Challenger
+    from .comm import comm_for
     from .context import default_context
-    from .polynomial_batch import PolynomialBatch
-    from .prover import CtlZData, StarkProof, table_aux_commit
-    from .stark import _trace_args, ctl_partial_sums
-    multi = dist.is_available() and dist.is_initialized()
-    world, rank = (dist.get_world_size(group), dist.get_rank(group)) if multi else (1, 0)
+    from .shard_prover import FRI_MODES
+    from .stark import _trace_args
     n_tab = all_stark.num_tables
-    hasher = config.hasher
-    fri = config.fri_config
-    deg = all_stark.constraint_degree
-
-    def step(what, fn):
-        """run a local step; afterwards every rank knows whether all ranks succeeded"""
-        err, val = None, None
-        try:
-            val = fn()
-        except Exception as e:                      # noqa: BLE001 -- re-raised by agree() on this rank
-            err = e
-        co.agree(err, what, group)
-        return val
     row_sharded = dict(row_sharded or {})
-    # every rank needs the shapes to compute the same assignment: (cols, log_n) of the tables it was given, (0, 0) = absent
-    mine_shapes = np.zeros((n_tab, 2), dtype=np.uint64)
-    for t, tr in enumerate(trace_poly_values):
+    dev0 = next((tr.device for tr in list(trace_poly_values) + list(row_sharded.values()) if tr is not None), None)
+    if ctx is None:
+        import torch
+        ctx = default_context((dev0.index or 0) if dev0 is not None else torch.cuda.current_device())
+    cm = comm if comm is not None else comm_for(ctx, group)
+    ctx.use_torch_current_stream()
+    world, rank = cm.world, cm.rank
+    # every rank needs every table's height: all-gather of what each rank was given (0 = absent)
+    mine_logs = np.zeros(n_tab, dtype=np.uint64)
+    for t in range(n_tab):
         if t in row_sharded:
-            blk = row_sharded[t]
-            mine_shapes[t] = (int(blk.shape[0]), (int(blk.shape[1]) * world).bit_length() - 1)
-        elif tr is not None:
-            c, n, ln, _ = _trace_args(tr)
-            mine_shapes[t] = (c, ln)
-    shapes = [None] * n_tab
-    for part in co.all_gather_words(mine_shapes.reshape(-1), 2 * n_tab, group):
-        for t, (c, ln) in enumerate(part.reshape(n_tab, 2)):
-            if int(c):
-                shapes[t] = (int(c), int(ln))
-
-    def plan():
-        if any(s is None for s in shapes):
-            raise ValueError("every table's trace must be present on at least one rank")
-        owner = [0] * n_tab
-        solo = [t for t in range(n_tab) if t not in row_sharded]
-        for r, ts in enumerate(assign_tables([shapes[t] for t in solo], world)):
-            for k in ts:
-                owner[solo[k]] = r
-        mine = [t for t in solo if owner[t] == rank]
-        missing = [t for t in mine if trace_poly_values[t] is None]
-        if missing:
-            raise ValueError("rank %d owns tables %s but was not given their traces" % (rank, missing))
-        return owner, mine
-    owner, mine = step("the table assignment", plan)
-    dev0 = trace_poly_values[mine[0]].device if mine else (next(iter(row_sharded.values())).device if row_sharded else None)
-    ctx = ctx or default_context((dev0.index or 0) if dev0 is not None else torch.cuda.current_device())
-    t0 = time.perf_counter()
-    # ---- phase 1: trace commitments of the owned tables, one all-gather of caps -----------------------------------
-    batches = step("a trace commitment", lambda: {
-        t: PolynomialBatch.from_values(trace_poly_values[t], fri.rate_bits, False, fri.cap_height, hasher=hasher, ctx=ctx)
-        for t in mine})
-    aux = {}
-    wide = {}
+            mine_logs[t] = 1 + (int(row_sharded[t].shape[1]) * world).bit_length() - 1
+        elif trace_poly_values[t] is not None:
+            mine_logs[t] = 1 + _trace_args(trace_poly_values[t])[2]
+    logs = cm.all_gather_words(mine_logs).max(axis=0)
+    if (logs == 0).any():
+        raise ValueError("every table's trace must be present on at least one rank")
+    shapes = [(all_stark.table_columns[t], int(logs[t]) - 1) for t in range(n_tab)]
+    owner = table_owners(shapes, world, sorted(row_sharded), ctx.lib)
+    mine = [t for t in range(n_tab) if t not in row_sharded and owner[t] == rank]
+    held = [tr if (t in mine) else None for t, tr in enumerate(trace_poly_values)]
+    tables, wiring, keep = sg.segment_tables(all_stark, held, table_in_use, shapes=[l for _, l in shapes], row_blocks=row_sharded)
+    wide = (C.c_uint8 * n_tab)(*[1 if t in row_sharded else 0 for t in range(n_tab)])
+    cfg = config.to_c()
+    pv = np.array(sg.public_values_elements(public_values), dtype=np.uint64)
+    h = C.c_void_p()
+    cm.timing_ms(reset=True)
+    ctx.check(ctx.lib.zk_prove_segment_table_parallel(
+        ctx.handle, cm.handle, C.byref(cfg), C.cast(tables, C.c_void_p), n_tab, wide if row_sharded else None, wiring.ctypes.data, wiring.size,
+        pv.ctypes.data, pv.size, all_stark.constraint_degree, sg.Table.MemBefore, sg.Table.MemAfter, FRI_MODES[fri], C.byref(h)))
     try:
-        # the row-sharded tables: every rank takes part in each commitment (column-sharded NTT, all-to-all, sub-root all-gather)
-        from .shard_prover import commit_rows_sharded, prove_table_row_sharded, table_ctl_specs
-        for t in sorted(row_sharded):
-            wide[t] = step("a row-sharded trace commitment", lambda t=t: commit_rows_sharded(row_sharded[t], config, ctx, group))
-        local = {t: batches[t].merkle_tree.cap.elements for t in mine}
-        if rank == 0:                                  # (every rank holds a row-sharded table's cap; one of them reports it)
-            local.update({t: wide[t].cap for t in wide})
-        caps = gather_caps(local, n_tab, 1 << fri.cap_height, group)
-        t1 = time.perf_counter()
-        # ---- transcript seed, replicated (prover.rs:114-144) ---------------------------------------------------------------
-        ch = Challenger(hasher)
-        for t in range(n_tab):
-            if t in all_stark.optional_table_indices and not table_in_use[t]:
-                ch.observe_elements([0] * (4 << fri.cap_height))
-            else:
-                ch.observe_cap(caps[t])
-        step("the public values", lambda: sg.observe_public_values(ch, public_values))
-        ctl_challenges = [(ch.get_challenge(), ch.get_challenge()) for _ in range(config.num_challenges)]
-        # ---- phase 2, parallel over the ranks: CTL data, logUp columns and the auxiliary commitment of the owned tables ----
-        zdata = {t: [] for t in mine}
-
-        def phase2():
-            for ctl in all_stark.cross_table_lookups:        # starky cross_table_lookup_data, restricted to this rank's tables
-                looked = ctl.looked_table
-                for beta, gamma in ctl_challenges:
-                    for table, grp in groupby(ctl.looking_tables, key=lambda x: x.table):
-                        entries = [(x.columns, x.filter) for x in grp]
-                        if table in zdata and table_in_use[table]:
-                            cols = ctl_partial_sums(trace_poly_values[table], entries, beta, gamma, deg, ctx=ctx)
-                            allc = [(x.columns, x.filter) for x in ctl.looking_tables if x.table == table]
-                            zdata[table].append(CtlZData(beta, gamma, allc, cols))
-                    if looked.table in zdata and table_in_use[looked.table]:
-                        z = ctl_partial_sums(trace_poly_values[looked.table], [(looked.columns, looked.filter)], beta, gamma, deg, ctx=ctx)
-                        zdata[looked.table].append(CtlZData(beta, gamma, [(looked.columns, looked.filter)], z))
-            for t in mine:
-                if table_in_use[t]:
-                    aux[t] = table_aux_commit(config, trace_poly_values[t], all_stark.lookups[t], zdata[t], ctl_challenges, deg,
-                                              hasher=hasher, ctx=ctx)
-        step("the auxiliary commitments (phase 2)", phase2)
-        t2 = time.perf_counter()
-        # ---- phase 3, the chain: tables in order on their owners, challenger state handed on (prover.rs:251-259) ----------
-        proofs = {}
-        for t in range(n_tab):
-            if not table_in_use[t]:
-                continue
-            if t in wide:                              # all ranks together, on the replicated transcript
-                pr = step("the row-sharded proof of table %d" % t, lambda t=t: prove_table_row_sharded(
-                    all_stark.table_air[t], config, row_sharded[t], table_ctl_specs(all_stark, t, ctl_challenges), ctl_challenges, ch,
-                    constraint_degree=deg, air_consts=all_stark.air_consts[t], lookups=all_stark.lookups[t], group=group, ctx=ctx,
-                    trace_oracle=wide.pop(t)))
-                if rank == 0:                          # (the sharded prover returns the proof on every rank)
-                    proofs[t] = sg.StarkProofWithMetadata(pr, pr.init_challenger_state)
-                continue
-            state, err = np.zeros(32, dtype=np.uint64), None
-            if owner[t] == rank:
-                try:
-                    proofs[t] = sg.prove_single_table(all_stark, t, config, trace_poly_values[t], batches[t], zdata[t],
-                                                      ctl_challenges, ch, aux_commitment=aux.get(t))
-                    state[1:] = ch.export_state()
-                except Exception as e:              # noqa: BLE001 -- announced to the other ranks below, then re-raised
-                    err = e
-                    state[0] = 1
-            if multi:
-                state = co.broadcast_words(state, 32, owner[t], group)
-            if err is not None:
-                raise err
-            if int(state[0]):
-                raise co.RemoteRankError("the proof of table %d failed on rank %d" % (t, owner[t]))
-            if owner[t] != rank:
-                ch.import_state(state[1:])
-            else:
-                if aux.get(t) is not None:
-                    aux.pop(t).free()
-                if t not in (sg.Table.MemBefore, sg.Table.MemAfter):
-                    batches[t].free()
-        t3 = time.perf_counter()
+        ms = (C.c_double * (2 + n_tab))()
+        ctx.lib.zk_segment_proof_stage_ms(h, ms, 2 + n_tab)
+        proof = sg.segment_proof_from_handle(ctx.lib, h, all_stark, config, table_in_use, public_values)
     finally:
-        for b in list(batches.values()) + [a for a in aux.values() if a is not None]:
-            if b.handle:
-                b.free()
-        for o in wide.values():
-            o.free()
+        ctx.lib.zk_segment_proof_free(h)
     if timing is not None:
-        timing.update({"compute owned trace commitments + cap all-gather": t1 - t0,
-                       "CTL data + auxiliary commitments (owned tables, parallel over ranks)": t2 - t1,
-                       "per-table proofs (serial chain over owners)": t3 - t2, "tables owned": mine})
-    # ---- the proofs to rank 0: flat words, one padded gather ------------------------------------------------------------
-    recs = []
-    for t in sorted(proofs):
-        recs.append(np.concatenate([np.array([t], dtype=np.uint64), proofs[t].proof.to_words()]))
-    parts = co.gather_varlen_words(co.pack_records(recs), dst=0, group=group)
-    if rank != 0:
-        return None
-    merged = {}
-    for part in parts:
-        for rec in co.unpack_records(part):
-            pr, _ = StarkProof.from_words(rec[1:])
-            merged[int(rec[0])] = sg.StarkProofWithMetadata(pr, pr.init_challenger_state)
-    mb, ma = caps[sg.Table.MemBefore], caps[sg.Table.MemAfter].copy()
-    if not table_in_use[sg.Table.MemAfter]:
-        ma[:] = 0
-    public_values.mem_before = sg.MemCap.from_merkle_cap(mb, hasher)
-    public_values.mem_after = sg.MemCap.from_merkle_cap(ma, hasher)
-    return sg.AllProof(sg.MultiProof([merged.get(t) for t in range(n_tab)], ctl_challenges), public_values, list(table_in_use))
+        timing.update({"compute owned trace commitments + cap all-gather": ms[0] / 1e3,
+                       "CTL data + auxiliary commitments (owned tables, parallel over ranks)": ms[1] / 1e3,
+                       "per-table proofs (serial chain over owners)": sum(ms[2:]) / 1e3, "tables owned": mine,
+                       "transport": cm.transport})
+        if row_sharded:
+            timing["row-sharded stages (s)"] = {k: v / 1e3 for k, v in cm.timing_ms().items()}
+    return proof
 
 
 # ---- sharding INSIDE one table's commitment (SURVEY 8(e) level 3; prototype of the commit phase) -------------------------
