@@ -713,6 +713,18 @@ def main():
             if not selftest.get("ok"):
                 out["dist"]["selftest_error"] = selftest.get("error")
             out["dist"]["selftest_ok"] = bool(selftest.get("ok"))
+    if world > 1 and rg.nccl is not None and os.environ.get("ZK_BENCH_RCCL_DRILL", "1") == "1":
+        # r04 verdict, item 6: the first multi-GPU box answers whether RCCL's corruption of messages above 1 GiB (seen with one rank,
+        # self copy) hits real peers -- one 1.27 GB send / recv and all-to-all between neighbours, and the library's 256 MiB pieces
+        try:
+            from tools.rccl_repro import run as rccl_drill
+            drill = rccl_drill((1.27,), True, rg.nccl, ctx, rg.gloo)
+            if rank == 0 and out is not None:
+                out["dist"].update({k: drill.get(k) for k in ("rccl_large_piece_intact_self", "rccl_large_piece_intact_peer", "library_pieces_intact")})
+                out["rccl_drill"] = drill
+        except Exception as e:
+            if rank == 0 and out is not None:
+                out["dist"]["rccl_drill_error"] = repr(e)[:200]
     # ---- secondaries: after everything the contract names is in `out`, each in its own process under a time limit -------
     if rank == 0 and world == 1 and out is not None and not a.no_secondary and secondaries:
         ctx.mem_trim()

@@ -754,3 +754,17 @@ def test_row_sharded_proof_with_ctl_helper_columns():
     for r in range(world):
         assert np.array_equal(res[r][1], ch.export_state())
     tb.free()
+
+
+def test_rccl_repro_drill_world1():
+    """tools/rccl_repro.py (r04 verdict, item 6) with the one rank this box has: the raw RCCL primitives above 1 GiB are REPORTED
+    (corrupted on this image's RCCL 2.26 -- if a newer RCCL fixes it the row flips, which is the point of the drill), the library's
+    256 MiB pieces are intact at every size; with two ranks on a multi-GPU box the same script answers the peer question."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_repro.py"), "--sizes-gb", "0.5,1.27"], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT, env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["world"] == 1 and out["library_pieces_intact"] is True and out["rccl_large_piece_intact_peer"] is None
+    small = [x for x in out["rows"] if x["GB"] == 0.5]
+    assert small and all(x["intact"] for x in small)
+    assert isinstance(out["rccl_large_piece_intact_self"], bool)

@@ -419,7 +419,8 @@ def contract_line(out, extra_path="bench_extra.json"):
     if d:
         line["dist"] = {k: d.get(k) for k in ("backend", "world", "ok", "selftest_ok", "fallback", "tried", "payload_device",
                                                "rccl_single_piece_above_1GiB_intact", "pieces_of_256MiB_intact",
-                                               "comm_c_api_ok", "comm_transport") if k in d}
+                                               "comm_c_api_ok", "comm_transport", "rccl_large_piece_intact_self",
+                                               "rccl_large_piece_intact_peer", "library_pieces_intact") if k in d}
         if d.get("error"):
             line["dist"]["error"] = str(d["error"])[:200]
     if out.get("per_rank_ms_per_step") is not None:
