@@ -68,6 +68,15 @@ def test_contract_line_is_small_strict_json_and_carries_the_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 and r["traffic"] > 0
     assert {"value", "unit", "cores", "kind", "sample"} <= set(d["cpu_baseline"])
     assert d["ntt"]["achieved_GBs"] > 0 and d["dist"]["backend"] == "nccl" and d["secondary"]["realistic_ms_per_proof"] > 0
+    # r05: the baseline in the headline's unit -- a whole-segment sample scaled by committed cells (tools/bench_secondary.py)
+    seg = copy.deepcopy(full)
+    seg["cpu_baseline"] = {"value": 1.0 / 1363.2, "unit": "segment proofs/s", "cores": 16, "kind": "port", "sample": "s" * 900, "seconds": 1363.2,
+                           "sample_seconds": 21.3, "sample_log_n": 14, "scale": 64.0, "shape": "9 tables x 2^14 rows measured",
+                           "gpu_same_sample_s": 0.05, "proofs_identical": True, "cpu_model": "x", "poseidon_perms_per_s_per_core": 9.7e5}
+    d = strict(contract_line(seg))
+    cb = d["cpu_baseline"]
+    assert cb["unit"] == d["unit"] == "segment proofs/s" and cb["proofs_identical"] is True and cb["scale"] == 64.0 and len(cb["sample"]) <= 400
+    assert abs(cb["value"] * cb["seconds"] - 1.0) < 1e-5 and abs(cb["sample_seconds"] * cb["scale"] - cb["seconds"]) < 1e-6 * cb["seconds"]
     # poisoned
     bad = copy.deepcopy(full)
     bad["value"] = float("nan")
