@@ -10,6 +10,10 @@ use anyhow::{anyhow, Result};
 pub use zkstark_sys as sys;
 use zkstark_sys::*;
 
+/// Every construction of a plonky2 / starky type whose spelling could not be checked against an in-tree use (feature `upstream`).
+#[cfg(feature = "upstream")]
+pub mod upstream_compat;
+
 /// `StarkConfig` / `FriConfig` fields the path consumes (`StarkConfig::standard_fast_config()` by default).
 #[derive(Clone, Copy)]
 pub struct Config(pub zk_cfg);
@@ -189,35 +193,132 @@ pub fn prove_segment(ctx: &Context, cfg: &Config, tables: &[TableIn], ctl_wiring
                          public_value_elements.as_ptr(), public_value_elements.len(), constraint_degree,
                          mem_before_table, mem_after_table, &mut h)
     })?;
+    read_segment_proof(ctx, cfg, h, tables.len())
+}
+
+/// Owned copy of a `zk_segment_proof` (freed here).
+fn read_segment_proof(ctx: &Context, cfg: &Config, h: *mut zk_segment_proof, n_tables: usize) -> Result<SegmentProof> {
     struct Guard(*mut zk_segment_proof);
     impl Drop for Guard { fn drop(&mut self) { unsafe { zk_segment_proof_free(self.0) } } }
     let _g = Guard(h);
     let nd = 1usize << cfg.0.cap_height;
     let mut out = SegmentProof { tables: Vec::new(), ctl_challenges: Vec::new(), mem_before: vec![[0; 4]; nd],
-                                 mem_after: vec![[0; 4]; nd], stage_ms: vec![0.0; 2 + tables.len()] };
+                                 mem_after: vec![[0; 4]; nd], stage_ms: vec![0.0; 2 + n_tables] };
     unsafe {
         let mut cc = vec![0u64; 2 * cfg.0.num_challenges as usize];
         zk_segment_proof_ctl_challenges(h, cc.as_mut_ptr(), cc.len());
         out.ctl_challenges = cc.chunks(2).map(|c| (c[0], c[1])).collect();
         zk_segment_proof_mem_caps(h, out.mem_before.as_mut_ptr() as *mut u64, out.mem_after.as_mut_ptr() as *mut u64, 4 * nd);
         zk_segment_proof_stage_ms(h, out.stage_ms.as_mut_ptr(), out.stage_ms.len());
-        for t in 0..tables.len() {
+        for t in 0..n_tables {
             let tp = zk_segment_proof_table(h, t);
-            if tp.is_null() { out.tables.push(None); continue; }
-            let mut v: zk_table_proof_view = std::mem::zeroed();
-            ctx.check(zk_table_proof_get(tp, &mut v))?;
-            let op = std::slice::from_raw_parts(v.openings, 2 * v.n_openings);
-            out.tables.push(Some(TableProof {
-                degree_bits: v.degree_bits, n_trace_cols: v.n_trace_cols, n_aux_cols: v.n_aux_cols,
-                n_quotient_cols: v.n_quotient_cols, n_ctl_zs: v.n_ctl_zs,
-                trace_cap: caps(v.trace_cap, v.cap_digests),
-                aux_cap: if v.aux_cap.is_null() { None } else { Some(caps(v.aux_cap, v.cap_digests)) },
-                quotient_cap: caps(v.quotient_cap, v.cap_digests),
-                openings: op.chunks(2).map(|c| [c[0], c[1]]).collect(),
-                opening_proof: std::slice::from_raw_parts(v.opening_proof, v.proof_words).to_vec(),
-                init_challenger_state: v.init_challenger_state,
-            }));
+            out.tables.push(if tp.is_null() { None } else { Some(read_table_proof(ctx, tp)?) });
         }
     }
     Ok(out)
+}
+
+unsafe fn read_table_proof(ctx: &Context, tp: *const zk_table_proof) -> Result<TableProof> {
+    let mut v: zk_table_proof_view = std::mem::zeroed();
+    ctx.check(zk_table_proof_get(tp, &mut v))?;
+    let op = std::slice::from_raw_parts(v.openings, 2 * v.n_openings);
+    Ok(TableProof {
+        degree_bits: v.degree_bits, n_trace_cols: v.n_trace_cols, n_aux_cols: v.n_aux_cols,
+        n_quotient_cols: v.n_quotient_cols, n_ctl_zs: v.n_ctl_zs,
+        trace_cap: caps(v.trace_cap, v.cap_digests),
+        aux_cap: if v.aux_cap.is_null() { None } else { Some(caps(v.aux_cap, v.cap_digests)) },
+        quotient_cap: caps(v.quotient_cap, v.cap_digests),
+        openings: op.chunks(2).map(|c| [c[0], c[1]]).collect(),
+        opening_proof: std::slice::from_raw_parts(v.opening_proof, v.proof_words).to_vec(),
+        init_challenger_state: v.init_challenger_state,
+    })
+}
+
+// ---- several GPUs behind one call (include/zkstark.h "the multi-GPU provers behind this ABI") ------------------------------
+/// The ranks of one job: one process (or thread) per GPU, one `Context` each.  `Comm::rccl` is collective like
+/// `ncclCommInitRank`: rank 0 makes the id (`Comm::unique_id`), hands it to the others by whatever the caller has (paladin's
+/// own channel, a pipe, a file), and every rank calls `Comm::rccl(ctx, &id, rank, world)`.  `Comm::host` is the host-staged
+/// transport over POSIX shared memory (ranks may share a GPU; tests, and the fallback where RCCL cannot come up).
+pub struct Comm<'c> { ctx: &'c Context, raw: *mut zk_comm }
+
+impl<'c> Comm<'c> {
+    pub fn unique_id() -> Result<[u8; ZK_COMM_ID_BYTES]> {
+        let mut id = [0u8; ZK_COMM_ID_BYTES];
+        let rc = unsafe { zk_comm_unique_id(id.as_mut_ptr()) };
+        if rc != ZK_OK { return Err(anyhow!("zk_comm_unique_id failed ({rc}): librccl.so could not be loaded")); }
+        Ok(id)
+    }
+    pub fn rccl(ctx: &'c Context, id: &[u8; ZK_COMM_ID_BYTES], rank: u32, world: u32) -> Result<Self> {
+        let mut raw = null_mut();
+        ctx.check(unsafe { zk_comm_create(ctx.raw, id.as_ptr(), rank, world, &mut raw) })?;
+        Ok(Comm { ctx, raw })
+    }
+    pub fn host(ctx: &'c Context, name: &str, rank: u32, world: u32) -> Result<Self> {
+        let cname = std::ffi::CString::new(name)?;
+        let mut raw = null_mut();
+        ctx.check(unsafe { zk_comm_create_host(ctx.raw, cname.as_ptr(), rank, world, 0, &mut raw) })?;
+        Ok(Comm { ctx, raw })
+    }
+    pub fn rank(&self) -> u32 { unsafe { zk_comm_rank(self.raw) } }
+    pub fn world(&self) -> u32 { unsafe { zk_comm_world(self.raw) } }
+    fn check(&self, rc: i32) -> Result<()> {
+        if rc == ZK_ERR_COMM {
+            let msg = unsafe { CStr::from_ptr(zk_comm_last_error(self.raw)) }.to_string_lossy().into_owned();
+            return Err(anyhow!("zkstark communicator failed (dead on every rank, free it): {msg}"));
+        }
+        self.ctx.check(rc)
+    }
+}
+impl Drop for Comm<'_> {
+    fn drop(&mut self) { unsafe { zk_comm_free(self.raw) } }
+}
+
+/// `zk_assign_tables`: which rank holds table t's trace (largest cost first onto the least loaded rank; deterministic, the same
+/// on every rank).  `row_sharded[t]`: table t is spread over all ranks instead.
+pub fn assign_tables(n_cols: &[usize], log_n: &[u32], world: u32, row_sharded: Option<&[u8]>) -> Result<Vec<u32>> {
+    let mut owner = vec![0u32; n_cols.len()];
+    let rc = unsafe { zk_assign_tables(n_cols.as_ptr(), log_n.as_ptr(), n_cols.len(), world,
+                                       row_sharded.map(|r| r.as_ptr()).unwrap_or(null()), owner.as_mut_ptr()) };
+    if rc != ZK_OK { return Err(anyhow!("zk_assign_tables failed ({rc})")); }
+    Ok(owner)
+}
+
+/// One table of a table-parallel segment on THIS rank: the whole trace where this rank owns the table, this rank's row block
+/// where the table is row-sharded, `None` elsewhere.  The description (`n_cols`, `log_n` of the WHOLE table, AIR, programs) is
+/// the same on every rank.
+pub struct ShardedTableIn<'a> {
+    pub trace: Option<&'a DeviceMatrix<'a>>,
+    pub n_cols: usize,
+    pub log_n: u32,
+    pub air_id: zk_air,
+    pub air_consts: &'a [u64],
+    pub lookup_program: &'a [u64],
+    pub in_use: bool,
+    pub optional: bool,
+}
+
+/// `prove_with_traces` (prover.rs:72-194) as a COLLECTIVE call over the ranks of `comm` (SURVEY 8(e) levels 2 and 3): every rank
+/// passes the same descriptions and gets the whole `AllProof`, bit-identical to `prove_segment`'s on one GPU.
+/// `fri_mode` 0: the two-column FRI layers replicated after one all-gather; 1: every layer on the rank that owns its leaves.
+#[allow(clippy::too_many_arguments)]
+pub fn prove_segment_table_parallel(ctx: &Context, comm: &Comm, cfg: &Config, tables: &[ShardedTableIn], row_sharded: Option<&[u8]>,
+                                    ctl_wiring: &[u64], public_value_elements: &[u64], constraint_degree: u32,
+                                    mem_before_table: i32, mem_after_table: i32, fri_mode: u32) -> Result<SegmentProof> {
+    if comm.ctx.raw != ctx.raw || tables.iter().any(|t| t.trace.map_or(false, |m| m.ctx.raw != ctx.raw || m.cols() != t.n_cols)) {
+        return Err(anyhow!("prove_segment_table_parallel: communicator and traces must live in this context"));
+    }
+    let tin: Vec<zk_table_in> = tables.iter().map(|t| zk_table_in {
+        d_trace: t.trace.map_or(null(), |m| m.ptr()), col_stride: t.trace.map_or(0, |m| m.rows()), n_cols: t.n_cols, log_n: t.log_n,
+        air_id: t.air_id as u32,
+        air_consts: if t.air_consts.is_empty() { null() } else { t.air_consts.as_ptr() }, n_air_consts: t.air_consts.len(),
+        lookup_program: if t.lookup_program.is_empty() { null() } else { t.lookup_program.as_ptr() },
+        lookup_words: t.lookup_program.len(), in_use: t.in_use as i32, optional: t.optional as i32,
+    }).collect();
+    let mut h: *mut zk_segment_proof = null_mut();
+    comm.check(unsafe {
+        zk_prove_segment_table_parallel(ctx.raw, comm.raw, &cfg.0, tin.as_ptr(), tin.len(), row_sharded.map(|r| r.as_ptr()).unwrap_or(null()),
+                                        ctl_wiring.as_ptr(), ctl_wiring.len(), public_value_elements.as_ptr(), public_value_elements.len(),
+                                        constraint_degree, mem_before_table, mem_after_table, fri_mode, &mut h)
+    })?;
+    read_segment_proof(ctx, cfg, h, tables.len())
 }

@@ -13,6 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATCH = os.path.join(ROOT, "rust", "evm_arithmetization_hip.patch")
+COMPAT = os.path.join(ROOT, "rust", "zkstark", "src", "upstream_compat.rs")      # the one file that names the recalled items
 OUT = os.path.join(ROOT, "rust", "upstream_api.json")
 REF = "/root/reference"
 
@@ -42,12 +43,12 @@ MEMBERS = [
 def patch_uses():
     """[(path, item)] of the `use plonky2:: / starky::` lines the patch ADDS"""
     out = []
-    for ln in open(PATCH):
+    for ln in list(open(PATCH)) + ["+" + x for x in open(COMPAT)]:
         m = re.match(r"\+use ((?:plonky2|starky)(?:::\w+)*)::(\{[^}]*\}|\w+);", ln.strip())
         if not m:
             continue
         items = m.group(2).strip("{}").split(",") if m.group(2).startswith("{") else [m.group(2)]
-        out += [(m.group(1), it.strip()) for it in items if it.strip()]
+        out += [(m.group(1), it.strip()) for it in items if it.strip() and (m.group(1), it.strip()) not in out]
     return out
 
 
