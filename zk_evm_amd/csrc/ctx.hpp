@@ -47,6 +47,7 @@ struct zk_ctx {
     std::map<int, u64 *> tw_fwd, tw_inv, tw_inv_br;         // log size -> table (tw_inv_br: block-order levels)
     std::map<std::pair<int, u64>, u64 *> coset_tabs;        // (log_n, shift) -> s^bitrev(i)
     std::map<std::pair<int, u64>, u64 *> coset_inv_tabs;    // (log_n, shift) -> n^-1 s^-bitrev(i)
+    std::map<std::pair<int, const u64 *>, u64 *> wave_coset2_tabs;   // (log_n, load-factor table | null) -> the second coset's (ntt_host.inc)
     hipStream_t side_stream = nullptr;  // lane 1: low priority, created on first use (segment_host.inc)
     hipStream_t tail_stream = nullptr;  // tree tops of main-lane trace commitments (segment_host.inc), created on first use
     hipStream_t commit_tail = nullptr;  // != nullptr: commit_enqueue sends the small Merkle levels + cap read-back of main-lane commits there

@@ -34,6 +34,7 @@ struct NttPass {
     const u64 *tw;       // DIT: level layout tw[D - 1 + k] = (root of order 2D)^k, k < D, for D = 1 .. 2^(log_tw-1);
                          // values -> coeffs: block-order levels tw[2^s - 1 + j] = (root of order 2^(s+1))^bitrev_s(j) (ntt_host.inc)
     const u64 *in_scale; // optional per-source-index factor applied on load (coset powers)
+    const u64 *in_scale2;// ntt_contig_wave_kernel_dit<2> only: the load factors of the second coset (ntt_swap.cuh)
     const u64 *out_scale;// optional per-index factor applied on store
     u64 out_const;       // constant factor applied on store when apply_out_const
     int log_tw;
@@ -518,272 +519,7 @@ __global__ void __launch_bounds__(1024) ntt_strided_persist_kernel(NttPass p, u3
 #endif
 }
 
-// ---- the strided pass on gfx950's lane-swap instructions (r05) -------------------------------------------------------------
-// ntt_pass_kernel moves every tile element through LDS four times (load -> LDS, three register steps each read + write, LDS ->
-// store) behind five workgroup barriers, and the in-kernel timeline of r04q has those exchanges at ~4 us of an 11.5 us tile with
-// nobody computing meanwhile.  CDNA4 added v_permlane16_swap / v_permlane32_swap: they exchange, between two registers, the
-// halves of a wave selected by lane bit 4 / lane bit 5 -- a 2 x 2 transpose between a REGISTER index bit and a LANE index bit at
-// one VALU instruction per 32-bit register.  A butterfly stage whose pairs sit in two different lanes becomes a stage whose
-// pairs sit in two registers of the same lane, so with the tile's 2^9 rows dealt as
-//         row bits  =  4 register bits (16 elements per lane)  +  2 lane bits (lanes 16 / 32 apart)  +  3 wave bits (8 waves)
-// SIX of the nine stages run out of registers straight after the global loads (four 128-byte row segments per wave and load
-// instruction, as before), ONE exchange through LDS brings the three wave bits into registers, and the last three stages store
-// straight from registers: one LDS round trip and one barrier per tile instead of four and five.
-// values -> coefficients (DIT = false): a stage's twiddle depends on the row bits ABOVE it, and with the lane bits always
-// holding the next two rows bits to be processed those are register bits for the first four stages -- compile-time offsets
-// from a wave-uniform base, i.e. SCALAR loads (15 values per tile through the constant cache instead of 2 x 7 vector loads
-// per lane); the other five stages take per-lane loads (8 + 8 + 2 + 4 + 8 for 16 elements).
-// coefficients -> values (DIT = true): a stage's twiddle depends on the row bits BELOW it and on the element's position in
-// its 128-byte segment -- per-lane loads as before (1 + 2 + 4 + 8 + 8 + 8 and 2 + 4 + 8).
-// Same butterflies on the same operands with the same twiddles as ntt_pass_kernel: bit-identical output.
-// Geometry is fixed: r = 9 rows bits, log_t = 4, 512 threads; no load / store factors (a strided pass never has any).
-#define ZK_NTT_SWAP_R 9
-#define ZK_NTT_SWAP_LOG_T 4
-#if defined(__HIP_DEVICE_COMPILE__)
-typedef const __attribute__((address_space(4))) u64 *ntt_const_u64p;         // constant address space: uniform loads are scalar loads
-template <int LANEBIT>
-__device__ __forceinline__ void ntt_lane_swap(u64 &a, u64 &b) {
-    // (register a, lane bit = 1)  <->  (register b, lane bit = 0)
-    const u32 alo = (u32)a, ahi = (u32)(a >> 32), blo = (u32)b, bhi = (u32)(b >> 32);
-    if (LANEBIT == 4) {
-        const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
-        a = ((u64)hi[0] << 32) | lo[0]; b = ((u64)hi[1] << 32) | lo[1];
-    } else {
-        const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
-        const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
-        a = ((u64)hi[0] << 32) | lo[0]; b = ((u64)hi[1] << 32) | lo[1];
-    }
-}
-#else
-typedef const u64 *ntt_const_u64p;
-template <int LANEBIT> __device__ inline void ntt_lane_swap(u64 &, u64 &) {}                     // (host pass: parsed, never run)
-#endif
-// transpose register bit REGBIT with lane bit LANEBIT over all sixteen registers
-template <int LANEBIT, int REGBIT>
-__device__ __forceinline__ void ntt_swap16(u64 (&v)[16]) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m)
-        if (!(m & (1 << REGBIT))) ntt_lane_swap<LANEBIT>(v[m], v[m | (1 << REGBIT)]);
-}
-
-template <bool DIT>
-__global__ void __launch_bounds__(512) ntt_strided_swap_kernel(NttPass p) {
-    extern __shared__ __attribute__((aligned(16))) u64 tile[];
-    const int log_d = p.log_d;
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, u = lane & 15, l4 = (lane >> 4) & 1, l5 = lane >> 5;
-    const int log_lo_tiles = log_d - ZK_NTT_SWAP_LOG_T;
-    const u32 tile_id = p.cols_fastest ? blockIdx.y : blockIdx.x;
-    const u32 col_id = p.cols_fastest ? blockIdx.x : blockIdx.y;
-    const u32 hi_idx = tile_id >> log_lo_tiles, lo_tile = tile_id & ((1u << log_lo_tiles) - 1);
-    const u32 base = (hi_idx << (log_d + ZK_NTT_SWAP_R)) + (lo_tile << ZK_NTT_SWAP_LOG_T);
-    const u64 *src = p.src + (size_t)col_id * p.src_stride;
-    u64 *dst = p.dst + (size_t)col_id * p.dst_stride;
-    const __amdgpu_buffer_rsrc_t twr = ntt_tw_rsrc(p.tw);
-    u64 v[16];
-
-    if (!DIT) {
-        // rows t = [t8 .. t0]; at the start lane bit 5 = t8, lane bit 4 = t7, register bits [3..0] = [t6 t5 t4 t3], wave = [t2 t1 t0]
-        {
-            const u64 *s = src + base + u + ((size_t)((l5 << 8) | (l4 << 7) | wv) << log_d);
-#pragma unroll
-            for (int m = 0; m < 16; ++m) v[m] = s[(size_t)m << (3 + log_d)];
-        }
-        // stage k (pairs 2^k rows apart): level s_k = log_n - 1 - log_d - k of the block-order table, block (hi_idx << (8 - k)) + (t >> (k + 1))
-        const ntt_const_u64p ctw = (ntt_const_u64p)(unsigned long long)p.tw;
-        const int s8 = p.log_n - 1 - log_d - 8;
-        auto lvl = [&](int k) { return ((1u << (s8 + 8 - k)) - 1) + (hi_idx << (8 - k)); };
-        {   // k = 8: t8 (lane 5) <-> register bit 3 (t6)
-            ntt_swap16<5, 3>(v);
-            const u64 w = ctw[lvl(8)];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) ntt_bfly(v[m], v[m | 8], w);
-        }
-        {   // k = 7: t7 (lane 4) <-> register bit 2 (t5); twiddle by t8 = register bit 3
-            ntt_swap16<4, 2>(v);
-            const u32 b = lvl(7);
-            const u64 w[2] = {ctw[b], ctw[b + 1]};
-#pragma unroll
-            for (int m = 0; m < 16; ++m) if (!(m & 4)) ntt_bfly(v[m], v[m | 4], w[m >> 3]);
-        }
-        {   // k = 6: t6 (lane 5) <-> register bit 1 (t4); twiddle by (t8 t7) = register bits (3 2)
-            ntt_swap16<5, 1>(v);
-            const u32 b = lvl(6);
-            const u64 w[4] = {ctw[b], ctw[b + 1], ctw[b + 2], ctw[b + 3]};
-#pragma unroll
-            for (int m = 0; m < 16; ++m) if (!(m & 2)) ntt_bfly(v[m], v[m | 2], w[m >> 2]);
-        }
-        {   // k = 5: t5 (lane 4) <-> register bit 0 (t3); twiddle by (t8 t7 t6) = register bits (3 2 1)
-            ntt_swap16<4, 0>(v);
-            const u32 b = lvl(5);
-            const u64 w[8] = {ctw[b], ctw[b + 1], ctw[b + 2], ctw[b + 3], ctw[b + 4], ctw[b + 5], ctw[b + 6], ctw[b + 7]};
-#pragma unroll
-            for (int m = 0; m < 16; ++m) if (!(m & 1)) ntt_bfly(v[m], v[m | 1], w[m >> 1]);
-        }
-        // registers [t8 t7 t6 t5], lane 5 = t4, lane 4 = t3
-        {   // k = 4: t4 (lane 5) <-> register bit 3 (t8); twiddle by (t8 t7 t6 t5) = (lane 5, registers 2 1 0)
-            ntt_swap16<5, 3>(v);
-            const u32 b = lvl(4);
-            u64 w[8];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) w[m] = ntt_tw_load(twr, l5 * 64, b + m);
-#pragma unroll
-            for (int m = 0; m < 8; ++m) ntt_bfly(v[m], v[m | 8], w[m]);
-        }
-        {   // k = 3: t3 (lane 4) <-> register bit 2 (t7); twiddle by (t8 t7 t6 t5 t4) = (lane 5, lane 4, registers 1 0 3)
-            ntt_swap16<4, 2>(v);
-            const u32 b = lvl(3);
-            u64 w[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = ntt_tw_load(twr, (l5 * 16 + l4 * 8) * 8, b + i);
-#pragma unroll
-            for (int m = 0; m < 16; ++m) if (!(m & 4)) ntt_bfly(v[m], v[m | 4], w[((m >> 1) & 1) * 4 + (m & 1) * 2 + (m >> 3)]);
-        }
-        // registers [3..0] = [t4 t3 t6 t5], lane 5 = t8, lane 4 = t7, wave = [t2 t1 t0].  LDS row of t: t with bit 0 flipped by
-        // t4 ^ t7 (a half wave writes two rows that differ in t7 and reads two that differ in t4: 128-byte rows, 64 banks)
-        {
-            const u32 tb = (l5 << 8) | (l4 << 7) | wv;
-#pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                const u32 t = (tb | ((m & 2) << 5) | ((m & 1) << 5) | ((m & 8) << 1) | ((m & 4) << 1)) ^ (((m >> 3) & 1) ^ l4);
-                tile[(t << 4) + u] = v[m];
-            }
-        }
-        __syncthreads();
-        // wave = [t8 t7 t6], lane 5 = t5, lane 4 = t4, registers = [t3 t2 t1 t0]
-        const u32 tb = (wv << 6) | (l5 << 5) | (l4 << 4);
-        {
-            const u32 par = l4 ^ ((wv >> 1) & 1);
-#pragma unroll
-            for (int m = 0; m < 16; ++m) v[m] = tile[(((tb | m) ^ par) << 4) + u];
-        }
-        {   // k = 2: twiddle by t >> 3
-            const u32 b = lvl(2) + wv * 8;
-            const u64 w[2] = {ntt_tw_load(twr, (l5 * 4 + l4 * 2) * 8, b), ntt_tw_load(twr, (l5 * 4 + l4 * 2) * 8, b + 1)};
-#pragma unroll
-            for (int m = 0; m < 16; ++m) if (!(m & 4)) ntt_bfly(v[m], v[m | 4], w[m >> 3]);
-        }
-        {   // k = 1: twiddle by t >> 2
-            const u32 b = lvl(1) + wv * 16;
-            u64 w[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w[i] = ntt_tw_load(twr, (l5 * 8 + l4 * 4) * 8, b + i);
-#pragma unroll
-            for (int m = 0; m < 16; ++m) if (!(m & 2)) ntt_bfly(v[m], v[m | 2], w[m >> 2]);
-        }
-        {   // k = 0: twiddle by t >> 1
-            const u32 b = lvl(0) + wv * 32;
-            u64 w[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = ntt_tw_load(twr, (l5 * 16 + l4 * 8) * 8, b + i);
-#pragma unroll
-            for (int m = 0; m < 16; ++m) if (!(m & 1)) ntt_bfly(v[m], v[m | 1], w[m >> 1]);
-        }
-        {
-            u64 *d = dst + base + u + ((size_t)tb << log_d);
-#pragma unroll
-            for (int m = 0; m < 16; ++m) d[(size_t)m << log_d] = p.last_pass ? gl_canon(v[m]) : v[m];
-        }
-    } else {
-        // lane bit 5 = t1, lane bit 4 = t0, register bits [3..0] = [t5 t4 t3 t2], wave = [t8 t7 t6]
-        {
-            const u64 *s = src + base + u + ((size_t)((wv << 6) | (l5 << 1) | l4) << log_d);
-#pragma unroll
-            for (int m = 0; m < 16; ++m) v[m] = s[(size_t)m << (2 + log_d)];
-        }
-        // stage k: level D = 2^(log_d + k) at offset D - 1, entry x mod D = ((t mod 2^k) << log_d) + (x mod d)
-        const u32 xl8 = ((lo_tile << ZK_NTT_SWAP_LOG_T) + u) * 8;
-        auto lvl = [&](int k) { return (1u << (log_d + k)) - 1; };
-        {   // k = 0: t0 (lane 4) <-> register bit 3 (t5)
-            ntt_swap16<4, 3>(v);
-            const u64 w = ntt_tw_load(twr, xl8, lvl(0));
-#pragma unroll
-            for (int m = 0; m < 8; ++m) ntt_bfly(v[m], v[m | 8], w);
-        }
-        {   // k = 1: t1 (lane 5) <-> register bit 2 (t4); twiddle by t0 = register bit 3
-            ntt_swap16<5, 2>(v);
-            const u64 w[2] = {ntt_tw_load(twr, xl8, lvl(1)), ntt_tw_load(twr, xl8, lvl(1) + (1u << log_d))};
-#pragma unroll
-            for (int m = 0; m < 16; ++m) if (!(m & 4)) ntt_bfly(v[m], v[m | 4], w[m >> 3]);
-        }
-        {   // k = 2: register bit 0; twiddle by (t1 t0) = register bits (2 3)
-            u64 w[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w[i] = ntt_tw_load(twr, xl8, lvl(2) + ((u32)i << log_d));
-#pragma unroll
-            for (int m = 0; m < 16; ++m) if (!(m & 1)) ntt_bfly(v[m], v[m | 1], w[((m >> 2) & 1) * 2 + (m >> 3)]);
-        }
-        {   // k = 3: register bit 1; twiddle by (t2 t1 t0) = register bits (0 2 3)
-            u64 w[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = ntt_tw_load(twr, xl8, lvl(3) + ((u32)i << log_d));
-#pragma unroll
-            for (int m = 0; m < 16; ++m) if (!(m & 2)) ntt_bfly(v[m], v[m | 2], w[(m & 1) * 4 + ((m >> 2) & 1) * 2 + (m >> 3)]);
-        }
-        {   // k = 4: t4 (lane 5) <-> register bit 3 (t0); twiddle by (t3 t2 t1 t0) = (registers 1 0 2, lane 5)
-            ntt_swap16<5, 3>(v);
-            const u32 lo8 = xl8 + ((l5 << log_d) << 3);
-            u64 w[8];
-#pragma unroll
-            for (int m = 0; m < 8; ++m) w[m] = ntt_tw_load(twr, lo8, lvl(4) + ((u32)(((m >> 1) & 1) * 8 + (m & 1) * 4 + ((m >> 2) & 1) * 2) << log_d));
-#pragma unroll
-            for (int m = 0; m < 8; ++m) ntt_bfly(v[m], v[m | 8], w[m]);
-        }
-        {   // k = 5: t5 (lane 4) <-> register bit 2 (t1); twiddle by (t4 t3 t2 t1 t0) = (registers 3 1 0, lane 4, lane 5)
-            ntt_swap16<4, 2>(v);
-            const u32 lo8 = xl8 + (((l4 * 2 + l5) << log_d) << 3);
-            u64 w[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {      // i = the butterfly's registers bits (3 1 0)
-                w[i] = ntt_tw_load(twr, lo8, lvl(5) + ((u32)(((i >> 2) & 1) * 16 + ((i >> 1) & 1) * 8 + (i & 1) * 4) << log_d));
-            }
-#pragma unroll
-            for (int m = 0; m < 16; ++m) if (!(m & 4)) ntt_bfly(v[m], v[m | 4], w[(m >> 3) * 4 + (m & 3)]);
-        }
-        // registers [3..0] = [t4 t5 t3 t2], lane 5 = t0, lane 4 = t1, wave = [t8 t7 t6].  LDS row of t: bit 0 flipped by t1
-        {
-            const u32 tb = ((wv << 6) | (l4 << 1) | l5) ^ l4;
-#pragma unroll
-            for (int m = 0; m < 16; ++m) {
-                const u32 t = tb | ((m & 4) << 3) | ((m & 8) << 1) | ((m & 2) << 2) | ((m & 1) << 2);
-                tile[(t << 4) + u] = v[m];
-            }
-        }
-        __syncthreads();
-        // registers [3..0] = [t8 t7 t6 t5], wave = [t4 t3 t2], lane 5 = t1, lane 4 = t0
-        const u32 tb = (wv << 2) | (l5 << 1) | l4;
-        {
-            const u32 tp = tb ^ l5;
-#pragma unroll
-            for (int m = 0; m < 16; ++m) v[m] = tile[(((u32)m << 9) + (tp << 4)) + u];
-        }
-        const u32 lo8 = xl8 + ((tb << log_d) << 3);
-        {   // k = 6: twiddle by t mod 64 = (register bit 0, tb)
-            const u64 w[2] = {ntt_tw_load(twr, lo8, lvl(6)), ntt_tw_load(twr, lo8, lvl(6) + (32u << log_d))};
-#pragma unroll
-            for (int m = 0; m < 16; ++m) if (!(m & 2)) ntt_bfly(v[m], v[m | 2], w[m & 1]);
-        }
-        {   // k = 7: twiddle by t mod 128 = (register bits 1 0, tb)
-            u64 w[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w[i] = ntt_tw_load(twr, lo8, lvl(7) + ((u32)(i * 32) << log_d));
-#pragma unroll
-            for (int m = 0; m < 16; ++m) if (!(m & 4)) ntt_bfly(v[m], v[m | 4], w[m & 3]);
-        }
-        {   // k = 8: twiddle by t mod 256 = (register bits 2 1 0, tb)
-            u64 w[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = ntt_tw_load(twr, lo8, lvl(8) + ((u32)(i * 32) << log_d));
-#pragma unroll
-            for (int m = 0; m < 8; ++m) ntt_bfly(v[m], v[m | 8], w[m]);
-        }
-        {
-            u64 *d = dst + base + u + ((size_t)tb << log_d);
-#pragma unroll
-            for (int m = 0; m < 16; ++m) d[(size_t)m << (5 + log_d)] = p.last_pass ? gl_canon(v[m]) : v[m];
-        }
-    }
-}
+#include "ntt_swap.cuh"      // r05: the passes on gfx950's lane-swap instructions (v_permlane16/32_swap)
 
 // The LAST values -> coefficients pass and the FIRST coefficients -> values pass of a commitment work on the same tiles: the
 // contiguous pass of the inverse transform leaves coefficients [k 2^c, (k + 1) 2^c) of a column (bit-reversed order) in tile k,
@@ -887,6 +623,16 @@ static __global__ void coset_table_kernel(u64 *out, int log_n, u64 s, u64 c) {
     if (i >> log_n) return;
     u32 e = bitrev32((u32)i, log_n);
     out[i] = gl_canon(gl_mul(c, gl_pow(s, e)));
+}
+
+// load factors of the SECOND coset for ntt_contig_wave_kernel_dit<2> (ntt_swap.cuh): a wave's 2^11 values are the 2^11-point transform
+// of its 2^10 coefficients in local bit-reversed order, whatever the tile, so value 2 i + 1 is the plain 2^10-point transform of
+// c_i * w^bitrev_10(i mod 2^10), w = the root of order 2^11 -- times the first coset's own factor when there is one
+static __global__ void wave_coset2_table_kernel(u64 *out, const u64 *first, int log_n, u64 w) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >> log_n) return;
+    const u64 f = gl_pow(w, bitrev32((u32)i & 1023u, 10));
+    out[i] = gl_canon(first ? gl_mul(first[i], f) : f);
 }
 
 // block-order levels (ntt_host.inc): out[2^s - 1 + j] = (root of order 2^(s+1))^bitrev_s(j) = w^(bitrev_s(j) * N / 2^(s+1))

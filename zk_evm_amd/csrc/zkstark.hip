@@ -94,6 +94,7 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     for (auto &kv : ctx->tw_inv_br) hipFree(kv.second);
     for (auto &kv : ctx->coset_tabs) hipFree(kv.second);
     for (auto &kv : ctx->coset_inv_tabs) hipFree(kv.second);
+    for (auto &kv : ctx->wave_coset2_tabs) hipFree(kv.second);
     for (auto &e : ctx->ev_pool) if (e) hipEventDestroy(e);
     if (ctx->h_caps) hipHostFree(ctx->h_caps);
     if (ctx->h_big) hipHostFree(ctx->h_big);
