@@ -50,6 +50,9 @@ __device__ __forceinline__ void ntt_lane_swap(u64 &a, u64 &b) {
         a = ((u64)hi[0] << 32) | lo[0]; b = ((u64)hi[1] << 32) | lo[1];
     }
 }
+// the wave's index in its workgroup IS wave-uniform; said so, everything derived from it (tile bases, twiddle offsets) lives in
+// scalar registers and a buffer load's scalar offset needs no waterfall loop
+__device__ __forceinline__ u32 ntt_uniform(u32 x) { return (u32)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ void ntt_wave_sync() {          // LDS traffic of ONE wave is in order: only the compiler must not reorder
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -58,6 +61,7 @@ __device__ __forceinline__ void ntt_wave_sync() {          // LDS traffic of ONE
 #else
 typedef const u64 *ntt_const_u64p;
 template <int LANEBIT> __device__ inline void ntt_lane_swap(u64 &, u64 &) {}                     // (host pass: parsed, never run)
+__device__ inline u32 ntt_uniform(u32 x) { return x; }
 __device__ inline void ntt_wave_sync() {}
 #endif
 // transpose register bit REGBIT with lane bit LANEBIT over all sixteen registers
@@ -186,7 +190,7 @@ template <bool DIT, int R>
 __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass p) {
     extern __shared__ __attribute__((aligned(16))) u64 tile[];
     const int log_d = p.log_d;
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, u = lane & 15, l4 = (lane >> 4) & 1, l5 = lane >> 5;
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = ntt_uniform(tid >> 6), u = lane & 15, l4 = (lane >> 4) & 1, l5 = lane >> 5;
     const int log_lo_tiles = log_d - ZK_NTT_SWAP_LOG_T;
     const u32 tile_id = p.cols_fastest ? blockIdx.y : blockIdx.x;
     const u32 col_id = p.cols_fastest ? blockIdx.x : blockIdx.y;
@@ -230,8 +234,7 @@ __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass
             v[m] = tile[(t << 4) + u];
         }
         auto lvl = [&](int k) { return ((1u << (s_top + R - 1 - k)) - 1) + (hi_idx << (R - 1 - k)); };
-        const u32 th = tb >> 4;                                        // t >> 4: wave-uniform but for the two lane bits
-        const u32 thl = l5 * 2 + l4, thu = th - thl;
+        const u32 thl = l5 * 2 + l4, thu = wv << 2;                    // t >> 4 = thu + thl: wave-uniform but for the two lane bits
         if (R == 10) {   // k = 3: twiddle by t >> 4
             const u64 w = ntt_tw_load(twr, thl * 8, lvl(3) + thu);
             ZK_NTT_STAGE16(3, w)
@@ -321,7 +324,7 @@ __device__ __forceinline__ u32 ntt_wave_lds(u32 row, u32 col) { return row * 17 
 // (out_scale table | out_const | canonical).  256 threads = four independent waves.
 static __global__ void __launch_bounds__(256) ntt_contig_wave_kernel_dif(NttPass p) {
     __shared__ u64 lds_all[4 * ZK_NTT_WAVE_LDS];
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, u = lane & 15, l4 = (lane >> 4) & 1, l5 = lane >> 5;
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = ntt_uniform(tid >> 6), u = lane & 15, l4 = (lane >> 4) & 1, l5 = lane >> 5;
     u64 *const lds = lds_all + wv * ZK_NTT_WAVE_LDS;
     const u32 tile_id = (p.cols_fastest ? blockIdx.y : blockIdx.x) * 4 + wv;
     const u32 col_id = p.cols_fastest ? blockIdx.x : blockIdx.y;
@@ -392,7 +395,7 @@ static __global__ void __launch_bounds__(256) ntt_contig_wave_kernel_dif(NttPass
 template <int NB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) ntt_contig_wave_kernel_dit(NttPass p, const u64 *in_scale2) {
     __shared__ u64 lds_all[4 * ZK_NTT_WAVE_LDS];
-    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, u = lane & 15, l4 = (lane >> 4) & 1, l5 = lane >> 5;
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = ntt_uniform(tid >> 6), u = lane & 15, l4 = (lane >> 4) & 1, l5 = lane >> 5;
     u64 *const lds = lds_all + wv * ZK_NTT_WAVE_LDS;
     const u32 tile_id = (p.cols_fastest ? blockIdx.y : blockIdx.x) * 4 + wv;
     const u32 col_id = p.cols_fastest ? blockIdx.x : blockIdx.y;
