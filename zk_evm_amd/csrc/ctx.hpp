@@ -51,6 +51,7 @@ struct zk_ctx {
     hipStream_t side_stream = nullptr;  // lane 1: low priority, created on first use (segment_host.inc)
     hipStream_t tail_stream = nullptr;  // tree tops of main-lane trace commitments (segment_host.inc), created on first use
     hipStream_t commit_tail = nullptr;  // != nullptr: commit_enqueue sends the small Merkle levels + cap read-back of main-lane commits there
+    std::vector<struct PendingCommit *> *tree_batch = nullptr;   // != nullptr: commit_enqueue leaves the small Merkle levels + cap read-back to commit_tree_batch_flush (zkstark.hip)
     std::vector<hipEvent_t> ev_pool;    // recycled timing / ordering events
     u64 *h_caps = nullptr;              // pinned host slots for cap read-backs of commits in flight (ZK_CAP_SLOTS x 64 words)
     uint64_t cap_slot_next = 0;

@@ -107,6 +107,33 @@ poseidon_merkle_level_coop_kernel(const u64 *__restrict__ child, u64 *__restrict
     if (e < 4) parent[(size_t)4 * node + e] = gl_canon(s);
 }
 
+// The same level of SEVERAL trees in one launch (r05: the trace commitments of a segment are independent of the transcript, so
+// the latency-bound small levels -- 16-45 us each whatever their size -- are paid once per level instead of once per tree and
+// level; merkle_host.inc merkle_levels_batched).  blockIdx.y = tree; every tree has n_parent nodes at this level.
+#define ZK_MERKLE_MULTI_MAX 16
+struct MerkleTrees { const u64 *child[ZK_MERKLE_MULTI_MAX]; u64 *parent[ZK_MERKLE_MULTI_MAX]; };
+static __global__ void __launch_bounds__(256)
+poseidon_merkle_level_multi_kernel(MerkleTrees t, size_t n_parent) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_parent) return;
+    const ulonglong2 *c = reinterpret_cast<const ulonglong2 *>(t.child[blockIdx.y] + 8 * i);
+    ulonglong2 a0 = c[0], a1 = c[1], a2 = c[2], a3 = c[3];
+    u64 s[12] = {a0.x, a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y, 0, 0, 0, 0};
+    poseidon_permute(s);
+    ulonglong2 *o = reinterpret_cast<ulonglong2 *>(t.parent[blockIdx.y] + 4 * i);
+    o[0] = make_ulonglong2(gl_canon(s[0]), gl_canon(s[1]));
+    o[1] = make_ulonglong2(gl_canon(s[2]), gl_canon(s[3]));
+}
+static __global__ void __launch_bounds__(256)
+poseidon_merkle_level_multi_coop_kernel(MerkleTrees t, u32 n_parent) {
+    const u32 th = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 node = th >> 4, e = th & 15;
+    if (node >= n_parent) return;                      // whole groups leave together
+    u64 s = e < 8 ? t.child[blockIdx.y][(size_t)8 * node + e] : 0;
+    s = poseidon_permute_coop(s, e, threadIdx.x & 63);
+    if (e < 4) t.parent[blockIdx.y][(size_t)4 * node + e] = gl_canon(s);
+}
+
 static __global__ void poseidon_permute_states_kernel(u64 *states, size_t n_states) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_states) return;

@@ -377,6 +377,7 @@ struct PendingCommit {
     u64 *h_cap_own = nullptr;           // caps above 64 words (cap_height > 4) land in their own pinned buffer
     CommitMode mode = COMMIT_VALUES;
     bool side = false;
+    bool deferred_tree = false;         // the small levels and the cap read-back are commit_tree_batch_flush's
 };
 static hipEvent_t ev_get(zk_ctx *ctx) {
     if (!ctx->ev_pool.empty()) { hipEvent_t e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); return e; }
@@ -449,6 +450,17 @@ static int commit_enqueue(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_
     // The levels of <= 2^kTreeTailLog nodes are latency-bound (one or two waves per SIMD at best, then the cooperative
     // kernels): when the caller enqueues several commitments back to back on the main lane (the trace commitments of a
     // segment) they and the cap read-back move to the tail stream, and the next commitment's NTT starts under them.
+    if (ctx->tree_batch && cfg->hasher == ZK_HASH_POSEIDON && b->cap.empty() && ((size_t)4 << cfg->cap_height) <= 64) {
+        // r05: the small levels of all the trees of a phase are built together, one launch per level (commit_tree_batch_flush);
+        // this lane only builds the levels that fill the chip and says when they are done
+        rc = merkle_levels(ctx, cfg->hasher, b->d_digests, log_N, cfg->cap_height, nullptr, nullptr, kTreeBatchTopLog);
+        if (rc != ZK_OK) return fail(rc);
+        pc->tail_ev = ev_get(ctx);
+        B_HIP(hipEventRecord(pc->tail_ev, ctx->stream));
+        pc->deferred_tree = true;
+        ctx->tree_batch->push_back(pc);
+        return ZK_OK;
+    }
     hipStream_t tail = ctx->commit_tail && !pc->side ? ctx->commit_tail : nullptr;
     if (tail) pc->tail_ev = ev_get(ctx);
     rc = merkle_levels(ctx, cfg->hasher, b->d_digests, log_N, cfg->cap_height, tail, pc->tail_ev);
@@ -466,6 +478,38 @@ static int commit_enqueue(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_
     ctx->stream = main_stream;
     B_HIP(cap_rc);
 #undef B_HIP
+    return ZK_OK;
+}
+
+// The commitments collected in ctx->tree_batch: wait (on `st`) for each one's large levels, build the remaining levels of all
+// the trees level by level in ONE launch each, read the caps back.  The caller synchronises `st` before commit_finish.
+static const int kTreeBatch = env_int("ZK_TREE_BATCH", 0, 0, 1);
+static int commit_tree_batch_flush(zk_ctx *ctx, const zk_cfg *cfg, hipStream_t st) {
+    std::vector<PendingCommit *> items;
+    if (ctx->tree_batch) items.swap(*ctx->tree_batch);
+    if (items.empty()) return ZK_OK;
+    std::vector<u64 *> dig;
+    std::vector<unsigned> logs;
+    for (PendingCommit *pc : items) {
+        HIP_TRY(ctx, hipStreamWaitEvent(st, pc->tail_ev, 0));
+        dig.push_back(pc->b->d_digests);
+        logs.push_back(pc->b->log_n + pc->b->rate_bits);
+    }
+    ZK_TRY(merkle_levels_batched(ctx, dig.data(), logs.data(), items.size(), cfg->cap_height, (unsigned)kTreeBatchTopLog, st));
+    hipStream_t const keep = ctx->stream;
+    ctx->stream = st;
+    hipError_t e = hipSuccess;
+    for (PendingCommit *pc : items) {
+        zk_batch *b = pc->b;
+        hipEventRecord(pc->ev[4], st);
+        b->cap.resize((size_t)4 << cfg->cap_height);
+        u64 *slot = ctx->h_caps + (ctx->cap_slot_next++ % ZK_CAP_SLOTS) * 64;
+        pc->h_cap = slot;
+        pc->stream = st;
+        if (e == hipSuccess) e = copy_to_pinned(ctx, slot, b->d_digests + 4 * (b->n_digests - ((size_t)1 << cfg->cap_height)), b->cap.size() * 8);
+    }
+    ctx->stream = keep;
+    if (e != hipSuccess) return set_err(ctx, ZK_ERR_HIP, "cap read-back: %s", hipGetErrorString(e));
     return ZK_OK;
 }
 
