@@ -180,10 +180,12 @@ def strided_tile(src, dst, log_n, log_d, R, tw, dit, tile_id):
                     v[lane][m] = lds[addr(lane)]
             thl = lambda lane: L5(lane) * 2 + L4(lane)
             thu = wv << 2
-            if R == 10:
+            if A >= 4:
                 stage16(v, 3, lambda lane, m: tw_load(tw, thl(lane) * 8, lvl(3) + thu))
-            stage16(v, 2, lambda lane, m: tw_load(tw, thl(lane) * 16, lvl(2) + thu * 2 + (m >> 3)))
-            stage16(v, 1, lambda lane, m: tw_load(tw, thl(lane) * 32, lvl(1) + thu * 4 + (m >> 2)))
+            if A >= 3:
+                stage16(v, 2, lambda lane, m: tw_load(tw, thl(lane) * 16, lvl(2) + thu * 2 + (m >> 3)))
+            if A >= 2:
+                stage16(v, 1, lambda lane, m: tw_load(tw, thl(lane) * 32, lvl(1) + thu * 4 + (m >> 2)))
             stage16(v, 0, lambda lane, m: tw_load(tw, thl(lane) * 64, lvl(0) + thu * 8 + (m >> 1)))
             for lane in range(64):
                 tb = (wv << 6) | (L5(lane) << 5) | (L4(lane) << 4)
@@ -220,10 +222,12 @@ def strided_tile(src, dst, log_n, log_d, R, tw, dit, tile_id):
                 for lane in range(64):
                     v[lane][m] = lds[addr(lane)]
             lo8 = lambda lane: xl8(lane) + ((tb(lane) << log_d) << 3)
-            if R == 10:
-                stage16(v, 0, lambda lane, m: tw_load(tw, lo8(lane), lvl(6)))
-            stage16(v, 1, lambda lane, m: tw_load(tw, lo8(lane), lvl(R - 3) + (((m & 1) << (R - 4)) << log_d)))
-            stage16(v, 2, lambda lane, m: tw_load(tw, lo8(lane), lvl(R - 2) + (((m & 3) << (R - 4)) << log_d)))
+            if R - 4 >= 6:
+                stage16(v, 0, lambda lane, m: tw_load(tw, lo8(lane), lvl(R - 4)))
+            if R - 3 >= 6:
+                stage16(v, 1, lambda lane, m: tw_load(tw, lo8(lane), lvl(R - 3) + (((m & 1) << (R - 4)) << log_d)))
+            if R - 2 >= 6:
+                stage16(v, 2, lambda lane, m: tw_load(tw, lo8(lane), lvl(R - 2) + (((m & 3) << (R - 4)) << log_d)))
             stage16(v, 3, lambda lane, m: tw_load(tw, lo8(lane), lvl(R - 1) + (((m & 7) << (R - 4)) << log_d)))
             for lane in range(64):
                 d = base + (lane & 15) + (tb(lane) << log_d)
@@ -247,12 +251,16 @@ def test_strided_swap_values_to_coeffs():
     run_strided(False, 9, 4, 0)
     run_strided(False, 9, 5, 1)
     run_strided(False, 10, 4, 1)
+    run_strided(False, 7, 5, 1)
+    run_strided(False, 8, 4, 2)
 
 
 def test_strided_swap_coeffs_to_values():
     run_strided(True, 9, 4, 0)
     run_strided(True, 9, 5, 1)
     run_strided(True, 10, 4, 1)
+    run_strided(True, 7, 5, 1)
+    run_strided(True, 8, 4, 2)
 
 
 # ---- ntt_contig_wave_kernel_dif ------------------------------------------------------------------------------------------------

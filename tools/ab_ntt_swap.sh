@@ -3,7 +3,7 @@
 # only) against the LDS tile kernels, alone and with the column batches of ab_ntt_col_batch.sh.  Checksums must be identical in
 # every line of a shape.
 cd "$(dirname "$0")/.."
-for shape in "116 20" "2431 18" "30 21" "86 19" "9 22" "116 17" "40 10"; do
+for shape in "116 20" "2431 18" "30 21" "86 19" "9 22" "116 17" "438 13" "40 10"; do
   for cfg in "0 1 0" "1 0 0" "1 1 0" "0 1 0" "1 0 0" "1 1 0" "0 1 96" "1 1 96"; do
     set -- $cfg
     echo -n "shape=$shape swap=$1 contig=$2 batch_MB=$3 : "; ZK_NTT_SWAP=$1 ZK_NTT_SWAP_CONTIG=$2 ZK_NTT_COL_BATCH_MB=$3 timeout 120 tools/kbench $shape 5 | tr '\n' ' '; echo

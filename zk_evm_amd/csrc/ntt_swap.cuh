@@ -9,7 +9,7 @@
 // 4, 5 -- are therefore reachable without LDS, in any order, provided the lanes' low four bits carry sixteen CONTIGUOUS elements
 // (a 128-byte segment per row: exactly the tile shape the strided pass loads anyway).
 //
-//   strided pass, 2^R rows x 16 contiguous elements, R = 9 | 10  (ntt_strided_swap_kernel)
+//   strided pass, 2^R rows x 16 contiguous elements, R = 7 .. 10  (ntt_strided_swap_kernel)
 //       row bits = 4 register bits + 2 lane bits + (R - 6) wave bits.  Six stages run out of registers straight after the global
 //       loads (four 128-byte row segments per wave and load instruction), ONE exchange through LDS brings the wave bits into
 //       registers, the last R - 6 stages store straight from registers: one LDS round trip and one barrier per tile.
@@ -184,10 +184,11 @@ __device__ __forceinline__ void ntt_swap_dit6(u64 (&vv)[NB][16], __amdgpu_buffer
 __device__ __forceinline__ constexpr u32 ntt_swap_dit6_row(int m) { return ((m & 4) << 3) | ((m & 8) << 1) | ((m & 2) << 2) | ((m & 1) << 2); }
 
 // ---- the strided pass ------------------------------------------------------------------------------------------------------
-// Geometry: 2^R rows (R = 9: 512 threads, 64 KiB of LDS; R = 10: 1024 threads, 128 KiB) x 16 contiguous elements; no load /
+// Geometry: 2^R rows (R = 7 .. 10: 2^(R - 6) waves, 2^(R + 7) bytes of LDS: 512 threads and 64 KiB at R = 9) x 16 contiguous elements; no load /
 // store factors (a strided pass never has any: they belong to the contiguous pass at the coefficient end).
 template <bool DIT, int R>
 __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass p) {
+    static_assert(R >= 7 && R <= 10, "six register / lane stages + one to four wave stages");
     extern __shared__ __attribute__((aligned(16))) u64 tile[];
     const int log_d = p.log_d;
     const u32 tid = threadIdx.x, lane = tid & 63, wv = ntt_uniform(tid >> 6), u = lane & 15, l4 = (lane >> 4) & 1, l5 = lane >> 5;
@@ -235,15 +236,16 @@ __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass
         }
         auto lvl = [&](int k) { return ((1u << (s_top + R - 1 - k)) - 1) + (hi_idx << (R - 1 - k)); };
         const u32 thl = l5 * 2 + l4, thu = wv << 2;                    // t >> 4 = thu + thl: wave-uniform but for the two lane bits
-        if (R == 10) {   // k = 3: twiddle by t >> 4
+        // the A = R - 6 stages of the wave bits: k = A - 1 .. 0
+        if (A >= 4) {   // k = 3: twiddle by t >> 4
             const u64 w = ntt_tw_load(twr, thl * 8, lvl(3) + thu);
             ZK_NTT_STAGE16(3, w)
         }
-        {   // k = 2: twiddle by t >> 3
+        if (A >= 3) {   // k = 2: twiddle by t >> 3
             const u64 w[2] = {ntt_tw_load(twr, thl * 16, lvl(2) + thu * 2), ntt_tw_load(twr, thl * 16, lvl(2) + thu * 2 + 1)};
             ZK_NTT_STAGE16(2, w[m >> 3])
         }
-        {   // k = 1: twiddle by t >> 2
+        if (A >= 2) {   // k = 1: twiddle by t >> 2
             u64 w[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) w[i] = ntt_tw_load(twr, thl * 32, lvl(1) + thu * 4 + i);
@@ -286,15 +288,16 @@ __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass
         auto lvl = [&](int k) { return (1u << (log_d + k)) - 1; };
         const u32 lo8 = xl8 + ((tb << log_d) << 3);
         // stage k: twiddle by t mod 2^k = ((m mod 2^(k - R + 4)) << (R - 4)) | tb
-        if (R == 10) {   // k = 6: register bit 0
-            const u64 w = ntt_tw_load(twr, lo8, lvl(6));
+        // register bit j is row bit R - 4 + j: a stage of this phase where that is >= 6
+        if (R - 4 >= 6) {   // register bit 0
+            const u64 w = ntt_tw_load(twr, lo8, lvl(R - 4));
             ZK_NTT_STAGE16(0, w)
         }
-        {   // k = R - 3: register bit 1
+        if (R - 3 >= 6) {   // register bit 1
             const u64 w[2] = {ntt_tw_load(twr, lo8, lvl(R - 3)), ntt_tw_load(twr, lo8, lvl(R - 3) + ((1u << (R - 4)) << log_d))};
             ZK_NTT_STAGE16(1, w[m & 1])
         }
-        {   // k = R - 2: register bit 2
+        if (R - 2 >= 6) {   // register bit 2
             u64 w[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) w[i] = ntt_tw_load(twr, lo8, lvl(R - 2) + (((u32)i << (R - 4)) << log_d));
