@@ -25,7 +25,7 @@ Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (Poseidon
 poseidon_hash_rows_kernel: ~60 % of the segment), timed with HIP events on the kernel's own stream inside the
 timed region and summed over its launches (one per commitment); `cpu_baseline` is the CPU oracle (C / OpenMP over
 columns / leaves / rows, the axes rayon uses in the reference) proving ONE WHOLE nine-table segment on a bounded sample of
-the workload (every table at 2^14 rows, ~20-35 s of CPU work), scaled by committed cells to the workload's heights: the
+the workload (every table at 2^15 rows, ~15-25 s of CPU work on the box's 16 cores), scaled by committed cells to the workload's heights: the
 unit is `value`'s, "segment proofs/s" (r04 verdict, item 7; the single-table comparison is `--secondary cpu_table`).
 """
 import argparse
@@ -96,7 +96,7 @@ def parse():
     ap.add_argument("--cpu-table-log-n", type=int, default=20,
                     help="height of the ArithmeticStark table proven on the CPU by --secondary cpu_table (0 = the commit-sample "
                          "extrapolation only)")
-    ap.add_argument("--cpu-segment-sample-log-n", type=int, default=14,
+    ap.add_argument("--cpu-segment-sample-log-n", type=int, default=15,
                     help="cpu_baseline: height of every table of the whole segment proven on the CPU (the bounded sample; scaled "
                          "by committed cells to the workload)")
     return ap.parse_args()

@@ -19,6 +19,7 @@
  */
 #include "goldilocks.h"
 #include "oracle.h"
+#include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -84,14 +85,18 @@ static void write_header(const fri_layout *L, uint64_t *p) {
 }
 
 /* ---- openings ------------------------------------------------------------------------------ */
+/* One Horner evaluation per opened polynomial, independent of one another: the polynomials of a batch are dealt over the
+ * threads (plonky2 evaluates them under rayon the same way); every value is what the serial loop computes. */
 void orc_fri_openings(const orc_batch *oracles, const orc_fri_batch *batches, size_t n_batches, uint64_t *out) {
     for (size_t b = 0; b < n_batches; ++b) {
-        for (size_t k = 0; k < batches[b].n_polys; ++k) {
+        const long np = (long)batches[b].n_polys;
+#pragma omp parallel for schedule(dynamic, 8)
+        for (long k = 0; k < np; ++k) {
             const orc_batch *o = &oracles[batches[b].oracle_idx[k]];
             size_t n = (size_t)1 << o->log_n;
-            orc_eval_poly_ext(o->coeffs + (size_t)batches[b].poly_idx[k] * n, n, batches[b].point, out);
-            out += 2;
+            orc_eval_poly_ext(o->coeffs + (size_t)batches[b].poly_idx[k] * n, n, batches[b].point, out + 2 * k);
         }
+        out += 2 * (size_t)np;
     }
 }
 
@@ -140,15 +145,26 @@ void orc_fri_prove_openings(const orc_cfg *cfg, unsigned degree_bits, const orc_
     gl2_t *final_poly = (gl2_t *)calloc(N, sizeof(gl2_t));
     gl2_t *comp = (gl2_t *)malloc(n * sizeof(gl2_t));
     for (size_t b = 0; b < n_batches; ++b) {
-        /* composition = sum_k alpha^k f_k */
-        memset(comp, 0, n * sizeof(gl2_t));
-        gl2_t apow = gl2_from(1);
-        for (size_t k = 0; k < batches[b].n_polys; ++k) {
-            const orc_batch *o = &oracles[batches[b].oracle_idx[k]];
-            const uint64_t *c = o->coeffs + (size_t)batches[b].poly_idx[k] * n;
-            for (size_t i = 0; i < n; ++i) comp[i] = gl2_add(comp[i], gl2_scale(apow, c[i]));
-            apow = gl2_mul(apow, alpha);
+        /* composition = sum_k alpha^k f_k: the same sum in the same order of k for every coefficient i, the coefficients in
+         * blocks over the threads (a block of `comp` stays in the cache while the columns stream past once) */
+        const size_t np = batches[b].n_polys;
+        gl2_t *apows = (gl2_t *)malloc((np + 1) * sizeof(gl2_t));
+        apows[0] = gl2_from(1);
+        for (size_t k = 0; k < np; ++k) apows[k + 1] = gl2_mul(apows[k], alpha);
+        const gl2_t apow = apows[np];
+        const size_t blk = 2048;
+#pragma omp parallel for schedule(static)
+        for (long i0 = 0; i0 < (long)n; i0 += (long)blk) {
+            const size_t i1 = (size_t)i0 + blk < n ? (size_t)i0 + blk : n;
+            for (size_t i = (size_t)i0; i < i1; ++i) comp[i] = gl2_from(0);
+            for (size_t k = 0; k < np; ++k) {
+                const orc_batch *o = &oracles[batches[b].oracle_idx[k]];
+                const uint64_t *c = o->coeffs + (size_t)batches[b].poly_idx[k] * n;
+                const gl2_t a = apows[k];
+                for (size_t i = (size_t)i0; i < i1; ++i) comp[i] = gl2_add(comp[i], gl2_scale(a, c[i]));
+            }
         }
+        free(apows);
         /* divide_by_linear(point): Horner scan from the top; drop the remainder; pad with 0 */
         gl2_t z = {{gl_canon(batches[b].point[0]), gl_canon(batches[b].point[1])}};
         gl2_t acc = gl2_from(0);
@@ -190,6 +206,7 @@ void orc_fri_prove_openings(const orc_cfg *cfg, unsigned degree_bits, const orc_
         gl2_t beta = get_ext(ch);
         /* coeffs'[k] = sum_i beta^i coeffs[arity*k + i] */
         size_t nxt = cur >> ab;
+        /* (in place: coeffs[k] is written from coeffs[arity k ..], which for k >= 1 lie above it -- not a loop for several threads) */
         for (size_t k = 0; k < nxt; ++k) {
             gl2_t acc = gl2_from(0);
             for (size_t i = arity; i-- > 0;) acc = gl2_add(gl2_mul(acc, beta), coeffs[arity * k + i]);
@@ -215,23 +232,31 @@ void orc_fri_prove_openings(const orc_cfg *cfg, unsigned degree_bits, const orc_
         memcpy(inter, ch->state, sizeof inter);
         for (int i = 0; i < ch->n_in; ++i) inter[i] = ch->in[i];
         int pos = ch->n_in;
+        /* candidates in blocks over the threads (plonky2 grinds under rayon); the SMALLEST valid witness of the first block
+         * that holds one is the smallest overall */
         uint64_t w = 0;
-        for (;; ++w) {
-            orc_challenger tmp = *ch;
-            memcpy(tmp.state, inter, sizeof inter);
-            tmp.state[pos] = w;
-            tmp.n_in = 0;
-            if (tmp.hasher == ORC_HASH_POSEIDON) orc_poseidon_permute(tmp.state);
-            else { /* reuse the challenger's own permutation through a duplex */
-                orc_challenger t2 = *ch;
-                t2.n_out = 0;
-                orc_challenger_observe(&t2, &w, 1);
-                (void)orc_challenger_get(&t2);
-                memcpy(tmp.state, t2.state, sizeof inter);
+        for (uint64_t base = 0;; base += 4096) {
+            uint64_t best = UINT64_MAX;
+#pragma omp parallel for schedule(static) reduction(min : best)
+            for (long d = 0; d < 4096; ++d) {
+                const uint64_t cand = base + (uint64_t)d;
+                orc_challenger tmp = *ch;
+                memcpy(tmp.state, inter, sizeof inter);
+                tmp.state[pos] = cand;
+                tmp.n_in = 0;
+                if (tmp.hasher == ORC_HASH_POSEIDON) orc_poseidon_permute_auto(tmp.state);
+                else { /* reuse the challenger's own permutation through a duplex */
+                    orc_challenger t2 = *ch;
+                    t2.n_out = 0;
+                    orc_challenger_observe(&t2, &cand, 1);
+                    (void)orc_challenger_get(&t2);
+                    memcpy(tmp.state, t2.state, sizeof inter);
+                }
+                uint64_t resp = tmp.state[7];
+                int lz = resp ? __builtin_clzll(resp) : 64;
+                if ((unsigned)lz >= cfg->proof_of_work_bits && cand < best) best = cand;
             }
-            uint64_t resp = tmp.state[7];
-            int lz = resp ? __builtin_clzll(resp) : 64;
-            if ((unsigned)lz >= cfg->proof_of_work_bits) break;
+            if (best != UINT64_MAX) { w = best; break; }
         }
         proof[L.off_pow] = w;
         orc_challenger_observe(ch, &w, 1);

@@ -18,6 +18,7 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#include <stdio.h>
 #endif
 
 int orc_num_threads(void) {
@@ -115,7 +116,14 @@ void orc_commit_coeffs(const uint64_t *coeffs, size_t n_cols, unsigned log_n, un
         free(tmp);
     }
     free(rev);
-    orc_merkle_build(leaves, log_N, n_cols, cap_height, hasher, digests);
+    {
+        const char *tm = getenv("ORC_COMMIT_TIMING");
+        static double t_last;
+        if (tm && tm[0] == '1') t_last = omp_get_wtime();
+        orc_merkle_build(leaves, log_N, n_cols, cap_height, hasher, digests);
+        if (tm && tm[0] == '1') fprintf(stderr, "    of which orc_merkle_build %.3f s\n", omp_get_wtime() - t_last);
+    }
+    if (0) orc_merkle_build(leaves, log_N, n_cols, cap_height, hasher, digests);
     if (cap_out) memcpy(cap_out, digests + 4 * (nd - ((size_t)1 << cap_height)), 32 << cap_height);
     if (!leaves_out) free(leaves);
     if (!digests_out) free(digests);
@@ -126,11 +134,15 @@ void orc_commit_values(const uint64_t *values, size_t n_cols, unsigned log_n, un
                        uint64_t *leaves_out, uint64_t *digests_out, uint64_t *cap_out) {
     size_t n = (size_t)1 << log_n;
     uint64_t *coeffs = coeffs_out ? coeffs_out : (uint64_t *)malloc(sizeof(uint64_t) * n * n_cols);
+    const char *tm = getenv("ORC_COMMIT_TIMING");
+    double t0 = omp_get_wtime();
     memcpy(coeffs, values, sizeof(uint64_t) * n * n_cols);
 #pragma omp parallel for schedule(dynamic)
     for (size_t c = 0; c < n_cols; ++c) orc_ifft(coeffs + c * n, log_n);
+    double t1 = omp_get_wtime();
     orc_commit_coeffs(coeffs, n_cols, log_n, rate_bits, cap_height, hasher, leaves_out, digests_out,
                       cap_out);
+    if (tm && tm[0] == '1') fprintf(stderr, "orc_commit_values %zu x 2^%u: copy + ifft %.3f s, lde + transpose + tree %.3f s\n", n_cols, log_n, t1 - t0, omp_get_wtime() - t1);
     if (!coeffs_out) free(coeffs);
 }
 

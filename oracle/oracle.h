@@ -27,6 +27,7 @@ void orc_gl2_inv(const uint64_t a[2], uint64_t out[2]);
 
 /* hashes */
 void orc_poseidon_permute(uint64_t st[12]);
+void orc_poseidon_permute_auto(uint64_t st[12]);   /* the fast or the plain evaluation, whichever the hashes use */
 /* the same permutation, blocked schedule + lazy arithmetic (poseidon_fast.c); orc_poseidon_use_fast: which one the hashes use */
 void orc_poseidon_permute_fast(uint64_t st[12]);
 void orc_poseidon_use_fast(int on);

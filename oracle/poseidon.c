@@ -76,6 +76,9 @@ static inline void permute(uint64_t st[12]) {
     else orc_poseidon_permute(st);
 }
 
+/* the permutation as the hashes above evaluate it (fri.c: the proof-of-work grind) */
+void orc_poseidon_permute_auto(uint64_t st[12]) { permute(st); }
+
 /* [EXT] hashing.rs `hash_n_to_m_no_pad` with m = 4. */
 void orc_poseidon_hash_no_pad(const uint64_t *in, size_t n, uint64_t out[4]) {
     uint64_t st[12] = {0};

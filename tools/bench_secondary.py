@@ -670,7 +670,7 @@ def _parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=18)
     ap.add_argument("--cpu-table-log-n", type=int, default=20)
-    ap.add_argument("--cpu-segment-sample-log-n", type=int, default=14)
+    ap.add_argument("--cpu-segment-sample-log-n", type=int, default=15)
     return ap.parse_args()
 
 
