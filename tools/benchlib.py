@@ -156,6 +156,9 @@ def commit_report(a, stage, ms_per_step):
 KERNEL_CLASSES = (   # (class, substring of the rocprofv3 kernel name)
     ("leaf_hash", "hash_rows_kernel<false>"), ("leaf_hash_coop", "hash_rows_coop_kernel"),
     ("ntt_coeffs_to_values", "ntt_pass_kernel<true"), ("ntt_values_to_coeffs", "ntt_pass_kernel<false"),
+    # r05, csrc/ntt_swap.cuh (template arguments print as <true, 9> / <false, 10>; the wave kernels carry their direction in the name)
+    ("ntt_coeffs_to_values", "ntt_strided_swap_kernel<true"), ("ntt_values_to_coeffs", "ntt_strided_swap_kernel<false"),
+    ("ntt_coeffs_to_values", "ntt_contig_wave_kernel_dit"), ("ntt_values_to_coeffs", "ntt_contig_wave_kernel_dif"),
     ("merkle_levels", "merkle_level"), ("fri_combine", "fri_combine_kernel"), ("openings", "eval_columns_partial_kernel"),
     ("helper_columns", "helper_cols_kernel"), ("lookup_singles", "lookup_singles_kernel"),
     ("quotient_checks", "quotient_checks_kernel"))

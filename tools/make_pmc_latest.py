@@ -27,7 +27,7 @@ def main():
         "valu_issue_utilisation": float(r["SQ_INSTS_VALU"]) * 4 / (gui / 8 * 1024),
     }
     for name in rows:
-        if "ntt_pass_kernel" in name:
+        if "ntt_pass_kernel" in name or "ntt_strided_swap_kernel" in name or "ntt_contig_wave_kernel" in name:
             rr = rows[name]
             out.setdefault("ntt", {})[name.strip()] = {
                 "dispatches": rr["dispatches"], "valu_wave_insts": float(rr["SQ_INSTS_VALU"]),
