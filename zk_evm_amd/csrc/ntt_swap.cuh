@@ -88,6 +88,16 @@ __device__ __forceinline__ void ntt_swap16(u64 (&v)[16]) {
 __device__ __forceinline__ void ntt_swap_dif6(u64 (&v)[16], const u64 *tw, __amdgpu_buffer_rsrc_t twr, int s_top, u32 H, u32 l4, u32 l5) {
     const ntt_const_u64p ctw = (ntt_const_u64p)(unsigned long long)tw;
     auto first = [&](int j) { return ((1u << (s_top + j)) - 1) + (H << j); };
+    // the per-lane twiddles of the last two stages are requested FIRST: a wave's vector loads return in order, and these have
+    // the four scalar-twiddle stages to arrive in (issued where they are used, each stage would stall on its own loads)
+    u64 w4[8], w5[8];
+    {
+        const u32 b4 = first(4), b5 = first(5);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w4[i] = ntt_tw_load(twr, l5 * 64, b4 + i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w5[i] = ntt_tw_load(twr, (l5 * 16 + l4 * 8) * 8, b5 + i);
+    }
     {   // q5 (lane 5) <-> register bit 3 (q3)
         ntt_swap16<5, 3>(v);
         const u64 w = ctw[first(0)];
@@ -114,19 +124,11 @@ __device__ __forceinline__ void ntt_swap_dif6(u64 (&v)[16], const u64 *tw, __amd
     // registers [q5 q4 q3 q2], lane 5 = q1, lane 4 = q0
     {   // q1 (lane 5) <-> register bit 3 (q5); twiddle by (q5 q4 q3 q2) = (lane 5, registers 2 1 0)
         ntt_swap16<5, 3>(v);
-        const u32 b = first(4);
-        u64 w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = ntt_tw_load(twr, l5 * 64, b + i);
-        ZK_NTT_STAGE16(3, w[m & 7])
+        ZK_NTT_STAGE16(3, w4[m & 7])
     }
     {   // q0 (lane 4) <-> register bit 2 (q4); twiddle by (q5 q4 q3 q2 q1) = (lane 5, lane 4, registers 1 0 3)
         ntt_swap16<4, 2>(v);
-        const u32 b = first(5);
-        u64 w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = ntt_tw_load(twr, (l5 * 16 + l4 * 8) * 8, b + i);
-        ZK_NTT_STAGE16(2, w[((m >> 1) & 1) * 4 + (m & 1) * 2 + (m >> 3)])
+        ZK_NTT_STAGE16(2, w5[((m >> 1) & 1) * 4 + (m & 1) * 2 + (m >> 3)])
     }
 }
 // row (six bits) held by register m after ntt_swap_dif6, without the lane bits: [q3 q2 q1 q0] = registers [1 0 3 2]
@@ -137,47 +139,53 @@ __device__ __forceinline__ constexpr u32 ntt_swap_dif6_row(int m) { return ((m &
 // reads the level table at (2^(log_d + k) - 1) + ((row mod 2^k) << log_d) + (position below the rows; lane part xl8 in bytes).
 // On exit registers [3..0] = [q4 q5 q3 q2], lane bit 5 = q0, lane bit 4 = q1.
 // NB arrays go through the same stages with the same twiddles (the two cosets of the contiguous kernel): each twiddle is loaded once.
+// Every stage's twiddles are requested one stage AHEAD of their use (a wave's vector loads return in order: requested where
+// they are used, each stage would start with a full cache round trip).
 template <int NB>
 __device__ __forceinline__ void ntt_swap_dit6(u64 (&vv)[NB][16], __amdgpu_buffer_rsrc_t twr, int log_d, u32 xl8, u32 l4, u32 l5) {
     auto lvl = [&](int k) { return (1u << (log_d + k)) - 1; };
+    const u64 w0 = ntt_tw_load(twr, xl8, lvl(0));
+    const u64 w1[2] = {ntt_tw_load(twr, xl8, lvl(1)), ntt_tw_load(twr, xl8, lvl(1) + (1u << log_d))};
     {   // k = 0: q0 (lane 4) <-> register bit 3 (q5)
         _Pragma("unroll") for (int b = 0; b < NB; ++b) ntt_swap16<4, 3>(vv[b]);
-        const u64 w = ntt_tw_load(twr, xl8, lvl(0));
-        ZK_NTT_STAGE16N(3, w)
+        ZK_NTT_STAGE16N(3, w0)
     }
+    u64 w2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w2[i] = ntt_tw_load(twr, xl8, lvl(2) + ((u32)i << log_d));
     {   // k = 1: q1 (lane 5) <-> register bit 2 (q4); twiddle by q0 = register bit 3
         _Pragma("unroll") for (int b = 0; b < NB; ++b) ntt_swap16<5, 2>(vv[b]);
-        const u64 w[2] = {ntt_tw_load(twr, xl8, lvl(1)), ntt_tw_load(twr, xl8, lvl(1) + (1u << log_d))};
-        ZK_NTT_STAGE16N(2, w[m >> 3])
+        ZK_NTT_STAGE16N(2, w1[m >> 3])
     }
-    {   // k = 2: register bit 0; twiddle by (q1 q0) = register bits (2 3)
-        u64 w[4];
+    u64 w3[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = ntt_tw_load(twr, xl8, lvl(2) + ((u32)i << log_d));
-        ZK_NTT_STAGE16N(0, w[((m >> 2) & 1) * 2 + (m >> 3)])
+    for (int i = 0; i < 8; ++i) w3[i] = ntt_tw_load(twr, xl8, lvl(3) + ((u32)i << log_d));
+    {   // k = 2: register bit 0; twiddle by (q1 q0) = register bits (2 3)
+        ZK_NTT_STAGE16N(0, w2[((m >> 2) & 1) * 2 + (m >> 3)])
+    }
+    u64 w4[8];
+    {
+        const u32 lo8 = xl8 + ((l5 << log_d) << 3);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w4[i] = ntt_tw_load(twr, lo8, lvl(4) + ((u32)(((i >> 1) & 1) * 8 + (i & 1) * 4 + ((i >> 2) & 1) * 2) << log_d));
     }
     {   // k = 3: register bit 1; twiddle by (q2 q1 q0) = register bits (0 2 3)
-        u64 w[8];
+        ZK_NTT_STAGE16N(1, w3[(m & 1) * 4 + ((m >> 2) & 1) * 2 + (m >> 3)])
+    }
+    u64 w5[8];
+    {
+        const u32 lo8 = xl8 + (((l4 * 2 + l5) << log_d) << 3);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = ntt_tw_load(twr, xl8, lvl(3) + ((u32)i << log_d));
-        ZK_NTT_STAGE16N(1, w[(m & 1) * 4 + ((m >> 2) & 1) * 2 + (m >> 3)])
+        for (int i = 0; i < 8; ++i)      // i = the butterfly's register bits (3 1 0)
+            w5[i] = ntt_tw_load(twr, lo8, lvl(5) + ((u32)(((i >> 2) & 1) * 16 + ((i >> 1) & 1) * 8 + (i & 1) * 4) << log_d));
     }
     {   // k = 4: q4 (lane 5) <-> register bit 3 (q0); twiddle by (q3 q2 q1 q0) = (registers 1 0 2, lane 5)
         _Pragma("unroll") for (int b = 0; b < NB; ++b) ntt_swap16<5, 3>(vv[b]);
-        const u32 lo8 = xl8 + ((l5 << log_d) << 3);
-        u64 w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = ntt_tw_load(twr, lo8, lvl(4) + ((u32)(((i >> 1) & 1) * 8 + (i & 1) * 4 + ((i >> 2) & 1) * 2) << log_d));
-        ZK_NTT_STAGE16N(3, w[m & 7])
+        ZK_NTT_STAGE16N(3, w4[m & 7])
     }
     {   // k = 5: q5 (lane 4) <-> register bit 2 (q1); twiddle by (q4 q3 q2 q1 q0) = (registers 3 1 0, lane 4, lane 5)
         _Pragma("unroll") for (int b = 0; b < NB; ++b) ntt_swap16<4, 2>(vv[b]);
-        const u32 lo8 = xl8 + (((l4 * 2 + l5) << log_d) << 3);
-        u64 w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)      // i = the butterfly's register bits (3 1 0)
-            w[i] = ntt_tw_load(twr, lo8, lvl(5) + ((u32)(((i >> 2) & 1) * 16 + ((i >> 1) & 1) * 8 + (i & 1) * 4) << log_d));
-        ZK_NTT_STAGE16N(2, w[(m >> 3) * 4 + (m & 3)])
+        ZK_NTT_STAGE16N(2, w5[(m >> 3) * 4 + (m & 3)])
     }
 }
 // row bits [q5 q4 q3 q2] held by register m after ntt_swap_dit6 (registers [3..0] = [q4 q5 q3 q2]), without the lane bits
@@ -214,6 +222,19 @@ __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass
         // stage k (pairs 2^k rows apart): level s_k = log_n - 1 - log_d - k, block (hi_idx << (R - 1 - k)) + (t >> (k + 1))
         const int s_top = p.log_n - log_d - R;
         ntt_swap_dif6(v, p.tw, twr, s_top, hi_idx, l4, l5);
+        // the twiddles of the stages after the exchange (by t >> (k + 1), t = (wave, lane 5, lane 4, register) there): requested
+        // now, so that they arrive during the exchange
+        auto lvl = [&](int k) { return ((1u << (s_top + R - 1 - k)) - 1) + (hi_idx << (R - 1 - k)); };
+        const u32 thl = l5 * 2 + l4, thu = wv << 2;                    // t >> 4 = thu + thl: wave-uniform but for the two lane bits
+        u64 bw3 = 0, bw2[2] = {0, 0}, bw1[4] = {0, 0, 0, 0}, bw0[8];
+        if (A >= 4) bw3 = ntt_tw_load(twr, thl * 8, lvl(3) + thu);
+        if (A >= 3) { bw2[0] = ntt_tw_load(twr, thl * 16, lvl(2) + thu * 2); bw2[1] = ntt_tw_load(twr, thl * 16, lvl(2) + thu * 2 + 1); }
+        if (A >= 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bw1[i] = ntt_tw_load(twr, thl * 32, lvl(1) + thu * 4 + i);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bw0[i] = ntt_tw_load(twr, thl * 64, lvl(0) + thu * 8 + i);
         // LDS row of t: t with bit 0 flipped by t4 ^ t(R-2) (a half wave writes two rows that differ in t(R-2) and reads two
         // that differ in t4: 128-byte rows, 64 banks)
         {
@@ -234,29 +255,11 @@ __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass
             t ^= ((t >> 4) ^ (t >> (R - 2))) & 1;
             v[m] = tile[(t << 4) + u];
         }
-        auto lvl = [&](int k) { return ((1u << (s_top + R - 1 - k)) - 1) + (hi_idx << (R - 1 - k)); };
-        const u32 thl = l5 * 2 + l4, thu = wv << 2;                    // t >> 4 = thu + thl: wave-uniform but for the two lane bits
-        // the A = R - 6 stages of the wave bits: k = A - 1 .. 0
-        if (A >= 4) {   // k = 3: twiddle by t >> 4
-            const u64 w = ntt_tw_load(twr, thl * 8, lvl(3) + thu);
-            ZK_NTT_STAGE16(3, w)
-        }
-        if (A >= 3) {   // k = 2: twiddle by t >> 3
-            const u64 w[2] = {ntt_tw_load(twr, thl * 16, lvl(2) + thu * 2), ntt_tw_load(twr, thl * 16, lvl(2) + thu * 2 + 1)};
-            ZK_NTT_STAGE16(2, w[m >> 3])
-        }
-        if (A >= 2) {   // k = 1: twiddle by t >> 2
-            u64 w[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w[i] = ntt_tw_load(twr, thl * 32, lvl(1) + thu * 4 + i);
-            ZK_NTT_STAGE16(1, w[m >> 2])
-        }
-        {   // k = 0: twiddle by t >> 1
-            u64 w[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = ntt_tw_load(twr, thl * 64, lvl(0) + thu * 8 + i);
-            ZK_NTT_STAGE16(0, w[m >> 1])
-        }
+        // the A = R - 6 stages of the wave bits: k = A - 1 .. 0 (twiddles bw*: requested before the exchange, above)
+        if (A >= 4) { ZK_NTT_STAGE16(3, bw3) }
+        if (A >= 3) { ZK_NTT_STAGE16(2, bw2[m >> 3]) }
+        if (A >= 2) { ZK_NTT_STAGE16(1, bw1[m >> 2]) }
+        { ZK_NTT_STAGE16(0, bw0[m >> 1]) }
         {
             u64 *d = dst + base + u + ((size_t)tb << log_d);
 #pragma unroll
@@ -271,6 +274,20 @@ __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass
         }
         const u32 xl8 = ((lo_tile << ZK_NTT_SWAP_LOG_T) + u) * 8;
         ntt_swap_dit6<1>(vv, twr, log_d, xl8, l4, l5);
+        // the twiddles of the stages after the exchange (t = (m << (R - 4)) | tb2 there; stage k: t mod 2^k = ((m mod 2^(k - R + 4)) <<
+        // (R - 4)) | tb2): requested now, so that they arrive during the exchange
+        const u32 tb2 = (wv << 2) | (l5 << 1) | l4;
+        auto lvl = [&](int k) { return (1u << (log_d + k)) - 1; };
+        const u32 lo8 = xl8 + ((tb2 << log_d) << 3);
+        u64 bw0 = 0, bw1[2] = {0, 0}, bw2[4] = {0, 0, 0, 0}, bw3[8];
+        if (R - 4 >= 6) bw0 = ntt_tw_load(twr, lo8, lvl(R - 4));
+        if (R - 3 >= 6) { bw1[0] = ntt_tw_load(twr, lo8, lvl(R - 3)); bw1[1] = ntt_tw_load(twr, lo8, lvl(R - 3) + ((1u << (R - 4)) << log_d)); }
+        if (R - 2 >= 6) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bw2[i] = ntt_tw_load(twr, lo8, lvl(R - 2) + (((u32)i << (R - 4)) << log_d));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bw3[i] = ntt_tw_load(twr, lo8, lvl(R - 1) + (((u32)i << (R - 4)) << log_d));
         // lane 5 = t0, lane 4 = t1.  LDS row of t: bit 0 flipped by t1
         {
             const u32 tb = ((wv << 6) | (l4 << 1) | l5) ^ l4;
@@ -285,30 +302,11 @@ __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass
 #pragma unroll
             for (int m = 0; m < 16; ++m) v[m] = tile[(((u32)m << (R - 4)) | tp) * 16 + u];
         }
-        auto lvl = [&](int k) { return (1u << (log_d + k)) - 1; };
-        const u32 lo8 = xl8 + ((tb << log_d) << 3);
-        // stage k: twiddle by t mod 2^k = ((m mod 2^(k - R + 4)) << (R - 4)) | tb
-        // register bit j is row bit R - 4 + j: a stage of this phase where that is >= 6
-        if (R - 4 >= 6) {   // register bit 0
-            const u64 w = ntt_tw_load(twr, lo8, lvl(R - 4));
-            ZK_NTT_STAGE16(0, w)
-        }
-        if (R - 3 >= 6) {   // register bit 1
-            const u64 w[2] = {ntt_tw_load(twr, lo8, lvl(R - 3)), ntt_tw_load(twr, lo8, lvl(R - 3) + ((1u << (R - 4)) << log_d))};
-            ZK_NTT_STAGE16(1, w[m & 1])
-        }
-        if (R - 2 >= 6) {   // register bit 2
-            u64 w[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) w[i] = ntt_tw_load(twr, lo8, lvl(R - 2) + (((u32)i << (R - 4)) << log_d));
-            ZK_NTT_STAGE16(2, w[m & 3])
-        }
-        {   // k = R - 1: register bit 3
-            u64 w[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = ntt_tw_load(twr, lo8, lvl(R - 1) + (((u32)i << (R - 4)) << log_d));
-            ZK_NTT_STAGE16(3, w[m & 7])
-        }
+        // register bit j is row bit R - 4 + j: a stage of this phase where that is >= 6 (twiddles bw*: requested before the exchange)
+        if (R - 4 >= 6) { ZK_NTT_STAGE16(0, bw0) }
+        if (R - 3 >= 6) { ZK_NTT_STAGE16(1, bw1[m & 1]) }
+        if (R - 2 >= 6) { ZK_NTT_STAGE16(2, bw2[m & 3]) }
+        { ZK_NTT_STAGE16(3, bw3[m & 7]) }
         {
             u64 *d = dst + base + u + ((size_t)tb << log_d);
 #pragma unroll
@@ -344,33 +342,26 @@ static __global__ void __launch_bounds__(256) ntt_contig_wave_kernel_dif(NttPass
     // stage k (pairs 2^k apart): level s_k = log_n - 1 - k, block (tile << (9 - k)) + (e >> (k + 1))
     const int s_top = p.log_n - ZK_NTT_WAVE_BITS;
     ntt_swap_dif6(v, p.tw, twr, s_top, tile_id, l4, l5);
+    // the twiddles of the four in-segment stages (by x >> (k + 1), x = base + lane * 16 + j after the transpose): requested now
+    auto lvl = [&](int k) { return ((1u << (s_top + 9 - k)) - 1) + (tile_id << (9 - k)); };
+    const u64 bw3 = ntt_tw_load(twr, lane * 8, lvl(3));
+    const u64 bw2[2] = {ntt_tw_load(twr, lane * 16, lvl(2)), ntt_tw_load(twr, lane * 16, lvl(2) + 1)};
+    u64 bw1[4], bw0[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bw1[i] = ntt_tw_load(twr, lane * 32, lvl(1) + i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bw0[i] = ntt_tw_load(twr, lane * 64, lvl(0) + i);
 #pragma unroll
     for (int m = 0; m < 16; ++m) lds[ntt_wave_lds(rb | ntt_swap_dif6_row(m), u)] = v[m];
     ntt_wave_sync();
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = lds[ntt_wave_lds(lane, j)];
     // the lane's row is `lane`; registers = position in the segment.  stage k = 3 .. 0: twiddle by x >> (k + 1), x = base + lane * 16 + j
-    auto lvl = [&](int k) { return ((1u << (s_top + 9 - k)) - 1) + (tile_id << (9 - k)); };
-    {
-        const u64 w = ntt_tw_load(twr, lane * 8, lvl(3));
-        ZK_NTT_STAGE16(3, w)
-    }
-    {
-        const u64 w[2] = {ntt_tw_load(twr, lane * 16, lvl(2)), ntt_tw_load(twr, lane * 16, lvl(2) + 1)};
-        ZK_NTT_STAGE16(2, w[m >> 3])
-    }
-    {
-        u64 w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = ntt_tw_load(twr, lane * 32, lvl(1) + i);
-        ZK_NTT_STAGE16(1, w[m >> 2])
-    }
-    {
-        u64 w[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w[i] = ntt_tw_load(twr, lane * 64, lvl(0) + i);
-        ZK_NTT_STAGE16(0, w[m >> 1])
-    }
+    // (bw*: requested before the transpose, above)
+    { ZK_NTT_STAGE16(3, bw3) }
+    { ZK_NTT_STAGE16(2, bw2[m >> 3]) }
+    { ZK_NTT_STAGE16(1, bw1[m >> 2]) }
+    { ZK_NTT_STAGE16(0, bw0[m >> 1]) }
     ntt_wave_sync();
 #pragma unroll
     for (int j = 0; j < 16; ++j) lds[ntt_wave_lds(lane, j)] = v[j];
