@@ -64,6 +64,13 @@ template <int LANEBIT> __device__ inline void ntt_lane_swap(u64 &, u64 &) {}    
 __device__ inline u32 ntt_uniform(u32 x) { return x; }
 __device__ inline void ntt_wave_sync() {}
 #endif
+// the butterfly with twiddle 1: gl_mul_canon(b, 1) is the canonical representative of b
+__device__ __forceinline__ void ntt_bfly_one(u64 &a, u64 &b) {
+    const u64 t = gl_canon(b);
+    const u64 na = gl_add_canon(a, t);
+    b = gl_sub_canon(a, t);
+    a = na;
+}
 // transpose register bit REGBIT with lane bit LANEBIT over all sixteen registers
 template <int LANEBIT, int REGBIT>
 __device__ __forceinline__ void ntt_swap16(u64 (&v)[16]) {
@@ -430,23 +437,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
 #pragma unroll
         for (int j = 0; j < 16; ++j) vv[b][j] = lds[ntt_wave_lds(lane, j)];
     }
-    // the four stages inside the lane's segment: pairs 2^q apart, twiddle T_(2^q)[j mod 2^q] -- the table's first 15 entries
+    // the four stages inside the lane's segment: pairs 2^q apart, twiddle T_(2^q)[j mod 2^q] -- the table's first 15 entries, of
+    // which T_(2^q)[0] = 1 (twiddle_levels_kernel): those 15 of the 32 butterflies skip the multiply (b * 1 = the canonical b)
+#define ZK_NTT_STAGE16N_PURE(BIT, W_OF_M)                                                     \
+    _Pragma("unroll") for (int b = 0; b < NB; ++b)                                            \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m)                                            \
+        if (!(m & (1 << (BIT)))) {                                                            \
+            if ((m & ((1 << (BIT)) - 1)) == 0) ntt_bfly_one(vv[b][m], vv[b][m | (1 << (BIT))]); \
+            else ntt_bfly(vv[b][m], vv[b][m | (1 << (BIT))], (W_OF_M));                       \
+        }
     {
-        const u64 w = ctw[0];
-        ZK_NTT_STAGE16N(0, w)
+        ZK_NTT_STAGE16N_PURE(0, 0)
     }
     {
-        const u64 w[2] = {ctw[1], ctw[2]};
-        ZK_NTT_STAGE16N(1, w[m & 1])
+        const u64 w[2] = {1, ctw[2]};
+        ZK_NTT_STAGE16N_PURE(1, w[m & 1])
     }
     {
-        const u64 w[4] = {ctw[3], ctw[4], ctw[5], ctw[6]};
-        ZK_NTT_STAGE16N(2, w[m & 3])
+        const u64 w[4] = {1, ctw[4], ctw[5], ctw[6]};
+        ZK_NTT_STAGE16N_PURE(2, w[m & 3])
     }
     {
-        const u64 w[8] = {ctw[7], ctw[8], ctw[9], ctw[10], ctw[11], ctw[12], ctw[13], ctw[14]};
-        ZK_NTT_STAGE16N(3, w[m & 7])
+        const u64 w[8] = {1, ctw[8], ctw[9], ctw[10], ctw[11], ctw[12], ctw[13], ctw[14]};
+        ZK_NTT_STAGE16N_PURE(3, w[m & 7])
     }
+#undef ZK_NTT_STAGE16N_PURE
     // back to segments with lane 5 = row bit 1, lane 4 = row bit 0, register m = row bits 5 .. 2
     const u32 rl = (l5 << 1) | l4;
 #pragma unroll
