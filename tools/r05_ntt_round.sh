@@ -15,4 +15,4 @@ for S in 0 1; do
   [ -n "$f" ] && { cp "$f" "$OUT/${TAG}_kernel_stats_kbench_116x2p20_swap$S.csv"; echo "-- swap=$S"; grep -i "ntt\|Name" "$f" | cut -d, -f1-4 | cut -c1-150; }
 done
 cd "$ROOT"
-echo "== parity test"; timeout 1500 python -m pytest tests/test_gpu_commit.py -m gpu -x -q -k "lane_swap or fused or persistent" 2>&1 | tail -5 | tee "$OUT/${TAG}_swap_parity_test.log"
+echo "== parity test"; ZK_TEST_UNVALIDATED_PLANS=1 timeout 1500 python -m pytest tests/test_gpu_commit.py -m gpu -x -q -k "lane_swap or fused or persistent" 2>&1 | tail -5 | tee "$OUT/${TAG}_swap_parity_test.log"
