@@ -4,6 +4,8 @@
 cd "$(dirname "$0")/.."
 for shape in "116 20" "2431 18" "30 21" "86 19"; do
   for MB in 0 32 64 96 128 192 0; do
-    echo -n "shape=$shape batch_MB=$MB : "; ZK_NTT_COL_BATCH_MB=$MB tools/kbench $shape 5 | tr '\n' ' '; echo
+    for ST in 1 2; do
+      echo -n "shape=$shape batch_MB=$MB streams=$ST : "; ZK_NTT_COL_BATCH_MB=$MB ZK_NTT_COL_BATCH_STREAMS=$ST tools/kbench $shape 5 | tr '\n' ' '; echo
+    done
   done
 done

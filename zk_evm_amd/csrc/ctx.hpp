@@ -50,6 +50,8 @@ struct zk_ctx {
     std::map<std::pair<int, const u64 *>, u64 *> wave_coset2_tabs;   // (log_n, load-factor table | null) -> the second coset's (ntt_host.inc)
     hipStream_t side_stream = nullptr;  // lane 1: low priority, created on first use (segment_host.inc)
     hipStream_t tail_stream = nullptr;  // tree tops of main-lane trace commitments (segment_host.inc), created on first use
+    hipStream_t ntt_batch_stream = nullptr;   // every other column batch of a commitment's NTT (ntt_host.inc ZK_NTT_COL_BATCH_STREAMS), created on first use
+    hipEvent_t ntt_batch_ev[2] = {nullptr, nullptr};
     hipStream_t commit_tail = nullptr;  // != nullptr: commit_enqueue sends the small Merkle levels + cap read-back of main-lane commits there
     std::vector<struct PendingCommit *> *tree_batch = nullptr;   // != nullptr: commit_enqueue leaves the small Merkle levels + cap read-back to commit_tree_batch_flush (zkstark.hip)
     std::vector<hipEvent_t> ev_pool;    // recycled timing / ordering events

@@ -95,6 +95,8 @@ extern "C" void zk_ctx_destroy(zk_ctx *ctx) {
     for (auto &kv : ctx->coset_tabs) hipFree(kv.second);
     for (auto &kv : ctx->coset_inv_tabs) hipFree(kv.second);
     for (auto &kv : ctx->wave_coset2_tabs) hipFree(kv.second);
+    if (ctx->ntt_batch_stream) hipStreamDestroy(ctx->ntt_batch_stream);
+    for (auto &e : ctx->ntt_batch_ev) if (e) hipEventDestroy(e);
     for (auto &e : ctx->ev_pool) if (e) hipEventDestroy(e);
     if (ctx->h_caps) hipHostFree(ctx->h_caps);
     if (ctx->h_big) hipHostFree(ctx->h_big);
