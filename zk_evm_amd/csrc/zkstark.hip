@@ -689,6 +689,15 @@ int zki_get_twiddles(zk_ctx *ctx, int log_size, bool inverse, const u64 **out) {
 int zki_get_coset_table(zk_ctx *ctx, int log_n, u64 shift, bool inverse, const u64 **out) {
     return get_coset_table(ctx, log_n, shift, inverse, out);
 }
+// (internal, for tests/test_ntt_plan_cpu.py: no device involved) the passes ntt_host.inc plans for a 2^L-point transform whose
+// contiguous pass gets `free_stages` stages by replication: out[2 k] = log_d, out[2 k + 1] = r of pass k, largest distance first
+extern "C" int zki_ntt_plan(int L, int free_stages, int *out, int max_passes) {
+    if (L < 0 || L > 31 || free_stages < 0 || !out) return -1;
+    const auto plan = plan_passes_for(L, free_stages);
+    int k = 0;
+    for (const auto &ps : plan) { if (k >= max_passes) return -1; out[2 * k] = ps.log_d; out[2 * k + 1] = ps.r; ++k; }
+    return k;
+}
 int zki_ntt_values_to_coeffs(zk_ctx *ctx, const u64 *src, size_t src_stride, u64 *dst, size_t dst_stride, size_t n_cols,
                              int log_n, const u64 *out_scale) {
     return ntt_values_to_coeffs(ctx, src, src_stride, dst, dst_stride, n_cols, log_n, out_scale);
