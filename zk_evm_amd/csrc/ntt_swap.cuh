@@ -58,6 +58,14 @@ __device__ __forceinline__ void ntt_wave_sync() {          // LDS traffic of ONE
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+#elif defined(ZK_NTT_EMULATE)
+// tests/emu/: this file compiled for the CPU, one OS thread per lane; the lanes of a wave meet in zk_emu_lane_swap / zk_emu_wave_sync
+typedef const u64 *ntt_const_u64p;
+void zk_emu_lane_swap(int lanebit, u64 &a, u64 &b);       // (register a, lane bit = 1) <-> (register b, lane bit = 0)
+void zk_emu_wave_sync();
+template <int LANEBIT> inline void ntt_lane_swap(u64 &a, u64 &b) { zk_emu_lane_swap(LANEBIT, a, b); }
+inline u32 ntt_uniform(u32 x) { return x; }
+inline void ntt_wave_sync() { zk_emu_wave_sync(); }
 #else
 typedef const u64 *ntt_const_u64p;
 template <int LANEBIT> __device__ inline void ntt_lane_swap(u64 &, u64 &) {}                     // (host pass: parsed, never run)
@@ -331,7 +339,7 @@ __device__ __forceinline__ u32 ntt_wave_lds(u32 row, u32 col) { return row * 17 
 // values -> coefficients, the LAST pass (log_d = 0, r = 10): stages 9 .. 0 on the wave's 2^10 elements, then the store factor
 // (out_scale table | out_const | canonical).  256 threads = four independent waves.
 static __global__ void __launch_bounds__(256) ntt_contig_wave_kernel_dif(NttPass p) {
-    __shared__ u64 lds_all[4 * ZK_NTT_WAVE_LDS];
+    extern __shared__ __attribute__((aligned(16))) u64 lds_all[];            // 4 x ZK_NTT_WAVE_LDS words (ntt_host.inc)
     const u32 tid = threadIdx.x, lane = tid & 63, wv = ntt_uniform(tid >> 6), u = lane & 15, l4 = (lane >> 4) & 1, l5 = lane >> 5;
     u64 *const lds = lds_all + wv * ZK_NTT_WAVE_LDS;
     const u32 tile_id = (p.cols_fastest ? blockIdx.y : blockIdx.x) * 4 + wv;
@@ -395,7 +403,7 @@ static __global__ void __launch_bounds__(256) ntt_contig_wave_kernel_dif(NttPass
 // in_scale2 = the same coset table for shift * w_(2n) (ntt_host.inc).  Output index (sbase + i) * NB + b.
 template <int NB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) ntt_contig_wave_kernel_dit(NttPass p, const u64 *in_scale2) {
-    __shared__ u64 lds_all[4 * ZK_NTT_WAVE_LDS];
+    extern __shared__ __attribute__((aligned(16))) u64 lds_all[];            // 4 x ZK_NTT_WAVE_LDS words (ntt_host.inc)
     const u32 tid = threadIdx.x, lane = tid & 63, wv = ntt_uniform(tid >> 6), u = lane & 15, l4 = (lane >> 4) & 1, l5 = lane >> 5;
     u64 *const lds = lds_all + wv * ZK_NTT_WAVE_LDS;
     const u32 tile_id = (p.cols_fastest ? blockIdx.y : blockIdx.x) * 4 + wv;
