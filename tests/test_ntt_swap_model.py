@@ -77,13 +77,10 @@ def tw_load(tw, lane_byte_off, uniform_index):
 
 def swap_dif6(v, tw, s_top, H):
     first = lambda j: ((1 << (s_top + j)) - 1) + (H << j)
-    lane_swap(v, 5, 3)
+    # entry: registers [3..0] = [q5 q4 q3 q2], lane 5 = q1, lane 4 = q0: four register stages, then one swap per lane stage
     stage16(v, 3, lambda lane, m: tw[first(0)])
-    lane_swap(v, 4, 2)
     stage16(v, 2, lambda lane, m: tw[first(1) + (m >> 3)])
-    lane_swap(v, 5, 1)
     stage16(v, 1, lambda lane, m: tw[first(2) + (m >> 2)])
-    lane_swap(v, 4, 0)
     stage16(v, 0, lambda lane, m: tw[first(3) + (m >> 1)])
     lane_swap(v, 5, 3)
     stage16(v, 3, lambda lane, m: tw_load(tw, L5(lane) * 64, first(4) + (m & 7)))
@@ -102,9 +99,8 @@ def swap_dit6(vs, tw, log_d, xl8_of):
     def each(f):
         for v in vs:
             f(v)
-    each(lambda v: lane_swap(v, 4, 3))
+    # entry: registers [3..0] = [q0 q1 q3 q2], lane 5 = q4, lane 4 = q5
     each(lambda v: stage16(v, 3, lambda lane, m: tw_load(tw, xl8_of(lane), lvl(0))))
-    each(lambda v: lane_swap(v, 5, 2))
     each(lambda v: stage16(v, 2, lambda lane, m: tw_load(tw, xl8_of(lane), lvl(1) + ((m >> 3) << log_d))))
     each(lambda v: stage16(v, 0, lambda lane, m: tw_load(tw, xl8_of(lane), lvl(2) + ((((m >> 2) & 1) * 2 + (m >> 3)) << log_d))))
     each(lambda v: stage16(v, 1, lambda lane, m: tw_load(tw, xl8_of(lane), lvl(3) + (((m & 1) * 4 + ((m >> 2) & 1) * 2 + (m >> 3)) << log_d))))
@@ -126,6 +122,10 @@ def swap_dit6(vs, tw, log_d, xl8_of):
 
 def dit6_row(m):
     return ((m & 4) << 3) | ((m & 8) << 1) | ((m & 2) << 2) | ((m & 1) << 2)
+
+
+def dit6_row_in(m):
+    return ((m & 2) << 2) | ((m & 1) << 2) | ((m & 4) >> 1) | ((m & 8) >> 3)
 
 
 def check_banks(addr_of_lane):
@@ -150,9 +150,9 @@ def strided_tile(src, dst, log_n, log_d, R, tw, dit, tile_id):
     if not dit:
         for wv in range(waves):
             for lane in range(64):
-                s = base + (lane & 15) + (((L5(lane) << (R - 1)) | (L4(lane) << (R - 2)) | wv) << log_d)
+                s = base + (lane & 15) + (((L5(lane) << (R - 5)) | (L4(lane) << (R - 6)) | wv) << log_d)
                 for m in range(16):
-                    V[wv][lane][m] = src[s + (m << (A + log_d))]
+                    V[wv][lane][m] = src[s + (m << (R - 4 + log_d))]
         s_top = log_n - log_d - R
         for wv in range(waves):
             swap_dif6(V[wv], tw, s_top, hi_idx)
@@ -195,9 +195,9 @@ def strided_tile(src, dst, log_n, log_d, R, tw, dit, tile_id):
     else:
         for wv in range(waves):
             for lane in range(64):
-                s = base + (lane & 15) + (((wv << 6) | (L5(lane) << 1) | L4(lane)) << log_d)
+                s = base + (lane & 15) + (((wv << 6) | (L4(lane) << 5) | (L5(lane) << 4)) << log_d)
                 for m in range(16):
-                    V[wv][lane][m] = src[s + (m << (2 + log_d))]
+                    V[wv][lane][m] = src[s + (dit6_row_in(m) << log_d)]
         xl8 = lambda lane: ((lo_tile << LOG_T) + (lane & 15)) * 8
         for wv in range(waves):
             swap_dit6([V[wv]], tw, log_d, xl8)
@@ -273,8 +273,9 @@ def contig_dif_wave(src, dst, log_n, tw, tile_id):
     v = [[None] * 16 for _ in range(64)]
     rb = lambda lane: (L5(lane) << 5) | (L4(lane) << 4)
     for lane in range(64):
+        rl = (L5(lane) << 1) | L4(lane)
         for m in range(16):
-            v[lane][m] = src[base + ((rb(lane) | m) << 4) + (lane & 15)]
+            v[lane][m] = src[base + ((((m << 2) | rl)) << 4) + (lane & 15)]
     s_top = log_n - 10
     swap_dif6(v, tw, s_top, tile_id)
     lds = {}
@@ -354,7 +355,7 @@ def contig_dit_wave(src, dst, NB, tw, scales, tile_id):
         stage16(v, 1, lambda lane, m: tw[1 + (m & 1)])
         stage16(v, 2, lambda lane, m: tw[3 + (m & 3)])
         stage16(v, 3, lambda lane, m: tw[7 + (m & 7)])
-    rl = lambda lane: (L5(lane) << 1) | L4(lane)
+    rl = lambda lane: (L4(lane) << 5) | (L5(lane) << 4)
     for v in vs:
         lds = {}
         for j in range(16):
@@ -362,7 +363,7 @@ def contig_dit_wave(src, dst, NB, tw, scales, tile_id):
                 lds[lds17(lane, j)] = v[lane][j]
         for m in range(16):
             for lane in range(64):
-                v[lane][m] = lds[lds17((m << 2) | rl(lane), lane & 15)]
+                v[lane][m] = lds[lds17(dit6_row_in(m) | rl(lane), lane & 15)]
     swap_dit6(vs, tw, 4, lambda lane: (lane & 15) * 8)
     for lane in range(64):
         ro = (L4(lane) << 1) | L5(lane)

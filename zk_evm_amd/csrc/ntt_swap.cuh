@@ -21,9 +21,11 @@
 //       coefficients -> values with rate_bits = 1 evaluates the tile's 2^10 coefficients on BOTH cosets (x = 2 i + b is the plain
 //       2^10-point transform of c_j (g w_2n^b)^j): the same twiddles for b = 0, 1, only the scale table differs, and the two
 //       results of an element leave as one 16-byte store.
-// Twiddles.  values -> coefficients: a stage's twiddle depends on the index bits ABOVE it; with the lane bits holding the next
-// two bits to be processed those are register bits for the first four stages -- compile-time offsets from a wave-uniform base,
-// i.e. SCALAR loads through the constant cache; the remaining stages take per-lane loads.  coefficients -> values: a stage's
+// Of a group's six stages the four on register bits need no exchange at all and the two on lane bits one swap each (32 swap
+// instructions per 16 elements and group).
+// Twiddles.  values -> coefficients: a stage's twiddle depends on the index bits ABOVE it; the four register stages come first and
+// work on the group's top bits, so those are register bits too -- compile-time offsets from a wave-uniform base, i.e. SCALAR
+// loads through the constant cache; the remaining stages take per-lane loads.  coefficients -> values: a stage's
 // twiddle depends on the bits BELOW it and on the element's position in its segment -- per-lane loads, except the four
 // in-segment stages of the contiguous kernel (positions are register indices there: scalar loads of the table's first 15 entries).
 // Same butterflies on the same operands with the same twiddles as ntt_pass_kernel: bit-identical output
@@ -96,9 +98,10 @@ __device__ __forceinline__ void ntt_swap16(u64 (&v)[16]) {
         if (!(m & (1 << (BIT)))) ntt_bfly(v[m], v[m | (1 << (BIT))], (W_OF_M));
 
 // ---- six stages, values -> coefficients (largest distance first) ------------------------------------------------------------
-// Six index bits q5 .. q0 ("rows"); on entry lane bit 5 = q5, lane bit 4 = q4, register bits [3..0] = [q3 q2 q1 q0].  Stage j
-// (j = 0: q5 .. j = 5: q0) reads the block-order table at first[j] + (the row bits above the stage's), first[j] =
-// (2^(s_top + j) - 1) + (H << j): level s_top + j, H = the index of this six-bit group among its peers.
+// Six index bits q5 .. q0 ("rows"); on entry register bits [3..0] = [q5 q4 q3 q2], lane bit 5 = q1, lane bit 4 = q0: the four
+// register stages need no exchange at all, the two lane stages one swap each.  Stage j (j = 0: q5 .. j = 5: q0) reads the
+// block-order table at first[j] + (the row bits above the stage's), first[j] = (2^(s_top + j) - 1) + (H << j): level s_top + j, H =
+// the index of this six-bit group among its peers.
 // On exit registers [3..0] = [q1 q0 q3 q2], lane bit 5 = q5, lane bit 4 = q4.
 __device__ __forceinline__ void ntt_swap_dif6(u64 (&v)[16], const u64 *tw, __amdgpu_buffer_rsrc_t twr, int s_top, u32 H, u32 l4, u32 l5) {
     const ntt_const_u64p ctw = (ntt_const_u64p)(unsigned long long)tw;
@@ -113,25 +116,21 @@ __device__ __forceinline__ void ntt_swap_dif6(u64 (&v)[16], const u64 *tw, __amd
 #pragma unroll
         for (int i = 0; i < 8; ++i) w5[i] = ntt_tw_load(twr, (l5 * 16 + l4 * 8) * 8, b5 + i);
     }
-    {   // q5 (lane 5) <-> register bit 3 (q3)
-        ntt_swap16<5, 3>(v);
+    {   // q5 = register bit 3
         const u64 w = ctw[first(0)];
         ZK_NTT_STAGE16(3, w)
     }
-    {   // q4 (lane 4) <-> register bit 2 (q2); twiddle by q5 = register bit 3
-        ntt_swap16<4, 2>(v);
+    {   // q4 = register bit 2; twiddle by q5 = register bit 3
         const u32 b = first(1);
         const u64 w[2] = {ctw[b], ctw[b + 1]};
         ZK_NTT_STAGE16(2, w[m >> 3])
     }
-    {   // q3 (lane 5) <-> register bit 1 (q1); twiddle by (q5 q4) = register bits (3 2)
-        ntt_swap16<5, 1>(v);
+    {   // q3 = register bit 1; twiddle by (q5 q4) = register bits (3 2)
         const u32 b = first(2);
         const u64 w[4] = {ctw[b], ctw[b + 1], ctw[b + 2], ctw[b + 3]};
         ZK_NTT_STAGE16(1, w[m >> 2])
     }
-    {   // q2 (lane 4) <-> register bit 0 (q0); twiddle by (q5 q4 q3) = register bits (3 2 1)
-        ntt_swap16<4, 0>(v);
+    {   // q2 = register bit 0; twiddle by (q5 q4 q3) = register bits (3 2 1)
         const u32 b = first(3);
         const u64 w[8] = {ctw[b], ctw[b + 1], ctw[b + 2], ctw[b + 3], ctw[b + 4], ctw[b + 5], ctw[b + 6], ctw[b + 7]};
         ZK_NTT_STAGE16(0, w[m >> 1])
@@ -150,8 +149,9 @@ __device__ __forceinline__ void ntt_swap_dif6(u64 (&v)[16], const u64 *tw, __amd
 __device__ __forceinline__ constexpr u32 ntt_swap_dif6_row(int m) { return ((m & 2) << 2) | ((m & 1) << 2) | ((m & 8) >> 2) | ((m & 4) >> 2); }
 
 // ---- six stages, coefficients -> values (smallest distance first) -----------------------------------------------------------
-// On entry lane bit 5 = q1, lane bit 4 = q0, register bits [3..0] = [q5 q4 q3 q2].  Stage k (pairs 2^k rows apart, k = 0 .. 5)
-// reads the level table at (2^(log_d + k) - 1) + ((row mod 2^k) << log_d) + (position below the rows; lane part xl8 in bytes).
+// On entry register bits [3..0] = [q0 q1 q3 q2], lane bit 5 = q4, lane bit 4 = q5: four register stages, then one swap for each
+// lane stage.  Stage k (pairs 2^k rows apart, k = 0 .. 5) reads the level table at (2^(log_d + k) - 1) + ((row mod 2^k) << log_d) +
+// (position below the rows; lane part xl8 in bytes).
 // On exit registers [3..0] = [q4 q5 q3 q2], lane bit 5 = q0, lane bit 4 = q1.
 // NB arrays go through the same stages with the same twiddles (the two cosets of the contiguous kernel): each twiddle is loaded once.
 // Every stage's twiddles are requested one stage AHEAD of their use (a wave's vector loads return in order: requested where
@@ -161,15 +161,13 @@ __device__ __forceinline__ void ntt_swap_dit6(u64 (&vv)[NB][16], __amdgpu_buffer
     auto lvl = [&](int k) { return (1u << (log_d + k)) - 1; };
     const u64 w0 = ntt_tw_load(twr, xl8, lvl(0));
     const u64 w1[2] = {ntt_tw_load(twr, xl8, lvl(1)), ntt_tw_load(twr, xl8, lvl(1) + (1u << log_d))};
-    {   // k = 0: q0 (lane 4) <-> register bit 3 (q5)
-        _Pragma("unroll") for (int b = 0; b < NB; ++b) ntt_swap16<4, 3>(vv[b]);
+    {   // k = 0: q0 = register bit 3
         ZK_NTT_STAGE16N(3, w0)
     }
     u64 w2[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) w2[i] = ntt_tw_load(twr, xl8, lvl(2) + ((u32)i << log_d));
-    {   // k = 1: q1 (lane 5) <-> register bit 2 (q4); twiddle by q0 = register bit 3
-        _Pragma("unroll") for (int b = 0; b < NB; ++b) ntt_swap16<5, 2>(vv[b]);
+    {   // k = 1: q1 = register bit 2; twiddle by q0 = register bit 3
         ZK_NTT_STAGE16N(2, w1[m >> 3])
     }
     u64 w3[8];
@@ -203,6 +201,8 @@ __device__ __forceinline__ void ntt_swap_dit6(u64 (&vv)[NB][16], __amdgpu_buffer
         ZK_NTT_STAGE16N(2, w5[(m >> 3) * 4 + (m & 3)])
     }
 }
+// row bits [q3 q2 q1 q0] held by register m on ENTRY to ntt_swap_dit6 (registers [3..0] = [q0 q1 q3 q2]), without the lane bits
+__device__ __forceinline__ constexpr u32 ntt_swap_dit6_row_in(int m) { return ((m & 2) << 2) | ((m & 1) << 2) | ((m & 4) >> 1) | ((m & 8) >> 3); }
 // row bits [q5 q4 q3 q2] held by register m after ntt_swap_dit6 (registers [3..0] = [q4 q5 q3 q2]), without the lane bits
 __device__ __forceinline__ constexpr u32 ntt_swap_dit6_row(int m) { return ((m & 4) << 3) | ((m & 8) << 1) | ((m & 2) << 2) | ((m & 1) << 2); }
 
@@ -228,11 +228,11 @@ __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass
     u64 (&v)[16] = vv[0];
 
     if (!DIT) {
-        // rows t = [t(R-1) .. t0]: lane 5 = t(R-1), lane 4 = t(R-2), register bits [3..0] = t(R-3) .. t(R-6), wave = t(A-1) .. t0
+        // rows t = [t(R-1) .. t0]: register bits [3..0] = t(R-1) .. t(R-4), lane 5 = t(R-5), lane 4 = t(R-6), wave = t(A-1) .. t0
         {
-            const u64 *s = src + base + u + ((size_t)((l5 << (R - 1)) | (l4 << (R - 2)) | wv) << log_d);
+            const u64 *s = src + base + u + ((size_t)((l5 << (R - 5)) | (l4 << (R - 6)) | wv) << log_d);
 #pragma unroll
-            for (int m = 0; m < 16; ++m) v[m] = s[(size_t)m << (A + log_d)];
+            for (int m = 0; m < 16; ++m) v[m] = s[(size_t)m << (R - 4 + log_d)];
         }
         // stage k (pairs 2^k rows apart): level s_k = log_n - 1 - log_d - k, block (hi_idx << (R - 1 - k)) + (t >> (k + 1))
         const int s_top = p.log_n - log_d - R;
@@ -281,11 +281,11 @@ __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass
             for (int m = 0; m < 16; ++m) d[(size_t)m << log_d] = p.last_pass ? gl_canon(v[m]) : v[m];
         }
     } else {
-        // lane bit 5 = t1, lane bit 4 = t0, register bits [3..0] = [t5 t4 t3 t2], wave = t(R-1) .. t6
+        // register bits [3..0] = [t0 t1 t3 t2], lane bit 5 = t4, lane bit 4 = t5, wave = t(R-1) .. t6
         {
-            const u64 *s = src + base + u + ((size_t)((wv << 6) | (l5 << 1) | l4) << log_d);
+            const u64 *s = src + base + u + ((size_t)((wv << 6) | (l4 << 5) | (l5 << 4)) << log_d);
 #pragma unroll
-            for (int m = 0; m < 16; ++m) v[m] = s[(size_t)m << (2 + log_d)];
+            for (int m = 0; m < 16; ++m) v[m] = s[(size_t)ntt_swap_dit6_row_in(m) << log_d];
         }
         const u32 xl8 = ((lo_tile << ZK_NTT_SWAP_LOG_T) + u) * 8;
         ntt_swap_dit6<1>(vv, twr, log_d, xl8, l4, l5);
@@ -350,10 +350,11 @@ static __global__ void __launch_bounds__(256) ntt_contig_wave_kernel_dif(NttPass
     u64 *dst = p.dst + (size_t)col_id * p.dst_stride + base;
     const __amdgpu_buffer_rsrc_t twr = ntt_tw_rsrc(p.tw);
     u64 v[16];
-    // element e = row * 16 + u; lane 5 = row bit 5, lane 4 = row bit 4, register m = row bits 3 .. 0
-    const u32 rb = (l5 << 5) | (l4 << 4);
+    // element e = row * 16 + u; on entry register m = row bits 5 .. 2, lane 5 = row bit 1, lane 4 = row bit 0 (a load instruction
+    // reads four adjacent rows: 512 contiguous bytes); from the transposes on lane 5 = row bit 5, lane 4 = row bit 4
+    const u32 rb = (l5 << 5) | (l4 << 4), rl = (l5 << 1) | l4;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = src[((rb | m) << 4) + u];
+    for (int m = 0; m < 16; ++m) v[m] = src[((((u32)m << 2) | rl) << 4) + u];
     // stage k (pairs 2^k apart): level s_k = log_n - 1 - k, block (tile << (9 - k)) + (e >> (k + 1))
     const int s_top = p.log_n - ZK_NTT_WAVE_BITS;
     ntt_swap_dif6(v, p.tw, twr, s_top, tile_id, l4, l5);
@@ -470,8 +471,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         ZK_NTT_STAGE16N_PURE(3, w[m & 7])
     }
 #undef ZK_NTT_STAGE16N_PURE
-    // back to segments with lane 5 = row bit 1, lane 4 = row bit 0, register m = row bits 5 .. 2
-    const u32 rl = (l5 << 1) | l4;
+    // back to segments in ntt_swap_dit6's entry layout: registers [3..0] = row bits [0 1 3 2], lane 5 = row bit 4, lane 4 = row bit 5
+    const u32 rl = (l4 << 5) | (l5 << 4);
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         ntt_wave_sync();
@@ -479,7 +480,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         for (int j = 0; j < 16; ++j) lds[ntt_wave_lds(lane, j)] = vv[b][j];
         ntt_wave_sync();
 #pragma unroll
-        for (int m = 0; m < 16; ++m) vv[b][m] = lds[ntt_wave_lds(((u32)m << 2) | rl, u)];
+        for (int m = 0; m < 16; ++m) vv[b][m] = lds[ntt_wave_lds(ntt_swap_dit6_row_in(m) | rl, u)];
     }
     // six stages on the row bits (pairs 2^(4 + k) apart: the level table with log_d = 4 and the segment position u below)
     ntt_swap_dit6<NB>(vv, twr, 4, u * 8, l4, l5);
