@@ -81,6 +81,10 @@ __device__ __forceinline__ void ntt_bfly_one(u64 &a, u64 &b) {
     b = gl_sub_canon(a, t);
     a = na;
 }
+// (wave-uniform pointer)[per-lane 32-bit BYTE offset]: the form that becomes `global_load v, v_off, s[base]` -- no vector address
+// arithmetic per access (column data is < 2^31 bytes per column: 2^28 points)
+__device__ __forceinline__ u64 ntt_ld(const u64 *uniform, u32 lane_bytes) { return *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(uniform) + lane_bytes); }
+__device__ __forceinline__ void ntt_st(u64 *uniform, u32 lane_bytes, u64 x) { *reinterpret_cast<u64 *>(reinterpret_cast<char *>(uniform) + lane_bytes) = x; }
 // transpose register bit REGBIT with lane bit LANEBIT over all sixteen registers
 template <int LANEBIT, int REGBIT>
 __device__ __forceinline__ void ntt_swap16(u64 (&v)[16]) {
@@ -230,9 +234,11 @@ __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass
     if (!DIT) {
         // rows t = [t(R-1) .. t0]: register bits [3..0] = t(R-1) .. t(R-4), lane 5 = t(R-5), lane 4 = t(R-6), wave = t(A-1) .. t0
         {
-            const u64 *s = src + base + u + ((size_t)((l5 << (R - 5)) | (l4 << (R - 6)) | wv) << log_d);
+            // (uniform pointer + uniform offset)[per-lane 32-bit index]: the address arithmetic stays on the scalar unit
+            const u64 *sb = src + base + ((size_t)wv << log_d);
+            const u32 lo8 = (u + (((l5 << (R - 5)) | (l4 << (R - 6))) << log_d)) * 8;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) v[m] = s[(size_t)m << (R - 4 + log_d)];
+            for (int m = 0; m < 16; ++m) v[m] = ntt_ld(sb + ((size_t)m << (R - 4 + log_d)), lo8);
         }
         // stage k (pairs 2^k rows apart): level s_k = log_n - 1 - log_d - k, block (hi_idx << (R - 1 - k)) + (t >> (k + 1))
         const int s_top = p.log_n - log_d - R;
@@ -276,16 +282,18 @@ __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass
         if (A >= 2) { ZK_NTT_STAGE16(1, bw1[m >> 2]) }
         { ZK_NTT_STAGE16(0, bw0[m >> 1]) }
         {
-            u64 *d = dst + base + u + ((size_t)tb << log_d);
+            u64 *db = dst + base + ((size_t)(wv << 6) << log_d);
+            const u32 so8 = (u + (((l5 << 5) | (l4 << 4)) << log_d)) * 8;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) d[(size_t)m << log_d] = p.last_pass ? gl_canon(v[m]) : v[m];
+            for (int m = 0; m < 16; ++m) ntt_st(db + ((size_t)m << log_d), so8, p.last_pass ? gl_canon(v[m]) : v[m]);
         }
     } else {
         // register bits [3..0] = [t0 t1 t3 t2], lane bit 5 = t4, lane bit 4 = t5, wave = t(R-1) .. t6
         {
-            const u64 *s = src + base + u + ((size_t)((wv << 6) | (l4 << 5) | (l5 << 4)) << log_d);
+            const u64 *sb = src + base + ((size_t)(wv << 6) << log_d);
+            const u32 ld8 = (u + (((l4 << 5) | (l5 << 4)) << log_d)) * 8;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) v[m] = s[(size_t)ntt_swap_dit6_row_in(m) << log_d];
+            for (int m = 0; m < 16; ++m) v[m] = ntt_ld(sb + ((size_t)ntt_swap_dit6_row_in(m) << log_d), ld8);
         }
         const u32 xl8 = ((lo_tile << ZK_NTT_SWAP_LOG_T) + u) * 8;
         ntt_swap_dit6<1>(vv, twr, log_d, xl8, l4, l5);
@@ -323,9 +331,10 @@ __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass
         if (R - 2 >= 6) { ZK_NTT_STAGE16(2, bw2[m & 3]) }
         { ZK_NTT_STAGE16(3, bw3[m & 7]) }
         {
-            u64 *d = dst + base + u + ((size_t)tb << log_d);
+            u64 *db = dst + base + ((size_t)(wv << 2) << log_d);
+            const u32 so8 = (u + (((l5 << 1) | l4) << log_d)) * 8;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) d[(size_t)m << (R - 4 + log_d)] = p.last_pass ? gl_canon(v[m]) : v[m];
+            for (int m = 0; m < 16; ++m) ntt_st(db + ((size_t)m << (R - 4 + log_d)), so8, p.last_pass ? gl_canon(v[m]) : v[m]);
         }
     }
 }
