@@ -4,6 +4,7 @@
 #   tools/r05_ntt_round.sh <tag>
 TAG=${1:-r05g}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out; mkdir -p "$OUT"; cd "$ROOT"
+echo "== the swap instructions"; timeout 60 tools/probe_permlane 2>&1 | tee "$OUT/${TAG}_probe_permlane.log" | head -70
 echo "== swap A/B"; timeout 1500 tools/ab_ntt_swap.sh 2>&1 | tee "$OUT/${TAG}_ab_ntt_swap.log" | cut -c1-230
 echo "== column batches"; timeout 600 tools/ab_ntt_col_batch.sh 2>&1 | tee "$OUT/${TAG}_ab_ntt_col_batch.log" | cut -c1-230
 echo "== per-kernel durations (kbench 116 x 2^20, 4 commitments each)"
