@@ -17,5 +17,13 @@ struct EmuIdx { unsigned x, y, z; };
 extern thread_local EmuIdx threadIdx, blockIdx, blockDim, gridDim;
 void __syncthreads();
 
+// builtins of the device compiler that the headers use outside their __HIP_DEVICE_COMPILE__ branches
+static inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) : 64; }
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+static inline unsigned long long wall_clock64() { return 0; }
+
 struct ulonglong2 { unsigned long long x, y; };
 static inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { return ulonglong2{x, y}; }
