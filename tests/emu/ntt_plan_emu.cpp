@@ -175,6 +175,10 @@ int main(int argc, char **argv) {
     // plans as ntt_host.inc makes them (tests/test_ntt_plan_cpu.py pins those): {log_d, r}, largest distance first
     ok &= check(17, quick ? 1 : 2, {{9, 8}, {0, 9}}, {{10, 7}, {0, 10}}, {{9, 9}, {0, 9}}, {{11, 7}, {0, 11}});
     if (!quick) ok &= check(18, 1, {{9, 9}, {0, 9}}, {{10, 8}, {0, 10}}, {{10, 9}, {0, 10}}, {{11, 8}, {0, 11}});
+    if (argc > 1 && argv[1][0] == 'b') {          // one-off (minutes of thread rendezvous): the 2^19 and 2^20 plans, R = 9 and 10
+        ok &= check(19, 1, {{10, 9}, {0, 10}}, {{10, 9}, {0, 10}}, {{11, 9}, {0, 11}}, {{11, 9}, {0, 11}});
+        ok &= check(20, 1, {{11, 9}, {0, 11}}, {{10, 10}, {0, 10}}, {{12, 9}, {0, 12}}, {{11, 10}, {0, 11}});
+    }
     printf(ok ? "ALL OK\n" : "FAILED\n");
     return ok ? 0 : 1;
 }
