@@ -83,8 +83,33 @@ __device__ __forceinline__ void ntt_bfly_one(u64 &a, u64 &b) {
 }
 // (wave-uniform pointer)[per-lane 32-bit BYTE offset]: the form that becomes `global_load v, v_off, s[base]` -- no vector address
 // arithmetic per access (column data is < 2^31 bytes per column: 2^28 points)
+// (left to itself the compiler folds the uniform part into a per-lane 64-bit pointer and pays a v_lshl_add_u64 per access: the empty
+// asm pins the uniform pointer in a scalar register pair -- as a GLOBAL-address-space pointer: a generic one behind an asm would
+// become flat_load)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) char *ntt_gptr;
+__device__ __forceinline__ u64 ntt_ld(const u64 *uniform, u32 lane_bytes) {
+    ntt_gptr q = (ntt_gptr)uniform;
+    asm("" : "+s"(q));
+    return *reinterpret_cast<const __attribute__((address_space(1))) u64 *>(q + lane_bytes);
+}
+__device__ __forceinline__ void ntt_st(u64 *uniform, u32 lane_bytes, u64 x) {
+    ntt_gptr q = (ntt_gptr)uniform;
+    asm("" : "+s"(q));
+    *reinterpret_cast<__attribute__((address_space(1))) u64 *>(q + lane_bytes) = x;
+}
+__device__ __forceinline__ void ntt_st2(u64 *uniform, u32 lane_bytes, u64 x, u64 y) {      // 16-byte aligned
+    typedef unsigned long long ntt_u64x2 __attribute__((ext_vector_type(2)));
+    ntt_gptr q = (ntt_gptr)uniform;
+    asm("" : "+s"(q));
+    ntt_u64x2 v = {x, y};
+    *reinterpret_cast<__attribute__((address_space(1))) ntt_u64x2 *>(q + lane_bytes) = v;
+}
+#else
 __device__ __forceinline__ u64 ntt_ld(const u64 *uniform, u32 lane_bytes) { return *reinterpret_cast<const u64 *>(reinterpret_cast<const char *>(uniform) + lane_bytes); }
+__device__ __forceinline__ void ntt_st2(u64 *uniform, u32 lane_bytes, u64 x, u64 y) { u64 *q = reinterpret_cast<u64 *>(reinterpret_cast<char *>(uniform) + lane_bytes); q[0] = x; q[1] = y; }
 __device__ __forceinline__ void ntt_st(u64 *uniform, u32 lane_bytes, u64 x) { *reinterpret_cast<u64 *>(reinterpret_cast<char *>(uniform) + lane_bytes) = x; }
+#endif
 // transpose register bit REGBIT with lane bit LANEBIT over all sixteen registers
 template <int LANEBIT, int REGBIT>
 __device__ __forceinline__ void ntt_swap16(u64 (&v)[16]) {
@@ -363,7 +388,7 @@ static __global__ void __launch_bounds__(256) ntt_contig_wave_kernel_dif(NttPass
     // reads four adjacent rows: 512 contiguous bytes); from the transposes on lane 5 = row bit 5, lane 4 = row bit 4
     const u32 rb = (l5 << 5) | (l4 << 4), rl = (l5 << 1) | l4;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = src[((((u32)m << 2) | rl) << 4) + u];
+    for (int m = 0; m < 16; ++m) v[m] = ntt_ld(src + ((u32)m << 6), ((rl << 4) + u) * 8);
     // stage k (pairs 2^k apart): level s_k = log_n - 1 - k, block (tile << (9 - k)) + (e >> (k + 1))
     const int s_top = p.log_n - ZK_NTT_WAVE_BITS;
     ntt_swap_dif6(v, p.tw, twr, s_top, tile_id, l4, l5);
@@ -395,7 +420,7 @@ static __global__ void __launch_bounds__(256) ntt_contig_wave_kernel_dif(NttPass
     u64 sc[16];
     if (p.out_scale) {
 #pragma unroll
-        for (int m = 0; m < 16; ++m) sc[m] = p.out_scale[base + ((rb | m) << 4) + u];
+        for (int m = 0; m < 16; ++m) sc[m] = ntt_ld(p.out_scale + base + ((u32)m << 4), ((rb << 4) + u) * 8);
     }
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
@@ -403,7 +428,7 @@ static __global__ void __launch_bounds__(256) ntt_contig_wave_kernel_dif(NttPass
         if (p.out_scale) w = gl_mul_canon(w, sc[m]);
         else if (p.apply_out_const) w = gl_mul_canon(w, p.out_const);
         else if (p.last_pass) w = gl_canon(w);
-        dst[((rb | m) << 4) + u] = w;
+        ntt_st(dst + ((u32)m << 4), ((rb << 4) + u) * 8, w);
     }
 }
 
@@ -434,10 +459,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         u64 c[8], sc[NB][8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
-            const u32 i = ((rb | (h + m)) << 4) + u;
-            c[m] = src[i];
-            if (p.in_scale) sc[0][m] = p.in_scale[sbase + i];
-            if (NB == 2) sc[NB - 1][m] = in_scale2[sbase + i];
+            const u32 um = (u32)(h + m) << 4, lb = ((rb << 4) + u) * 8;              // i = um (uniform) + lane part
+            c[m] = ntt_ld(src + um, lb);
+            if (p.in_scale) sc[0][m] = ntt_ld(p.in_scale + sbase + um, lb);
+            if (NB == 2) sc[NB - 1][m] = ntt_ld(in_scale2 + sbase + um, lb);
         }
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
@@ -497,12 +522,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
     const u32 ro = (l4 << 1) | l5;
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
-        const u32 i = ((ntt_swap_dit6_row(m) | ro) << 4) + u;
+        const u32 um = ntt_swap_dit6_row(m) << 4, li = (ro << 4) + u;             // i = um (uniform) + li
         if (NB == 2) {
             const u64 a = p.last_pass ? gl_canon(vv[0][m]) : vv[0][m], c = p.last_pass ? gl_canon(vv[NB - 1][m]) : vv[NB - 1][m];
-            *reinterpret_cast<ulonglong2 *>(dst + 2 * (size_t)i) = make_ulonglong2(a, c);
+            ntt_st2(dst + 2 * (size_t)um, li * 16, a, c);
         } else {
-            dst[i] = p.last_pass ? gl_canon(vv[0][m]) : vv[0][m];
+            ntt_st(dst + um, li * 8, p.last_pass ? gl_canon(vv[0][m]) : vv[0][m]);
         }
     }
 }
