@@ -633,6 +633,18 @@ def main():
                 "segment_timing_s": timing,
                 "arena": {k: v / 1e9 for k, v in mem.items()},
             }
+            try:          # which NTT plan each transform shape got, and why (ntt_host.inc ntt_swap_decide; ZK_NTT_SWAP = 2)
+                import ctypes as _C
+                from zk_evm_amd._lib import load_library
+                _l = load_library()
+                _l.zki_ntt_tune_report.restype = _C.c_size_t
+                _l.zki_ntt_tune_report.argtypes = [_C.c_char_p, _C.c_size_t]
+                _buf = _C.create_string_buffer(8192)
+                _l.zki_ntt_tune_report(_buf, len(_buf))
+                out["ntt"]["plan_autotune"] = [ln for ln in _buf.value.decode("ascii", "replace").splitlines() if ln]
+                out["ntt"]["lane_swap_plans"] = sum("-> lane-swap" in ln for ln in out["ntt"]["plan_autotune"])
+            except Exception as e:
+                out["ntt"]["plan_autotune"] = ["unavailable: %r" % (e,)]
             default_shape = log_ns == [20] * n_tab
             if a.in_flight > 1:
                 secondaries.append(("in_flight", ["--arena-peak", str(mem["peak_in_use"])]))

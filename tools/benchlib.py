@@ -418,6 +418,9 @@ def contract_line(out, extra_path="bench_extra.json"):
     if n:
         line["ntt"] = {"achieved_GBs": _num(n.get("achieved_GBs")), "frac": _num(n.get("frac_of_hbm_peak")),
                        "traffic_over_algorithmic": _num(n.get("traffic_over_algorithmic"))}
+        if n.get("lane_swap_plans") is not None:          # transform shapes the plan autotuner gave to the lane-swap kernels (of those it met)
+            line["ntt"]["lane_swap_plans"] = _num(n.get("lane_swap_plans"))
+            line["ntt"]["plans_tuned"] = len(n.get("plan_autotune") or [])
     d = out.get("dist") or {}
     if d:
         line["dist"] = {k: d.get(k) for k in ("backend", "world", "ok", "selftest_ok", "fallback", "tried", "payload_device",

@@ -565,6 +565,20 @@ static __global__ void coset_table_kernel(u64 *out, int log_n, u64 s, u64 c) {
     out[i] = gl_canon(gl_mul(c, gl_pow(s, e)));
 }
 
+// the plan autotuner's input and verdict (ntt_host.inc ntt_swap_decide): pseudo-random words, word-for-word comparison
+static __global__ void ntt_tune_fill_kernel(u64 *out, size_t n, u64 seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    out[i] = z ^ (z >> 31);
+}
+static __global__ void ntt_tune_compare_kernel(const u64 *a, const u64 *b, size_t n, unsigned long long *mismatches) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && a[i] != b[i]) atomicAdd(mismatches, 1ULL);
+}
+
 // load factors of the SECOND coset for ntt_contig_wave_kernel_dit<2> (ntt_swap.cuh): a wave's 2^11 values are the 2^11-point transform
 // of its 2^10 coefficients in local bit-reversed order, whatever the tile, so value 2 i + 1 is the plain 2^10-point transform of
 // c_i * w^bitrev_10(i mod 2^10), w = the root of order 2^11 -- times the first coset's own factor when there is one

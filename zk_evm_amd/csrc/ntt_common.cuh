@@ -11,6 +11,7 @@ struct NttPass {
                          // values -> coeffs: block-order levels tw[2^s - 1 + j] = (root of order 2^(s+1))^bitrev_s(j) (ntt_host.inc)
     const u64 *in_scale; // optional per-source-index factor applied on load (coset powers)
     const u64 *in_scale2;// ntt_contig_wave_kernel_dit<2> only: the load factors of the second coset (ntt_swap.cuh)
+    int swap_ok;         // host only: this transform was planned for the lane-swap kernels (ntt_host.inc launch_swap_pass)
     const u64 *out_scale;// optional per-index factor applied on store
     u64 out_const;       // constant factor applied on store when apply_out_const
     int log_tw;

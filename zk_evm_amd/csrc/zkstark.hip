@@ -689,11 +689,17 @@ int zki_get_twiddles(zk_ctx *ctx, int log_size, bool inverse, const u64 **out) {
 int zki_get_coset_table(zk_ctx *ctx, int log_n, u64 shift, bool inverse, const u64 **out) {
     return get_coset_table(ctx, log_n, shift, inverse, out);
 }
+// (internal) the plan autotuner's verdicts so far in this process, one line per transform shape (ntt_host.inc ntt_swap_decide)
+extern "C" size_t zki_ntt_tune_report(char *out, size_t max) {
+    std::lock_guard<std::mutex> lock(g_ntt_tune_mu);
+    if (out && max) { const size_t n = g_ntt_tune_report.size() < max - 1 ? g_ntt_tune_report.size() : max - 1; memcpy(out, g_ntt_tune_report.data(), n); out[n] = 0; }
+    return g_ntt_tune_report.size();
+}
 // (internal, for tests/test_ntt_plan_cpu.py: no device involved) the passes ntt_host.inc plans for a 2^L-point transform whose
 // contiguous pass gets `free_stages` stages by replication: out[2 k] = log_d, out[2 k + 1] = r of pass k, largest distance first
 extern "C" int zki_ntt_plan(int L, int free_stages, int *out, int max_passes) {
     if (L < 0 || L > 31 || free_stages < 0 || !out) return -1;
-    const auto plan = plan_passes_for(L, free_stages);
+    const auto plan = plan_passes_for(L, free_stages, kNttSwap != 0);      // (the lane-swap plan wherever the switch allows one at all)
     int k = 0;
     for (const auto &ps : plan) { if (k >= max_passes) return -1; out[2 * k] = ps.log_d; out[2 * k + 1] = ps.r; ++k; }
     return k;
