@@ -24,6 +24,7 @@ static inline int __clzll(unsigned long long x) { return x ? __builtin_clzll(x) 
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 static inline unsigned long long wall_clock64() { return 0; }
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
 struct ulonglong2 { unsigned long long x, y; };
 static inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { return ulonglong2{x, y}; }
