@@ -642,6 +642,13 @@ def main():
                 _buf = _C.create_string_buffer(8192)
                 _l.zki_ntt_tune_report(_buf, len(_buf))
                 out["ntt"]["plan_autotune"] = [ln for ln in _buf.value.decode("ascii", "replace").splitlines() if ln]
+                _l.zki_ntt_tune_export.restype = _C.c_size_t
+                _l.zki_ntt_tune_export.argtypes = [_C.c_char_p, _C.c_size_t]
+                _exp = _C.create_string_buffer(1024)
+                _l.zki_ntt_tune_export(_exp, len(_exp))
+                if _exp.value:        # the counter passes and the secondaries (child processes) run the plans this timed region ran
+                    os.environ["ZK_NTT_SWAP_PLANS"] = _exp.value.decode("ascii")
+                    out["ntt"]["plans_exported"] = os.environ["ZK_NTT_SWAP_PLANS"]
                 out["ntt"]["lane_swap_plans"] = sum("-> lane-swap" in ln for ln in out["ntt"]["plan_autotune"])
             except Exception as e:
                 out["ntt"]["plan_autotune"] = ["unavailable: %r" % (e,)]

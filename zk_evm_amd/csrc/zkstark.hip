@@ -695,6 +695,18 @@ extern "C" size_t zki_ntt_tune_report(char *out, size_t max) {
     if (out && max) { const size_t n = g_ntt_tune_report.size() < max - 1 ? g_ntt_tune_report.size() : max - 1; memcpy(out, g_ntt_tune_report.data(), n); out[n] = 0; }
     return g_ntt_tune_report.size();
 }
+// (internal) the verdicts as ZK_NTT_SWAP_PLANS takes them: what a parent process hands to its children
+extern "C" size_t zki_ntt_tune_export(char *out, size_t max) {
+    std::lock_guard<std::mutex> lock(g_ntt_tune_mu);
+    std::string e;
+    for (const auto &kv : g_ntt_tune) {
+        char item[48];
+        snprintf(item, sizeof item, "%c%df%d=%d;", std::get<1>(kv.first) ? 'd' : 'v', std::get<2>(kv.first), std::get<3>(kv.first), kv.second);
+        if (e.find(item) == std::string::npos) e += item;
+    }
+    if (out && max) { const size_t n = e.size() < max - 1 ? e.size() : max - 1; memcpy(out, e.data(), n); out[n] = 0; }
+    return e.size();
+}
 // (internal, for tests/test_ntt_plan_cpu.py: no device involved) the passes ntt_host.inc plans for a 2^L-point transform whose
 // contiguous pass gets `free_stages` stages by replication: out[2 k] = log_d, out[2 k + 1] = r of pass k, largest distance first
 extern "C" int zki_ntt_plan(int L, int free_stages, int *out, int max_passes) {
