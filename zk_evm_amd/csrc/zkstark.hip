@@ -704,6 +704,11 @@ extern "C" size_t zki_ntt_tune_export(char *out, size_t max) {
         snprintf(item, sizeof item, "%c%df%d=%d;", std::get<1>(kv.first) ? 'd' : 'v', std::get<2>(kv.first), std::get<3>(kv.first), kv.second);
         if (e.find(item) == std::string::npos) e += item;
     }
+    for (const auto &kv : g_ntt_batch_tune) {
+        char item[48];
+        snprintf(item, sizeof item, "b%dr%d=%dx%d;", std::get<1>(kv.first), std::get<2>(kv.first), kv.second.first, kv.second.second);
+        if (e.find(item) == std::string::npos) e += item;
+    }
     if (out && max) { const size_t n = e.size() < max - 1 ? e.size() : max - 1; memcpy(out, e.data(), n); out[n] = 0; }
     return e.size();
 }
