@@ -75,7 +75,7 @@ template <bool DIT>
 static void launch(NttPass p, unsigned n_cols, bool swap_kernels) {
     const size_t n = (size_t)1 << p.log_n;
     p.cols_fastest = 1;
-    if (swap_kernels && p.log_d >= 4) {
+    if (swap_kernels && p.log_d >= 4 && p.r >= 7) {
         p.log_t = 4;
         const unsigned tiles = (unsigned)(n >> (p.r + 4)), nthr = 64u << (p.r - 6);
         switch (p.r) {
@@ -86,7 +86,27 @@ static void launch(NttPass p, unsigned n_cols, bool swap_kernels) {
         }
         return;
     }
-    if (swap_kernels) {
+    if (swap_kernels && p.log_d >= 4 && p.r >= 1 && p.r <= 6 && p.log_d >= 10 - p.r && (!DIT || p.r >= 4)) {      // one wave per tile, no LDS
+        const unsigned blocks = (unsigned)(((n >> 10) + 3) / 4);
+        if constexpr (DIT) {
+            switch (p.r) {
+                case 4: run_grid(n_cols, blocks, 256, [&] { ntt_strided_reg_kernel<true, 4>(p); }); break;
+                case 5: run_grid(n_cols, blocks, 256, [&] { ntt_strided_reg_kernel<true, 5>(p); }); break;
+                default: run_grid(n_cols, blocks, 256, [&] { ntt_strided_reg_kernel<true, 6>(p); }); break;
+            }
+        } else {
+            switch (p.r) {
+                case 1: run_grid(n_cols, blocks, 256, [&] { ntt_strided_reg_kernel<false, 1>(p); }); break;
+                case 2: run_grid(n_cols, blocks, 256, [&] { ntt_strided_reg_kernel<false, 2>(p); }); break;
+                case 3: run_grid(n_cols, blocks, 256, [&] { ntt_strided_reg_kernel<false, 3>(p); }); break;
+                case 4: run_grid(n_cols, blocks, 256, [&] { ntt_strided_reg_kernel<false, 4>(p); }); break;
+                case 5: run_grid(n_cols, blocks, 256, [&] { ntt_strided_reg_kernel<false, 5>(p); }); break;
+                default: run_grid(n_cols, blocks, 256, [&] { ntt_strided_reg_kernel<false, 6>(p); }); break;
+            }
+        }
+        return;
+    }
+    if (swap_kernels && p.log_d == 0 && (DIT ? p.r - p.log_rep == 10 && p.first_stage == p.log_rep : p.r == 10)) {
         if (!DIT) { run_grid(n_cols, (unsigned)(((n >> 10) + 3) / 4), 256, [&] { ntt_contig_wave_kernel_dif(p); }); return; }
         const unsigned blocks = (unsigned)(((n >> p.r) + 3) / 4);
         if (p.log_rep == 1) run_grid(n_cols, blocks, 256, [&] { ntt_contig_wave_kernel_dit<2>(p, p.in_scale2); });
@@ -173,6 +193,11 @@ int main(int argc, char **argv) {
     const bool quick = argc > 1 && argv[1][0] == 'q';
     bool ok = true;
     // plans as ntt_host.inc makes them (tests/test_ntt_plan_cpu.py pins those): {log_d, r}, largest distance first
+    // small tables: the wave kernel + the register-only strided pass (values -> coefficients), the tile plan's own strided pass through
+    // the register-only kernel where the extension has fewer than four row bits left
+    ok &= check(13, 3, {{7, 6}, {0, 7}}, {{10, 3}, {0, 10}}, {{8, 6}, {0, 8}}, {{8, 6}, {0, 8}});
+    ok &= check(14, 2, {{8, 6}, {0, 8}}, {{10, 4}, {0, 10}}, {{9, 6}, {0, 9}}, {{11, 4}, {0, 11}});
+    ok &= check(16, 1, {{8, 8}, {0, 8}}, {{10, 6}, {0, 10}}, {{9, 8}, {0, 9}}, {{11, 6}, {0, 11}});
     ok &= check(17, quick ? 1 : 2, {{9, 8}, {0, 9}}, {{10, 7}, {0, 10}}, {{9, 9}, {0, 9}}, {{11, 7}, {0, 11}});
     if (!quick) ok &= check(18, 1, {{9, 9}, {0, 9}}, {{10, 8}, {0, 10}}, {{10, 9}, {0, 10}}, {{11, 8}, {0, 11}});
     if (argc > 1 && argv[1][0] == 'b') {          // one-off (minutes of thread rendezvous): the 2^19 and 2^20 plans, R = 9 and 10

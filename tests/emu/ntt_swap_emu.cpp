@@ -129,6 +129,31 @@ static bool check_strided(int log_d, int extra_hi, unsigned n_cols) {
     return ok;
 }
 
+template <bool DIT, int R>
+static bool check_reg(int log_d, int extra_hi, unsigned n_cols) {              // ntt_strided_reg_kernel: one wave per tile, no LDS
+    const int log_n = log_d + R + extra_hi;
+    const size_t n = (size_t)1 << log_n;
+    std::vector<u64> src(n * n_cols), tw(n), dst(n * n_cols, 0);
+    for (auto &x : src) x = rnd();
+    for (auto &x : tw) x = gl_canon(rnd());
+    NttPass p = {};
+    p.src = src.data(); p.dst = dst.data(); p.src_stride = p.dst_stride = n; p.tw = tw.data(); p.log_tw = log_n; p.log_n = log_n;
+    p.log_d = log_d; p.r = R; p.cols_fastest = 1; p.last_pass = DIT ? 1 : 0;
+    const unsigned blocks = (unsigned)(((n >> 10) + 3) / 4);
+    run_grid(n_cols, blocks, 256, [&] { ntt_strided_reg_kernel<DIT, R>(p); });
+    bool ok = true;
+    for (unsigned c = 0; c < n_cols && ok; ++c) {
+        std::vector<u64> want(src.begin() + c * n, src.begin() + (c + 1) * n), got(dst.begin() + c * n, dst.begin() + (c + 1) * n);
+        reference_pass(want, log_n, log_d, R, tw, DIT, 0);
+        char what[96];
+        snprintf(what, sizeof what, "register-only strided %s R=%d log_d=%d log_n=%d col %u", DIT ? "DIT" : "DIF", R, log_d, log_n, c);
+        ok = same(got, want, what);
+        if (DIT) for (u64 x : got) ok = ok && x < GL_P;
+    }
+    printf("%s register-only strided %s R=%d log_d=%d log_n=%d cols=%u\n", ok ? "ok  " : "FAIL", DIT ? "DIT" : "DIF", R, log_d, log_n, n_cols);
+    return ok;
+}
+
 static bool check_contig_dif(int log_n, int factor) {        // factor 0: canonical only, 1: out_const, 2: out_scale
     const size_t n = (size_t)1 << log_n;
     std::vector<u64> src(n), tw(n), dst(n, 0), scale(n);
@@ -198,6 +223,21 @@ int main(int argc, char **argv) {
         ok &= check_strided<false, 10>(4, 1, 1);
         ok &= check_strided<true, 10>(5, 0, 1);
     }
+    ok &= check_reg<false, 1>(10, 0, 1);
+    ok &= check_reg<false, 2>(10, 1, 2);
+    ok &= check_reg<false, 3>(10, 0, 1);
+    ok &= check_reg<false, 4>(10, 0, 1);
+    ok &= check_reg<false, 4>(7, 1, 1);
+    ok &= check_reg<false, 5>(10, 0, 1);
+    ok &= check_reg<false, 5>(5, 1, 2);
+    ok &= check_reg<false, 6>(10, 0, 1);
+    ok &= check_reg<false, 6>(4, 2, 1);
+    ok &= check_reg<true, 4>(11, 0, 1);
+    ok &= check_reg<true, 4>(6, 1, 2);
+    ok &= check_reg<true, 5>(11, 0, 1);
+    ok &= check_reg<true, 5>(5, 2, 1);
+    ok &= check_reg<true, 6>(11, 0, 1);
+    ok &= check_reg<true, 6>(4, 1, 1);
     ok &= check_contig_dif(10, 0);
     ok &= check_contig_dif(12, 1);
     ok &= check_contig_dif(11, 2);

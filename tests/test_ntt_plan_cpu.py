@@ -16,13 +16,16 @@ sys.path.insert(0, %r)
 from zk_evm_amd import build
 lib = C.CDLL(build.build())
 lib.zki_ntt_plan.restype = C.c_int
-lib.zki_ntt_plan.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
+lib.zki_ntt_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int]
 out = {}
 for L in range(0, 29):
     for free in (0, 1, 3):
-        buf = (C.c_int * 16)()
-        k = lib.zki_ntt_plan(L, free, buf, 8)
-        out["%%d,%%d" %% (L, free)] = [[buf[2 * i], buf[2 * i + 1]] for i in range(k)] if k >= 0 else None
+        for dit in (0, 1):
+            if free and not dit:
+                continue                                   # (only an extension has free stages)
+            buf = (C.c_int * 16)()
+            k = lib.zki_ntt_plan(L, free, dit, buf, 8)
+            out["%%d,%%d%%s" %% (L, free, ",dit" if dit and not free else "")] = [[buf[2 * i], buf[2 * i + 1]] for i in range(k)] if k >= 0 else None
 print("RESULT " + json.dumps(out))
 """ % ROOT
 
@@ -35,7 +38,7 @@ def _plans(env):
 
 def _well_formed(plans):
     for key, plan in plans.items():
-        L, free = map(int, key.split(","))
+        L, free = map(int, key.split(",")[:2])
         assert plan, key
         assert sum(r for _, r in plan) == L, (key, plan)
         assert plan[-1][0] == 0, (key, plan)
@@ -58,15 +61,21 @@ def test_swap_plans_use_the_new_kernels_shapes():
     q = _plans({"ZK_NTT_SWAP": "1", "ZK_NTT_SWAP_CONTIG": "0"})
     _well_formed(q)
     d = _plans({"ZK_NTT_SWAP": "0"})
-    for L in range(17, 21):                              # values -> coefficients: strided L - 10 in 7 .. 10, the wave kernel's 10
+    for L in range(11, 21):                              # values -> coefficients: the wave kernel's 10 + a strided pass of 1 .. 10 row bits
         assert p["%d,0" % L] == [[10, L - 10], [0, 10]]
-    for L in range(18, 22):                              # rate_bits = 1: the contiguous pass takes the free stage as well
-        assert p["%d,1" % L] == [[11, L - 11], [0, 11]]
+    for L in range(15, 22):                              # rate_bits = 1: the contiguous pass takes the free stage as well; the strided
+        assert p["%d,1" % L] == [[11, L - 11], [0, 11]]     # pass of coefficients -> values needs >= 4 row bits
+    for L in range(14, 21):                              # coefficients -> values without extension
+        assert p["%d,0,dit" % L] == [[10, L - 10], [0, 10]]
+    for key in ("12,1", "13,1", "14,1", "11,0,dit", "12,0,dit", "13,0,dit"):
+        assert p[key] == d[key], key
     assert p["21,0"] == [[11, 10], [0, 11]] and p["22,0"] == [[12, 10], [0, 12]] and p["22,1"] == [[12, 10], [0, 12]]
     for key in d:                                        # everything the new kernels do not cover keeps the old plan
-        L, free = map(int, key.split(","))
-        if free > 1 or L < 17 or L > 22:
+        L, free = map(int, key.split(",")[:2])
+        if free > 1 or L < 11 or L > 22:
             assert p[key] == d[key] and q[key] == d[key], key
+        if L < 17:
+            assert q[key] == d[key], key                 # (strided kernels only: nothing below 2^17)
     assert q["20,0"] == [[11, 9], [0, 11]] and q["21,1"] == [[11, 10], [0, 11]]      # strided kernels only: contiguous 11 | 12 by the tile kernel
 
 

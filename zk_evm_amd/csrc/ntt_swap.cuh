@@ -132,16 +132,22 @@ __device__ __forceinline__ void ntt_swap16(u64 (&v)[16]) {
 // block-order table at first[j] + (the row bits above the stage's), first[j] = (2^(s_top + j) - 1) + (H << j): level s_top + j, H =
 // the index of this six-bit group among its peers.
 // On exit registers [3..0] = [q1 q0 q3 q2], lane bit 5 = q5, lane bit 4 = q4.
+// STAGES < 6: only the first STAGES of them (ntt_strided_reg_kernel: the bits below are column bits); the layout then stays the
+// entry layout (STAGES <= 4) or registers [3..0] = [q1 q4 q3 q2], lane 5 = q5, lane 4 = q0 (STAGES = 5).
+template <int STAGES = 6>
 __device__ __forceinline__ void ntt_swap_dif6(u64 (&v)[16], const u64 *tw, __amdgpu_buffer_rsrc_t twr, int s_top, u32 H, u32 l4, u32 l5) {
     const ntt_const_u64p ctw = (ntt_const_u64p)(unsigned long long)tw;
     auto first = [&](int j) { return ((1u << (s_top + j)) - 1) + (H << j); };
     // the per-lane twiddles of the last two stages are requested FIRST: a wave's vector loads return in order, and these have
     // the four scalar-twiddle stages to arrive in (issued where they are used, each stage would stall on its own loads)
     u64 w4[8], w5[8];
-    {
-        const u32 b4 = first(4), b5 = first(5);
+    if (STAGES > 4) {
+        const u32 b4 = first(4);
 #pragma unroll
         for (int i = 0; i < 8; ++i) w4[i] = ntt_tw_load(twr, l5 * 64, b4 + i);
+    }
+    if (STAGES > 5) {
+        const u32 b5 = first(5);
 #pragma unroll
         for (int i = 0; i < 8; ++i) w5[i] = ntt_tw_load(twr, (l5 * 16 + l4 * 8) * 8, b5 + i);
     }
@@ -149,27 +155,27 @@ __device__ __forceinline__ void ntt_swap_dif6(u64 (&v)[16], const u64 *tw, __amd
         const u64 w = ctw[first(0)];
         ZK_NTT_STAGE16(3, w)
     }
-    {   // q4 = register bit 2; twiddle by q5 = register bit 3
+    if (STAGES > 1) {   // q4 = register bit 2; twiddle by q5 = register bit 3
         const u32 b = first(1);
         const u64 w[2] = {ctw[b], ctw[b + 1]};
         ZK_NTT_STAGE16(2, w[m >> 3])
     }
-    {   // q3 = register bit 1; twiddle by (q5 q4) = register bits (3 2)
+    if (STAGES > 2) {   // q3 = register bit 1; twiddle by (q5 q4) = register bits (3 2)
         const u32 b = first(2);
         const u64 w[4] = {ctw[b], ctw[b + 1], ctw[b + 2], ctw[b + 3]};
         ZK_NTT_STAGE16(1, w[m >> 2])
     }
-    {   // q2 = register bit 0; twiddle by (q5 q4 q3) = register bits (3 2 1)
+    if (STAGES > 3) {   // q2 = register bit 0; twiddle by (q5 q4 q3) = register bits (3 2 1)
         const u32 b = first(3);
         const u64 w[8] = {ctw[b], ctw[b + 1], ctw[b + 2], ctw[b + 3], ctw[b + 4], ctw[b + 5], ctw[b + 6], ctw[b + 7]};
         ZK_NTT_STAGE16(0, w[m >> 1])
     }
     // registers [q5 q4 q3 q2], lane 5 = q1, lane 4 = q0
-    {   // q1 (lane 5) <-> register bit 3 (q5); twiddle by (q5 q4 q3 q2) = (lane 5, registers 2 1 0)
+    if (STAGES > 4) {   // q1 (lane 5) <-> register bit 3 (q5); twiddle by (q5 q4 q3 q2) = (lane 5, registers 2 1 0)
         ntt_swap16<5, 3>(v);
         ZK_NTT_STAGE16(3, w4[m & 7])
     }
-    {   // q0 (lane 4) <-> register bit 2 (q4); twiddle by (q5 q4 q3 q2 q1) = (lane 5, lane 4, registers 1 0 3)
+    if (STAGES > 5) {   // q0 (lane 4) <-> register bit 2 (q4); twiddle by (q5 q4 q3 q2 q1) = (lane 5, lane 4, registers 1 0 3)
         ntt_swap16<4, 2>(v);
         ZK_NTT_STAGE16(2, w5[((m >> 1) & 1) * 4 + (m & 1) * 2 + (m >> 3)])
     }
@@ -185,8 +191,11 @@ __device__ __forceinline__ constexpr u32 ntt_swap_dif6_row(int m) { return ((m &
 // NB arrays go through the same stages with the same twiddles (the two cosets of the contiguous kernel): each twiddle is loaded once.
 // Every stage's twiddles are requested one stage AHEAD of their use (a wave's vector loads return in order: requested where
 // they are used, each stage would start with a full cache round trip).
-template <int NB>
+// STAGES < 6 (4 or 5): only the first STAGES of them (ntt_strided_reg_kernel: the bits above are column bits); the layout then
+// stays the entry layout (STAGES = 4) or registers [3..0] = [q4 q1 q3 q2], lane 5 = q0, lane 4 = q5 (STAGES = 5).
+template <int NB, int STAGES = 6>
 __device__ __forceinline__ void ntt_swap_dit6(u64 (&vv)[NB][16], __amdgpu_buffer_rsrc_t twr, int log_d, u32 xl8, u32 l4, u32 l5) {
+    static_assert(STAGES >= 4 && STAGES <= 6, "the four register stages, then one swap per lane stage");
     auto lvl = [&](int k) { return (1u << (log_d + k)) - 1; };
     const u64 w0 = ntt_tw_load(twr, xl8, lvl(0));
     const u64 w1[2] = {ntt_tw_load(twr, xl8, lvl(1)), ntt_tw_load(twr, xl8, lvl(1) + (1u << log_d))};
@@ -206,7 +215,7 @@ __device__ __forceinline__ void ntt_swap_dit6(u64 (&vv)[NB][16], __amdgpu_buffer
         ZK_NTT_STAGE16N(0, w2[((m >> 2) & 1) * 2 + (m >> 3)])
     }
     u64 w4[8];
-    {
+    if (STAGES > 4) {
         const u32 lo8 = xl8 + ((l5 << log_d) << 3);
 #pragma unroll
         for (int i = 0; i < 8; ++i) w4[i] = ntt_tw_load(twr, lo8, lvl(4) + ((u32)(((i >> 1) & 1) * 8 + (i & 1) * 4 + ((i >> 2) & 1) * 2) << log_d));
@@ -215,17 +224,17 @@ __device__ __forceinline__ void ntt_swap_dit6(u64 (&vv)[NB][16], __amdgpu_buffer
         ZK_NTT_STAGE16N(1, w3[(m & 1) * 4 + ((m >> 2) & 1) * 2 + (m >> 3)])
     }
     u64 w5[8];
-    {
+    if (STAGES > 5) {
         const u32 lo8 = xl8 + (((l4 * 2 + l5) << log_d) << 3);
 #pragma unroll
         for (int i = 0; i < 8; ++i)      // i = the butterfly's register bits (3 1 0)
             w5[i] = ntt_tw_load(twr, lo8, lvl(5) + ((u32)(((i >> 2) & 1) * 16 + ((i >> 1) & 1) * 8 + (i & 1) * 4) << log_d));
     }
-    {   // k = 4: q4 (lane 5) <-> register bit 3 (q0); twiddle by (q3 q2 q1 q0) = (registers 1 0 2, lane 5)
+    if (STAGES > 4) {   // k = 4: q4 (lane 5) <-> register bit 3 (q0); twiddle by (q3 q2 q1 q0) = (registers 1 0 2, lane 5)
         _Pragma("unroll") for (int b = 0; b < NB; ++b) ntt_swap16<5, 3>(vv[b]);
         ZK_NTT_STAGE16N(3, w4[m & 7])
     }
-    {   // k = 5: q5 (lane 4) <-> register bit 2 (q1); twiddle by (q4 q3 q2 q1 q0) = (registers 3 1 0, lane 4, lane 5)
+    if (STAGES > 5) {   // k = 5: q5 (lane 4) <-> register bit 2 (q1); twiddle by (q4 q3 q2 q1 q0) = (registers 3 1 0, lane 4, lane 5)
         _Pragma("unroll") for (int b = 0; b < NB; ++b) ntt_swap16<4, 2>(vv[b]);
         ZK_NTT_STAGE16N(2, w5[(m >> 3) * 4 + (m & 3)])
     }
@@ -321,7 +330,7 @@ __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass
             for (int m = 0; m < 16; ++m) v[m] = ntt_ld(sb + ((size_t)ntt_swap_dit6_row_in(m) << log_d), ld8);
         }
         const u32 xl8 = ((lo_tile << ZK_NTT_SWAP_LOG_T) + u) * 8;
-        ntt_swap_dit6<1>(vv, twr, log_d, xl8, l4, l5);
+        ntt_swap_dit6<1, 6>(vv, twr, log_d, xl8, l4, l5);
         // the twiddles of the stages after the exchange (t = (m << (R - 4)) | tb2 there; stage k: t mod 2^k = ((m mod 2^(k - R + 4)) <<
         // (R - 4)) | tb2): requested now, so that they arrive during the exchange
         const u32 tb2 = (wv << 2) | (l5 << 1) | l4;
@@ -360,6 +369,71 @@ __global__ void __launch_bounds__(64 << (R - 6)) ntt_strided_swap_kernel(NttPass
             const u32 so8 = (u + (((l5 << 1) | l4) << log_d)) * 8;
 #pragma unroll
             for (int m = 0; m < 16; ++m) ntt_st(db + ((size_t)m << (R - 4 + log_d)), so8, p.last_pass ? gl_canon(v[m]) : v[m]);
+        }
+    }
+}
+
+// ---- the strided pass with few row bits: one WAVE per tile, no LDS ------------------------------------------------------------------
+// R <= 6 row bits: a wave's 2^10 elements are 2^R rows x 2^(10 - R) CONTIGUOUS columns (R = 4: the sixteen rows of a column in the
+// lane's sixteen registers, the 64 lanes 512 contiguous bytes of a row), i.e. the six-bit group of ntt_swap_dif6 / _dit6 with
+// 6 - R of its bits being column bits: below the rows for values -> coefficients (the group's LAST stages fall away, and with them
+// the swaps: R <= 4 needs none), above them for coefficients -> values (again the last stages).  Loads and stores straight from /
+// to global memory in the group's entry / exit layout: no LDS, no barrier, four independent waves per workgroup.
+// values -> coefficients: R = 1 .. 6 (every twiddle scalar up to R = 4); coefficients -> values: R = 4 .. 6 (below that column bits
+// would sit in registers and a lane's twiddle position would differ per register).  Needs log_d >= 10 - R.
+template <bool DIT, int R>
+__global__ void __launch_bounds__(256) ntt_strided_reg_kernel(NttPass p) {
+    static_assert(R >= 1 && R <= 6 && (!DIT || R >= 4), "see above");
+    constexpr int C = 6 - R;                       // column bits inside the six-bit group
+    const int log_d = p.log_d;
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = ntt_uniform(tid >> 6), u = lane & 15, l4 = (lane >> 4) & 1, l5 = lane >> 5;
+    const u32 tile_id = (p.cols_fastest ? blockIdx.y : blockIdx.x) * 4 + wv;
+    const u32 col_id = p.cols_fastest ? blockIdx.x : blockIdx.y;
+    if (((size_t)tile_id << ZK_NTT_WAVE_BITS) >> p.log_n) return;                 // (whole waves leave: nothing is shared)
+    const int log_blocks = log_d - 4 - C;          // wave tiles side by side in a row of d elements
+    const u32 hi_idx = tile_id >> log_blocks, lo_block = tile_id & ((1u << log_blocks) - 1);
+    const u32 base = (hi_idx << (log_d + R)) + (lo_block << (4 + C));
+    const u64 *src = p.src + (size_t)col_id * p.src_stride + base;
+    u64 *dst = p.dst + (size_t)col_id * p.dst_stride + base;
+    const __amdgpu_buffer_rsrc_t twr = ntt_tw_rsrc(p.tw);
+    u64 vv[1][16];
+    u64 (&v)[16] = vv[0];
+    // element of the group's index q (six bits) and lane column u: values -> coefficients q = [row | column bits], the other way
+    // q = [column bits | row]
+    auto offset = [&](u32 q) {
+        const u32 row = DIT ? (q & ((1u << R) - 1)) : (q >> C), ch = DIT ? (q >> R) : (q & ((1u << C) - 1));
+        return (row << log_d) + (ch << 4);
+    };
+    if constexpr (!DIT) {
+        // entry: registers [3..0] = [q5 q4 q3 q2], lane 5 = q1, lane 4 = q0
+        const u32 ql = (l5 << 1) | l4;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = src[offset(((u32)m << 2) | ql) + u];
+        ntt_swap_dif6<R>(v, p.tw, twr, p.log_n - log_d - R, hi_idx, l4, l5);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            u32 q;
+            if (R <= 4) q = ((u32)m << 2) | ql;                                                           // as on entry
+            else if (R == 5) q = (l5 << 5) | ((m & 4) << 2) | ((m & 2) << 2) | ((m & 1) << 2) | ((m & 8) >> 2) | l4;   // registers [q1 q4 q3 q2], lane 5 = q5
+            else q = (l5 << 5) | (l4 << 4) | ntt_swap_dif6_row(m);
+            dst[offset(q) + u] = p.last_pass ? gl_canon(v[m]) : v[m];
+        }
+    } else {
+        // entry: registers [3..0] = [q0 q1 q3 q2], lane 5 = q4, lane 4 = q5
+        const u32 ql = (l4 << 5) | (l5 << 4);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) v[m] = src[offset(ql | ntt_swap_dit6_row_in(m)) + u];
+        // the lane's position below the rows: tile's column block, the group's column bits (lane bits here: C <= 2), u
+        const u32 chl = C == 2 ? ((l4 << 1) | l5) : C == 1 ? l4 : 0;
+        const u32 xl8 = ((lo_block << (4 + C)) + (chl << 4) + u) * 8;
+        ntt_swap_dit6<1, R>(vv, twr, log_d, xl8, l4, l5);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            u32 q;
+            if (R == 4) q = ql | ntt_swap_dit6_row_in(m);                                                   // as on entry
+            else if (R == 5) q = (l4 << 5) | ((m & 8) << 1) | ((m & 2) << 2) | ((m & 1) << 2) | ((m & 4) >> 1) | l5;   // registers [q4 q1 q3 q2], lane 5 = q0
+            else q = ntt_swap_dit6_row(m) | (l4 << 1) | l5;
+            dst[offset(q) + u] = p.last_pass ? gl_canon(v[m]) : v[m];
         }
     }
 }
@@ -517,7 +591,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))
         for (int m = 0; m < 16; ++m) vv[b][m] = lds[ntt_wave_lds(ntt_swap_dit6_row_in(m) | rl, u)];
     }
     // six stages on the row bits (pairs 2^(4 + k) apart: the level table with log_d = 4 and the segment position u below)
-    ntt_swap_dit6<NB>(vv, twr, 4, u * 8, l4, l5);
+    ntt_swap_dit6<NB, 6>(vv, twr, 4, u * 8, l4, l5);
     // lane 5 = row bit 0, lane 4 = row bit 1; registers [3..0] = row bits [4 5 3 2]; the NB values of an element leave together
     const u32 ro = (l4 << 1) | l5;
 #pragma unroll

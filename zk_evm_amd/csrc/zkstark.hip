@@ -714,9 +714,9 @@ extern "C" size_t zki_ntt_tune_export(char *out, size_t max) {
 }
 // (internal, for tests/test_ntt_plan_cpu.py: no device involved) the passes ntt_host.inc plans for a 2^L-point transform whose
 // contiguous pass gets `free_stages` stages by replication: out[2 k] = log_d, out[2 k + 1] = r of pass k, largest distance first
-extern "C" int zki_ntt_plan(int L, int free_stages, int *out, int max_passes) {
+extern "C" int zki_ntt_plan(int L, int free_stages, int dit, int *out, int max_passes) {
     if (L < 0 || L > 31 || free_stages < 0 || !out) return -1;
-    const auto plan = plan_passes_for(L, free_stages, kNttSwap != 0);      // (the lane-swap plan wherever the switch allows one at all)
+    const auto plan = plan_passes_for(L, free_stages, kNttSwap != 0, dit != 0);      // (the lane-swap plan wherever the switch allows one at all)
     int k = 0;
     for (const auto &ps : plan) { if (k >= max_passes) return -1; out[2 * k] = ps.log_d; out[2 * k + 1] = ps.r; ++k; }
     return k;
