@@ -3,7 +3,7 @@
 # only) against the LDS tile kernels, alone and with the column batches of ab_ntt_col_batch.sh.  Checksums must be identical in
 # every line of a shape.
 cd "$(dirname "$0")/.."
-for shape in "116 20" "2431 18" "30 21" "86 19" "9 22" "116 17" "438 13" "40 10"; do
+for shape in "116 20" "2431 18" "30 21" "86 19" "9 22" "116 17" "438 13" "64 14" "300 16" "40 10"; do
   echo -n "shape=$shape swap=2 (autotuned: what a default run does) : "; ZK_NTT_SWAP=2 ZK_NTT_TUNE_VERBOSE=1 timeout 120 tools/kbench $shape 5 2>&1 | tr '\n' ' '; echo
   for cfg in "0 1 0 1" "1 0 0 1" "1 1 0 1" "0 1 0 1" "1 0 0 1" "1 1 0 1" "0 1 96 1" "1 1 96 1" "0 1 96 2" "1 1 96 2" "1 1 192 2"; do
     set -- $cfg
