@@ -17,3 +17,10 @@ for S in 0 1; do
 done
 cd "$ROOT"
 echo "== parity test"; ZK_TEST_UNVALIDATED_PLANS=1 timeout 1500 python -m pytest tests/test_gpu_commit.py -m gpu -x -q -k "lane_swap or fused or persistent" 2>&1 | tail -5 | tee "$OUT/${TAG}_swap_parity_test.log"
+echo "== the headline with the plans arbitrated on the box (default) and with the r04 plans forced"
+QUICK="--steps 5 --warmup 3 --no-cpu-baseline --no-pmc --no-secondary --commit-steps 0 --in-flight 1"
+ZK_NTT_TUNE_VERBOSE=1 timeout 900 python bench.py $QUICK > "$OUT/${TAG}_bench_quick_auto.json" 2> "$OUT/${TAG}_bench_quick_auto.err"; grep "^ntt " "$OUT/${TAG}_bench_quick_auto.err" | cut -c1-220; tail -1 "$OUT/${TAG}_bench_quick_auto.json" | cut -c1-400
+ZK_NTT_SWAP=0 ZK_NTT_COL_BATCH_MB=0 timeout 900 python bench.py $QUICK > "$OUT/${TAG}_bench_quick_r04_plans.json" 2> /dev/null; tail -1 "$OUT/${TAG}_bench_quick_r04_plans.json" | cut -c1-400
+ZK_NTT_TUNE_VERBOSE=1 timeout 900 python bench.py $QUICK --log-ns realistic > "$OUT/${TAG}_bench_quick_realistic_auto.json" 2> "$OUT/${TAG}_bench_quick_realistic_auto.err"; grep "^ntt " "$OUT/${TAG}_bench_quick_realistic_auto.err" | cut -c1-220; tail -1 "$OUT/${TAG}_bench_quick_realistic_auto.json" | cut -c1-300
+ZK_NTT_SWAP=0 ZK_NTT_COL_BATCH_MB=0 timeout 900 python bench.py $QUICK --log-ns realistic > "$OUT/${TAG}_bench_quick_realistic_r04_plans.json" 2> /dev/null; tail -1 "$OUT/${TAG}_bench_quick_realistic_r04_plans.json" | cut -c1-300
+ZK_TREE_BATCH=1 timeout 900 python bench.py $QUICK --log-ns realistic > "$OUT/${TAG}_bench_quick_realistic_tree_batch.json" 2> /dev/null; tail -1 "$OUT/${TAG}_bench_quick_realistic_tree_batch.json" | cut -c1-300
