@@ -644,7 +644,7 @@ def main():
                 out["ntt"]["plan_autotune"] = [ln for ln in _buf.value.decode("ascii", "replace").splitlines() if ln]
                 _l.zki_ntt_tune_export.restype = _C.c_size_t
                 _l.zki_ntt_tune_export.argtypes = [_C.c_char_p, _C.c_size_t]
-                _exp = _C.create_string_buffer(1024)
+                _exp = _C.create_string_buffer(8192)
                 _l.zki_ntt_tune_export(_exp, len(_exp))
                 if _exp.value:        # the counter passes and the secondaries (child processes) run the plans this timed region ran
                     os.environ["ZK_NTT_SWAP_PLANS"] = _exp.value.decode("ascii")

@@ -1,0 +1,117 @@
+"""CPU-only: the NTT plan trials run in a process of their own (csrc/ntt_host.inc ntt_tune_isolated), and whatever happens to
+that process -- verdicts, a crash, a hang, a bad exit, no helper at all -- the calling process gets an answer and keeps running.
+
+The helper is replaced by shell scripts (ZK_NTT_TUNE_HELPER); no device is involved: zki_ntt_swap_verdict is the device-free part
+of ntt_swap_decide."""
+import os
+import stat
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = textwrap.dedent("""
+    import ctypes as C, json, sys
+    from zk_evm_amd import build
+    lib = C.CDLL(build.build())
+    lib.zki_ntt_swap_verdict.restype = C.c_int
+    lib.zki_ntt_swap_verdict.argtypes = [C.c_int] * 4
+    lib.zki_ntt_tune_report.restype = C.c_size_t
+    lib.zki_ntt_tune_report.argtypes = [C.c_char_p, C.c_size_t]
+    libc = C.CDLL(None)
+    libc.getenv.restype = C.c_char_p
+    libc.getenv.argtypes = [C.c_char_p]
+    shapes = [(0, 20, 0), (1, 21, 1), (1, 20, 0), (0, 13, 0), (1, 30, 1)]
+    got = [lib.zki_ntt_swap_verdict(0, *s) for s in shapes]
+    again = [lib.zki_ntt_swap_verdict(0, *s) for s in shapes]
+    buf = C.create_string_buffer(1 << 16)
+    lib.zki_ntt_tune_report(buf, len(buf))
+    print(json.dumps({"got": got, "again": again, "report": buf.value.decode(),
+                      "env": (libc.getenv(b"ZK_NTT_SWAP_PLANS") or b"").decode()}))
+""")
+
+
+def _run(tmp_path, helper_body, extra_env=None, timeout=60):
+    env = {k: v for k, v in os.environ.items() if not k.startswith("ZK_NTT_")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    count = tmp_path / "calls"
+    if helper_body is not None:
+        h = tmp_path / "helper.sh"
+        h.write_text("#!/bin/bash\necho x >> %s\n%s\n" % (count, helper_body))
+        h.chmod(h.stat().st_mode | stat.S_IXUSR)
+        env["ZK_NTT_TUNE_HELPER"] = str(h)
+    else:
+        env["ZK_NTT_TUNE_HELPER"] = str(tmp_path / "no_such_helper")
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    out["calls"] = len(count.read_text().split()) if count.exists() else 0
+    return out
+
+
+def test_helper_verdicts_are_used_once_and_exported(tmp_path):
+    out = _run(tmp_path, 'echo "v20f0=2;d21f1=1;d20f0=2;"; echo "ntt plan values->coefficients 2^20 ... -> lane-swap"')
+    assert out["got"] == [2, 1, 2, 1, -1]          # 2^13: not listed by the helper -> tile; 2^30: no second plan
+    assert out["again"] == out["got"]
+    assert out["calls"] == 1                        # one helper run per process and device
+    assert "v20f0=2;" in out["env"] and "d21f1=1;" in out["env"]
+    assert "lane-swap" in out["report"]
+
+
+def test_helper_gets_inproc_switch_and_device(tmp_path):
+    out = _run(tmp_path, 'echo "dev=$1 inproc=$ZK_NTT_TUNE_INPROC swap=$ZK_NTT_SWAP plans=$ZK_NTT_SWAP_PLANS" >> %s; echo "v20f0=2;"'
+               % (tmp_path / "seen"), extra_env={"ZK_NTT_SWAP_PLANS": "d21f1=2;"})
+    assert (tmp_path / "seen").read_text().strip() == "dev=0 inproc=1 swap=2 plans="
+    assert out["got"][:2] == [2, 2]                 # the inherited verdict and the helper's
+    assert out["env"].startswith("d21f1=2;")
+
+
+@pytest.mark.parametrize("body,why", [
+    ("kill -SEGV $$", "died of signal 11"),
+    ("kill -ABRT $$", "died of signal 6"),
+    ("exit 4", "exited with status 4"),
+    ('echo "rm -rf /; not a verdict"', "not a verdict list"),
+])
+def test_dead_helper_means_tile_kernels_everywhere(tmp_path, body, why):
+    out = _run(tmp_path, body)
+    assert out["got"] == [1, 1, 1, 1, -1]
+    assert why in out["report"] and "tile kernels for every shape" in out["report"]
+    assert out["calls"] == 1
+    # the children of this process must not try again: every shape is pinned to the tile kernels in the environment
+    assert "v20f0=1;" in out["env"] and "d21f1=1;" in out["env"] and "d22f1=1;" in out["env"]
+
+
+def test_hung_helper_is_killed(tmp_path):
+    out = _run(tmp_path, "exec sleep 600", extra_env={"ZK_NTT_TUNE_TIMEOUT_S": "2"}, timeout=40)
+    assert out["got"] == [1, 1, 1, 1, -1]
+    assert "time limit" in out["report"]
+
+
+def test_no_helper(tmp_path):
+    out = _run(tmp_path, None)
+    assert out["got"] == [1, 1, 1, 1, -1]
+    assert "no helper at" in out["report"]
+
+
+def test_inherited_verdicts_need_no_helper(tmp_path):
+    out = _run(tmp_path, "kill -SEGV $$", extra_env={"ZK_NTT_SWAP_PLANS": "v20f0=2;d21f1=2;d20f0=1;v13f0=2;"})
+    assert out["got"] == [2, 2, 1, 2, -1]
+    assert out["calls"] == 0
+
+
+def test_inproc_mode_never_spawns(tmp_path):
+    out = _run(tmp_path, "kill -SEGV $$", extra_env={"ZK_NTT_TUNE_INPROC": "1"})
+    assert out["got"] == [0, 0, 0, 0, -1]          # 0 = "run the trial here" (what the helper process itself sees)
+    assert out["calls"] == 0
+
+
+def test_helper_is_built_next_to_the_library():
+    from zk_evm_amd import build
+    build.build()
+    assert os.access(build.TUNE, os.X_OK)
+    assert os.path.dirname(build.TUNE) == os.path.dirname(build.OUT)

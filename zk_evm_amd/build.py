@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OBJ = os.path.join(_HERE, "csrc", "build")
 OUT = os.path.join(_HERE, "libzkstark_hip.so")
+TUNE = os.path.join(_HERE, "zk_ntt_tune")          # the process the library tries its NTT plans in (csrc/ntt_tune_main.c)
 UNITS = ["zkstark", "zk_airs_a", "zk_airs_b", "zk_airs_c", "zk_airs_d", "zk_plonk", "zk_tracegen"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 _INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)
@@ -41,7 +42,7 @@ def _stale(unit):
 
 
 def needs_build() -> bool:
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or not os.path.exists(TUNE) or os.path.getmtime(TUNE) < os.path.getmtime(OUT):
         return True
     t = os.path.getmtime(OUT)
     return any(_stale(u) or os.path.getmtime(os.path.join(OBJ, u + ".o")) > t for u in UNITS)
@@ -68,6 +69,8 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
                 raise subprocess.CalledProcessError(r.returncode, "hipcc -c %s.hip" % u)
     subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] +
                    [os.path.join(OBJ, u + ".o") for u in UNITS], check=True)
+    subprocess.run([shutil.which("gcc") or "gcc", "-O1", "-o", TUNE, os.path.join(CSRC, "ntt_tune_main.c"),
+                    "-L" + _HERE, "-lzkstark_hip", "-Wl,-rpath,$ORIGIN"], check=True)
     return OUT
 
 

@@ -698,7 +698,8 @@ extern "C" size_t zki_ntt_tune_report(char *out, size_t max) {
 // (internal) the verdicts as ZK_NTT_SWAP_PLANS takes them: what a parent process hands to its children
 extern "C" size_t zki_ntt_tune_export(char *out, size_t max) {
     std::lock_guard<std::mutex> lock(g_ntt_tune_mu);
-    std::string e;
+    std::string e = g_ntt_preset;                    // inherited verdicts and the helper's (after a dead helper: every shape pinned to the tile kernels)
+    if (!e.empty() && e.back() != ';') e += ';';
     for (const auto &kv : g_ntt_tune) {
         char item[48];
         snprintf(item, sizeof item, "%c%df%d=%d;", std::get<1>(kv.first) ? 'd' : 'v', std::get<2>(kv.first), std::get<3>(kv.first), kv.second);
@@ -711,6 +712,29 @@ extern "C" size_t zki_ntt_tune_export(char *out, size_t max) {
     }
     if (out && max) { const size_t n = e.size() < max - 1 ? e.size() : max - 1; memcpy(out, e.data(), n); out[n] = 0; }
     return e.size();
+}
+// (internal; csrc/ntt_tune_main.c, the process ntt_swap_decide spawns) the trial of every transform shape that has a lane-swap plan, in
+// THIS process (the caller runs with ZK_NTT_TUNE_INPROC=1); the verdicts are then in zki_ntt_tune_export / zki_ntt_tune_report
+extern "C" int zki_ntt_tune_all(zk_ctx *ctx) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
+    if (!kNttTuneInproc) return set_err(ctx, ZK_ERR_BAD_ARG, "zki_ntt_tune_all: for a process started with ZK_NTT_TUNE_INPROC=1");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int dit = 0; dit < 2; ++dit)
+        for (int free_stages = 0; free_stages <= dit; ++free_stages)
+            for (int L = ZK_NTT_WAVE_BITS + free_stages; L <= 22; ++L) {
+                if (!ntt_swap_has_plan(dit != 0, L, free_stages)) continue;
+                bool use = false;
+                ZK_TRY(ntt_swap_decide(ctx, dit != 0, L, free_stages, &use));
+            }
+    return ZK_OK;
+}
+// (internal, for tests/test_ntt_tune_isolation.py: no device involved) the verdict for one shape by every way that needs no trial in
+// this process -- the cache, ZK_NTT_SWAP_PLANS, the helper process: 0 = none (ZK_NTT_TUNE_INPROC), 1 = tile, 2 = lane-swap, -1 = the
+// shape has no second plan
+extern "C" int zki_ntt_swap_verdict(int device, int dit, int L, int free_stages) {
+    if (!ntt_swap_has_plan(dit != 0, L, free_stages)) return -1;
+    std::lock_guard<std::mutex> lock(g_ntt_tune_mu);
+    return ntt_swap_verdict_locked(device, dit != 0, L, free_stages);
 }
 // (internal, for tests/test_ntt_plan_cpu.py: no device involved) the passes ntt_host.inc plans for a 2^L-point transform whose
 // contiguous pass gets `free_stages` stages by replication: out[2 k] = log_d, out[2 k + 1] = r of pass k, largest distance first
