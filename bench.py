@@ -446,6 +446,11 @@ def main():
     import zk_evm_amd
     ctx = zk_evm_amd.Context(local)
     ctx.use_torch_current_stream()
+    try:          # the NTT plan trials (a helper process of the library's) before any warm-up, their verdicts in os.environ for every child
+        from zk_evm_amd._lib import settle_ntt_plans
+        settle_ntt_plans(local)
+    except Exception as e:
+        sys.stderr.write("bench: NTT plans not settled up front (%r); the library settles them on first use\n" % (e,))
     hname = "poseidon" if a.hasher == 0 else "keccak25"
     wanted = (set(SECONDARY_LIMITS_S) - EXPLICIT_ONLY) if a.secondary == "all" else {s for s in a.secondary.split(",") if s}
     unknown = wanted - set(SECONDARY_LIMITS_S)
