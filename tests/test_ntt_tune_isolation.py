@@ -25,16 +25,21 @@ CHILD = textwrap.dedent("""
     libc.getenv.restype = C.c_char_p
     libc.getenv.argtypes = [C.c_char_p]
     shapes = [(0, 20, 0), (1, 21, 1), (1, 20, 0), (0, 13, 0), (1, 30, 1)]
+    trees_first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    lib.zki_tree_batch_verdict.restype = C.c_int
+    lib.zki_tree_batch_verdict.argtypes = [C.c_int]
+    trees = lib.zki_tree_batch_verdict(0) if trees_first else None
     got = [lib.zki_ntt_swap_verdict(0, *s) for s in shapes]
+    trees = lib.zki_tree_batch_verdict(0) if trees is None else trees
     again = [lib.zki_ntt_swap_verdict(0, *s) for s in shapes]
     buf = C.create_string_buffer(1 << 16)
     lib.zki_ntt_tune_report(buf, len(buf))
-    print(json.dumps({"got": got, "again": again, "report": buf.value.decode(),
+    print(json.dumps({"got": got, "again": again, "report": buf.value.decode(), "trees": trees,
                       "env": (libc.getenv(b"ZK_NTT_SWAP_PLANS") or b"").decode()}))
 """)
 
 
-def _run(tmp_path, helper_body, extra_env=None, timeout=60):
+def _run(tmp_path, helper_body, extra_env=None, timeout=60, trees_first=0):
     env = {k: v for k, v in os.environ.items() if not k.startswith("ZK_NTT_")}
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     count = tmp_path / "calls"
@@ -46,7 +51,7 @@ def _run(tmp_path, helper_body, extra_env=None, timeout=60):
     else:
         env["ZK_NTT_TUNE_HELPER"] = str(tmp_path / "no_such_helper")
     env.update(extra_env or {})
-    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    r = subprocess.run([sys.executable, "-c", CHILD, str(trees_first)], env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     import json
     out = json.loads(r.stdout.strip().splitlines()[-1])
@@ -61,6 +66,22 @@ def test_helper_verdicts_are_used_once_and_exported(tmp_path):
     assert out["calls"] == 1                        # one helper run per process and device
     assert "v20f0=2;" in out["env"] and "d21f1=1;" in out["env"]
     assert "lane-swap" in out["report"]
+
+
+@pytest.mark.parametrize("trees_first", [0, 1])
+def test_tree_batch_verdict_comes_from_the_same_helper_run(tmp_path, trees_first):
+    out = _run(tmp_path, 'echo "v20f0=2;d21f1=1;T=1;"; echo "tree tops ... -> batched"', trees_first=trees_first)
+    assert out["trees"] == 1 and out["got"][:2] == [2, 1]
+    assert out["calls"] == 1                        # whichever decision is asked for first starts the helper; the other reuses it
+    assert "T=1;" in out["env"]
+    out = _run(tmp_path, 'echo "v20f0=2;"', trees_first=trees_first)      # a helper that skipped the tree trial: per tree
+    assert out["trees"] == 0
+    out = _run(tmp_path, 'echo "v20f0=2;T=1;"', extra_env={"ZK_TREE_BATCH": "0"})       # forced off / on: no question asked
+    assert out["trees"] == 0
+    out = _run(tmp_path, 'kill -SEGV $$', extra_env={"ZK_TREE_BATCH": "1"})
+    assert out["trees"] == 1 and out["got"][0] == 1
+    out = _run(tmp_path, 'kill -SEGV $$', extra_env={"ZK_NTT_SWAP_PLANS": "T=1;"}, trees_first=1)
+    assert out["trees"] == 1 and out["got"][0] == 1 and "T=0" not in out["env"]      # an inherited verdict stands
 
 
 def test_helper_gets_inproc_switch_and_device(tmp_path):
@@ -83,7 +104,8 @@ def test_dead_helper_means_tile_kernels_everywhere(tmp_path, body, why):
     assert why in out["report"] and "tile kernels for every shape" in out["report"]
     assert out["calls"] == 1
     # the children of this process must not try again: every shape is pinned to the tile kernels in the environment
-    assert "v20f0=1;" in out["env"] and "d21f1=1;" in out["env"] and "d22f1=1;" in out["env"]
+    assert "v20f0=1;" in out["env"] and "d21f1=1;" in out["env"] and "d22f1=1;" in out["env"] and "T=0;" in out["env"]
+    assert out["trees"] == 0
 
 
 def test_hung_helper_is_killed(tmp_path):
@@ -99,7 +121,7 @@ def test_no_helper(tmp_path):
 
 
 def test_inherited_verdicts_need_no_helper(tmp_path):
-    out = _run(tmp_path, "kill -SEGV $$", extra_env={"ZK_NTT_SWAP_PLANS": "v20f0=2;d21f1=2;d20f0=1;v13f0=2;"})
+    out = _run(tmp_path, "kill -SEGV $$", extra_env={"ZK_NTT_SWAP_PLANS": "v20f0=2;d21f1=2;d20f0=1;v13f0=2;T=0;"})
     assert out["got"] == [2, 2, 1, 2, -1]
     assert out["calls"] == 0
 
@@ -107,6 +129,7 @@ def test_inherited_verdicts_need_no_helper(tmp_path):
 def test_inproc_mode_never_spawns(tmp_path):
     out = _run(tmp_path, "kill -SEGV $$", extra_env={"ZK_NTT_TUNE_INPROC": "1"})
     assert out["got"] == [0, 0, 0, 0, -1]          # 0 = "run the trial here" (what the helper process itself sees)
+    assert out["trees"] == -1                       # no verdict, none to be had here: per tree
     assert out["calls"] == 0
 
 

@@ -13,6 +13,7 @@
 size_t zki_ntt_tune_report(char *out, size_t max);
 size_t zki_ntt_tune_export(char *out, size_t max);
 int zki_ntt_tune_all(zk_ctx *ctx);
+int zki_tree_batch_trial(zk_ctx *ctx, const unsigned *log_ns);
 
 int main(int argc, char **argv) {
     const int device = argc > 1 ? atoi(argv[1]) : 0;
@@ -21,6 +22,10 @@ int main(int argc, char **argv) {
     if (rc != ZK_OK || !ctx) { fprintf(stderr, "zk_ntt_tune: zk_ctx_create(%d) = %d\n", device, rc); return 3; }
     rc = zki_ntt_tune_all(ctx);
     if (rc != ZK_OK) { fprintf(stderr, "zk_ntt_tune: %d %s\n", rc, zk_last_error(ctx)); zk_ctx_destroy(ctx); return 4; }
+    if (!getenv("ZK_TUNE_SKIP_TREES")) {      /* with the NTT plans just decided: a segment proven with the tree tops per tree and batched */
+        rc = zki_tree_batch_trial(ctx, NULL);
+        if (rc != ZK_OK) { fprintf(stderr, "zk_ntt_tune: tree trial %d %s\n", rc, zk_last_error(ctx)); zk_ctx_destroy(ctx); return 6; }
+    }
     static char verdicts[4096], report[1 << 16];
     zki_ntt_tune_export(verdicts, sizeof verdicts);
     zki_ntt_tune_report(report, sizeof report);

@@ -485,7 +485,15 @@ static int commit_enqueue(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_
 
 // The commitments collected in ctx->tree_batch: wait (on `st`) for each one's large levels, build the remaining levels of all
 // the trees level by level in ONE launch each, read the caps back.  The caller synchronises `st` before commit_finish.
-static const int kTreeBatch = env_int("ZK_TREE_BATCH", 0, 0, 1);
+// ZK_TREE_BATCH: 0 = per tree (r01-r04), 1 = batched, 2 (default) = what the trial process found (tune_host.inc: a whole segment proven
+// both ways, batched only if the proofs are identical and it was faster; ntt_host.inc tree_batch_verdict)
+static const int kTreeBatch = env_int("ZK_TREE_BATCH", 2, 0, 2);
+static thread_local int t_tree_batch_force = -1;          // the trial's own runs
+static bool tree_batch_on(const zk_ctx *ctx) {
+    if (t_tree_batch_force >= 0) return t_tree_batch_force == 1;
+    if (kTreeBatch != 2) return kTreeBatch == 1;
+    return tree_batch_verdict(ctx->device) == 1;
+}
 static int commit_tree_batch_flush(zk_ctx *ctx, const zk_cfg *cfg, hipStream_t st) {
     std::vector<PendingCommit *> items;
     if (ctx->tree_batch) items.swap(*ctx->tree_batch);
@@ -676,6 +684,7 @@ extern "C" int zk_batch_merkle_path(const zk_batch *b, size_t leaf_index, uint64
 #include "stark_host.inc"
 #include "quotient_host.inc"
 #include "segment_host.inc"
+#include "tune_host.inc"
 #include "shard_host.inc"
 #include "comm_host.inc"
 #include "shard_prove_host.inc"
@@ -705,6 +714,7 @@ extern "C" size_t zki_ntt_tune_export(char *out, size_t max) {
         snprintf(item, sizeof item, "%c%df%d=%d;", std::get<1>(kv.first) ? 'd' : 'v', std::get<2>(kv.first), std::get<3>(kv.first), kv.second);
         if (e.find(item) == std::string::npos) e += item;
     }
+    if (g_tree_batch_trial_verdict >= 0 && e.find("T=") == std::string::npos) e += g_tree_batch_trial_verdict ? "T=1;" : "T=0;";
     for (const auto &kv : g_ntt_batch_tune) {
         char item[48];
         snprintf(item, sizeof item, "b%dr%d=%dx%d;", std::get<1>(kv.first), std::get<2>(kv.first), kv.second.first, kv.second.second);
@@ -735,6 +745,12 @@ extern "C" int zki_ntt_swap_verdict(int device, int dit, int L, int free_stages)
     if (!ntt_swap_has_plan(dit != 0, L, free_stages)) return -1;
     std::lock_guard<std::mutex> lock(g_ntt_tune_mu);
     return ntt_swap_verdict_locked(device, dit != 0, L, free_stages);
+}
+// (internal, for tests/test_ntt_tune_isolation.py: no device involved) whether the trace trees' small levels are built together: what
+// ZK_TREE_BATCH says, or (2, the default) what ZK_NTT_SWAP_PLANS / the helper process says ("T=0|1;")
+extern "C" int zki_tree_batch_verdict(int device) {
+    if (kTreeBatch != 2) return kTreeBatch;
+    return tree_batch_verdict(device);
 }
 // (internal, for tests/test_ntt_plan_cpu.py: no device involved) the passes ntt_host.inc plans for a 2^L-point transform whose
 // contiguous pass gets `free_stages` stages by replication: out[2 k] = log_d, out[2 k + 1] = r of pass k, largest distance first
