@@ -655,6 +655,8 @@ def main():
                     os.environ["ZK_NTT_SWAP_PLANS"] = _exp.value.decode("ascii")
                     out["ntt"]["plans_exported"] = os.environ["ZK_NTT_SWAP_PLANS"]
                 out["ntt"]["lane_swap_plans"] = sum("-> lane-swap" in ln for ln in out["ntt"]["plan_autotune"])
+                out["ntt"]["tree_tops_batched"] = any(ln.startswith("tree tops") and ln.rstrip().endswith("-> batched") for ln in out["ntt"]["plan_autotune"])
+                out["ntt"]["trial_process_failed"] = any("tile kernels for every shape" in ln for ln in out["ntt"]["plan_autotune"])
             except Exception as e:
                 out["ntt"]["plan_autotune"] = ["unavailable: %r" % (e,)]
             default_shape = log_ns == [20] * n_tab

@@ -420,7 +420,10 @@ def contract_line(out, extra_path="bench_extra.json"):
                        "traffic_over_algorithmic": _num(n.get("traffic_over_algorithmic"))}
         if n.get("lane_swap_plans") is not None:          # transform shapes the plan autotuner gave to the lane-swap kernels (of those it met)
             line["ntt"]["lane_swap_plans"] = _num(n.get("lane_swap_plans"))
-            line["ntt"]["plans_tuned"] = len(n.get("plan_autotune") or [])
+            line["ntt"]["plans_tuned"] = sum(1 for ln in (n.get("plan_autotune") or []) if ln.startswith("ntt plan"))
+            line["ntt"]["tree_tops_batched"] = bool(n.get("tree_tops_batched"))
+            if n.get("trial_process_failed"):
+                line["ntt"]["trial_process_failed"] = True
     d = out.get("dist") or {}
     if d:
         line["dist"] = {k: d.get(k) for k in ("backend", "world", "ok", "selftest_ok", "fallback", "tried", "payload_device",
