@@ -25,6 +25,8 @@ def test_every_shape_has_a_verdict_after_settling():
     for key in ["v%df0" % l for l in range(10, 23)] + ["d%df1" % l for l in range(11, 23)]:
         assert items.get(key, "1") in ("1", "2"), (key, plans)
     assert items.get("T") in ("0", "1"), plans
+    for l in range(17, 22):                          # column batches of the shapes that have a trial: "<MiB>x<streams>"
+        assert re.fullmatch(r"\d+x[12]", items.get("b%dr1" % l, "")), (l, plans)
     assert os.environ["ZK_NTT_SWAP_PLANS"] == plans
 
 

@@ -31,10 +31,13 @@ CHILD = textwrap.dedent("""
     trees = lib.zki_tree_batch_verdict(0) if trees_first else None
     got = [lib.zki_ntt_swap_verdict(0, *s) for s in shapes]
     trees = lib.zki_tree_batch_verdict(0) if trees is None else trees
+    lib.zki_ntt_batch_verdict.restype = C.c_int
+    lib.zki_ntt_batch_verdict.argtypes = [C.c_int] * 3
+    batches = [lib.zki_ntt_batch_verdict(0, l, 1) for l in (16, 17, 20, 21, 22)]
     again = [lib.zki_ntt_swap_verdict(0, *s) for s in shapes]
     buf = C.create_string_buffer(1 << 16)
     lib.zki_ntt_tune_report(buf, len(buf))
-    print(json.dumps({"got": got, "again": again, "report": buf.value.decode(), "trees": trees,
+    print(json.dumps({"got": got, "again": again, "report": buf.value.decode(), "trees": trees, "batches": batches,
                       "env": (libc.getenv(b"ZK_NTT_SWAP_PLANS") or b"").decode()}))
 """)
 
@@ -43,6 +46,8 @@ def _run(tmp_path, helper_body, extra_env=None, timeout=60, trees_first=0):
     env = {k: v for k, v in os.environ.items() if not k.startswith("ZK_NTT_")}
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     count = tmp_path / "calls"
+    if count.exists():
+        count.unlink()
     if helper_body is not None:
         h = tmp_path / "helper.sh"
         h.write_text("#!/bin/bash\necho x >> %s\n%s\n" % (count, helper_body))
@@ -84,6 +89,21 @@ def test_tree_batch_verdict_comes_from_the_same_helper_run(tmp_path, trees_first
     assert out["trees"] == 1 and out["got"][0] == 1 and "T=0" not in out["env"]      # an inherited verdict stands
 
 
+def test_column_batch_verdicts_come_from_the_helper_too(tmp_path):
+    out = _run(tmp_path, 'echo "v20f0=2;b17r1=0x1;b20r1=96x2;b21r1=96x1;T=0;"')
+    # 2^16 and 2^22 rows have no trial (-1: all at once, nobody asked); 2^17: all at once; 2^20: 96 MiB on two streams; 2^21: on one
+    assert out["batches"] == [-1, 0 * 4 + 1, 96 * 4 + 2, 96 * 4 + 1, -1]
+    assert out["calls"] == 1
+    out = _run(tmp_path, 'echo "v20f0=2;T=0;"')                       # a helper without batch verdicts: all at once
+    assert out["batches"] == [-1, 1, 1, 1, -1]
+    out = _run(tmp_path, "kill -SEGV $$")                             # a dead helper: all at once, and the children are told
+    assert out["batches"] == [-1, 1, 1, 1, -1] and "b20r1=0x1;" in out["env"] and "b21r1=0x1;" in out["env"]
+    out = _run(tmp_path, "kill -SEGV $$", extra_env={"ZK_NTT_COL_BATCH_MB": "64", "ZK_NTT_COL_BATCH_STREAMS": "2"})      # forced
+    assert out["batches"] == [64 * 4 + 2] * 5
+    out = _run(tmp_path, "kill -SEGV $$", extra_env={"ZK_NTT_TUNE_INPROC": "1"})                 # the helper itself: it runs the trial
+    assert out["batches"] == [-1] * 5 and out["calls"] == 0
+
+
 def test_helper_gets_inproc_switch_and_device(tmp_path):
     out = _run(tmp_path, 'echo "dev=$1 inproc=$ZK_NTT_TUNE_INPROC swap=$ZK_NTT_SWAP plans=$ZK_NTT_SWAP_PLANS" >> %s; echo "v20f0=2;"'
                % (tmp_path / "seen"), extra_env={"ZK_NTT_SWAP_PLANS": "d21f1=2;"})
@@ -121,7 +141,7 @@ def test_no_helper(tmp_path):
 
 
 def test_inherited_verdicts_need_no_helper(tmp_path):
-    out = _run(tmp_path, "kill -SEGV $$", extra_env={"ZK_NTT_SWAP_PLANS": "v20f0=2;d21f1=2;d20f0=1;v13f0=2;T=0;"})
+    out = _run(tmp_path, "kill -SEGV $$", extra_env={"ZK_NTT_SWAP_PLANS": "v20f0=2;d21f1=2;d20f0=1;v13f0=2;T=0;b17r1=0x1;b20r1=96x1;b21r1=0x1;"})
     assert out["got"] == [2, 2, 1, 2, -1]
     assert out["calls"] == 0
 

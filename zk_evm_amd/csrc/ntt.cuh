@@ -579,6 +579,16 @@ static __global__ void ntt_tune_compare_kernel(const u64 *a, const u64 *b, size_
     if (i < n && a[i] != b[i]) atomicAdd(mismatches, 1ULL);
 }
 
+// an order-independent 64-bit digest of n words (the column-batch trial, ntt_host.inc: did a batched form produce the same output?)
+static __global__ void ntt_tune_digest_kernel(const u64 *a, size_t n, u64 salt, unsigned long long *acc) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 z = a[i] + (i + 1) * 0x9E3779B97F4A7C15ULL + salt * 0xD1B54A32D192ED03ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    atomicAdd(acc, (unsigned long long)(z ^ (z >> 31)));
+}
+
 // load factors of the SECOND coset for ntt_contig_wave_kernel_dit<2> (ntt_swap.cuh): a wave's 2^11 values are the 2^11-point transform
 // of its 2^10 coefficients in local bit-reversed order, whatever the tile, so value 2 i + 1 is the plain 2^10-point transform of
 // c_i * w^bitrev_10(i mod 2^10), w = the root of order 2^11 -- times the first coset's own factor when there is one

@@ -736,7 +736,7 @@ extern "C" int zki_ntt_tune_all(zk_ctx *ctx) {
                 bool use = false;
                 ZK_TRY(ntt_swap_decide(ctx, dit != 0, L, free_stages, &use));
             }
-    return ZK_OK;
+    return ntt_batch_trials_all(ctx, 1);          // with the plans decided: the column batches of the shapes that have a trial (rate_bits = 1: the STARK tables)
 }
 // (internal, for tests/test_ntt_tune_isolation.py: no device involved) the verdict for one shape by every way that needs no trial in
 // this process -- the cache, ZK_NTT_SWAP_PLANS, the helper process: 0 = none (ZK_NTT_TUNE_INPROC), 1 = tile, 2 = lane-swap, -1 = the
@@ -745,6 +745,14 @@ extern "C" int zki_ntt_swap_verdict(int device, int dit, int L, int free_stages)
     if (!ntt_swap_has_plan(dit != 0, L, free_stages)) return -1;
     std::lock_guard<std::mutex> lock(g_ntt_tune_mu);
     return ntt_swap_verdict_locked(device, dit != 0, L, free_stages);
+}
+// (internal, for tests/test_ntt_tune_isolation.py: no device involved) the column-batch verdict of a shape: MiB * 4 + streams, -1 = none
+extern "C" int zki_ntt_batch_verdict(int device, int log_n, int rate_bits) {
+    if (kNttColBatchMB >= 0) return kNttColBatchMB * 4 + (kNttColBatchStreams ? kNttColBatchStreams : 1);
+    std::lock_guard<std::mutex> lock(g_ntt_tune_mu);
+    std::pair<int, int> v;
+    if (!ntt_batch_verdict_locked(device, log_n, rate_bits, log_n >= 17 && log_n + rate_bits <= 22, &v)) return -1;
+    return v.first * 4 + v.second;
 }
 // (internal, for tests/test_ntt_tune_isolation.py: no device involved) whether the trace trees' small levels are built together: what
 // ZK_TREE_BATCH says, or (2, the default) what ZK_NTT_SWAP_PLANS / the helper process says ("T=0|1;")
