@@ -153,6 +153,22 @@ def test_inproc_mode_never_spawns(tmp_path):
     assert out["calls"] == 0
 
 
+def test_real_helper_is_found_next_to_the_library_and_its_failure_is_survived(tmp_path):
+    """No ZK_NTT_TUNE_HELPER: the library locates zk_ntt_tune through its own path (dladdr).  Without a GPU the helper cannot create a
+    context and exits 3 -- which is one more way for it to fail: tile kernels everywhere."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the real helper would succeed (tests/test_gpu_tune.py)")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("ZK_NTT_")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import json
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["got"] == [1, 1, 1, 1, -1] and out["trees"] == 0
+    assert "exited with status 3" in out["report"], out["report"]
+
+
 def test_helper_is_built_next_to_the_library():
     from zk_evm_amd import build
     build.build()
