@@ -446,11 +446,6 @@ def main():
     import zk_evm_amd
     ctx = zk_evm_amd.Context(local)
     ctx.use_torch_current_stream()
-    try:          # the NTT plan trials (a helper process of the library's) before any warm-up, their verdicts in os.environ for every child
-        from zk_evm_amd._lib import settle_ntt_plans
-        settle_ntt_plans(local)
-    except Exception as e:
-        sys.stderr.write("bench: NTT plans not settled up front (%r); the library settles them on first use\n" % (e,))
     hname = "poseidon" if a.hasher == 0 else "keccak25"
     wanted = (set(SECONDARY_LIMITS_S) - EXPLICIT_ONLY) if a.secondary == "all" else {s for s in a.secondary.split(",") if s}
     unknown = wanted - set(SECONDARY_LIMITS_S)
@@ -638,27 +633,13 @@ def main():
                 "segment_timing_s": timing,
                 "arena": {k: v / 1e9 for k, v in mem.items()},
             }
-            try:          # which NTT plan each transform shape got, and why (ntt_host.inc ntt_swap_decide; ZK_NTT_SWAP = 2)
-                import ctypes as _C
-                from zk_evm_amd._lib import load_library
-                _l = load_library()
-                _l.zki_ntt_tune_report.restype = _C.c_size_t
-                _l.zki_ntt_tune_report.argtypes = [_C.c_char_p, _C.c_size_t]
-                _buf = _C.create_string_buffer(8192)
-                _l.zki_ntt_tune_report(_buf, len(_buf))
-                out["ntt"]["plan_autotune"] = [ln for ln in _buf.value.decode("ascii", "replace").splitlines() if ln]
-                _l.zki_ntt_tune_export.restype = _C.c_size_t
-                _l.zki_ntt_tune_export.argtypes = [_C.c_char_p, _C.c_size_t]
-                _exp = _C.create_string_buffer(8192)
-                _l.zki_ntt_tune_export(_exp, len(_exp))
-                if _exp.value:        # the counter passes and the secondaries (child processes) run the plans this timed region ran
-                    os.environ["ZK_NTT_SWAP_PLANS"] = _exp.value.decode("ascii")
-                    out["ntt"]["plans_exported"] = os.environ["ZK_NTT_SWAP_PLANS"]
-                out["ntt"]["lane_swap_plans"] = sum("-> lane-swap" in ln for ln in out["ntt"]["plan_autotune"])
-                out["ntt"]["tree_tops_batched"] = any(ln.startswith("tree tops") and ln.rstrip().endswith("-> batched") for ln in out["ntt"]["plan_autotune"])
-                out["ntt"]["trial_process_failed"] = any("tile kernels for every shape" in ln for ln in out["ntt"]["plan_autotune"])
-            except Exception as e:
-                out["ntt"]["plan_autotune"] = ["unavailable: %r" % (e,)]
+            # which of the equivalent kernels served this run: the ctx's plan table (data, not a trial; include/zkstark.h zk_ctx_set_plans)
+            plans = ctx.get_plans()
+            out["ntt"]["plans"] = plans
+            out["ntt"]["plans_source"] = "ZK_NTT_SWAP_PLANS" if os.environ.get("ZK_NTT_SWAP_PLANS") else "compiled in"
+            out["ntt"]["lane_swap_plans"] = sum(1 for it in plans.split(";") if it[:1] in ("v", "d") and it.endswith("=2"))
+            out["ntt"]["tree_tops_batched"] = "T=1" in plans.split(";")
+            out["ntt"]["forced"] = {k: os.environ[k] for k in ("ZK_NTT_SWAP", "ZK_TREE_BATCH", "ZK_NTT_COL_BATCH_MB") if os.environ.get(k)}
             default_shape = log_ns == [20] * n_tab
             if a.in_flight > 1:
                 secondaries.append(("in_flight", ["--arena-peak", str(mem["peak_in_use"])]))

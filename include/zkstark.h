@@ -92,6 +92,17 @@ int zk_ctx_set_abort_flag(zk_ctx *ctx, volatile const int *abort_flag);
  * (prover.rs:56) -- the Rust side passes `AtomicBool::as_ptr()` and a store from any thread (`zero`'s abort handler,
  * polled per table at fixed_recursive_verifier.rs:2123) is seen mid-proof.  Either flag aborts; NULL disables this one. */
 int zk_ctx_set_abort_flag_u8(zk_ctx *ctx, volatile const uint8_t *abort_flag);
+/* The plan table.  Three internal decisions have two implementations that produce the same words (the NTT passes of a
+ * transform shape: LDS tile kernels | lane-swap kernels; from_values over all columns at once | in column batches; the small
+ * Merkle levels of a segment's trace trees per tree | batched).  Which one serves a shape is DATA held by the ctx -- a string
+ * of items "v20f0=2;d21f1=2;b20r1=96x1;T=1;" (csrc/ntt_host.inc) -- never a run-time experiment: a ctx starts with the
+ * process's ZK_NTT_SWAP_PLANS (read once, when the library is loaded) or else the table compiled into the library, and this
+ * call replaces it (NULL: back to that initial table; "": the first implementation everywhere).  The library starts no
+ * process, runs no timing trial and never writes the environment; the offline tool `zk_ntt_tune` prints such a string for a
+ * device.  No reference counterpart (the CPU prover has one FFT); results do not depend on the table.
+ * zk_ctx_get_plans copies the current string (NUL-terminated, truncated to max) and returns its full length. */
+int zk_ctx_set_plans(zk_ctx *ctx, const char *plans);
+size_t zk_ctx_get_plans(const zk_ctx *ctx, char *out, size_t max);
 /* Per-stage device timings of the last commit on this ctx, in ms, keyed like the reference's
  * TimingTree scopes (prover.rs:92,99): [0]=ifft [1]=lde/coset-fft [2]=leaf hash [3]=tree. */
 int zk_ctx_last_timings(const zk_ctx *ctx, float out_ms[4]);

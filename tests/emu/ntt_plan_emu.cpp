@@ -122,7 +122,7 @@ static void launch(NttPass p, unsigned n_cols, bool swap_kernels) {
     if (nthr > 1024) nthr = 1024;
     size_t tiles = n / elems;
     if (tiles == 0) tiles = 1;
-    run_grid(n_cols, (unsigned)tiles, nthr, [&] { ntt_pass_kernel<DIT, false>(p); });
+    run_grid(n_cols, (unsigned)tiles, nthr, [&] { ntt_pass_kernel<DIT>(p); });
 }
 static void values_to_coeffs(const u64 *src, u64 *dst, unsigned n_cols, int log_n, const std::vector<Plan> &plan, const u64 *tw, bool swap_kernels) {
     const size_t n = (size_t)1 << log_n;

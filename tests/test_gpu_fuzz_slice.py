@@ -24,11 +24,9 @@ def test_fuzz_slice(mode, seed):
 
 # Paths the library picks by size or by a load-time switch, forced the other way for a fuzz slice of the per-table provers
 # (the device proofs must equal the oracle's word for word on either path): the FRI batch combination on the coefficients
-# (default only from ~2^27 opened coefficients, i.e. never at fuzz heights), the padded LDS layout of the contiguous NTT
-# pass, the tile-major NTT grid, one lane instead of two.
-@pytest.mark.parametrize("env", [{"ZK_FRI_COEFF_COMBINE_MIN_LOG": "0"}, {"ZK_NTT_PAD": "1", "ZK_NTT_COLS_FASTEST": "0"},
-                                 {"ZK_FRI_COEFF_COMBINE": "0", "ZK_LANES": "0"}],
-                         ids=["fri_coeff_combine", "ntt_pad_tile_major", "value_combine_one_lane"])
+# (default only from ~2^27 opened coefficients, i.e. never at fuzz heights), one lane instead of two.
+@pytest.mark.parametrize("env", [{"ZK_FRI_COEFF_COMBINE_MIN_LOG": "0"}, {"ZK_FRI_COEFF_COMBINE": "0", "ZK_LANES": "0"}],
+                         ids=["fri_coeff_combine", "value_combine_one_lane"])
 def test_fuzz_slice_alternate_paths(env):
     cmd = [sys.executable, "-m", "tests.fuzz_parity", "12", "4242"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, **env))

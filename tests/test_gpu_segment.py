@@ -998,25 +998,3 @@ def test_check_ctls_debug_mode(oracle):
     with pytest.raises(zk.ZkStarkError, match="check_ctls: CTL 6 is not balanced"):
         run(traces, (kh ^ 1, len(code)))                               # the Memory CTL's extra looking rows
     run(bad, None)                                                     # without the switch the prover does not care
-
-
-@pytest.mark.skipif(os.environ.get("ZK_TEST_UNVALIDATED_PLANS", "0") != "1",
-                    reason="the optional plans of r05 were written while the round had no GPU access: opt in with "
-                           "ZK_TEST_UNVALIDATED_PLANS=1 until a hardware run has pinned them (tools/r05_ntt_round.sh)")
-@pytest.mark.parametrize("switches", [{"ZK_TREE_BATCH": "1"}, {"ZK_TREE_BATCH": "1", "ZK_LANES": "0"}, {"ZK_NTT_SWAP": "1"},
-                                      {"ZK_NTT_SWAP": "1", "ZK_NTT_COL_BATCH_MB": "8", "ZK_TREE_BATCH": "1", "ZK_TREE_BATCH_TOP_LOG": "12"}],
-                         ids=["tree_batch", "tree_batch_lanes_off", "ntt_swap", "all"])
-def test_optional_plans_prove_the_same_segments(switches):
-    """The plans that are read from the environment once at load time -- the trace trees' small levels built for all nine trees
-    at once (ZK_TREE_BATCH, r05), the lane-swap NTT kernels (ZK_NTT_SWAP), column batches -- against the ORACLE, not against
-    the default plan: the whole-segment parity tests of this file (2^4 .. 2^5 and 2^12 .. 2^17 rows, both hashers) in a child
-    pytest with the switches set."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_segment.py"), "-m", "gpu", "-x", "-q",
-                        "-k", "test_segment_proof_matches_oracle or test_segment_matches_golden_fixture", "-p", "no:cacheprovider"],
-                       capture_output=True, text=True, cwd=root, env=dict(os.environ, PYTHONPATH=root, **switches), timeout=1500)
-    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
-    assert " passed" in r.stdout and "failed" not in r.stdout

@@ -77,18 +77,3 @@ def test_swap_plans_use_the_new_kernels_shapes():
         if L < 17:
             assert q[key] == d[key], key                 # (strided kernels only: nothing below 2^17)
     assert q["20,0"] == [[11, 9], [0, 11]] and q["21,1"] == [[11, 10], [0, 11]]      # strided kernels only: contiguous 11 | 12 by the tile kernel
-
-
-def test_verdicts_can_be_handed_to_a_child_process():
-    """ZK_NTT_SWAP_PLANS (what bench.py exports after its timed region so that its rocprofv3 passes and secondaries run the same
-    plans): the export of a process without any verdict is empty, and the string's items have the documented form."""
-    import ctypes as C
-    from zk_evm_amd import build
-    lib = C.CDLL(build.build())
-    lib.zki_ntt_tune_export.restype = C.c_size_t
-    lib.zki_ntt_tune_export.argtypes = [C.c_char_p, C.c_size_t]
-    lib.zki_ntt_tune_report.restype = C.c_size_t
-    lib.zki_ntt_tune_report.argtypes = [C.c_char_p, C.c_size_t]
-    buf = C.create_string_buffer(256)
-    assert lib.zki_ntt_tune_export(buf, len(buf)) == 0 and buf.value == b""
-    assert lib.zki_ntt_tune_report(buf, len(buf)) == 0 and buf.value == b""

@@ -1,6 +1,6 @@
 # A/B of an environment switch inside one gpurun call.  Usage: ab_env.sh VAR "test -k expression"
 cd $GRAFT_REPO_ROOT
-VAR=${1:-ZK_NTT_PAD}
+VAR=${1:-ZK_NTT_SWAP}
 QUICK="--steps 6 --warmup 2 --no-cpu-baseline --no-secondary --commit-steps 0 --in-flight 1 --no-pmc --no-dist-selftest"
 timeout 900 python -m pytest tests -m gpu -x -q -k "${2:-ntt or commit or kat or segment_proof_matches_oracle}" 2>&1 | tail -2
 for rep in 1 2 3; do

@@ -4,7 +4,6 @@
 # every line of a shape.
 cd "$(dirname "$0")/.."
 for shape in "116 20" "2431 18" "30 21" "86 19" "9 22" "116 17" "438 13" "64 14" "300 16" "40 10"; do
-  echo -n "shape=$shape swap=2 (autotuned: what a default run does) : "; ZK_NTT_SWAP=2 ZK_NTT_TUNE_INPROC=1 ZK_NTT_TUNE_VERBOSE=1 timeout 120 tools/kbench $shape 5 2>&1 | tr '\n' ' '; echo
   for cfg in "0 1 0 1" "1 0 0 1" "1 1 0 1" "0 1 0 1" "1 0 0 1" "1 1 0 1" "0 1 96 1" "1 1 96 1" "0 1 96 2" "1 1 96 2" "1 1 192 2"; do
     set -- $cfg
     echo -n "shape=$shape swap=$1 contig=$2 batch_MB=$3 streams=$4 : "; ZK_NTT_SWAP=$1 ZK_NTT_SWAP_CONTIG=$2 ZK_NTT_COL_BATCH_MB=$3 ZK_NTT_COL_BATCH_STREAMS=$4 timeout 120 tools/kbench $shape 5 | tr '\n' ' '; echo

@@ -418,12 +418,12 @@ def contract_line(out, extra_path="bench_extra.json"):
     if n:
         line["ntt"] = {"achieved_GBs": _num(n.get("achieved_GBs")), "frac": _num(n.get("frac_of_hbm_peak")),
                        "traffic_over_algorithmic": _num(n.get("traffic_over_algorithmic"))}
-        if n.get("lane_swap_plans") is not None:          # transform shapes the plan autotuner gave to the lane-swap kernels (of those it met)
+        if n.get("lane_swap_plans") is not None:          # the ctx's plan table: transform shapes on the lane-swap kernels, tree tops batched
             line["ntt"]["lane_swap_plans"] = _num(n.get("lane_swap_plans"))
-            line["ntt"]["plans_tuned"] = sum(1 for ln in (n.get("plan_autotune") or []) if ln.startswith("ntt plan"))
             line["ntt"]["tree_tops_batched"] = bool(n.get("tree_tops_batched"))
-            if n.get("trial_process_failed"):
-                line["ntt"]["trial_process_failed"] = True
+            line["ntt"]["plans_source"] = n.get("plans_source")
+            if n.get("forced"):
+                line["ntt"]["forced"] = n.get("forced")
     d = out.get("dist") or {}
     if d:
         line["dist"] = {k: d.get(k) for k in ("backend", "world", "ok", "selftest_ok", "fallback", "tried", "payload_device",

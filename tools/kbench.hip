@@ -68,9 +68,9 @@ int main(int argc, char **argv) {
     hipSetDevice(0);
     hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking);
     ctx->stream = ctx->own_stream;
+    ctx->plans = initial_plans();          // ZK_NTT_SWAP_PLANS / the table compiled in; ZK_NTT_SWAP=0|1 forces one form
     hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     u64 *vals, *coeffs, *lde, *dig;
     const size_t nd = zk_merkle_num_digests(log_N, cap_height);
     hipMalloc(&vals, cols * n * 8); hipMalloc(&coeffs, cols * n * 8); hipMalloc(&lde, cols * N * 8); hipMalloc(&dig, nd * 32);
@@ -82,7 +82,7 @@ int main(int argc, char **argv) {
     double tot[4] = {0, 0, 0, 0};
     for (int it = 0; it < reps + 1; ++it) {
         hipEventRecord(ev[0], ctx->stream);
-        // the commitment's own plan (ZK_NTT_FUSE=0: the two separate transforms); ev[1] = after the fused pass
+        // the commitment's own plan; ev[1] = between the two transforms
         int rc = ntt_values_to_coeffs_to_lde(ctx, vals, n, coeffs, n, lde, N, cols, log_n, rate_bits, coset, ev[1]);
         hipEventRecord(ev[2], ctx->stream);
         if (rc == ZK_OK) rc = hash_rows(ctx, ZK_HASH_POSEIDON, lde, N, cols, N, log_N, 1, dig);
@@ -97,16 +97,5 @@ int main(int argc, char **argv) {
            tot[0], tot[1], tot[2], tot[3], 40.0 * cols * n / ((tot[0] + tot[1]) * 1e-3) / 1e9);
     printf("fnv coeffs %016llx lde %016llx digests %016llx\n", (unsigned long long)checksum(ctx, coeffs, cols * n),
            (unsigned long long)checksum(ctx, lde, cols * N), (unsigned long long)checksum(ctx, dig, nd * 4));
-#ifdef ZK_NTT_DEBUG
-    if (getenv("ZK_NTT_NT") && (atoi(getenv("ZK_NTT_NT")) & 64)) {
-        u64 tr[16];
-        hipMemcpyFromSymbol(tr, HIP_SYMBOL(zk_ntt_trace), sizeof tr);
-        const char *nm[8] = {"top (copy, index)", "step 1 + waits (tile, t1)", "issue T, N", "exchange 1", "step 2 + wait (t2; prev N)", "exchange 2", "step 3 (+ wait t3)", "issue A, S"};
-        double tot = 0;
-        for (int k = 0; k < 8; ++k) tot += (double)tr[k];
-        printf("persistent strided pass (last launched), one wave, %llu bodies, %.2f us per body:\n", (unsigned long long)tr[9], tot / tr[9] / 100.0);
-        for (int k = 0; k < 8; ++k) printf("    %-30s %7.2f us\n", nm[k], (double)tr[k] / tr[9] / 100.0);
-    }
-#endif
     return 0;
 }

@@ -41,6 +41,8 @@ SIGNATURES = {
     "zk_last_error": (C.c_char_p, [vp]),
     "zk_ctx_set_abort_flag": (C.c_int, [vp, vp]),
     "zk_ctx_set_abort_flag_u8": (C.c_int, [vp, vp]),
+    "zk_ctx_set_plans": (C.c_int, [vp, C.c_char_p]),
+    "zk_ctx_get_plans": (C.c_size_t, [vp, C.c_char_p, C.c_size_t]),
     "zk_ctx_last_timings": (C.c_int, [vp, C.POINTER(C.c_float)]),
     "zk_ctx_commit_totals": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int]),
@@ -201,26 +203,3 @@ def load_library():
         fn.argtypes = args
     _lib = lib
     return lib
-
-
-def settle_ntt_plans(device: int = 0) -> str:
-    """Have the library decide its NTT plans for `device` NOW (csrc/ntt_host.inc: the trials run in the helper process
-    zk_ntt_tune next to the library; a dead helper means the tile kernels everywhere) and copy the verdicts into os.environ, so
-    that child processes started with an explicit `env=` neither repeat the trials nor disagree with this process.  Returns
-    the verdict string (the form ZK_NTT_SWAP_PLANS takes); "" if plans are forced (ZK_NTT_SWAP=0 / 1).  bench.py calls this
-    before its warm-up, tests/conftest.py once per GPU session."""
-    lib = load_library()
-    lib.zki_ntt_swap_verdict.restype = C.c_int
-    lib.zki_ntt_swap_verdict.argtypes = [C.c_int] * 4
-    lib.zki_ntt_tune_export.restype = C.c_size_t
-    lib.zki_ntt_tune_export.argtypes = [C.c_char_p, C.c_size_t]
-    if os.environ.get("ZK_NTT_SWAP", "2") not in ("2", ""):
-        return ""
-    lib.zki_ntt_swap_verdict(int(device), 0, 20, 0)
-    buf = C.create_string_buffer(8192)
-    lib.zki_ntt_tune_export(buf, len(buf))
-    plans = buf.value.decode("ascii", "replace")
-    if plans:
-        os.environ["ZK_NTT_SWAP_PLANS"] = plans
-    return plans
-

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OBJ = os.path.join(_HERE, "csrc", "build")
 OUT = os.path.join(_HERE, "libzkstark_hip.so")
-TUNE = os.path.join(_HERE, "zk_ntt_tune")          # the process the library tries its NTT plans in (csrc/ntt_tune_main.c)
+TUNE = os.path.join(_HERE, "zk_ntt_tune")          # the offline tuner of the plan table (csrc/ntt_tune_main.c); the library never runs it
 UNITS = ["zkstark", "zk_airs_a", "zk_airs_b", "zk_airs_c", "zk_airs_d", "zk_plonk", "zk_tracegen"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 _INC = re.compile(r'^\s*#\s*include\s+"([^"]+)"', re.M)

@@ -45,6 +45,17 @@ class Context:
         else:
             self.check(self.lib.zk_ctx_set_abort_flag(self.handle, ptr))
 
+    def set_plans(self, plans: "str | None"):
+        """The ctx's plan table (include/zkstark.h zk_ctx_set_plans): which of two equivalent kernels serves a shape, as a
+        string of items ("v20f0=2;b20r1=96x1;T=1;").  None = the initial table (ZK_NTT_SWAP_PLANS or the one compiled in),
+        "" = the first implementation everywhere.  Results never depend on it."""
+        self.check(self.lib.zk_ctx_set_plans(self.handle, None if plans is None else plans.encode("ascii")))
+
+    def get_plans(self) -> str:
+        buf = C.create_string_buffer(4100)
+        self.lib.zk_ctx_get_plans(self.handle, buf, len(buf))
+        return buf.value.decode("ascii")
+
     def synchronize(self):
         self.check(self.lib.zk_ctx_synchronize(self.handle))
 

@@ -53,6 +53,11 @@ struct zk_ctx {
     hipStream_t ntt_batch_stream = nullptr;   // every other column batch of a commitment's NTT (ntt_host.inc ZK_NTT_COL_BATCH_STREAMS), created on first use
     hipEvent_t ntt_batch_ev[2] = {nullptr, nullptr};
     hipStream_t commit_tail = nullptr;  // != nullptr: commit_enqueue sends the small Merkle levels + cap read-back of main-lane commits there
+    // Which of two equivalent implementations serves a shape (ntt_host.inc "the plan table"): the ctx's own copy of the plan string,
+    // set at creation (ZK_NTT_SWAP_PLANS or the table compiled in) and by zk_ctx_set_plans.  The *_force fields and the report belong to
+    // the offline tuner (zki_ntt_tune_all, zki_tree_batch_trial), which runs both forms on this ctx.
+    std::string plans, tune_report;
+    int ntt_swap_force = -1, tree_batch_force = -1;
     std::vector<struct PendingCommit *> *tree_batch = nullptr;   // != nullptr: commit_enqueue leaves the small Merkle levels + cap read-back to commit_tree_batch_flush (zkstark.hip)
     std::vector<hipEvent_t> ev_pool;    // recycled timing / ordering events
     u64 *h_caps = nullptr;              // pinned host slots for cap read-backs of commits in flight (ZK_CAP_SLOTS x 64 words)

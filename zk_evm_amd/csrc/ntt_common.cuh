@@ -23,13 +23,7 @@ struct NttPass {
     int log_rep;         // load: dst index x reads src index x >> log_rep
     int apply_out_const;
     int last_pass;       // the values leave the transform: store canonical representatives
-    int nt;              // stream the tile data with non-temporal loads / stores (the twiddle levels keep the L2)
     int cols_fastest;    // grid = (columns, tiles): consecutive workgroups run the SAME tile of different columns (ntt_host.inc)
-    // Phase stagger (ntt_host.inc kNttStagger*): the workgroups that share a CU start together and would stay in lock step --
-    // all loading, then all in their butterflies, then all storing -- so the memory phases (HBM at 5 TB/s, VALU idle) and the
-    // compute phases (HBM idle) never overlap.  The first-resident workgroups selected by stagger_mode wait stagger_ticks
-    // (100 MHz wall clock) before their load; every later workgroup inherits the phase of the slot it takes over.
-    u32 stagger_ticks, stagger_mode, stagger_blocks;
 };
 
 // One radix-2 butterfly (a, b) -> (a + w b, a - w b).  BOTH directions use this Cooley-Tukey form: the canonical product

@@ -48,6 +48,7 @@ extern "C" int zk_device_info(int device, char *name_out, size_t name_len, int *
     return ZK_OK;
 }
 
+static std::string initial_plans();
 extern "C" int zk_ctx_create(int device, zk_ctx **out) {
     if (!out) return ZK_ERR_BAD_ARG;
     *out = nullptr;
@@ -65,15 +66,9 @@ extern "C" int zk_ctx_create(int device, zk_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->cu_count = prop.multiProcessorCount;
     // allow the NTT kernels their full LDS tile (default dynamic limit is 64 KiB)
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false, false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true, false>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false, true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true, true>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    ctx->plans = initial_plans();              // (ntt_host.inc: ZK_NTT_SWAP_PLANS as read at load, else the table compiled in)
     *out = ctx;
     return ZK_OK;
 }
@@ -485,14 +480,12 @@ static int commit_enqueue(zk_ctx *ctx, const zk_cfg *cfg, const u64 *d_in, size_
 
 // The commitments collected in ctx->tree_batch: wait (on `st`) for each one's large levels, build the remaining levels of all
 // the trees level by level in ONE launch each, read the caps back.  The caller synchronises `st` before commit_finish.
-// ZK_TREE_BATCH: 0 = per tree (r01-r04), 1 = batched, 2 (default) = what the trial process found (tune_host.inc: a whole segment proven
-// both ways, batched only if the proofs are identical and it was faster; ntt_host.inc tree_batch_verdict)
+// ZK_TREE_BATCH: 0 = per tree (r01-r04), 1 = batched, 2 (default) = what the ctx's plan table says ("T=1;"; no item: per tree).
 static const int kTreeBatch = env_int("ZK_TREE_BATCH", 2, 0, 2);
-static thread_local int t_tree_batch_force = -1;          // the trial's own runs
 static bool tree_batch_on(const zk_ctx *ctx) {
-    if (t_tree_batch_force >= 0) return t_tree_batch_force == 1;
+    if (ctx->tree_batch_force >= 0) return ctx->tree_batch_force == 1;      // (the tuner's own runs, tune_host.inc)
     if (kTreeBatch != 2) return kTreeBatch == 1;
-    return tree_batch_verdict(ctx->device) == 1;
+    return plans_tree_tops(ctx->plans) == 1;
 }
 static int commit_tree_batch_flush(zk_ctx *ctx, const zk_cfg *cfg, hipStream_t st) {
     std::vector<PendingCommit *> items;
@@ -698,68 +691,61 @@ int zki_get_twiddles(zk_ctx *ctx, int log_size, bool inverse, const u64 **out) {
 int zki_get_coset_table(zk_ctx *ctx, int log_n, u64 shift, bool inverse, const u64 **out) {
     return get_coset_table(ctx, log_n, shift, inverse, out);
 }
-// (internal) the plan autotuner's verdicts so far in this process, one line per transform shape (ntt_host.inc ntt_swap_decide)
-extern "C" size_t zki_ntt_tune_report(char *out, size_t max) {
-    std::lock_guard<std::mutex> lock(g_ntt_tune_mu);
-    if (out && max) { const size_t n = g_ntt_tune_report.size() < max - 1 ? g_ntt_tune_report.size() : max - 1; memcpy(out, g_ntt_tune_report.data(), n); out[n] = 0; }
-    return g_ntt_tune_report.size();
-}
-// (internal) the verdicts as ZK_NTT_SWAP_PLANS takes them: what a parent process hands to its children
-extern "C" size_t zki_ntt_tune_export(char *out, size_t max) {
-    std::lock_guard<std::mutex> lock(g_ntt_tune_mu);
-    std::string e = g_ntt_preset;                    // inherited verdicts and the helper's (after a dead helper: every shape pinned to the tile kernels)
-    if (!e.empty() && e.back() != ';') e += ';';
-    for (const auto &kv : g_ntt_tune) {
-        char item[48];
-        snprintf(item, sizeof item, "%c%df%d=%d;", std::get<1>(kv.first) ? 'd' : 'v', std::get<2>(kv.first), std::get<3>(kv.first), kv.second);
-        if (e.find(item) == std::string::npos) e += item;
-    }
-    if (g_tree_batch_trial_verdict >= 0 && e.find("T=") == std::string::npos) e += g_tree_batch_trial_verdict ? "T=1;" : "T=0;";
-    for (const auto &kv : g_ntt_batch_tune) {
-        char item[48];
-        snprintf(item, sizeof item, "b%dr%d=%dx%d;", std::get<1>(kv.first), std::get<2>(kv.first), kv.second.first, kv.second.second);
-        if (e.find(item) == std::string::npos) e += item;
-    }
-    if (out && max) { const size_t n = e.size() < max - 1 ? e.size() : max - 1; memcpy(out, e.data(), n); out[n] = 0; }
-    return e.size();
-}
-// (internal; csrc/ntt_tune_main.c, the process ntt_swap_decide spawns) the trial of every transform shape that has a lane-swap plan, in
-// THIS process (the caller runs with ZK_NTT_TUNE_INPROC=1); the verdicts are then in zki_ntt_tune_export / zki_ntt_tune_report
-extern "C" int zki_ntt_tune_all(zk_ctx *ctx) {
+// ---- the plan table (ntt_host.inc) ----------------------------------------------------------------------------------
+extern "C" int zk_ctx_set_plans(zk_ctx *ctx, const char *plans) {
     if (!ctx) return ZK_ERR_BAD_ARG;
-    if (!kNttTuneInproc) return set_err(ctx, ZK_ERR_BAD_ARG, "zki_ntt_tune_all: for a process started with ZK_NTT_TUNE_INPROC=1");
+    if (!plans) { ctx->plans = initial_plans(); return ZK_OK; }
+    if (!plans_well_formed(plans) || strlen(plans) > 4096) return set_err(ctx, ZK_ERR_BAD_ARG, "zk_ctx_set_plans: not a plan string (items \"v20f0=2;b20r1=96x1;T=1;\")");
+    ctx->plans = plans;
+    return ZK_OK;
+}
+extern "C" size_t zk_ctx_get_plans(const zk_ctx *ctx, char *out, size_t max) {
+    if (!ctx) return 0;
+    if (out && max) { const size_t n = ctx->plans.size() < max - 1 ? ctx->plans.size() : max - 1; memcpy(out, ctx->plans.data(), n); out[n] = 0; }
+    return ctx->plans.size();
+}
+// (internal; the offline tuner csrc/ntt_tune_main.c) what the trials on this ctx said, one line each
+extern "C" size_t zki_ntt_tune_report(const zk_ctx *ctx, char *out, size_t max) {
+    if (!ctx) return 0;
+    if (out && max) { const size_t n = ctx->tune_report.size() < max - 1 ? ctx->tune_report.size() : max - 1; memcpy(out, ctx->tune_report.data(), n); out[n] = 0; }
+    return ctx->tune_report.size();
+}
+// (internal; the offline tuner) both plans of every transform shape that has a lane-swap plan and the column-batch forms of every
+// from_values shape that has a trial, run on the device and compared; the verdicts go into THIS ctx's plan table (zk_ctx_get_plans)
+// and report.  *n_differ = the number of trials in which the second form produced different words: a parity failure of shipped code.
+extern "C" int zki_ntt_tune_all(zk_ctx *ctx, int *n_differ) {
+    if (!ctx) return ZK_ERR_BAD_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int differ = 0;
     for (int dit = 0; dit < 2; ++dit)
         for (int free_stages = 0; free_stages <= dit; ++free_stages)
             for (int L = ZK_NTT_WAVE_BITS + free_stages; L <= 22; ++L) {
                 if (!ntt_swap_has_plan(dit != 0, L, free_stages)) continue;
-                bool use = false;
-                ZK_TRY(ntt_swap_decide(ctx, dit != 0, L, free_stages, &use));
+                bool d = false;
+                ZK_TRY(ntt_swap_trial(ctx, dit != 0, L, free_stages, &d));
+                differ += d;
             }
-    return ntt_batch_trials_all(ctx, 1);          // with the plans decided: the column batches of the shapes that have a trial (rate_bits = 1: the STARK tables)
+    // with the plans decided: the column batches of the shapes that have a trial (rate_bits = 1: the STARK tables)
+    for (int log_n = 17; log_n + 1 <= 22; ++log_n) {
+        bool d = false;
+        ZK_TRY(ntt_batch_trial(ctx, log_n, 1, &d));
+        differ += d;
+    }
+    if (n_differ) *n_differ = differ;
+    return ZK_OK;
 }
-// (internal, for tests/test_ntt_tune_isolation.py: no device involved) the verdict for one shape by every way that needs no trial in
-// this process -- the cache, ZK_NTT_SWAP_PLANS, the helper process: 0 = none (ZK_NTT_TUNE_INPROC), 1 = tile, 2 = lane-swap, -1 = the
-// shape has no second plan
-extern "C" int zki_ntt_swap_verdict(int device, int dit, int L, int free_stages) {
+// (internal, for tests: no device involved) what a plan string says about a shape: 0 = no item, 1 = tile, 2 = lane-swap, -1 = the
+// shape has no second plan; the column-batch item as MiB * 4 + streams (-1 = none); the tree tops (-1 = none)
+extern "C" int zki_plans_ntt(const char *plans, int dit, int L, int free_stages) {
     if (!ntt_swap_has_plan(dit != 0, L, free_stages)) return -1;
-    std::lock_guard<std::mutex> lock(g_ntt_tune_mu);
-    return ntt_swap_verdict_locked(device, dit != 0, L, free_stages);
+    return plans_ntt(plans ? plans : "", dit != 0, L, free_stages);
 }
-// (internal, for tests/test_ntt_tune_isolation.py: no device involved) the column-batch verdict of a shape: MiB * 4 + streams, -1 = none
-extern "C" int zki_ntt_batch_verdict(int device, int log_n, int rate_bits) {
-    if (kNttColBatchMB >= 0) return kNttColBatchMB * 4 + (kNttColBatchStreams ? kNttColBatchStreams : 1);
-    std::lock_guard<std::mutex> lock(g_ntt_tune_mu);
-    std::pair<int, int> v;
-    if (!ntt_batch_verdict_locked(device, log_n, rate_bits, log_n >= 17 && log_n + rate_bits <= 22, &v)) return -1;
-    return v.first * 4 + v.second;
+extern "C" int zki_plans_batch(const char *plans, int log_n, int rate_bits) {
+    int mb = 0, st = 1;
+    return plans_batch(plans ? plans : "", log_n, rate_bits, &mb, &st) ? mb * 4 + st : -1;
 }
-// (internal, for tests/test_ntt_tune_isolation.py: no device involved) whether the trace trees' small levels are built together: what
-// ZK_TREE_BATCH says, or (2, the default) what ZK_NTT_SWAP_PLANS / the helper process says ("T=0|1;")
-extern "C" int zki_tree_batch_verdict(int device) {
-    if (kTreeBatch != 2) return kTreeBatch;
-    return tree_batch_verdict(device);
-}
+extern "C" int zki_plans_tree_tops(const char *plans) { return plans_tree_tops(plans ? plans : ""); }
+extern "C" const char *zki_builtin_plans(void) { return kBuiltinPlans; }
 // (internal, for tests/test_ntt_plan_cpu.py: no device involved) the passes ntt_host.inc plans for a 2^L-point transform whose
 // contiguous pass gets `free_stages` stages by replication: out[2 k] = log_d, out[2 k + 1] = r of pass k, largest distance first
 extern "C" int zki_ntt_plan(int L, int free_stages, int dit, int *out, int max_passes) {
