@@ -38,10 +38,13 @@ def _a2a(lib, h, send, recv):
     return lib.zk_comm_all_to_all_host(h, sp, sn, rp, rn)
 
 
-def _worker(rank, world, name, q, absent=None):
+def _worker(rank, world, name, q, absent=None, rank0_late=0.0):
     try:
         lib = _lib()
         h = C.c_void_p()
+        if rank == 0 and rank0_late:
+            import time
+            time.sleep(rank0_late)
         rc = lib.zk_comm_create_host(None, name.encode(), rank, world, 4096 * world, C.byref(h))      # 4 KiB per (src, dst) and round
         assert rc == 0 and lib.zk_comm_world(h) == world and lib.zk_comm_rank(h) == rank and lib.zk_comm_transport(h) == b"host"
         ok = True
@@ -93,14 +96,27 @@ def _worker(rank, world, name, q, absent=None):
         q.put((rank, False, repr(e)))
 
 
-def _run(world, absent=None, env=None):
+def _make_stale_region(name, world, failed):
+    """What a crashed earlier job with the same name leaves in /dev/shm: a fully initialised region (ShmHeader of csrc/comm_host.inc:
+    magic, world, slot_bytes, arrived, sense, attached, detached, failed) that rank 0 never got to unlink."""
+    import struct
+    slot = 4096 * world
+    head = (104 + world * world * 8 + 4095) & ~4095
+    with open("/dev/shm/" + name, "wb") as f:
+        f.write(struct.pack("<IIQIIIIi", 0x5A4B434D, world, slot, 0, 0, world, 0, failed))
+        f.truncate(head + world * slot)
+
+
+def _run(world, absent=None, env=None, stale_failed=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     name = "zk_test_%d_%s" % (os.getpid(), os.urandom(4).hex())
+    if stale_failed is not None:
+        _make_stale_region(name, world, stale_failed)
     old = {k: os.environ.get(k) for k in (env or {})}
     os.environ.update(env or {})
     try:
-        procs = [ctx.Process(target=_worker, args=(r, world, name, q, absent)) for r in range(world)]
+        procs = [ctx.Process(target=_worker, args=(r, world, name, q, absent, 1.5 if stale_failed is not None else 0.0)) for r in range(world)]
         for p in procs:
             p.start()
         res = [q.get(timeout=120) for _ in procs]
@@ -125,6 +141,19 @@ def test_host_transport_absent_rank_is_a_timeout_not_a_hang():
     res = _run(2, absent=1, env={"ZK_COMM_TIMEOUT_S": "3"})
     assert res[1] == (True, 0)
     assert res[0][0] is True and res[0][1] == ZK_ERR_COMM, res
+
+
+@pytest.mark.parametrize("failed", [0, 2])
+def test_a_stale_region_of_a_crashed_job_is_not_joined(failed):
+    """r05 advisor: a region left in /dev/shm by an earlier job with the same name passes the size and magic checks; a rank that
+    opens it before rank 0 has replaced it used to sit at that region's barrier until the 300 s limit.  Rank 0 arrives 1.5 s late
+    here: the other rank must end up in rank 0's region (it disowns the old one before unlinking the name) and every collective
+    must work -- within seconds.  `failed` = the old job's failure word (0: it looks healthy, 2: it died noisily)."""
+    import time
+    t0 = time.time()
+    res = _run(2, env={"ZK_COMM_TIMEOUT_S": "30"}, stale_failed=failed)
+    assert res == {0: (True, 0), 1: (True, 0)}, res
+    assert time.time() - t0 < 25
 
 
 def test_comm_argument_checks():
