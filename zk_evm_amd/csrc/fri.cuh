@@ -38,6 +38,13 @@ __device__ __forceinline__ void dot_acc_init(DotAcc &d) { d.s00 = d.s01 = d.s11 
 // c0, c1: SGPR halves of the coefficient; v: the lane's value
 __device__ __forceinline__ void dot_acc_mac(DotAcc &d, u32 c0, u32 c1, u64 v) {
     const u32 v0 = (u32)v, v1 = (u32)(v >> 32);
+#if !defined(__HIP_DEVICE_COMPILE__)      // portable: the same words (the host pass of hipcc -- parsed, never run -- and the CPU emulation, tests/emu/)
+    u64 t;
+    t = d.s00 + (u64)c0 * v0; d.h00 += t < d.s00; d.s00 = t;
+    t = d.s01 + (u64)c0 * v1; d.h01 += t < d.s01; d.s01 = t;
+    t = d.s01 + (u64)c1 * v0; d.h01 += t < d.s01; d.s01 = t;
+    t = d.s11 + (u64)c1 * v1; d.h11 += t < d.s11; d.s11 = t;
+#else
     asm("v_mad_u64_u32 %[s00], vcc, %[c0], %[v0], %[s00]\n\t"
         "v_addc_co_u32 %[h00], vcc, 0, %[h00], vcc\n\t"
         "v_mad_u64_u32 %[s01], vcc, %[c0], %[v1], %[s01]\n\t"
@@ -50,6 +57,7 @@ __device__ __forceinline__ void dot_acc_mac(DotAcc &d, u32 c0, u32 c1, u64 v) {
           [h11] "+v"(d.h11)
         : [c0] "s"(c0), [c1] "s"(c1), [v0] "v"(v0), [v1] "v"(v1)
         : "vcc");
+#endif
 }
 // (lo + hi * 2^64) mod p as a lazy u64; hi < 2^32:  2^64 = 2^32 - 1
 __device__ __forceinline__ u64 fold96(u64 lo, u32 hi) { return gl_add(lo, ((u64)hi << 32) - hi); }
@@ -62,6 +70,21 @@ __device__ __forceinline__ u64 fold96(u64 lo, u32 hi) { return gl_add(lo, ((u64)
 __device__ __forceinline__ u64 dot_acc_reduce(const DotAcc &d) {
     const u32 a0 = (u32)d.s00, a1 = (u32)(d.s00 >> 32), b0 = (u32)d.s01, b1 = (u32)(d.s01 >> 32), c0 = (u32)d.s11,
               c1 = (u32)(d.s11 >> 32);
+#if !defined(__HIP_DEVICE_COMPILE__)      // portable: the same twelve + three word operations
+    u64 x = (u64)a1 + b0;                      const u32 pw1 = (u32)x;
+    x = (u64)b1 + c0 + (x >> 32);              u32 pw2 = (u32)x;
+    x = (u64)c1 + (x >> 32);                   u32 pw3 = (u32)x;
+    u32 pw4 = d.h11 + (u32)(x >> 32);
+    x = (u64)pw2 + d.h00;                      pw2 = (u32)x;
+    x = (u64)pw3 + d.h01 + (x >> 32);          pw3 = (u32)x;
+    pw4 += (u32)(x >> 32);
+    const u64 m = ((u64)pw1 << 32) | a0, sub = ((u64)pw4 << 32) | pw3;
+    u64 pr = m - sub;
+    if (m < sub) pr -= 0xFFFFFFFFu;                                    /* borrow: -= EPS (== += p) */
+    u64 q = pr + (u64)pw2 * 0xFFFFFFFFu;                               /* += w2 (2^32 - 1) */
+    if (q < pr) q += 0xFFFFFFFFu;                                      /* a carry is 2^64 = 2^32 - 1 again */
+    return q;
+#else
     u32 w1, w2, w3, w4, lo, hi, e;
     asm("v_add_co_u32 %[w1], vcc, %[a1], %[b0]\n\t"
         "v_addc_co_u32 %[w2], vcc, %[b1], %[c0], vcc\n\t"
@@ -87,11 +110,19 @@ __device__ __forceinline__ u64 dot_acc_reduce(const DotAcc &d) {
         : [t2] "v"(w2)
         : "vcc");
     return r;
+#endif
 }
 
 // same with per-lane (VGPR) coefficients
 __device__ __forceinline__ void dot_acc_mac_v(DotAcc &d, u64 c, u64 v) {
     const u32 c0 = (u32)c, c1 = (u32)(c >> 32), v0 = (u32)v, v1 = (u32)(v >> 32);
+#if !defined(__HIP_DEVICE_COMPILE__)      // portable: the same words (the host pass of hipcc -- parsed, never run -- and the CPU emulation, tests/emu/)
+    u64 t;
+    t = d.s00 + (u64)c0 * v0; d.h00 += t < d.s00; d.s00 = t;
+    t = d.s01 + (u64)c0 * v1; d.h01 += t < d.s01; d.s01 = t;
+    t = d.s01 + (u64)c1 * v0; d.h01 += t < d.s01; d.s01 = t;
+    t = d.s11 + (u64)c1 * v1; d.h11 += t < d.s11; d.s11 = t;
+#else
     asm("v_mad_u64_u32 %[s00], vcc, %[c0], %[v0], %[s00]\n\t"
         "v_addc_co_u32 %[h00], vcc, 0, %[h00], vcc\n\t"
         "v_mad_u64_u32 %[s01], vcc, %[c0], %[v1], %[s01]\n\t"
@@ -104,6 +135,7 @@ __device__ __forceinline__ void dot_acc_mac_v(DotAcc &d, u64 c, u64 v) {
           [h11] "+v"(d.h11)
         : [c0] "v"(c0), [c1] "v"(c1), [v0] "v"(v0), [v1] "v"(v1)
         : "vcc");
+#endif
 }
 
 // W[p] = z^bitrev(p, log_n);  zpow[k] = z^(2^k) (ext), k < log_n

@@ -36,6 +36,11 @@
 #define ZK_NTT_WAVE_BITS 10                 // elements per wave of the contiguous kernels
 #define ZK_NTT_WAVE_LDS 1088                // 64 rows x 17 words
 
+#if defined(ZK_HIPEMU)                      // (tests/emu/: the attribute exists for kernels of the device compiler only)
+#define ZK_NTT_WAVES_PER_EU(lo, hi)
+#else
+#define ZK_NTT_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const __attribute__((address_space(4))) u64 *ntt_const_u64p;         // constant address space: uniform loads are scalar loads
 template <int LANEBIT>
@@ -511,7 +516,7 @@ static __global__ void __launch_bounds__(256) ntt_contig_wave_kernel_dif(NttPass
 // value x = 2 i + b = the plain 2^10-point transform of c_i * scale_b[i], scale_0 = in_scale (may be null: ones), scale_1 =
 // in_scale2 = the same coset table for shift * w_(2n) (ntt_host.inc).  Output index (sbase + i) * NB + b.
 template <int NB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) ntt_contig_wave_kernel_dit(NttPass p, const u64 *in_scale2) {
+__global__ void __launch_bounds__(256) ZK_NTT_WAVES_PER_EU(4, 8) ntt_contig_wave_kernel_dit(NttPass p, const u64 *in_scale2) {
     extern __shared__ __attribute__((aligned(16))) u64 lds_all[];            // 4 x ZK_NTT_WAVE_LDS words (ntt_host.inc)
     const u32 tid = threadIdx.x, lane = tid & 63, wv = ntt_uniform(tid >> 6), u = lane & 15, l4 = (lane >> 4) & 1, l5 = lane >> 5;
     u64 *const lds = lds_all + wv * ZK_NTT_WAVE_LDS;

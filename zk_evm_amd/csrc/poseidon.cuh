@@ -52,7 +52,11 @@ __device__ __forceinline__ u64 pos_sbox(u64 x) {
 // acc += x * C  (one v_mad_u64_u32)
 template <u32 C>
 __device__ __forceinline__ void pos_mac(u64 &acc, u32 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
     asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "n"(C) : "vcc");
+#else        // the same integers in portable C++: the host pass of hipcc (parsed, never run) and the CPU emulation (tests/emu/)
+    acc += (u64)x * C;
+#endif
 }
 
 // One MDS row for both 32-bit halves as ONE asm statement (24 v_mad_u64_u32 with inline
@@ -79,6 +83,11 @@ __device__ __forceinline__ void pos_mac(u64 &acc, u32 x) {
 template <bool HAS_RC>
 __device__ __forceinline__ void pos_row(u64 &al, u64 &ah, u64 rcl, u64 rch, const u32 (&lo)[12],
                                         const u32 (&hi)[12], int r) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    constexpr u32 C_[12] = ZK_POSEIDON_MDS_CIRC_INIT;
+    al = HAS_RC ? rcl : 0; ah = HAS_RC ? rch : 0;
+    for (int i = 0; i < 12; ++i) { al += (u64)lo[(i + r) % 12] * C_[i]; ah += (u64)hi[(i + r) % 12] * C_[i]; }
+#else
 #define X(i) "v"(lo[((i) + r) % 12])
 #define Y(i) "v"(hi[((i) + r) % 12])
     if (HAS_RC) {
@@ -96,12 +105,14 @@ __device__ __forceinline__ void pos_row(u64 &al, u64 &ah, u64 rcl, u64 rch, cons
     }
 #undef X
 #undef Y
+#endif
 }
 
 // value = al + ah * 2^32  (al, ah < 2^50: < 2^44 from a plain MDS row, < 2^50 from pos_partial_pair's M^2 row plus the
 // delta term)  ->  lazy u64 representative
 __device__ __forceinline__ u64 pos_fold(u64 al, u64 ah) {
     u32 ah0 = (u32)ah, ah1 = (u32)(ah >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
     // ah1 * 2^64 == ah1 * (2^32 - 1) with ah1 < 2^18; al + that < 2^51: no overflow
     asm("v_mad_u64_u32 %0, vcc, %1, -1, %0" : "+v"(al) : "v"(ah1) : "vcc");
     u32 l = (u32)al, h = (u32)(al >> 32), e;
@@ -119,6 +130,12 @@ __device__ __forceinline__ u64 pos_fold(u64 al, u64 ah) {
             : "vcc");
     }
     return ((u64)h << 32) | l;
+#else        // portable: the same 64-bit words, lane by lane
+    al += (u64)ah1 * 0xFFFFFFFFu;
+    u64 t = al + ((u64)ah0 << 32);                     // h += ah0 ...
+    if (t < al) t += 0xFFFFFFFFu;                      // ... a carry out is 2^64 == EPS
+    return t;
+#endif
 }
 
 // s <- MDS * s + rc   (rc = constants of the following round, or nothing when HAS_RC is false)
@@ -159,6 +176,10 @@ __device__ __forceinline__ void pos_mds(u64 (&s)[12], const RcSplit *rc) {
 template <u32 CD>
 __device__ __forceinline__ u64 pos_row2_half(u64 kinit, const u32 (&x)[12], const u32 (&k)[12], u32 d) {
     u64 acc;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    acc = kinit + (u64)d * CD;
+    for (int j = 0; j < 12; ++j) acc += (u64)x[j] * k[j];
+#else
     asm("v_mad_u64_u32 %0, vcc, %25, %26, %27\n\t"
         "v_mad_u64_u32 %0, vcc, %1, %13, %0\n\t"
         "v_mad_u64_u32 %0, vcc, %2, %14, %0\n\t"
@@ -177,6 +198,7 @@ __device__ __forceinline__ u64 pos_row2_half(u64 kinit, const u32 (&x)[12], cons
           "v"(x[11]), "s"(k[0]), "s"(k[1]), "s"(k[2]), "s"(k[3]), "s"(k[4]), "s"(k[5]), "s"(k[6]), "s"(k[7]), "s"(k[8]), "s"(k[9]),
           "s"(k[10]), "s"(k[11]), "v"(d), "n"(CD), "s"(kinit)
         : "vcc");
+#endif
     return acc;
 }
 template <int R>
@@ -233,6 +255,7 @@ __device__ __forceinline__ void pos_partial_pair(u64 (&s)[12], int round, int pa
 // these rows use the branch-free four-instruction pos_fold_wide.
 __device__ __forceinline__ u64 pos_fold_wide(u64 al, u64 ah) {
     const u32 ah0 = (u32)ah, ah1 = (u32)(ah >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
     // ah1 * 2^64 == ah1 * (2^32 - 1), ah1 < 2^25: al + that < 2^58
     asm("v_mad_u64_u32 %0, vcc, %1, -1, %0" : "+v"(al) : "v"(ah1) : "vcc");
     u32 l = (u32)al, h = (u32)(al >> 32), c;
@@ -245,12 +268,22 @@ __device__ __forceinline__ u64 pos_fold_wide(u64 al, u64 ah) {
     u64 t = ((u64)h << 32) | l;
     asm("v_mad_u64_u32 %0, vcc, %1, -1, %0" : "+v"(t) : "v"(c) : "vcc");
     return t;
+#else
+    al += (u64)ah1 * 0xFFFFFFFFu;
+    u64 t = al + ((u64)ah0 << 32);
+    if (t < al) t += 0xFFFFFFFFu;
+    return t;
+#endif
 }
 // kinit + d2 * CD + d1 * kc + sum_j x[j] * k[j]   (kinit, k, kc: wave-uniform constants in SGPRs, CD inline; d2 * CD first,
 // see pos_row2_half)
 template <u32 CD>
 __device__ __forceinline__ u64 pos_row3_half(u64 kinit, const u32 (&x)[12], const u32 (&k)[12], u32 d1, u32 kc, u32 d2) {
     u64 acc;
+#if !defined(__HIP_DEVICE_COMPILE__)
+    acc = kinit + (u64)d2 * CD + (u64)d1 * kc;
+    for (int j = 0; j < 12; ++j) acc += (u64)x[j] * k[j];
+#else
     asm("v_mad_u64_u32 %0, vcc, %27, %28, %29\n\t"
         "v_mad_u64_u32 %0, vcc, %25, %26, %0\n\t"
         "v_mad_u64_u32 %0, vcc, %1, %13, %0\n\t"
@@ -270,6 +303,7 @@ __device__ __forceinline__ u64 pos_row3_half(u64 kinit, const u32 (&x)[12], cons
           "v"(x[11]), "s"(k[0]), "s"(k[1]), "s"(k[2]), "s"(k[3]), "s"(k[4]), "s"(k[5]), "s"(k[6]), "s"(k[7]), "s"(k[8]), "s"(k[9]),
           "s"(k[10]), "s"(k[11]), "v"(d1), "s"(kc), "v"(d2), "n"(CD), "s"(kinit)
         : "vcc");
+#endif
     return acc;
 }
 template <int R>
