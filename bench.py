@@ -578,7 +578,7 @@ def main():
                                 "achieved_wave_insts_per_s": ach, "peak_wave_insts_per_s": 1024 * 2.4e9 / 4.0,
                                 "frac": ach / (1024 * 2.4e9 / 4.0),
                                 "assumes": "1024 SIMDs x 2.4 GHz / 4 cycles per wave-instruction (carry / mad / select class); "
-                                           "v_mov / v_add_u32-class ops issue at ~2.4 cycles (profiles/r01_ubench_valu_issue_rates.txt), "
+                                           "v_mov / v_add_u32-class ops issue at ~2.4 cycles (profiles/archive/r01_ubench_valu_issue_rates.txt), "
                                            "so a mix with many movs can exceed 1.0: the SIMDs are issue-saturated either way",
                                 "source": pm["source"], "source_commit": pm.get("git_commit"),
                                 "measured_in_this_run": False}
@@ -680,7 +680,7 @@ def main():
                         "frac": 2.0 / cpi,
                         "frac_is": "wave-instructions issued / issue slots, one wave64 VALU op per 2 cycles per SIMD being the floor "
                                    "(MI355X_MICROARCH.md); the kernel's own mix is dominated by v_mad_u64_u32 / carry-chain / "
-                                   "v_cndmask ops that issue at ~4.3 cycles each (profiles/r01_ubench_valu_issue_rates.txt), so a "
+                                   "v_cndmask ops that issue at ~4.3 cycles each (profiles/archive/r01_ubench_valu_issue_rates.txt), so a "
                                    "cycles_per_wave_instruction of 3.5-3.8 is an issue-saturated SIMD",
                         "source": "rocprofv3 --pmc SQ_INSTS_VALU and GRBM_GUI_ACTIVE (/ 8 XCDs x 1024 SIMDs) of the same launches, "
                                   "this run", "measured_in_this_run": True}

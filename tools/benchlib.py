@@ -130,7 +130,7 @@ def commit_report(a, stage, ms_per_step):
             insts = pmc.get("leaf_hash_valu_wave_insts_per_launch")
             if insts:
                 # integer-issue roofline: every useful integer VALU op on gfx950 issues at ~4 cycles per wave64
-                # per SIMD (profiles/r01_ubench_valu_issue_rates.txt)
+                # per SIMD (profiles/archive/r01_ubench_valu_issue_rates.txt)
                 peak = 1024 * 2.4e9 / 4.0
                 ach = insts / (dom_ms * 1e-3)
                 valu = {"wave_insts_per_launch": insts, "achieved_wave_insts_per_s": ach,

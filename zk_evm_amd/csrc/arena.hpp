@@ -1,7 +1,7 @@
 // Device-memory arena of one zk_ctx: grow-only hipMalloc slabs with a best-fit, coalescing free list.
 //
 // Why not hipMallocAsync: on this ROCm (7.2) a 40 GB request costs 0.2-2.7 s whether it is a fresh hipMalloc
-// or a "reuse" from the stream-ordered pool (measured: tools/scratch/pooltest.hip, profiles/r01f_pool_alloc.txt),
+// or a "reuse" from the stream-ordered pool (measured: tools/scratch/pooltest.hip, profiles/archive/r01f_pool_alloc.txt),
 // which at 2^20 rows is more than the whole proof.  A table commitment at that size needs 20-40 GB buffers
 // (Keccak: 2431 columns -> 40.8 GB of LDE), so the library keeps the HBM it has touched and hands it out again
 // in O(log blocks) host time.  288 GB of HBM is the budget this is sized for: nothing is returned to the driver

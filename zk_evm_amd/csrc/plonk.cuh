@@ -391,7 +391,7 @@ __device__ __noinline__ void plonk_eval_wide_gate(const PlonkQuotientArgs &A, co
 #undef PLONK_W
 
 // One lane per point of the quotient coset.  For circuits of <= 2^14 rows the coset has <= 2^17 points = at most two
-// waves per SIMD, and ONE wave per SIMD issues at half rate whatever its ILP (profiles/r02g_ubench_single_wave_issue.txt):
+// waves per SIMD, and ONE wave per SIMD issues at half rate whatever its ILP (profiles/archive/r02g_ubench_single_wave_issue.txt):
 // there the launch has gridDim.y == 2 and each slice evaluates the gates the host gave it (cost-balanced; slice 0 also
 // the permutation terms).  The vanishing polynomial is a SUM of terms, so the slices' results just add.
 static __global__ void __launch_bounds__(256) plonk_quotient_kernel(PlonkQuotientArgs A) {

@@ -8,7 +8,7 @@
 //
 // MI355X mapping.  The permutation is integer-ALU bound, and on gfx950 every useful integer op
 // (v_mad_u64_u32, carry adds, 64-bit shifts, cndmask) issues at ~4.3 cycles per wave64 per SIMD
-// (profiles/r01_ubench_valu_issue_rates.txt), so the design minimises *instruction count*:
+// (profiles/archive/r01_ubench_valu_issue_rates.txt), so the design minimises *instruction count*:
 //   * MDS layer: each state word is split into 32-bit halves; row r accumulates
 //     sum_i C[i]*half[(i+r)%12] in one 64-bit register with 12 v_mad_u64_u32 (inline constants,
 //     no per-term reduction: sums stay < 2^43).  The NEXT round's constant is the accumulator's

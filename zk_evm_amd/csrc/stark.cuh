@@ -72,9 +72,9 @@ __device__ __forceinline__ u64 prog_eval_filter(const u64 *__restrict__ prog, u3
 // challenges do not fit the registers next to the entry evaluator and live in scratch (528 bytes per lane; r03u: the kernel at
 // 10.5 cycles per instruction, i.e. waiting, not issuing); with 8 or 4 the batch loop unrolls and they are registers (no scratch;
 // 144 / 94 VGPRs).  The kernel has issue slots to spare, so four times the inversions (74 multiplies each since r03t) still come
-// out ahead -- A/B in one call (profiles/r03u_ab_helper_batch.log): CTL data 15.2 / 13.7 / 11.8 ms for 16 / 8 / 4 at 2^20
+// out ahead -- A/B in one call (profiles/archive/r03u_ab_helper_batch.log): CTL data 15.2 / 13.7 / 11.8 ms for 16 / 8 / 4 at 2^20
 // (578 -> 575 ms per segment), 112.6 -> 110.2 ms per realistic-height segment; 2 is worse again (13.2 ms,
-// profiles/r03w_ab_batch_sizes.log).  lookup_singles_kernel is the opposite case -- no interpreter, issue-bound (4.1 cycles
+// profiles/archive/r03w_ab_batch_sizes.log).  lookup_singles_kernel is the opposite case -- no interpreter, issue-bound (4.1 cycles
 // per instruction), its arrays are registers at any size -- so there FEWER inversions pay: 32 per batch (225 VGPRs, two waves
 // per SIMD) against 16: the Arithmetic table's proof 40.0 -> 38.1 ms, the segment -1.2 ms; 8 is slower.
 #ifndef ZK_HELPER_BATCH
