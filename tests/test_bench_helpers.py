@@ -77,6 +77,15 @@ def test_contract_line_is_small_strict_json_and_carries_the_contract():
     cb = d["cpu_baseline"]
     assert cb["unit"] == d["unit"] == "segment proofs/s" and cb["proofs_identical"] is True and cb["scale"] == 64.0 and len(cb["sample"]) <= 400
     assert abs(cb["value"] * cb["seconds"] - 1.0) < 1e-5 and abs(cb["sample_seconds"] * cb["scale"] - cb["seconds"]) < 1e-6 * cb["seconds"]
+    assert cb.get("cpu_model") == "x"
+    # r06: a cached MEASUREMENT of the workload's own shape (tools/cpu_baseline_cache.py) says so on the line, with shape, cores, CPU model
+    from tools.bench_secondary import cached_cpu_baseline
+    hit = {"oracle_hash": "0123456789abcdef", "cpu_model": "AMD EPYC 9575F 64-Core Processor", "cores": 16, "log_ns": [20] * 9, "hasher": 0,
+           "cdk_erigon": False, "cpu_seconds": 1402.7, "committed_cells": 4.47e9, "measured_at": "2026-09-30T12:00:00Z"}
+    seg["cpu_baseline"] = cached_cpu_baseline(hit)
+    cb = strict(contract_line(seg))["cpu_baseline"]
+    assert cb["measured"] is True and cb["shape"] == "9 x 2^20 rows" and cb["cores"] == 16 and cb["cpu_model"].startswith("AMD EPYC")
+    assert cb["unit"] == "segment proofs/s" and abs(cb["value"] * 1402.7 - 1.0) < 1e-6 and "MEASURED" in cb["sample"] and "scale" not in cb
     # poisoned
     bad = copy.deepcopy(full)
     bad["value"] = float("nan")
@@ -95,3 +104,21 @@ def test_contract_line_is_small_strict_json_and_carries_the_contract():
     with tempfile.TemporaryDirectory() as td:
         wrote = write_extra(bad, root=td)
         assert len(wrote) == 2 and strict(open(wrote[0]).read())["value"] is None
+
+
+def test_cpu_baseline_cache_is_keyed_by_oracle_host_and_shape(tmp_path):
+    """tools/cpu_baseline_cache.py: a measurement is used only for exactly the oracle sources, CPU model, core count, segment shape
+    and hasher it was made with; storing replaces the entry of the same key."""
+    from tools import cpu_baseline_cache as cbc
+    path = str(tmp_path / "cache.json")
+    e = {"oracle_hash": "aaaa", "cpu_model": "cpu A", "cores": 16, "log_ns": [20] * 9, "hasher": 0, "cdk_erigon": False, "cpu_seconds": 1400.0}
+    cbc.store(e, path)
+    cbc.store(dict(e, log_ns=[17, 14, 19, 17, 13, 16, 21, 19, 19], cpu_seconds=79.5), path)
+    cbc.store(dict(e, cpu_seconds=1390.0), path)                        # same key: replaced
+    entries = cbc.load(path)
+    assert len(entries) == 2
+    look = lambda **k: cbc.lookup(k.get("model", "cpu A"), k.get("cores", 16), k.get("log_ns", [20] * 9), k.get("hasher", 0), entries=entries, oracle_hash=k.get("oh", "aaaa"))
+    assert look()["cpu_seconds"] == 1390.0
+    assert look(log_ns=[17, 14, 19, 17, 13, 16, 21, 19, 19])["cpu_seconds"] == 79.5
+    assert look(oh="bbbb") is None and look(model="cpu B") is None and look(cores=8) is None and look(hasher=1) is None and look(log_ns=[19] * 9) is None
+    assert len(cbc.oracle_source_hash()) == 16 and cbc.oracle_source_hash() == cbc.oracle_source_hash()

@@ -411,7 +411,7 @@ def contract_line(out, extra_path="bench_extra.json"):
         else:
             line["cpu_baseline"] = {"value": _num(cb.get("value")), "unit": cb.get("unit"), "cores": _num(cb.get("cores")),
                                     "kind": cb.get("kind"), "sample": str(cb.get("sample", ""))[:400]}
-            for k in ("seconds", "sample_seconds", "scale", "proofs_identical", "shape", "gpu_same_sample_s"):
+            for k in ("measured", "cpu_model", "seconds", "sample_seconds", "scale", "scale_rule", "proofs_identical", "shape", "gpu_same_sample_s"):
                 if k in cb:
                     line["cpu_baseline"][k] = _num(cb[k]) if not isinstance(cb[k], (str, bool, list)) else cb[k]
     n = out.get("ntt") or {}
