@@ -94,6 +94,8 @@ hipError_t hipFuncSetAttribute(const void *func, hipFuncAttribute attr, int valu
 /* hipemu's own controls (tests): counters of what ran; failure injection.  HIPEMU_FAIL_MALLOC_AT=n makes the n-th hipMalloc of the
  * process (1-based) return hipErrorOutOfMemory; hipemu_fail_malloc_at does the same from code (0 = off). */
 void hipemu_fail_malloc_at(long nth);
+void hipemu_fail_malloc_from(long nth);   /* every hipMalloc from the n-th on fails (a device that is full), until reset with 0 */
+void hipemu_fail_launch_at(long nth);     /* the n-th kernel launch from now on is refused (hipGetLastError: launch failure), 0 = off */
 void hipemu_counters(uint64_t out[8]);     /* launches, blocks, fibers, fiber switches, copies, mallocs, deferred ops run late, streams made */
 
 #ifdef __cplusplus

@@ -70,7 +70,8 @@ static const bool kAsync = env_long("HIPEMU_ASYNC", 0) != 0;
 static const long kThreads = env_long("HIPEMU_THREADS", 0);
 static const long kVerbose = env_long("HIPEMU_VERBOSE", 0);
 static std::atomic<uint64_t> g_counters[8];          // launches, blocks, fibers, switches, copies, mallocs, late ops, streams
-static std::atomic<long> g_fail_malloc_at{env_long("HIPEMU_FAIL_MALLOC_AT", 0)}, g_malloc_seq{0};
+static std::atomic<long> g_fail_launch_at{0}, g_launch_seq{0};
+static std::atomic<long> g_fail_malloc_at{env_long("HIPEMU_FAIL_MALLOC_AT", 0)}, g_fail_malloc_from{env_long("HIPEMU_FAIL_MALLOC_FROM", 0)}, g_malloc_seq{0};
 
 [[noreturn]] static void die(const char *fmt, const char *a = "", const char *b = "") {
     fprintf(stderr, "hipemu: ");
@@ -527,6 +528,10 @@ void launch(dim3 grid, dim3 block, size_t lds, hipStream_t st, std::function<voi
     const uint64_t total = (uint64_t)grid.x * grid.y * grid.z;
     const unsigned n = block.x * block.y * block.z;
     if (total == 0 || n == 0 || n > 1024 || grid.y > 65535 || grid.z > 65535 || lds > 160 * 1024) { t_last_error = hipErrorInvalidValue; return; }   // what the real launch refuses
+    {
+        const long at = g_fail_launch_at.load();
+        if (at > 0 && g_launch_seq.fetch_add(1) + 1 == at) { t_last_error = hipErrorLaunchFailure; return; }      // (test control: this launch is refused)
+    }
     Op op;
     auto shared = std::make_shared<std::function<void()>>(std::move(body));
     op.fn = [=]() { run_grid(grid, block, lds, *shared, name); };
@@ -564,7 +569,9 @@ void zk_emu_wave_sync() { wave_sync(); }
 
 extern "C" {
 
-void hipemu_fail_malloc_at(long nth) { g_fail_malloc_at = nth; g_malloc_seq = 0; }
+void hipemu_fail_malloc_at(long nth) { g_fail_malloc_at = nth; g_fail_malloc_from = 0; g_malloc_seq = 0; }
+void hipemu_fail_launch_at(long nth) { g_fail_launch_at = nth; g_launch_seq = 0; }
+void hipemu_fail_malloc_from(long nth) { g_fail_malloc_from = nth; g_fail_malloc_at = 0; g_malloc_seq = 0; }
 void hipemu_counters(uint64_t out[8]) { for (int i = 0; i < 8; ++i) out[i] = g_counters[i].load(); }
 
 hipError_t hipGetDeviceCount(int *count) { if (!count) return hipErrorInvalidValue; *count = (int)env_long("HIPEMU_DEVICES", 1); return hipSuccess; }
@@ -688,8 +695,8 @@ hipError_t hipMalloc(void **p, size_t bytes) {
     if (!p) return hipErrorInvalidValue;
     *p = nullptr;
     g_counters[5].fetch_add(1, std::memory_order_relaxed);
-    const long at = g_fail_malloc_at.load();
-    if (at > 0 && g_malloc_seq.fetch_add(1) + 1 == at) { t_last_error = hipErrorOutOfMemory; return hipErrorOutOfMemory; }
+    const long at = g_fail_malloc_at.load(), from = g_fail_malloc_from.load(), seq = g_malloc_seq.fetch_add(1) + 1;
+    if ((at > 0 && seq == at) || (from > 0 && seq >= from)) { t_last_error = hipErrorOutOfMemory; return hipErrorOutOfMemory; }
     if (bytes > ((size_t)12 << 30)) { t_last_error = hipErrorOutOfMemory; return hipErrorOutOfMemory; }
     void *m = nullptr;
     if (posix_memalign(&m, 256, bytes ? bytes : 1) != 0) { t_last_error = hipErrorOutOfMemory; return hipErrorOutOfMemory; }
