@@ -147,9 +147,17 @@ static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) {
 #include "hip_runtime_api.h"
 
 // ---- launches ---------------------------------------------------------------------------------------------------------------------
+#include <tuple>
 namespace hipemu {
 void launch(dim3 grid, dim3 block, size_t dyn_lds_bytes, hipStream_t stream, std::function<void()> body, const char *name);
+// The arguments are EVALUATED AND COPIED when the launch is enqueued, as the real runtime does (an argument like `*d_out`, or a
+// struct filled in a loop, must not be read when the kernel finally runs); every thread of the grid then calls the kernel with them.
+template <class F, class... Args>
+void launch_args(dim3 grid, dim3 block, size_t dyn_lds_bytes, hipStream_t stream, const char *name, F f, Args... args) {
+    auto packed = std::make_tuple(args...);
+    launch(grid, block, dyn_lds_bytes, stream, [f, packed]() { std::apply(f, packed); }, name);
 }
+}  // namespace hipemu
 // (KERNEL) is parenthesised by the translator: template arguments may contain commas
 #define HIPEMU_LAUNCH(KERNEL, GRID, BLOCK, LDS, STREAM, ...) \
-    hipemu::launch(dim3 GRID, dim3 BLOCK, (size_t)(LDS), (hipStream_t)(STREAM), [=]() { KERNEL(__VA_ARGS__); }, #KERNEL)
+    hipemu::launch_args(dim3 GRID, dim3 BLOCK, (size_t)(LDS), (hipStream_t)(STREAM), #KERNEL, [](auto... a_) { KERNEL(a_...); }, __VA_ARGS__)

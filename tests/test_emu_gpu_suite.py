@@ -1,0 +1,96 @@
+"""CPU (pytest -m "not gpu"): the GPU parity tests -- tests/test_gpu_*.py, unchanged -- against the CPU EMULATION BUILD of the library
+(tests/emu/): libzkstark's own kernels and host code, compiled for the host from the sources where they lie, on a
+stand-in HIP runtime (fibers per block, wave operations, streams in order or deferred).  What this gives the rows of SURVEY section 8
+without hardware: zk_commit_* / zk_prove_* END TO END equal the oracle -- including the kernels and host paths written in rounds 5 and
+6, which no GPU has run (lane-swap NTT kernels, column batches on two streams, batched tree tops, the plan table, the comm failure
+protocol).  What it does not give: the gfx950 inline assembly (portable bodies are taken), timing, RCCL.
+
+The slice run here is tests/emu/quick_slice.txt (~140 tests); tools/emu_full_suite.sh runs everything that fits a CPU, and
+tools/emu_sanitizers.sh the same under ASan + UBSan and TSan (logs under profiles/)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _ids(name):
+    return [ln.strip() for ln in open(os.path.join(ROOT, "tests", "emu", name)) if "::" in ln and not ln.startswith("#")]
+
+
+@pytest.fixture(scope="module")
+def emu_env():
+    sys.path.insert(0, ROOT)
+    from tools.emu_survey import emu_env as make
+    return make()
+
+
+def _run(ids, env, timeout):
+    r = subprocess.run([sys.executable, "-m", "pytest", *ids, "-q", "-p", "no:cacheprovider", "-x"], capture_output=True, text=True, cwd=ROOT,
+                       env=env, timeout=timeout)
+    tail = r.stdout[-3000:] + r.stderr[-1500:]
+    assert r.returncode == 0, tail
+    last = [ln for ln in r.stdout.splitlines() if " passed" in ln][-1]
+    assert "failed" not in last and "error" not in last, tail
+    return int(last.split(" passed")[0].split()[-1])
+
+
+def test_the_emulation_build_has_the_librarys_c_abi(emu_env):
+    """Same symbols as the real library: every prototype of include/zkstark.h resolves in libzkstark_emu.so (and the emulator's own
+    controls are there)."""
+    import ctypes as C
+    sys.path.insert(0, ROOT)
+    from zk_evm_amd._lib import SIGNATURES
+    lib = C.CDLL(emu_env["ZK_STARK_LIB"])
+    for name in SIGNATURES:
+        getattr(lib, name)
+    for name in ("hipemu_counters", "hipemu_fail_malloc_from", "hipemu_fail_launch_at", "hipMalloc", "hipStreamWaitEvent"):
+        getattr(lib, name)
+
+
+def test_gpu_tests_pass_on_the_emulation_build(emu_env):
+    ids = _ids("quick_slice.txt")
+    assert len(ids) >= 120
+    assert _run(ids, emu_env, 1500) >= len(ids)
+
+
+def test_gpu_tests_pass_with_deferred_streams(emu_env):
+    """HIPEMU_ASYNC=1: no operation runs until the host waits for something that depends on it, and then only that -- a missing
+    event wait between the lanes, a pinned buffer reused before its copy kernel ran, an arena block handed out under a pending
+    kernel would change the words of a proof here."""
+    ids = _ids("async_slice.txt")
+    assert len(ids) >= 40
+    assert _run(ids, dict(emu_env, HIPEMU_ASYNC="1"), 1500) >= len(ids)
+
+
+def test_a_failing_rank_never_strands_its_peer(emu_env):
+    """Two ranks on the host transport, zk_commit_rows_sharded; rank 1's device is full, or one of its kernel launches is refused, at
+    seven different points between and around the collectives.  Every time: rank 1 returns its own error, rank 0 ZK_ERR_COMM, both at
+    once (the 60 s transport limit is never waited for), and the SAME communicator then commits the table with the right cap
+    (csrc/comm_host.inc "the failure protocol"; r05 advisor)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(emu_env, HIPEMU_THREADS="2", ZK_COMM_TIMEOUT_S="60", ZK_FAIL_AT="-1,1,2,4,6,8,10,40")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "emu", "multirank_failure_driver.py"), str(r), "2", str(port)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    res = [json.loads([ln for ln in o[0].splitlines() if ln.startswith("RESULT ")][-1][7:]) for o in outs]
+    r0, r1 = (res[0], res[1]) if res[0]["rank"] == 0 else (res[1], res[0])
+    assert r0["transport"] == "host"
+    failed = 0
+    for a, b in zip(r0["runs"], r1["runs"]):
+        assert a["fail_at"] == b["fail_at"] and a["cap0"] == b["cap0"] == r0["runs"][0]["cap0"]      # the retry always succeeds, same cap
+        if b["code"] != 0:
+            failed += 1
+            assert b["code"] in (-2, -3) and a["code"] == -6, (a, b)                                   # own error | ZK_ERR_COMM
+            assert a["seconds"] < 20 and b["seconds"] < 20, (a, b)                                     # nobody sat out a time limit
+        else:
+            assert a["code"] == 0, (a, b)
+    assert failed >= 6 and r0["runs"][-1]["code"] == 0                                                  # (launch 40 does not exist: a clean run)

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Every GPU test (pytest -m gpu), one by one, against the CPU emulation build (tests/emu/), each in its own process
+under a hard time limit -- a test that hangs or is simply too large for a CPU costs its limit, nothing more.  Writes a JSON map
+test id -> {status, seconds, tail of the output if it failed}; tests/emu/quick_slice.txt (the slice `pytest -m "not gpu"` runs) is
+cut from it.
+    python tools/emu_survey.py [--limit 100] [--out /tmp/emu_survey.json] [--only <file with test ids>] [--async] [--workers 2]"""
+import json
+import os
+import subprocess
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def emu_env(threads=None, async_streams=False, lib=None):
+    from tests.emu import build_emu
+    env = dict(os.environ, ZK_STARK_LIB=lib or build_emu.build(), HIPEMU_TORCH_SHIM="1",
+               PYTHONPATH=os.path.join(ROOT, "tests", "emu", "site") + os.pathsep + ROOT)
+    if threads:
+        env["HIPEMU_THREADS"] = str(threads)
+    if async_streams:
+        env["HIPEMU_ASYNC"] = "1"
+    return env
+
+
+def main(argv):
+    def opt(name, dflt):
+        return argv[argv.index(name) + 1] if name in argv else dflt
+    limit, out_path, workers = float(opt("--limit", 100)), opt("--out", "/tmp/emu_survey.json"), int(opt("--workers", 2))
+    env = emu_env(threads=max(1, (os.cpu_count() or 2) // workers), async_streams="--async" in argv)
+    if "--only" in argv:
+        ids = [ln.strip() for ln in open(opt("--only", "")) if "::" in ln]
+    else:
+        r = subprocess.run([sys.executable, "-m", "pytest", "tests", "-m", "gpu", "--collect-only", "-q", "-p", "no:cacheprovider"],
+                           capture_output=True, text=True, cwd=ROOT, env=env)
+        ids = [ln.strip() for ln in r.stdout.splitlines() if "::" in ln]
+    print(len(ids), "tests", flush=True)
+
+    def run(tid):
+        t0 = time.time()
+        try:
+            p = subprocess.run([sys.executable, "-m", "pytest", tid, "-q", "-x", "-p", "no:cacheprovider"], capture_output=True, text=True,
+                               cwd=ROOT, env=env, timeout=limit)
+            status = "passed" if p.returncode == 0 else ("skipped" if " skipped" in p.stdout and "failed" not in p.stdout else "failed")
+            tail = (p.stdout[-1500:] + p.stderr[-500:]) if status == "failed" else ""
+        except subprocess.TimeoutExpired:
+            status, tail = "timeout", ""
+        return tid, status, round(time.time() - t0, 1), tail
+    out = {}
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        for tid, status, dt, tail in ex.map(run, ids):
+            out[tid] = {"status": status, "s": dt, "tail": tail}
+            print(status, dt, tid, flush=True)
+            with open(out_path, "w") as f:
+                json.dump(out, f, indent=0)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv))

@@ -36,7 +36,7 @@
 #define ZK_NTT_WAVE_BITS 10                 // elements per wave of the contiguous kernels
 #define ZK_NTT_WAVE_LDS 1088                // 64 rows x 17 words
 
-#if defined(ZK_HIPEMU)                      // (tests/emu/: the attribute exists for kernels of the device compiler only)
+#if !defined(__HIP__)                       // (tests/emu/: a plain C++ compiler; the attribute exists for kernels of the HIP compiler only)
 #define ZK_NTT_WAVES_PER_EU(lo, hi)
 #else
 #define ZK_NTT_WAVES_PER_EU(lo, hi) __attribute__((amdgpu_waves_per_eu(lo, hi)))
@@ -409,36 +409,43 @@ __global__ void __launch_bounds__(256) ntt_strided_reg_kernel(NttPass p) {
         const u32 row = DIT ? (q & ((1u << R) - 1)) : (q >> C), ch = DIT ? (q >> R) : (q & ((1u << C) - 1));
         return (row << log_d) + (ch << 4);
     };
+    // A group index is (bits that come from the register number m) | (bits that come from the lane), on disjoint positions, and
+    // offset() maps every bit of q to its own address bit: offset(qm | ql) = offset(qm) + offset(ql) -- a wave-uniform pointer plus one
+    // 32-bit lane offset per access (ntt_ld / ntt_st), no 64-bit address arithmetic per register.
+    auto ld = [&](u32 qm, u32 lane_off8) { return ntt_ld(src + offset(qm), lane_off8); };
+    auto st = [&](u32 qm, u32 lane_off8, u64 x) { ntt_st(dst + offset(qm), lane_off8, p.last_pass ? gl_canon(x) : x); };
     if constexpr (!DIT) {
         // entry: registers [3..0] = [q5 q4 q3 q2], lane 5 = q1, lane 4 = q0
         const u32 ql = (l5 << 1) | l4;
+        const u32 in8 = (offset(ql) + u) * 8;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = src[offset(((u32)m << 2) | ql) + u];
+        for (int m = 0; m < 16; ++m) v[m] = ld((u32)m << 2, in8);
         ntt_swap_dif6<R>(v, p.tw, twr, p.log_n - log_d - R, hi_idx, l4, l5);
+        // exit: R <= 4 as on entry; R = 5: registers [q1 q4 q3 q2], lane 5 = q5, lane 4 = q0; R = 6: ntt_swap_dif6_row, lanes = q5 q4
+        const u32 qlo = R <= 4 ? ql : R == 5 ? ((l5 << 5) | l4) : ((l5 << 5) | (l4 << 4));
+        const u32 out8 = (offset(qlo) + u) * 8;
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
-            u32 q;
-            if (R <= 4) q = ((u32)m << 2) | ql;                                                           // as on entry
-            else if (R == 5) q = (l5 << 5) | ((m & 4) << 2) | ((m & 2) << 2) | ((m & 1) << 2) | ((m & 8) >> 2) | l4;   // registers [q1 q4 q3 q2], lane 5 = q5
-            else q = (l5 << 5) | (l4 << 4) | ntt_swap_dif6_row(m);
-            dst[offset(q) + u] = p.last_pass ? gl_canon(v[m]) : v[m];
+            const u32 qm = R <= 4 ? ((u32)m << 2) : R == 5 ? (((m & 4) << 2) | ((m & 2) << 2) | ((m & 1) << 2) | ((m & 8) >> 2)) : ntt_swap_dif6_row(m);
+            st(qm, out8, v[m]);
         }
     } else {
         // entry: registers [3..0] = [q0 q1 q3 q2], lane 5 = q4, lane 4 = q5
         const u32 ql = (l4 << 5) | (l5 << 4);
+        const u32 in8 = (offset(ql) + u) * 8;
 #pragma unroll
-        for (int m = 0; m < 16; ++m) v[m] = src[offset(ql | ntt_swap_dit6_row_in(m)) + u];
+        for (int m = 0; m < 16; ++m) v[m] = ld(ntt_swap_dit6_row_in(m), in8);
         // the lane's position below the rows: tile's column block, the group's column bits (lane bits here: C <= 2), u
         const u32 chl = C == 2 ? ((l4 << 1) | l5) : C == 1 ? l4 : 0;
         const u32 xl8 = ((lo_block << (4 + C)) + (chl << 4) + u) * 8;
         ntt_swap_dit6<1, R>(vv, twr, log_d, xl8, l4, l5);
+        // exit: R = 4 as on entry; R = 5: registers [q4 q1 q3 q2], lane 5 = q0, lane 4 = q5; R = 6: ntt_swap_dit6_row, lanes = q1 q0
+        const u32 qlo = R == 4 ? ql : R == 5 ? ((l4 << 5) | l5) : ((l4 << 1) | l5);
+        const u32 out8 = (offset(qlo) + u) * 8;
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
-            u32 q;
-            if (R == 4) q = ql | ntt_swap_dit6_row_in(m);                                                   // as on entry
-            else if (R == 5) q = (l4 << 5) | ((m & 8) << 1) | ((m & 2) << 2) | ((m & 1) << 2) | ((m & 4) >> 1) | l5;   // registers [q4 q1 q3 q2], lane 5 = q0
-            else q = ntt_swap_dit6_row(m) | (l4 << 1) | l5;
-            dst[offset(q) + u] = p.last_pass ? gl_canon(v[m]) : v[m];
+            const u32 qm = R == 4 ? ntt_swap_dit6_row_in(m) : R == 5 ? (((m & 8) << 1) | ((m & 2) << 2) | ((m & 1) << 2) | ((m & 4) >> 1)) : ntt_swap_dit6_row(m);
+            st(qm, out8, v[m]);
         }
     }
 }
@@ -516,7 +523,7 @@ static __global__ void __launch_bounds__(256) ntt_contig_wave_kernel_dif(NttPass
 // value x = 2 i + b = the plain 2^10-point transform of c_i * scale_b[i], scale_0 = in_scale (may be null: ones), scale_1 =
 // in_scale2 = the same coset table for shift * w_(2n) (ntt_host.inc).  Output index (sbase + i) * NB + b.
 template <int NB>
-__global__ void __launch_bounds__(256) ZK_NTT_WAVES_PER_EU(4, 8) ntt_contig_wave_kernel_dit(NttPass p, const u64 *in_scale2) {
+__global__ void __launch_bounds__(256) ZK_NTT_WAVES_PER_EU(NB == 2 ? 3 : 4, 8) ntt_contig_wave_kernel_dit(NttPass p, const u64 *in_scale2) {
     extern __shared__ __attribute__((aligned(16))) u64 lds_all[];            // 4 x ZK_NTT_WAVE_LDS words (ntt_host.inc)
     const u32 tid = threadIdx.x, lane = tid & 63, wv = ntt_uniform(tid >> 6), u = lane & 15, l4 = (lane >> 4) & 1, l5 = lane >> 5;
     u64 *const lds = lds_all + wv * ZK_NTT_WAVE_LDS;
