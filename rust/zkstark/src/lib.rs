@@ -59,6 +59,24 @@ impl Context {
     }
     pub fn mem_reserve(&self, bytes: usize) -> Result<()> { self.check(unsafe { zk_ctx_mem_reserve(self.raw, bytes) }) }
     pub fn synchronize(&self) -> Result<()> { self.check(unsafe { zk_ctx_synchronize(self.raw) }) }
+    /// The ctx's plan table (`zk_ctx_set_plans`): which of two equivalent kernels serves a shape, as data -- e.g.
+    /// `"v20f0=2;b20r1=96x1;T=1;"`.  `None` = the initial table (`ZK_NTT_SWAP_PLANS` or the one compiled in), `Some("")` = the first
+    /// implementation everywhere.  Proofs do not depend on it; the library never measures or spawns anything to fill it.
+    pub fn set_plans(&self, plans: Option<&str>) -> Result<()> {
+        match plans {
+            None => self.check(unsafe { zk_ctx_set_plans(self.raw, null()) }),
+            Some(p) => {
+                let c = std::ffi::CString::new(p).map_err(|_| anyhow!("plan string with an interior NUL"))?;
+                self.check(unsafe { zk_ctx_set_plans(self.raw, c.as_ptr()) })
+            }
+        }
+    }
+    pub fn plans(&self) -> String {
+        let mut buf = vec![0u8; 4100];
+        let n = unsafe { zk_ctx_get_plans(self.raw, buf.as_mut_ptr() as *mut std::os::raw::c_char, buf.len()) };
+        buf.truncate(n.min(4099));
+        String::from_utf8_lossy(&buf).into_owned()
+    }
     /// [ifft, lde, leaf hash, tree] ms of the last commit: children of the reference's "compute trace commitment" scope.
     pub fn last_timings(&self) -> Result<[f32; 4]> {
         let mut t = [0f32; 4];

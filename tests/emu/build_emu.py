@@ -21,7 +21,7 @@ UNITS = ["zkstark", "zk_airs_a", "zk_airs_b", "zk_airs_c", "zk_airs_d", "zk_plon
 CXX = "/opt/rocm/lib/llvm/bin/clang++" if os.path.exists("/opt/rocm/lib/llvm/bin/clang++") else (shutil.which("clang++") or "g++")
 SAN_FLAGS = {
     "": [],
-    "asan": ["-fsanitize=address", "-fno-omit-frame-pointer"],
+    "asan": ["-fsanitize=address,undefined", "-fno-sanitize=vptr,function", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"],      # ASan + UBSan
     "ubsan": ["-fsanitize=undefined", "-fno-sanitize=vptr,function", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"],
     "tsan": ["-fsanitize=thread", "-fno-omit-frame-pointer"],
 }

@@ -1,0 +1,30 @@
+#!/bin/bash
+# The GPU tests of tests/emu/quick_slice.txt against the CPU emulation build (tests/emu/) under the sanitizers that
+# cannot run beside the GPU runtime (r05 verdict, next 5):
+#   asan  AddressSanitizer + UndefinedBehaviorSanitizer: "device" memory is host memory, so every out-of-bounds or use-after-free access
+#         of a KERNEL, of the arena, of the staging buffers is caught; stack-use-after-scope across the fiber switches included
+#   tsan  ThreadSanitizer: the host side's threads (two contexts proving concurrently, the PLONK batch workers, the emulator's block pool)
+# -> profiles/<tag>_emu_asan_ubsan.log, profiles/<tag>_emu_tsan.log (the pytest summary + every sanitizer report, if any)
+#   tools/emu_sanitizers.sh [tag=r06c] [asan|tsan|both]
+TAG=${1:-r06c}; WHICH=${2:-both}
+ROOT=$(cd "$(dirname "$0")/.." && pwd); cd "$ROOT"
+RTD=$(dirname "$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)")
+IDS=$(grep "::" tests/emu/quick_slice.txt | grep -v "^#")
+run() {   # san, runtime .so, options-variable=value, out file, extra pytest ids
+  local san=$1 rt=$2 opt=$3 out=$4; shift 4
+  python tests/emu/build_emu.py --san "$san" > /dev/null || { echo "build of the $san variant failed"; return 1; }
+  local lib=$ROOT/tests/emu/build_$san/libzkstark_emu_$san.so
+  { echo "# quick slice of the GPU tests on the CPU emulation build under -fsanitize=$san ($(git rev-parse --short HEAD)); NOT a hardware run";
+    env ZK_STARK_LIB="$lib" HIPEMU_TORCH_SHIM=1 PYTHONPATH="$ROOT/tests/emu/site:$ROOT" LD_PRELOAD="$rt" "$opt" \
+        ASAN_SYMBOLIZER_PATH=/opt/rocm/lib/llvm/bin/llvm-symbolizer TSAN_SYMBOLIZER_PATH=/opt/rocm/lib/llvm/bin/llvm-symbolizer \
+        timeout 7200 python -m pytest "$@" -q -p no:cacheprovider 2>&1 | grep -v "^$" | tail -400; } > "$out"
+  tail -3 "$out"
+}
+if [ "$WHICH" = asan ] || [ "$WHICH" = both ]; then
+  run asan "$RTD/libclang_rt.asan-x86_64.so" "ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1" profiles/${TAG}_emu_asan_ubsan.log $IDS
+fi
+if [ "$WHICH" = tsan ] || [ "$WHICH" = both ]; then
+  # the tests with host threads first (two contexts, the scheduler, PLONK batches), then the slice
+  run tsan "$RTD/libclang_rt.tsan-x86_64.so" "TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0:second_deadlock_stack=1" profiles/${TAG}_emu_tsan.log \
+      "tests/test_gpu_segment.py::test_two_contexts_prove_concurrently" "tests/test_gpu_plonk.py::test_plonk_prove_batch_equals_single_proofs" $IDS
+fi
