@@ -94,3 +94,42 @@ def test_a_failing_rank_never_strands_its_peer(emu_env):
         else:
             assert a["code"] == 0, (a, b)
     assert failed >= 6 and r0["runs"][-1]["code"] == 0                                                  # (launch 40 does not exist: a clean run)
+
+
+_TUNER_CHILD = r"""
+import ctypes as C, json, sys
+import zk_evm_amd as zk
+ctx = zk.Context(0)
+lib = ctx.lib
+lib.zki_ntt_tune_range.restype = C.c_int
+lib.zki_ntt_tune_range.argtypes = [C.c_void_p] + [C.c_int] * 5 + [C.POINTER(C.c_int)]
+lib.zki_tree_batch_trial.restype = C.c_int
+lib.zki_tree_batch_trial.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_int)]
+lib.zki_ntt_tune_report.restype = C.c_size_t
+lib.zki_ntt_tune_report.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+ctx.set_plans("")
+d, td = C.c_int(-1), C.c_int(-1)
+rc1 = lib.zki_ntt_tune_range(ctx.handle, 10, 15, 10, 12, 1, C.byref(d))
+rc2 = lib.zki_tree_batch_trial(ctx.handle, (C.c_uint * 9)(5, 4, 5, 4, 4, 4, 6, 4, 4), C.byref(td))
+buf = C.create_string_buffer(1 << 16)
+lib.zki_ntt_tune_report(ctx.handle, buf, len(buf))
+print("RESULT " + json.dumps({"rc": [rc1, rc2], "differ": [d.value, td.value], "plans": ctx.get_plans(), "report": buf.value.decode()}))
+"""
+
+
+def test_the_offline_tuners_trials_find_identical_outputs(emu_env):
+    """What `zk_ntt_tune` does on a device, at sizes a CPU can carry: both NTT plans of every transform shape 2^10 .. 2^15 (values ->
+    coefficients, coefficients -> values with and without a free stage) on pseudo-random columns, compared word for word; the
+    column-batch forms of from_values (one stream, two streams) digest for digest; a nine-table segment proven with the tree tops per
+    tree and batched, proof word for proof word.  No second form may differ, and the plan string the trials leave in the ctx parses."""
+    import re
+    r = subprocess.run([sys.executable, "-c", _TUNER_CHILD], capture_output=True, text=True, cwd=ROOT, timeout=1500,
+                       env=dict(emu_env, ZK_NTT_TUNE_ELEMS_LOG="15", ZK_NTT_TUNE_COLS="3"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert out["rc"] == [0, 0] and out["differ"] == [0, 0], out
+    assert re.fullmatch(r"([vd][0-9]+f[01]=[12];|b[0-9]+r1=[0-9]+x[12];|T=[01];)+", out["plans"]), out["plans"]
+    lines = out["report"].splitlines()
+    assert not any("DIFFER" in ln or "failed" in ln for ln in lines), out["report"]
+    assert sum(ln.startswith("ntt plan") for ln in lines) >= 10 and sum(ln.startswith("ntt column batches") for ln in lines) == 3
+    assert any(ln.startswith("tree tops") and "differing words 0" in ln for ln in lines)

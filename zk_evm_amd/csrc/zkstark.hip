@@ -710,30 +710,33 @@ extern "C" size_t zki_ntt_tune_report(const zk_ctx *ctx, char *out, size_t max) 
     if (out && max) { const size_t n = ctx->tune_report.size() < max - 1 ? ctx->tune_report.size() : max - 1; memcpy(out, ctx->tune_report.data(), n); out[n] = 0; }
     return ctx->tune_report.size();
 }
-// (internal; the offline tuner) both plans of every transform shape that has a lane-swap plan and the column-batch forms of every
-// from_values shape that has a trial, run on the device and compared; the verdicts go into THIS ctx's plan table (zk_ctx_get_plans)
-// and report.  *n_differ = the number of trials in which the second form produced different words: a parity failure of shipped code.
-extern "C" int zki_ntt_tune_all(zk_ctx *ctx, int *n_differ) {
+// (internal; the offline tuner, and at small sizes the CPU emulation tests) the trials of the transform shapes 2^min_log .. 2^max_log
+// and of the from_values shapes 2^batch_min_log .. 2^batch_max_log rows (batch_mb MiB batches): see zki_ntt_tune_all
+extern "C" int zki_ntt_tune_range(zk_ctx *ctx, int min_log, int max_log, int batch_min_log, int batch_max_log, int batch_mb, int *n_differ) {
     if (!ctx) return ZK_ERR_BAD_ARG;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int differ = 0;
     for (int dit = 0; dit < 2; ++dit)
         for (int free_stages = 0; free_stages <= dit; ++free_stages)
-            for (int L = ZK_NTT_WAVE_BITS + free_stages; L <= 22; ++L) {
+            for (int L = std::max(min_log, ZK_NTT_WAVE_BITS + free_stages); L <= std::min(max_log, 22); ++L) {
                 if (!ntt_swap_has_plan(dit != 0, L, free_stages)) continue;
                 bool d = false;
                 ZK_TRY(ntt_swap_trial(ctx, dit != 0, L, free_stages, &d));
                 differ += d;
             }
     // with the plans decided: the column batches of the shapes that have a trial (rate_bits = 1: the STARK tables)
-    for (int log_n = 17; log_n + 1 <= 22; ++log_n) {
+    for (int log_n = batch_min_log; log_n <= batch_max_log && log_n + 1 <= 22; ++log_n) {
         bool d = false;
-        ZK_TRY(ntt_batch_trial(ctx, log_n, 1, &d));
+        ZK_TRY(ntt_batch_trial(ctx, log_n, 1, &d, batch_mb));
         differ += d;
     }
     if (n_differ) *n_differ = differ;
     return ZK_OK;
 }
+// (internal; the offline tuner) both plans of every transform shape that has a lane-swap plan and the column-batch forms of every
+// from_values shape that has a trial, run on the device and compared; the verdicts go into THIS ctx's plan table (zk_ctx_get_plans)
+// and report.  *n_differ = the number of trials in which the second form produced different words: a parity failure of shipped code.
+extern "C" int zki_ntt_tune_all(zk_ctx *ctx, int *n_differ) { return zki_ntt_tune_range(ctx, ZK_NTT_WAVE_BITS, 22, 17, 21, 96, n_differ); }
 // (internal, for tests: no device involved) what a plan string says about a shape: 0 = no item, 1 = tile, 2 = lane-swap, -1 = the
 // shape has no second plan; the column-batch item as MiB * 4 + streams (-1 = none); the tree tops (-1 = none)
 extern "C" int zki_plans_ntt(const char *plans, int dit, int L, int free_stages) {
