@@ -13,11 +13,25 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _flags(hip_runtime=False):
+    """compile / link flags of a plain-C driver: the in-tree library and (for the drivers that allocate device memory themselves) the
+    HIP runtime -- or, in a process running the CPU emulation build (ZK_STARK_LIB = tests/emu/build*/libzkstark_emu*.so, tests/emu/), that
+    library, which carries the stand-in runtime too"""
+    emu = os.environ.get("ZK_STARK_LIB", "")
+    if "libzkstark_emu" in os.path.basename(emu):
+        d = os.path.dirname(emu)
+        return ["-I", os.path.join(ROOT, "tests", "emu", "hipemu"), "-L", d, "-l:" + os.path.basename(emu), "-Wl,-rpath," + d]
+    libdir = os.path.join(ROOT, "zk_evm_amd")
+    out = ["-L", libdir, "-lzkstark_hip", "-Wl,-rpath," + libdir]
+    if hip_runtime:
+        out = ["-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__"] + out + ["-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"]
+    return out
+
+
 def _build(tmp_path):
     exe = str(tmp_path / "cabi_harness")
-    libdir = os.path.join(ROOT, "zk_evm_amd")
     cmd = [shutil.which("gcc") or "gcc", "-std=c11", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "cabi", "harness.c"),
-           "-I", os.path.join(ROOT, "include"), "-L", libdir, "-lzkstark_hip", "-Wl,-rpath," + libdir, "-o", exe]
+           "-I", os.path.join(ROOT, "include"), *_flags(), "-o", exe]
     subprocess.run(cmd, check=True)
     return exe
 
@@ -54,12 +68,9 @@ def test_c_segment_proof_matches_python_mirror(tmp_path, cdk_erigon):
     from tests.test_gpu_segment import make_pv, make_traces, make_traces_cdk_erigon, to_public_values
     from zk_evm_amd.all_stark import AllStark
     exe = str(tmp_path / "cabi_segment")
-    libdir = os.path.join(ROOT, "zk_evm_amd")
     subprocess.run([shutil.which("gcc") or "gcc", "-std=c11", "-O1", "-Wall", "-Werror",
                     os.path.join(ROOT, "tests", "cabi", "segment.c"), "-I", os.path.join(ROOT, "include"),
-                    "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L", libdir, "-lzkstark_hip",
-                    "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
-                    "-o", exe], check=True)
+                    *_flags(hip_runtime=True), "-o", exe], check=True)
     rng = np.random.default_rng(77 + cdk_erigon)
     traces = (make_traces_cdk_erigon if cdk_erigon else make_traces)(rng)
     in_use = [True] * len(traces)
@@ -117,12 +128,9 @@ def test_c_multi_rank_segment_proof_matches_single_gpu(tmp_path, world, wide, fr
     from tests.test_gpu_segment import make_pv, make_traces, to_public_values
     from zk_evm_amd.all_stark import AllStark
     exe = str(tmp_path / "cabi_sharded")
-    libdir = os.path.join(ROOT, "zk_evm_amd")
     subprocess.run([shutil.which("gcc") or "gcc", "-std=c11", "-O1", "-Wall", "-Werror",
                     os.path.join(ROOT, "tests", "cabi", "sharded.c"), "-I", os.path.join(ROOT, "include"),
-                    "-I", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__", "-L", libdir, "-lzkstark_hip",
-                    "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
-                    "-o", exe], check=True)
+                    *_flags(hip_runtime=True), "-o", exe], check=True)
     rng = np.random.default_rng(91)
     log_ns = [9, 8, 10, 8, 8, 8, 11, 8, 8]
     traces = make_traces(rng, log_ns)
