@@ -46,6 +46,7 @@
 #if defined(__SANITIZE_THREAD__) && !defined(HIPEMU_TSAN)
 #define HIPEMU_TSAN 1
 #endif
+// (tests/emu/build_emu.py --san tsan compiles THIS file without -fsanitize=thread and passes -DHIPEMU_TSAN=1)
 #ifdef HIPEMU_ASAN
 extern "C" void __sanitizer_start_switch_fiber(void **fake_stack_save, const void *bottom, size_t size);
 extern "C" void __sanitizer_finish_switch_fiber(void *fake_stack_save, const void **bottom_old, size_t *size_old);
@@ -55,6 +56,21 @@ extern "C" void *__tsan_get_current_fiber(void);
 extern "C" void *__tsan_create_fiber(unsigned flags);
 extern "C" void __tsan_destroy_fiber(void *fiber);
 extern "C" void __tsan_switch_to_fiber(void *fiber, unsigned flags);
+extern "C" void __tsan_acquire(void *addr);
+extern "C" void __tsan_release(void *addr);
+// Under ThreadSanitizer every fiber is a thread of its own and a switch is NOT a synchronisation (flag 1 = no_sync): what orders the
+// threads of a block is what orders them on the hardware -- __syncthreads(), the wave operations, the start and the end of the block --
+// each annotated as release + acquire on an object of the worker.  A kernel that reads LDS (or global memory) another thread of its
+// block wrote, with no barrier in between, is then reported as a data race: a missing __syncthreads() shows up without a GPU.
+// (Lanes of ONE wave that rely on lock-step execution without ntt_wave_sync would be reported too; the library has no such place.)
+#define HIPEMU_NO_TSAN __attribute__((no_sanitize("thread")))
+#define HIPEMU_TSAN_RELEASE(p) __tsan_release((void *)(p))
+#define HIPEMU_TSAN_ACQUIRE(p) __tsan_acquire((void *)(p))
+static constexpr unsigned kTsanSwitchFlags = 1;
+#else
+#define HIPEMU_NO_TSAN
+#define HIPEMU_TSAN_RELEASE(p) ((void)0)
+#define HIPEMU_TSAN_ACQUIRE(p) ((void)0)
 #endif
 
 namespace hipemu {
@@ -114,6 +130,7 @@ static constexpr size_t kStackBytes = 256 * 1024;     // (a kernel thread's fram
 enum FiberState : uint8_t { F_RUNNABLE, F_WAIT_BLOCK, F_WAIT_WAVE, F_DONE };
 
 struct Wave {
+    char sync = 0;
     uint64_t xchg[2][64];
     uint32_t stamp[2][64];
     unsigned live = 0, waiting = 0;
@@ -141,6 +158,7 @@ struct Worker {                                        // one per OS thread that
     unsigned n = 0, n_waves = 0, live = 0, block_waiting = 0;
     bool deadlock = false, from_main = false;
     uint64_t switches = 0;
+    char sync_start = 0, sync_end = 0, sync_block = 0;      // (TSan: addresses of the block's synchronisation objects)
     const char *kernel = "";
 #ifdef HIPEMU_ASAN
     const void *sched_bottom = nullptr;
@@ -163,7 +181,7 @@ thread_local ThreadState *t_cur = nullptr;
 static thread_local Worker *t_worker = nullptr;
 
 // Fiber -> fiber, directly (the worker's own context only starts a block and takes over again when it is finished or stuck).
-static inline void switch_fiber(Worker *w, Fiber *from, Fiber *to) {
+HIPEMU_NO_TSAN static inline void switch_fiber(Worker *w, Fiber *from, Fiber *to) {
     ++w->switches;
     w->cur = to;
     t_cur = &to->ts;
@@ -171,27 +189,27 @@ static inline void switch_fiber(Worker *w, Fiber *from, Fiber *to) {
     __sanitizer_start_switch_fiber(from->state == F_DONE ? nullptr : &from->asan_fake, to->stack, kStackBytes);
 #endif
 #ifdef HIPEMU_TSAN
-    __tsan_switch_to_fiber(to->tsan, 0);
+    __tsan_switch_to_fiber(to->tsan, kTsanSwitchFlags);
 #endif
     hipemu_ctx_switch(&from->sp, to->sp);
 #ifdef HIPEMU_ASAN
     __sanitizer_finish_switch_fiber(from->asan_fake, nullptr, nullptr);
 #endif
 }
-static void switch_to_main(Worker *w, Fiber *from) {
+HIPEMU_NO_TSAN static void switch_to_main(Worker *w, Fiber *from) {
     t_cur = nullptr;
 #ifdef HIPEMU_ASAN
     __sanitizer_start_switch_fiber(from->state == F_DONE ? nullptr : &from->asan_fake, w->sched_bottom, w->sched_size);
 #endif
 #ifdef HIPEMU_TSAN
-    __tsan_switch_to_fiber(w->sched_tsan, 0);
+    __tsan_switch_to_fiber(w->sched_tsan, kTsanSwitchFlags);
 #endif
     hipemu_ctx_switch(&from->sp, w->sched_sp);
 #ifdef HIPEMU_ASAN
     __sanitizer_finish_switch_fiber(from->asan_fake, nullptr, nullptr);
 #endif
 }
-static bool open_barriers(Worker *w) {
+HIPEMU_NO_TSAN static bool open_barriers(Worker *w) {
     bool opened = false;
     if (w->block_waiting && w->block_waiting == w->live) {
         for (unsigned t = 0; t < w->n; ++t) if (w->fibers[t].state == F_WAIT_BLOCK) w->fibers[t].state = F_RUNNABLE;
@@ -209,7 +227,7 @@ static bool open_barriers(Worker *w) {
     return opened;
 }
 // The running fiber has just blocked (or finished): run the next one that can run; returns when this fiber is runnable again.
-static void yield_blocked(Worker *w) {
+HIPEMU_NO_TSAN static void yield_blocked(Worker *w) {
     Fiber *f = w->cur;
     const unsigned me = (unsigned)(f - w->fibers.data()), n = w->n;
     for (;;) {
@@ -227,8 +245,9 @@ static void yield_blocked(Worker *w) {
         return;
     }
 }
-static void fiber_entry() {
+HIPEMU_NO_TSAN static void fiber_entry() {
     Worker *w = t_worker;
+    HIPEMU_TSAN_ACQUIRE(&w->sync_start);
 #ifdef HIPEMU_ASAN
     {
         const void *b = nullptr; size_t sz = 0;
@@ -238,6 +257,7 @@ static void fiber_entry() {
 #endif
     w->from_main = false;
     (*w->body)();
+    HIPEMU_TSAN_RELEASE(&w->sync_end);
     Fiber *f = w->cur;
     f->state = F_DONE;
     --w->live;
@@ -246,7 +266,7 @@ static void fiber_entry() {
     die("a finished fiber was resumed");
 }
 
-static void run_block(Worker *w, dim3 grid, dim3 block, dim3 bidx, size_t lds, const std::function<void()> &body, const char *name) {
+HIPEMU_NO_TSAN static void run_block(Worker *w, dim3 grid, dim3 block, dim3 bidx, size_t lds, const std::function<void()> &body, const char *name) {
     const unsigned n = block.x * block.y * block.z;
     if (n == 0 || n > 1024) die("kernel %s launched with a bad block size", name);
     w->n = n; w->live = n; w->block_waiting = 0; w->body = &body; w->kernel = name; w->deadlock = false;
@@ -287,11 +307,12 @@ static void run_block(Worker *w, dim3 grid, dim3 block, dim3 bidx, size_t lds, c
     w->cur = first;
     t_cur = &first->ts;
     w->from_main = true;
+    HIPEMU_TSAN_RELEASE(&w->sync_start);
 #ifdef HIPEMU_ASAN
     __sanitizer_start_switch_fiber(&w->sched_fake, first->stack, kStackBytes);
 #endif
 #ifdef HIPEMU_TSAN
-    __tsan_switch_to_fiber(first->tsan, 0);
+    __tsan_switch_to_fiber(first->tsan, kTsanSwitchFlags);
 #endif
     hipemu_ctx_switch(&w->sched_sp, first->sp);
 #ifdef HIPEMU_ASAN
@@ -299,6 +320,7 @@ static void run_block(Worker *w, dim3 grid, dim3 block, dim3 bidx, size_t lds, c
 #endif
     w->cur = nullptr;
     t_cur = nullptr;
+    HIPEMU_TSAN_ACQUIRE(&w->sync_end);
     if (w->deadlock) {
         fprintf(stderr, "hipemu: DEADLOCK in kernel %s, block (%u,%u,%u): %u threads alive, %u at __syncthreads", name, bidx.x, bidx.y, bidx.z, w->live, w->block_waiting);
         for (unsigned v = 0; v < n_waves; ++v) if (w->waves[v].waiting) fprintf(stderr, ", wave %u: %u of %u at a wave operation", v, w->waves[v].waiting, w->waves[v].live);
@@ -315,22 +337,26 @@ void *dyn_lds() {
     Worker *w = t_worker;
     return (void *)(((uintptr_t)w->dyn.data() + 63) & ~(uintptr_t)63);
 }
-void sync_threads() {
+HIPEMU_NO_TSAN void sync_threads() {
     Worker *w = t_worker;
     if (!w || !w->cur) die("__syncthreads outside a kernel");
+    HIPEMU_TSAN_RELEASE(&w->sync_block);
     w->cur->state = F_WAIT_BLOCK;
     ++w->block_waiting;
     yield_blocked(w);
+    HIPEMU_TSAN_ACQUIRE(&w->sync_block);
 }
-void wave_sync() {
+HIPEMU_NO_TSAN void wave_sync() {
     Worker *w = t_worker;
     if (!w || !w->cur) die("a wave operation outside a kernel");
     Fiber *f = w->cur;
+    HIPEMU_TSAN_RELEASE(&w->waves[f->ts.wave].sync);
     f->state = F_WAIT_WAVE;
     ++w->waves[f->ts.wave].waiting;
     yield_blocked(w);
+    HIPEMU_TSAN_ACQUIRE(&w->waves[f->ts.wave].sync);
 }
-uint64_t wave_exchange(uint64_t mine, unsigned src) {
+HIPEMU_NO_TSAN uint64_t wave_exchange(uint64_t mine, unsigned src) {
     Worker *w = t_worker;
     if (!w || !w->cur) die("a wave operation outside a kernel");
     Fiber *f = w->cur;

@@ -133,3 +133,31 @@ def test_the_offline_tuners_trials_find_identical_outputs(emu_env):
     assert not any("DIFFER" in ln or "failed" in ln for ln in lines), out["report"]
     assert sum(ln.startswith("ntt plan") for ln in lines) >= 10 and sum(ln.startswith("ntt column batches") for ln in lines) == 3
     assert any(ln.startswith("tree tops") and "differing words 0" in ln for ln in lines)
+
+
+def test_the_emulator_checks_what_it_claims(tmp_path):
+    """tests/emu/hipemu_selftest.cpp: a kernel that reverses a block through LDS WITH its __syncthreads() is clean in every mode (streams in
+    order / deferred behind an event wait, plain / ThreadSanitizer); the same kernel WITHOUT the barrier is reported as a data race by
+    the ThreadSanitizer build (every fiber a thread of its own, only barriers order them) -- so "no report" on the library's kernels
+    (tools/emu_sanitizers.sh) means something.  Wave shuffles and threads that leave before a barrier are checked on the way."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    from build_emu import CXX
+    from translate import translate
+    src = tmp_path / "st.cpp"
+    src.write_text(translate(open(os.path.join(ROOT, "tests", "emu", "hipemu_selftest.cpp")).read()))
+    base = [CXX, "-std=c++17", "-O1", "-g", "-pthread", "-I", os.path.join(ROOT, "tests", "emu", "hipemu")]
+    emu_cpp = os.path.join(ROOT, "tests", "emu", "hipemu", "hipemu.cpp")
+    for tag, flags, emuflags in (("plain", [], []), ("tsan", ["-fsanitize=thread"], ["-fno-sanitize=thread", "-DHIPEMU_TSAN=1"])):
+        subprocess.run(base + flags + ["-c", str(src), "-o", str(tmp_path / ("st_%s.o" % tag))], check=True)
+        subprocess.run(base + flags + emuflags + ["-c", emu_cpp, "-o", str(tmp_path / ("emu_%s.o" % tag))], check=True)
+        subprocess.run(base + flags + [str(tmp_path / ("st_%s.o" % tag)), str(tmp_path / ("emu_%s.o" % tag)), "-o", str(tmp_path / ("st_" + tag))], check=True)
+    for tag in ("plain", "tsan"):
+        for mode in ("ok", "racy"):
+            for asy in ("0", "1"):
+                r = subprocess.run([str(tmp_path / ("st_" + tag)), mode], capture_output=True, text=True, timeout=300,
+                                   env=dict(os.environ, HIPEMU_ASYNC=asy, HIPEMU_THREADS="2", TSAN_OPTIONS="exitcode=66"))
+                reports = r.stderr.count("WARNING: ThreadSanitizer: data race")
+                if mode == "ok":
+                    assert r.returncode == 0 and reports == 0 and "0 wrong values" in r.stdout, (tag, asy, r.stdout, r.stderr[-1500:])
+                elif tag == "tsan":
+                    assert r.returncode == 66 and reports >= 1 and "reverse_without_barrier" in r.stderr, (asy, r.stderr[-1500:])
