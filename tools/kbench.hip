@@ -71,6 +71,8 @@ int main(int argc, char **argv) {
     ctx->plans = initial_plans();          // ZK_NTT_SWAP_PLANS / the table compiled in; ZK_NTT_SWAP=0|1 forces one form
     hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_strided_swap_kernel<true, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_strided_swap_kernel<false, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     u64 *vals, *coeffs, *lde, *dig;
     const size_t nd = zk_merkle_num_digests(log_N, cap_height);
     hipMalloc(&vals, cols * n * 8); hipMalloc(&coeffs, cols * n * 8); hipMalloc(&lde, cols * N * 8); hipMalloc(&dig, nd * 32);

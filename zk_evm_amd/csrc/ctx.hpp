@@ -73,6 +73,7 @@ struct zk_ctx {
     double side_leaf_bytes = 0, side_ntt_bytes = 0;
     uint64_t side_commits = 0;
     int cu_count = 0;
+    uint32_t func_attrs = 0;            // kernels whose dynamic-LDS limit this ctx has raised on ITS device (a process may drive several GPUs: never once per process)
     std::set<zk_batch *> live_batches;  // freed by zk_ctx_destroy if the caller leaked them
     ArenaSet arena;                     // all batch + scratch HBM, one arena per lane (arena.hpp)
     // debug: starky `check_ctls` after get_ctl_data (zk_ctx_set_check_ctls); extra looking rows per CTL index

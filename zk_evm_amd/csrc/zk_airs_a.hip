@@ -16,12 +16,11 @@ int zki_quotient_airs_a(zk_ctx *ctx, uint32_t air_id, const QuotientArgs &A, u32
             if (count || !kArithTiled || A.sharded)   // the constraint count, ZK_ARITH_TILED=0, or a row shard (its rows are not
                                                       // consecutive points): the one-lane-per-point form
                 return launch_quotient_air<AirArithmetic, true>(ctx, A, size, scratch, count);
-            static bool attr_set = false;     // (idempotent; a race only repeats the call)
             const size_t lds = (size_t)ZK_ARITH_LDS_WORDS * sizeof(u64);
-            if (!attr_set) {
+            if (!(ctx->func_attrs & 2u)) {    // once per ctx = on every device a process drives
                 HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&quotient_arith_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set = true;
+                ctx->func_attrs |= 2u;
             }
             quotient_arith_kernel<<<(size + ZK_ARITH_POINTS - 1) / ZK_ARITH_POINTS, 64 * ZK_ARITH_WAVES, lds, ctx->stream>>>(A);
             return check_launch(ctx, "quotient_arith_kernel");

@@ -68,6 +68,9 @@ extern "C" int zk_ctx_create(int device, zk_ctx **out) {
     // allow the NTT kernels their full LDS tile (default dynamic limit is 64 KiB)
     hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_pass_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (per DEVICE, hence here and not behind a once-per-process flag: a process may drive several GPUs, one ctx each)
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_strided_swap_kernel<true, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(&ntt_strided_swap_kernel<false, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     ctx->plans = initial_plans();              // (ntt_host.inc: ZK_NTT_SWAP_PLANS as read at load, else the table compiled in)
     *out = ctx;
     return ZK_OK;
