@@ -19,6 +19,7 @@ def emu_env(threads=None, async_streams=False, lib=None):
     from tests.emu import build_emu
     env = dict(os.environ, ZK_STARK_LIB=lib or build_emu.build(), HIPEMU_TORCH_SHIM="1",
                PYTHONPATH=os.path.join(ROOT, "tests", "emu", "site") + os.pathsep + ROOT)
+    env.setdefault("ZK_COMM_TIMEOUT_S", "180")          # (host transport: a rank left alone by a killed test gives up soon)
     if threads:
         env["HIPEMU_THREADS"] = str(threads)
     if async_streams:
@@ -40,14 +41,25 @@ def main(argv):
     print(len(ids), "tests", flush=True)
 
     def run(tid):
+        import signal
         t0 = time.time()
+        # its own session: a test that times out takes the ranks / child interpreters it started with it (a multi-rank test left
+        # alone keeps spinning at a barrier for the transport's whole time limit)
+        p = subprocess.Popen([sys.executable, "-m", "pytest", tid, "-q", "-x", "-p", "no:cacheprovider"], stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env, start_new_session=True)
         try:
-            p = subprocess.run([sys.executable, "-m", "pytest", tid, "-q", "-x", "-p", "no:cacheprovider"], capture_output=True, text=True,
-                               cwd=ROOT, env=env, timeout=limit)
-            status = "passed" if p.returncode == 0 else ("skipped" if " skipped" in p.stdout and "failed" not in p.stdout else "failed")
-            tail = (p.stdout[-1500:] + p.stderr[-500:]) if status == "failed" else ""
+            so, se = p.communicate(timeout=limit)
+            status = "passed" if p.returncode == 0 else ("skipped" if " skipped" in so and "failed" not in so else "failed")
+            tail = (so[-1500:] + se[-500:]) if status == "failed" else ""
         except subprocess.TimeoutExpired:
             status, tail = "timeout", ""
+        finally:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except (ProcessLookupError, PermissionError):
+                pass
+            if p.poll() is None:
+                p.communicate()
         return tid, status, round(time.time() - t0, 1), tail
     out = {}
     with ThreadPoolExecutor(max_workers=workers) as ex:
