@@ -29,6 +29,11 @@ ALL_SECOND = ("".join("v%df0=2;d%df0=2;d%df1=2;" % (l, l, l) for l in range(10, 
 SWAP_ONLY = "".join("v%df0=2;d%df0=2;d%df1=2;" % (l, l, l) for l in range(10, 23))
 
 
+def _pythonpath():
+    """the repository first, whatever the parent had after it (tests/emu/site when this suite runs on the emulation build)"""
+    return ROOT + (os.pathsep + os.environ["PYTHONPATH"] if os.environ.get("PYTHONPATH") else "")
+
+
 @pytest.fixture
 def default_ctx():
     import zk_evm_amd as zk
@@ -128,7 +133,7 @@ def test_process_wide_switches_give_the_same_commitments():
     for key, env in (("tile", {"ZK_NTT_SWAP": "0"}), ("strided", {"ZK_NTT_SWAP": "1", "ZK_NTT_SWAP_CONTIG": "0"}),
                      ("all", {"ZK_NTT_SWAP": "1", "ZK_NTT_SWAP_CONTIG": "1"}), ("all+batches", {"ZK_NTT_SWAP": "1", "ZK_NTT_COL_BATCH_MB": "64"})):
         r = subprocess.run([sys.executable, "-c", _COMMIT_CHILD, json.dumps(shapes)], capture_output=True, text=True, cwd=ROOT,
-                           env=dict(os.environ, PYTHONPATH=ROOT, **env), timeout=900)
+                           env=dict(os.environ, PYTHONPATH=_pythonpath(), **env), timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         res[key] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert len(res["tile"]) == len(shapes)
@@ -157,7 +162,7 @@ def test_process_wide_switches_prove_the_same_segments(switches):
     once with the batch boundary moved down to 2^12 nodes."""
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_segment.py"), "-m", "gpu", "-x", "-q",
                         "-k", "test_segment_proof_matches_oracle or test_segment_matches_golden_fixture", "-p", "no:cacheprovider"],
-                       capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, PYTHONPATH=ROOT, **switches), timeout=1500)
+                       capture_output=True, text=True, cwd=ROOT, env=dict(os.environ, PYTHONPATH=_pythonpath(), **switches), timeout=1500)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
     assert " passed" in r.stdout and "failed" not in r.stdout
 
