@@ -161,3 +161,25 @@ def test_the_emulator_checks_what_it_claims(tmp_path):
                     assert r.returncode == 0 and reports == 0 and "0 wrong values" in r.stdout, (tag, asy, r.stdout, r.stderr[-1500:])
                 elif tag == "tsan":
                     assert r.returncode == 66 and reports >= 1 and "reverse_without_barrier" in r.stderr, (asy, r.stderr[-1500:])
+
+
+def test_bench_prints_its_contract_line_on_the_emulation_build(emu_env):
+    """bench.py end to end (one tiny nine-table segment per step, no secondaries) with the emulation build as its device: the LAST
+    line of stdout is the contract's strict-JSON object -- metric, value, unit, n_gpus, steps, warmup, ms_per_step, roofline,
+    config.workload -- and the sidecar names the plan table the run used (compiled in, empty).  Not a measurement of anything: the
+    point is that the driver's command parses (r04's record did not) on the code as it is now."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "6", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pmc",
+                        "--no-secondary", "--commit-steps", "0", "--in-flight", "1", "--no-dist-selftest"],
+                       capture_output=True, text=True, cwd=ROOT, env=emu_env, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = r.stdout.strip().splitlines()[-1]
+
+    def bad(c):
+        raise ValueError(c)
+    d = json.loads(line, parse_constant=bad)
+    assert len(line) < 4096 and d["unit"] == "segment proofs/s" and d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 0
+    assert d["value"] > 0 and abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"] and d["higher_is_better"] is True
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["peak"] == 8000.0 and "workload" in d["config"] and "model" not in d["config"]
+    assert d["ntt"]["lane_swap_plans"] == 0 and d["ntt"]["tree_tops_batched"] is False and d["ntt"]["plans_source"] == "compiled in"
+    extra = json.load(open(os.path.join(ROOT, "bench_extra.json")))
+    assert extra["ntt"]["plans"] == "" and extra["ntt"]["forced"] == {}

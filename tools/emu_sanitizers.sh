@@ -10,15 +10,23 @@ TAG=${1:-r06c}; WHICH=${2:-both}
 ROOT=$(cd "$(dirname "$0")/.." && pwd); cd "$ROOT"
 RTD=$(dirname "$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)")
 IDS=$(grep "::" tests/emu/quick_slice.txt | grep -v "^#")
-run() {   # san, runtime .so, options-variable=value, out file, extra pytest ids
+run() {   # san, runtime .so, options-variable=value, out file, pytest ids...
   local san=$1 rt=$2 opt=$3 out=$4; shift 4
   python tests/emu/build_emu.py --san "$san" > /dev/null || { echo "build of the $san variant failed"; return 1; }
-  local lib=$ROOT/tests/emu/build_$san/libzkstark_emu_$san.so
+  local lib=$ROOT/tests/emu/build_$san/libzkstark_emu_$san.so rep=/tmp/emu_${san}_reports_$$
+  rm -f "$rep".*
+  # (the sanitizers write their reports to files: pytest captures the tests' stderr)
   { echo "# quick slice of the GPU tests on the CPU emulation build under -fsanitize=$san ($(git rev-parse --short HEAD)); NOT a hardware run";
-    env ZK_STARK_LIB="$lib" HIPEMU_TORCH_SHIM=1 PYTHONPATH="$ROOT/tests/emu/site:$ROOT" LD_PRELOAD="$rt" "$opt" \
+    env ZK_STARK_LIB="$lib" HIPEMU_TORCH_SHIM=1 HIPEMU_THREADS=2 PYTHONPATH="$ROOT/tests/emu/site:$ROOT" LD_PRELOAD="$rt" "$opt:log_path=$rep" \
         ASAN_SYMBOLIZER_PATH=/opt/rocm/lib/llvm/bin/llvm-symbolizer TSAN_SYMBOLIZER_PATH=/opt/rocm/lib/llvm/bin/llvm-symbolizer \
-        timeout 7200 python -m pytest "$@" -q -p no:cacheprovider 2>&1 | grep -v "^$" | tail -400; } > "$out"
-  tail -3 "$out"
+        timeout 10800 python -m pytest "$@" -q -p no:cacheprovider 2>&1 | grep -v "^$" | tail -60;
+    local n; n=$(cat "$rep".* 2>/dev/null | grep -c "^WARNING: \|^==.*ERROR: \|runtime error:")
+    echo "# sanitizer reports: $n"
+    if [ "$n" != 0 ]; then
+      echo "# reports whose stacks lie in liboracle.so / libgomp (the CPU oracle's OpenMP loops: uninstrumented test infrastructure) are not the library's"
+      cat "$rep".* | cut -c1-260 | head -400
+    fi; } > "$out"
+  tail -4 "$out"
 }
 if [ "$WHICH" = asan ] || [ "$WHICH" = both ]; then
   run asan "$RTD/libclang_rt.asan-x86_64.so" "ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1" profiles/${TAG}_emu_asan_ubsan.log $IDS
