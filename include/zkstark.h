@@ -672,7 +672,13 @@ int zk_fri_initial_openings(zk_ctx *ctx, const zk_cfg *cfg, const zk_batch *cons
  *       (tests on a one-GPU box; a fallback where RCCL cannot come up).  slot_bytes = outbox per rank (0 = 32 MiB,
  *       ZK_COMM_SLOT_MB overrides); ctx may be NULL for a communicator that only moves host payloads (zk_comm_*_host).
  *       A rank that waits ZK_COMM_TIMEOUT_S (300) for a peer gives up with ZK_ERR_COMM -- and so do all the others.
- * After ZK_ERR_COMM the communicator is dead: free it on every rank.  world must be a power of two. */
+ * Failures.  The ranks run the same sequence of collectives, and every collective starts with an exchange of one status word per
+ * rank.  A rank whose LOCAL step fails (out of memory, a refused launch, a bad argument only it can see) returns its own error
+ * from the multi-rank call it is in; the others learn of it inside the collective they were entering and return ZK_ERR_COMM from
+ * the same call -- at once, no time limit involved, on RCCL as on the host transport -- and the communicator is still in step:
+ * the next multi-rank call may use it.  Only a failure INSIDE a data exchange (a copy that fails, an RCCL error, a peer that is
+ * gone: the host transport's time limit) kills the communicator: every later call on it returns ZK_ERR_COMM immediately; free it
+ * on every rank.  world must be a power of two. */
 #define ZK_COMM_ID_BYTES 128
 typedef struct zk_comm zk_comm;
 int zk_comm_unique_id(uint8_t out[ZK_COMM_ID_BYTES]);
