@@ -62,7 +62,7 @@ def test_gpu_tests_pass_with_deferred_streams(emu_env):
     event wait between the lanes, a pinned buffer reused before its copy kernel ran, an arena block handed out under a pending
     kernel would change the words of a proof here."""
     ids = _ids("async_slice.txt")
-    assert len(ids) >= 40
+    assert len(ids) >= 30
     assert _run(ids, dict(emu_env, HIPEMU_ASYNC="1"), 1500) >= len(ids)
 
 
@@ -110,7 +110,7 @@ lib.zki_ntt_tune_report.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
 ctx.set_plans("")
 d, td = C.c_int(-1), C.c_int(-1)
 rc1 = lib.zki_ntt_tune_range(ctx.handle, 10, 15, 10, 12, 1, C.byref(d))
-rc2 = lib.zki_tree_batch_trial(ctx.handle, (C.c_uint * 9)(5, 4, 5, 4, 4, 4, 6, 4, 4), C.byref(td))
+rc2 = lib.zki_tree_batch_trial(ctx.handle, (C.c_uint * 9)(4, 4, 4, 4, 4, 4, 5, 4, 4), C.byref(td))
 buf = C.create_string_buffer(1 << 16)
 lib.zki_ntt_tune_report(ctx.handle, buf, len(buf))
 print("RESULT " + json.dumps({"rc": [rc1, rc2], "differ": [d.value, td.value], "plans": ctx.get_plans(), "report": buf.value.decode()}))
@@ -196,7 +196,7 @@ from zk_evm_amd.all_stark import AllStark
 from zk_evm_amd.scheduler import SegmentJob, SegmentScheduler
 st = AllStark((1, 2, 3, 4))
 cfg = zk_evm_amd.StarkConfig(fri_config=zk_evm_amd.FriConfig(num_query_rounds=5, proof_of_work_bits=4))
-host = [(make_traces(np.random.default_rng(100 + i)), make_pv(np.random.default_rng(200 + i))) for i in range(4)]
+host = [(make_traces(np.random.default_rng(100 + i)), make_pv(np.random.default_rng(200 + i))) for i in range(2)]
 words = lambda p: sg.all_proof_to_words(p)
 direct = [words(sg.prove_with_traces(st, cfg, [to_dev(t) for t in tr], [True] * 9, to_public_values(pv))) for tr, pv in host]
 jobs = [SegmentJob(lambda dev, tr=tr: [to_dev(t) for t in tr], [True] * 9, to_public_values(pv), tag=i) for i, (tr, pv) in enumerate(host)]
@@ -217,4 +217,4 @@ def test_one_process_drives_two_devices(emu_env):
                        env=dict(emu_env, HIPEMU_DEVICES="2"))
     assert r.returncode == 0, r.stderr[-2500:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
-    assert out["same"] is True and sorted(out["per_device"]) == ["0", "1"] and sum(out["per_device"].values()) == 4, out
+    assert out["same"] is True and sorted(out["per_device"]) == ["0", "1"] and sum(out["per_device"].values()) == 2 and all(v == 1 for v in out["per_device"].values()), out
