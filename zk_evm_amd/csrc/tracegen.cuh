@@ -172,7 +172,7 @@ static __global__ void mem_continuation_trace_kernel(const u64 *__restrict__ ent
     const u32 row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= n_rows) return;
     const bool live = row < n;
-    const u64 *e = entries + (size_t)row * 7;
+    const u64 *e = live ? entries + (size_t)row * 7 : nullptr;       // (`entries` is null for an empty table: no arithmetic on it -- UBSan, r06c)
     out[row] = live ? 1 : 0;
     for (u32 k = 0; k < 3; ++k) out[(size_t)(1 + k) * stride + row] = live ? e[k] : 0;
     for (u32 l = 0; l < 4; ++l) {
