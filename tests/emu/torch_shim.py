@@ -80,8 +80,30 @@ def install():
     tc.get_device_name = lambda d=None: "hipemu (CPU emulation)"
 
     T = torch.Tensor
+
+    def sync_current():
+        # what torch does before the host reads a CUDA tensor: the copy is ordered on the CURRENT stream and waited for.  With
+        # deferred streams (HIPEMU_ASYNC=1) this is what makes the kernels the test enqueued on that stream run.
+        emu.hipStreamSynchronize(C.c_void_p(cur[0].cuda_stream))
+
+    def cpu(self, *a, **k):
+        sync_current()
+        return self.clone()
     T.cuda = lambda self, *a, **k: self.clone()
-    T.cpu = lambda self, *a, **k: self.clone()
+    T.cpu = cpu
+    for name in ("item", "tolist", "numpy"):
+        def make(orig):
+            def f(self, *a, **k):
+                sync_current()
+                return orig(self, *a, **k)
+            return f
+        setattr(T, name, make(getattr(T, name)))
+    orig_equal = torch.equal
+
+    def equal(a, b):
+        sync_current()
+        return orig_equal(a, b)
+    torch.equal = equal
     T.is_cuda = property(lambda self: True)
     orig_to = T.to
 
