@@ -463,6 +463,7 @@ struct Op {
     std::function<void()> fn;                          // what to do (empty for markers)
     hipemu_event *wait = nullptr;                      // != null: a hipStreamWaitEvent marker
     uint64_t wait_seq = 0;                             // ... for this recording of the event
+    hipemu_stream *wait_stream = nullptr;              // ... which went to this stream (the event may be recorded elsewhere again before the wait runs)
     hipemu_event *record = nullptr;                    // != null: a hipEventRecord marker
     uint64_t record_seq = 0;
 };
@@ -497,9 +498,9 @@ static bool is_pinned(const void *p) {
 
 static void drain(hipemu_stream *s, size_t upto);      // run the first `upto` queued operations of s (and what they wait for)
 static void drain_all(hipemu_stream *s) { drain(s, s->q.size()); }
-static void wait_event_record(hipemu_event *e, uint64_t seq) {
+static void wait_event_record(hipemu_event *e, uint64_t seq, hipemu_stream *t = nullptr) {
     if (e->completed >= seq) return;
-    hipemu_stream *t = e->stream;
+    if (!t) t = e->stream;
     if (!t) return;
     size_t upto = 0;
     for (size_t i = 0; i < t->q.size(); ++i)
@@ -513,7 +514,7 @@ static void drain(hipemu_stream *s, size_t upto) {
         Op op = std::move(s->q.front());
         s->q.pop_front();
         --upto;
-        if (op.wait) wait_event_record(op.wait, op.wait_seq);
+        if (op.wait) wait_event_record(op.wait, op.wait_seq, op.wait_stream);
         if (op.fn) op.fn();
         if (op.record) { op.record->completed = std::max(op.record->completed, op.record_seq); op.record->when = std::chrono::steady_clock::now(); }
         g_counters[6].fetch_add(1, std::memory_order_relaxed);
@@ -668,7 +669,7 @@ hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) {
     if (!g_events.count(e)) return hipErrorInvalidResourceHandle;
     if (e->recorded == 0 || !kAsync) return hipSuccess;     // never recorded: a no-op, as in HIP
     Op op;
-    op.wait = e; op.wait_seq = e->recorded;
+    op.wait = e; op.wait_seq = e->recorded; op.wait_stream = e->stream;
     enqueue(s, std::move(op));
     return hipSuccess;
 }

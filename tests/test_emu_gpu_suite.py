@@ -185,27 +185,6 @@ def test_bench_prints_its_contract_line_on_the_emulation_build(emu_env):
     assert extra["ntt"]["plans"] == "" and extra["ntt"]["forced"] == {}
 
 
-_TWO_DEVICES_CHILD = r"""
-import json, sys
-import numpy as np, torch
-import zk_evm_amd
-import zk_evm_amd.segment as sg
-from tests.gpu_util import to_dev
-from tests.test_gpu_segment import make_pv, make_traces, to_public_values
-from zk_evm_amd.all_stark import AllStark
-from zk_evm_amd.scheduler import SegmentJob, SegmentScheduler
-st = AllStark((1, 2, 3, 4))
-cfg = zk_evm_amd.StarkConfig(fri_config=zk_evm_amd.FriConfig(num_query_rounds=5, proof_of_work_bits=4))
-host = [(make_traces(np.random.default_rng(100 + i)), make_pv(np.random.default_rng(200 + i))) for i in range(2)]
-words = lambda p: sg.all_proof_to_words(p)
-direct = [words(sg.prove_with_traces(st, cfg, [to_dev(t) for t in tr], [True] * 9, to_public_values(pv))) for tr, pv in host]
-jobs = [SegmentJob(lambda dev, tr=tr: [to_dev(t) for t in tr], [True] * 9, to_public_values(pv), tag=i) for i, (tr, pv) in enumerate(host)]
-with SegmentScheduler(st, cfg, devices=[0, 1], in_flight=1) as sch:
-    got = sch.map(jobs)
-    per_device = {s.device: s.segments for s in sch.stats}
-same = all(np.array_equal(d, words(g)) for d, g in zip(direct, got))
-print("RESULT " + json.dumps({"same": bool(same), "per_device": per_device}))
-"""
 
 
 def test_one_process_drives_two_devices(emu_env):
@@ -213,7 +192,7 @@ def test_one_process_drives_two_devices(emu_env):
     on an emulated node with two devices (HIPEMU_DEVICES=2).  Every proof equals the one a single ctx makes, and both devices worked.
     (What this pins: nothing in the library is set up once per PROCESS where it must be once per device / ctx -- r06 moved three
     kernel-attribute calls from static flags into the ctx.)"""
-    r = subprocess.run([sys.executable, "-c", _TWO_DEVICES_CHILD], capture_output=True, text=True, cwd=ROOT, timeout=1200,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "two_devices_driver.py")], capture_output=True, text=True, cwd=ROOT, timeout=1200,
                        env=dict(emu_env, HIPEMU_DEVICES="2"))
     assert r.returncode == 0, r.stderr[-2500:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])

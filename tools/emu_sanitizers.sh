@@ -32,7 +32,14 @@ if [ "$WHICH" = asan ] || [ "$WHICH" = both ]; then
   run asan "$RTD/libclang_rt.asan-x86_64.so" "ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=1" profiles/${TAG}_emu_asan_ubsan.log $IDS
 fi
 if [ "$WHICH" = tsan ] || [ "$WHICH" = both ]; then
-  # the tests with host threads first (two contexts, the scheduler, PLONK batches), then the slice
-  run tsan "$RTD/libclang_rt.tsan-x86_64.so" "TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0:second_deadlock_stack=1" profiles/${TAG}_emu_tsan.log \
-      "tests/test_gpu_segment.py::test_two_contexts_prove_concurrently" "tests/test_gpu_plonk.py::test_plonk_prove_batch_equals_single_proofs" $IDS
+  run tsan "$RTD/libclang_rt.tsan-x86_64.so" "TSAN_OPTIONS=halt_on_error=0:report_signal_unsafe=0:second_deadlock_stack=1:exitcode=0" profiles/${TAG}_emu_tsan.log $IDS
+  # host threads: two worker threads, a zk_ctx and a stream each, on two emulated devices in one process
+  { echo "# tests/emu/two_devices_driver.py (two scheduler threads, two emulated devices) under TSan:";
+    rm -f /tmp/emu_tsan_threads_$$.*
+    env ZK_STARK_LIB="$ROOT/tests/emu/build_tsan/libzkstark_emu_tsan.so" HIPEMU_TORCH_SHIM=1 HIPEMU_THREADS=2 HIPEMU_DEVICES=2 PYTHONPATH="$ROOT/tests/emu/site:$ROOT" \
+        LD_PRELOAD="$RTD/libclang_rt.tsan-x86_64.so" TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:exitcode=0:log_path=/tmp/emu_tsan_threads_$$" \
+        TSAN_SYMBOLIZER_PATH=/opt/rocm/lib/llvm/bin/llvm-symbolizer timeout 3600 python tests/emu/two_devices_driver.py 2>&1 | grep "RESULT"
+    n=$(cat /tmp/emu_tsan_threads_$$.* 2>/dev/null | grep -c "^WARNING: "); echo "# sanitizer reports: $n"
+    [ "$n" != 0 ] && cat /tmp/emu_tsan_threads_$$.* | cut -c1-260 | head -300; } >> profiles/${TAG}_emu_tsan.log
+  tail -3 profiles/${TAG}_emu_tsan.log
 fi
