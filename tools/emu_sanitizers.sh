@@ -20,12 +20,7 @@ run() {   # san, runtime .so, options-variable=value, out file, pytest ids...
     env ZK_STARK_LIB="$lib" HIPEMU_TORCH_SHIM=1 HIPEMU_THREADS=2 PYTHONPATH="$ROOT/tests/emu/site:$ROOT" LD_PRELOAD="$rt" "$opt:log_path=$rep" \
         ASAN_SYMBOLIZER_PATH=/opt/rocm/lib/llvm/bin/llvm-symbolizer TSAN_SYMBOLIZER_PATH=/opt/rocm/lib/llvm/bin/llvm-symbolizer \
         timeout 10800 python -m pytest "$@" -q -p no:cacheprovider 2>&1 | grep -v "^$" | tail -60;
-    local n; n=$(cat "$rep".* 2>/dev/null | grep -c "^WARNING: \|^==.*ERROR: \|runtime error:")
-    echo "# sanitizer reports: $n"
-    if [ "$n" != 0 ]; then
-      echo "# reports whose stacks lie in liboracle.so / libgomp (the CPU oracle's OpenMP loops: uninstrumented test infrastructure) are not the library's"
-      cat "$rep".* | cut -c1-260 | head -400
-    fi; } > "$out"
+    python tools/sanitizer_report_summary.py "$rep".*; } > "$out"
   tail -4 "$out"
 }
 if [ "$WHICH" = asan ] || [ "$WHICH" = both ]; then
@@ -39,7 +34,6 @@ if [ "$WHICH" = tsan ] || [ "$WHICH" = both ]; then
     env ZK_STARK_LIB="$ROOT/tests/emu/build_tsan/libzkstark_emu_tsan.so" HIPEMU_TORCH_SHIM=1 HIPEMU_THREADS=2 HIPEMU_DEVICES=2 PYTHONPATH="$ROOT/tests/emu/site:$ROOT" \
         LD_PRELOAD="$RTD/libclang_rt.tsan-x86_64.so" TSAN_OPTIONS="halt_on_error=0:report_signal_unsafe=0:exitcode=0:log_path=/tmp/emu_tsan_threads_$$" \
         TSAN_SYMBOLIZER_PATH=/opt/rocm/lib/llvm/bin/llvm-symbolizer timeout 3600 python tests/emu/two_devices_driver.py 2>&1 | grep "RESULT"
-    n=$(cat /tmp/emu_tsan_threads_$$.* 2>/dev/null | grep -c "^WARNING: "); echo "# sanitizer reports: $n"
-    [ "$n" != 0 ] && cat /tmp/emu_tsan_threads_$$.* | cut -c1-260 | head -300; } >> profiles/${TAG}_emu_tsan.log
+    python tools/sanitizer_report_summary.py /tmp/emu_tsan_threads_$$.*; } >> profiles/${TAG}_emu_tsan.log
   tail -3 profiles/${TAG}_emu_tsan.log
 fi
