@@ -40,3 +40,6 @@ f=$(find /tmp/kt_b -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && { cp "$f
 cd "$ROOT"
 echo "== kbench A/B of every plan (checksums must agree per shape)"; timeout 1500 tools/ab_ntt_swap.sh 2>&1 | tee "$OUT/${TAG}_ab_ntt_swap.log" | cut -c1-230 | tail -40
 echo "== the default bench line, full"; timeout 1200 python bench.py > "$OUT/${TAG}_bench_default.json" 2> "$OUT/${TAG}_bench_default.err"; tail -1 "$OUT/${TAG}_bench_default.json" | cut -c1-1500
+echo "== the CPU oracle on this box's cores: one block-shaped segment, cached for cpu_baseline (copy tools/cpu_baseline_cache.json back)"
+timeout 900 python tools/cpu_baseline_cache.py measure --log-ns realistic > "$OUT/${TAG}_cpu_baseline_segment.json" 2> /dev/null; cut -c1-300 "$OUT/${TAG}_cpu_baseline_segment.json"
+cp tools/cpu_baseline_cache.json "$OUT/${TAG}_cpu_baseline_cache.json"
