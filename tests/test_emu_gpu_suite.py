@@ -197,3 +197,32 @@ def test_one_process_drives_two_devices(emu_env):
     assert r.returncode == 0, r.stderr[-2500:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
     assert out["same"] is True and sorted(out["per_device"]) == ["0", "1"] and sum(out["per_device"].values()) == 2, out
+
+
+def test_a_failing_rank_never_strands_its_peer_inside_a_table_proof(emu_env):
+    """The same drill one level up: zk_prove_table_sharded (a row-sharded table proof: about fifteen collectives -- all-to-alls,
+    all-gathers of caps, carries, openings, FRI values) with one of rank 1's kernel launches refused at six points spread over the
+    proof.  Every time both ranks are back within seconds -- rank 1 with its own error, rank 0 with ZK_ERR_COMM -- and the SAME
+    communicator then produces the reference proof on both ranks."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(emu_env, HIPEMU_THREADS="3", ZK_COMM_TIMEOUT_S="60", ZK_FAIL_AT="1,12,30,60,80,5000")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "emu", "multirank_prove_failure_driver.py"), str(r), "2", str(port)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    res = [json.loads([ln for ln in o[0].splitlines() if ln.startswith("RESULT ")][-1][7:]) for o in outs]
+    r0, r1 = (res[0], res[1]) if res[0]["rank"] == 0 else (res[1], res[0])
+    assert r0["reference"] == r1["reference"]
+    failed = 0
+    for a, b in zip(r0["runs"], r1["runs"]):
+        assert a["fail_at"] == b["fail_at"] and a["retry_same"] is True and b["retry_same"] is True, (a, b)
+        if b["code"] != 0:
+            failed += 1
+            assert b["code"] == -3 and a["code"] == -6 and a["seconds"] < 20 and b["seconds"] < 20, (a, b)
+        else:
+            assert a["code"] == 0 and a["same_as_reference"] is True and b["same_as_reference"] is True, (a, b)
+    assert failed >= 4 and r0["runs"][-1]["code"] == 0
